@@ -1,0 +1,196 @@
+/*
+ * playaid_hip.h -- C ABI of the MI355X (gfx950) action-recognition hot path.
+ *
+ * The reference (NathanBWaters/playaid_core) is pure Python and has no FFI; the
+ * path sits behind three Python call boundaries. Each
+ * entry point below names the reference interface it replaces. The Python host
+ * in playaid_core_amd/ binds this library with ctypes and re-exposes the
+ * reference's own classes (CNNActionDetector, AIRunner, YoloCrop); see
+ * INTEGRATION.md for the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - All data pointers are DEVICE pointers (HBM) unless the name ends in
+ *     _host. The caller owns every buffer. `stream` is a hipStream_t passed as
+ *     void* (NULL = default stream). Calls only enqueue work; nothing here
+ *     synchronises except pa_create / pa_destroy / pa_profile_read and the
+ *     *_sync helpers.
+ *   - Return value: PA_OK (0) or a negative pa_status. pa_last_error() gives a
+ *     human-readable message for the last failing call on that engine. The
+ *     reference's asserts / exit() (ai_runner.py:240-242,447,458; fighter.py
+ *     :356-362) become status codes; per-crop failures are reported in the
+ *     per-crop `status` words, not as a failed call.
+ *   - One engine per device; an engine is not thread-safe (the reference is
+ *     single-threaded).
+ *   - Frames are numbered from 1 like the reference's YOLO files
+ *     (ai_runner.py:516); `frame0` arguments are 0-based indices into a clip.
+ */
+#ifndef PLAYAID_HIP_H
+#define PLAYAID_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PA_ABI_VERSION 1
+#define PA_WEIGHT_MAGIC 0x31574150 /* "PAW1" */
+#define PA_FEATURE_STRIDE 1024     /* floats per cached feature row (1000 used) */
+#define PA_CROP 128
+
+typedef enum pa_status {
+    PA_OK = 0,
+    PA_ERR_INVALID_ARG = -1,
+    PA_ERR_HIP = -2,          /* a HIP runtime call failed; see pa_last_error */
+    PA_ERR_BAD_WEIGHTS = -3,  /* blob size / magic / shape mismatch */
+    PA_ERR_CAPACITY = -4,     /* more frames/windows than the engine was created for */
+    PA_ERR_NO_DEVICE = -5,
+    PA_ERR_NOT_READY = -6     /* head asked for frames whose features are not cached */
+} pa_status;
+
+/* per-crop status words written by the preprocess stage */
+#define PA_CROP_OK 0
+#define PA_CROP_EMPTY 1        /* empty / off-screen slice: reference returns (False, None), fighter.py:356-362 */
+#define PA_CROP_BAD_BOX 2      /* non-finite box or square side <= 0 (reference raises) */
+#define PA_CROP_UPSCALE 3      /* square side < 128 px: INTER_AREA enlarging branch, not implemented */
+#define PA_CROP_FILTER_TOO_WIDE 4 /* bicubic support beyond the kernel's table size (scale > 3.5) */
+
+typedef struct pa_engine pa_engine;
+
+/* Geometry of the path. Defaults mirror ai_runner.py:426-439 and
+ * cnn_action_detector.py:14-27. */
+typedef struct pa_config {
+    int32_t abi_version;       /* PA_ABI_VERSION */
+    int32_t device_id;         /* HIP device ordinal */
+    int32_t sequence_length;   /* S, odd; 7 (ai_runner.py:432) */
+    int32_t frame_delta;       /* 3 (ai_runner.py:433-437) */
+    int32_t num_actions;       /* A; 63 (anim_ontology.py:592-600) */
+    int32_t num_fighters;      /* crops per frame; 2 (ai_runner.py:240-242) */
+    int32_t crop_padding;      /* 30 px (ai_runner.py:417-418) */
+    int32_t max_batch_frames;  /* most frames handed to one pa_backbone_frames call */
+    int32_t max_clip_frames;   /* feature-cache capacity in frames */
+    int32_t max_frame_height;  /* scratch sizing for the resampler */
+    int32_t max_frame_width;
+    int32_t fighter_class_ids[4]; /* CHAR_LIST index of each fighter slot (constants.py:51) */
+} pa_config;
+
+/* Result record per (frame, fighter): the fields AIRunner.action_recognition
+ * derives at ai_runner.py:474-479. confidence% = prob * 100 is left to the host
+ * (the reference multiplies in Python double). */
+typedef struct pa_record {
+    int32_t char_id;    /* CHAR_LIST.index(fighter) */
+    int32_t action_id;  /* int(torch.argmax(predictions)) */
+    float prob;         /* exp(logp[action_id]) */
+    int32_t status;     /* PA_CROP_* of the window's middle crop */
+} pa_record;
+
+/* One row per kernel family of the last profiled call(s). */
+typedef struct pa_kernel_stat {
+    char name[48];
+    int32_t launches;
+    float total_ms;     /* sum of HIP-event durations on the engine's stream */
+    double flops;       /* algorithmic FLOPs summed over those launches */
+    double bytes;       /* algorithmic (compulsory) HBM bytes summed over those launches */
+} pa_kernel_stat;
+
+/* ---- lifetime ----------------------------------------------------------- */
+
+/* Replaces CNNActionDetector.load_from_checkpoint(...).eval()
+ * (ai_runner.py:164-168; cnn_action_detector.py:46-92).
+ * weight_blob_host: int32 header {PA_WEIGHT_MAGIC, 1, S, A, 0,0,0,0} followed by
+ * the fp32 tensors of the Lightning state_dict in this order, PyTorch layouts:
+ *   model.cnn2d.conv1.weight[64,3,7,7], bn1.{weight,bias,running_mean,running_var}[64],
+ *   for layer 1..4, block 0..1: conv1.weight, bn1.{w,b,mean,var}, conv2.weight,
+ *     bn2.{w,b,mean,var}, then (block 0 of layers 2..4) downsample.0.weight,
+ *     downsample.1.{w,b,mean,var};
+ *   fc.weight[1000,512], fc.bias[1000];
+ *   model.cnn1d.0.weight[512,1000,S], model.cnn1d.0.bias[512];
+ *   model.classifier.0.weight[128,512], .bias[128];
+ *   model.classifier.2.weight[A,128], .bias[A].
+ * BatchNorm (eval, eps 1e-5) is folded into the preceding convolution in fp64
+ * on the host and the tensors are re-laid-out for the kernels here. */
+int pa_create(const pa_config* cfg, const void* weight_blob_host, size_t blob_bytes, pa_engine** out);
+void pa_destroy(pa_engine* e);
+const char* pa_last_error(const pa_engine* e);
+const char* pa_status_string(int status);
+int pa_abi_version(void);
+/* Expected blob size in bytes for (S, A). */
+size_t pa_weight_blob_bytes(int sequence_length, int num_actions);
+
+/* ---- b1: the operator --------------------------------------------------- */
+
+/* Replaces `logp = model(x)` (cnn_action_detector.py:86-92; ai_runner.py:472).
+ * x: float32[B,S,3,128,128] NCHW contiguous, values in [0,1].
+ * logp: float32[B,A] log-probabilities. B*S <= max_batch_frames*num_fighters. */
+int pa_infer_windows(pa_engine* e, const float* x, int32_t batch, float* logp, void* stream);
+
+/* ---- a6: crop preprocessing --------------------------------------------- */
+
+/* Replaces YoloCrop.square_crop(frame, 128, padding) (fighter.py:323-381) for
+ * n frames x num_fighters boxes at once.
+ * frames: uint8[n,H,W,3] HWC (BGR as cv2 delivers it, ai_runner.py:404-405).
+ * boxes:  float64[n,num_fighters,4] normalised (cx,cy,w,h) (ai_runner.py:53-71).
+ * crops:  uint8[n,num_fighters,128,128,3]; channel order kept when swap_rb=0
+ *         (square_crop), reversed when swap_rb=1 (the BGR2RGB of ai_runner.py:448).
+ * status: int32[n,num_fighters] PA_CROP_*; failed crops are all zero. */
+int pa_square_crops(pa_engine* e, const uint8_t* frames, int32_t n, int32_t height, int32_t width,
+                    const double* boxes, int32_t padding, int32_t swap_rb, uint8_t* crops,
+                    int32_t* status, void* stream);
+
+/* ---- b2: the runner loop ------------------------------------------------ */
+
+/* Start a clip of clip_frames frames (= the reference's max_frames,
+ * ai_runner.py:244-245): sets the clamp range of the window sampler and marks
+ * the feature cache empty. */
+int pa_clip_begin(pa_engine* e, int32_t clip_frames);
+
+/* Crop + backbone for frames frame0 .. frame0+n-1 (0-based) of the clip:
+ * square_crop(pad) -> BGR2RGB -> /255 -> ResNet-18 -> 1000-d feature per
+ * (frame, fighter), stored in the engine's feature cache. Replaces the crop
+ * read + `self.model.cnn2d` part of ai_runner.py:443-472 with each crop run
+ * through the backbone once instead of once per window.
+ * crops_rgb (optional, may be NULL): uint8[n,num_fighters,128,128,3] copy of the
+ * model inputs (the `frames` entry of action_recognition's dict, :489).
+ * status (optional): int32[n,num_fighters]. */
+int pa_backbone_frames(pa_engine* e, const uint8_t* frames, int32_t n, int32_t height, int32_t width,
+                       const double* boxes, int32_t frame0, uint8_t* crops_rgb, int32_t* status,
+                       void* stream);
+
+/* Window gather + Conv1d/MLP head + log_softmax + argmax for frame numbers
+ * frame_num_lo .. frame_num_hi-1 (1-based, as run_action_recognition iterates
+ * range(1, max_frames), ai_runner.py:508). Replaces
+ * action_sample_from_frame_middle_out (dataset_utils.py:109-138) and the head
+ * half of ai_runner.py:472-477.
+ * records: pa_record[count,num_fighters]; logp (optional): float32[count,num_fighters,A]. */
+int pa_head_frames(pa_engine* e, int32_t frame_num_lo, int32_t frame_num_hi, pa_record* records,
+                   float* logp, void* stream);
+
+/* pa_clip_begin + pa_backbone_frames(all n frames) + pa_head_frames(1..n-1):
+ * AIRunner.run_action_recognition (ai_runner.py:493-520) for an n-frame clip.
+ * records: pa_record[n-1,num_fighters]; logp optional float32[n-1,num_fighters,A]. */
+int pa_infer_clip(pa_engine* e, const uint8_t* frames, int32_t n, int32_t height, int32_t width,
+                  const double* boxes, pa_record* records, float* logp, uint8_t* crops_rgb,
+                  int32_t* status, void* stream);
+
+/* Feature-cache access for frame-parallel sharding: copy
+ * the cached rows of frames frame0..frame0+n-1 out of / into the engine.
+ * feats: float32[n,num_fighters,PA_FEATURE_STRIDE]. */
+int pa_features_export(pa_engine* e, int32_t frame0, int32_t n, float* feats, void* stream);
+int pa_features_import(pa_engine* e, int32_t frame0, int32_t n, const float* feats, void* stream);
+
+/* ---- measurement -------------------------------------------------------- */
+
+/* When enabled, every kernel launch is bracketed by HIP events recorded on the
+ * stream it is launched on. pa_profile_read synchronises that stream, returns
+ * one row per kernel family and clears the log. */
+int pa_profile_enable(pa_engine* e, int32_t on);
+int pa_profile_read(pa_engine* e, pa_kernel_stat* stats, int32_t max_stats, int32_t* n_stats);
+
+/* Blocks until all work enqueued on `stream` is done (hipStreamSynchronize). */
+int pa_stream_sync(pa_engine* e, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLAYAID_HIP_H */

@@ -1,0 +1,122 @@
+"""ctypes binding of ``libplayaid_hip.so`` (the C ABI in include/playaid_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing or does
+not load, importing the engine raises ``HipLibraryError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libplayaid_hip.so")
+
+PA_ABI_VERSION = 1
+PA_WEIGHT_MAGIC = 0x31574150
+PA_FEATURE_STRIDE = 1024
+
+PA_OK = 0
+PA_ERR_INVALID_ARG = -1
+PA_ERR_HIP = -2
+PA_ERR_BAD_WEIGHTS = -3
+PA_ERR_CAPACITY = -4
+PA_ERR_NO_DEVICE = -5
+PA_ERR_NOT_READY = -6
+
+PA_CROP_OK = 0
+PA_CROP_EMPTY = 1
+PA_CROP_BAD_BOX = 2
+PA_CROP_UPSCALE = 3
+PA_CROP_FILTER_TOO_WIDE = 4
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+class pa_config(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("device_id", C.c_int32),
+        ("sequence_length", C.c_int32),
+        ("frame_delta", C.c_int32),
+        ("num_actions", C.c_int32),
+        ("num_fighters", C.c_int32),
+        ("crop_padding", C.c_int32),
+        ("max_batch_frames", C.c_int32),
+        ("max_clip_frames", C.c_int32),
+        ("max_frame_height", C.c_int32),
+        ("max_frame_width", C.c_int32),
+        ("fighter_class_ids", C.c_int32 * 4),
+    ]
+
+
+class pa_record(C.Structure):
+    _fields_ = [
+        ("char_id", C.c_int32),
+        ("action_id", C.c_int32),
+        ("prob", C.c_float),
+        ("status", C.c_int32),
+    ]
+
+
+class pa_kernel_stat(C.Structure):
+    _fields_ = [
+        ("name", C.c_char * 48),
+        ("launches", C.c_int32),
+        ("total_ms", C.c_float),
+        ("flops", C.c_double),
+        ("bytes", C.c_double),
+    ]
+
+
+# every symbol include/playaid_hip.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = [
+    ("pa_create", C.c_int, [C.POINTER(pa_config), _P, C.c_size_t, C.POINTER(_P)]),
+    ("pa_destroy", None, [_P]),
+    ("pa_last_error", C.c_char_p, [_P]),
+    ("pa_status_string", C.c_char_p, [C.c_int]),
+    ("pa_abi_version", C.c_int, []),
+    ("pa_weight_blob_bytes", C.c_size_t, [C.c_int, C.c_int]),
+    ("pa_infer_windows", C.c_int, [_P, _P, C.c_int32, _P, _P]),
+    ("pa_square_crops", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, _P]),
+    ("pa_clip_begin", C.c_int, [_P, C.c_int32]),
+    ("pa_backbone_frames", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, _P]),
+    ("pa_head_frames", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P]),
+    ("pa_infer_clip", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P]),
+    ("pa_features_export", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
+    ("pa_features_import", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
+    ("pa_profile_enable", C.c_int, [_P, C.c_int32]),
+    ("pa_profile_read", C.c_int, [_P, C.POINTER(pa_kernel_stat), C.c_int32, C.POINTER(C.c_int32)]),
+    ("pa_stream_sync", C.c_int, [_P, _P]),
+]
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library and bind every exported symbol (fails loudly)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} not found: build it with `python -m playaid_core_amd._build` "
+            "(hipcc, --offload-arch=gfx950). There is no CPU fallback for this path."
+        )
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as exc:  # pragma: no cover - depends on the box
+        raise HipLibraryError(f"cannot load {LIB_PATH}: {exc}") from exc
+    for name, restype, argtypes in SYMBOLS:
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:
+            raise HipLibraryError(f"{LIB_PATH} does not export {name}") from exc
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.pa_abi_version() != PA_ABI_VERSION:
+        raise HipLibraryError("libplayaid_hip.so ABI version mismatch; rebuild it")
+    _lib = lib
+    return lib

@@ -1,0 +1,232 @@
+// Small memory-bound kernels around the implicit-GEMM engine: layout change
+// for the b1 entry point, the two pooling layers, the window index table and
+// the MLP + log-softmax + argmax tail. All are streaming / reduction work:
+// 16-byte accesses where the layout allows, wave64 shuffle reductions, no LDS
+// beyond one staged row.
+#include "pa_kernels.h"
+#include "../../include/playaid_hip.h"
+
+namespace pa {
+
+// x[n][3][128][128] (NCHW fp32, the tensor `model(x)` receives,
+// cnn_action_detector.py:29-31) -> zero-bordered NHWC4 [n][134][134][4].
+__global__ __launch_bounds__(256) void nchw_to_padded_kernel(const float* __restrict__ x, float* __restrict__ out, int n) {
+    const size_t total = (size_t)n * 128 * 128;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int img = (int)(i >> 14);
+        const int pix = (int)(i & 16383);
+        const int y = pix >> 7, xx = pix & 127;
+        const float* s = x + (size_t)img * 3 * 16384 + pix;
+        float4 v;
+        v.x = s[0];
+        v.y = s[16384];
+        v.z = s[32768];
+        v.w = 0.f;
+        reinterpret_cast<float4*>(out)[((size_t)img * 134 + (y + 3)) * 134 + (xx + 3)] = v;
+    }
+}
+
+hipError_t launch_nchw_to_padded(const float* x, float* out, int32_t n, hipStream_t s) {
+    const size_t total = (size_t)n * 16384;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(nchw_to_padded_kernel, dim3(grid), dim3(256), 0, s, x, out, n);
+    return hipGetLastError();
+}
+
+// max_pool2d(3, stride 2, padding 1) on the post-ReLU stem output. Input is the
+// zero-bordered [n][66][66][64]; since every value is >= 0 the zero border
+// gives the same maximum as torch's -inf padding. Output zero-bordered
+// [n][34][34][64].
+__global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ in, float* __restrict__ out, int n) {
+    const size_t total = (size_t)n * 32 * 32 * 16;  // float4 units
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i & 15);
+        const int ox = (int)((i >> 4) & 31);
+        const int oy = (int)((i >> 9) & 31);
+        const int img = (int)(i >> 14);
+        const float4* src = reinterpret_cast<const float4*>(in) + (((size_t)img * 66 + oy * 2) * 66 + ox * 2) * 16 + c4;
+        float4 m = src[0];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float4 v = src[((size_t)ky * 66 + kx) * 16];
+                m.x = fmaxf(m.x, v.x);
+                m.y = fmaxf(m.y, v.y);
+                m.z = fmaxf(m.z, v.z);
+                m.w = fmaxf(m.w, v.w);
+            }
+        reinterpret_cast<float4*>(out)[(((size_t)img * 34 + oy + 1) * 34 + ox + 1) * 16 + c4] = m;
+    }
+}
+
+hipError_t launch_maxpool(const float* in, float* out, int32_t n, hipStream_t s) {
+    const size_t total = (size_t)n * 32 * 32 * 16;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(maxpool_kernel, dim3(grid), dim3(256), 0, s, in, out, n);
+    return hipGetLastError();
+}
+
+// adaptive_avg_pool2d((1,1)) over the 4x4 interior of the zero-bordered
+// [n][6][6][512] layer4 output -> [n][512].
+__global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ in, float* __restrict__ out, int n) {
+    const size_t total = (size_t)n * 128;  // float4 units
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i & 127);
+        const int img = (int)(i >> 7);
+        const float4* src = reinterpret_cast<const float4*>(in) + (size_t)img * 36 * 128 + c4;
+        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int y = 1; y <= 4; ++y)
+#pragma unroll
+            for (int x = 1; x <= 4; ++x) {
+                const float4 v = src[(size_t)(y * 6 + x) * 128];
+                sum.x += v.x;
+                sum.y += v.y;
+                sum.z += v.z;
+                sum.w += v.w;
+            }
+        sum.x *= 0.0625f;
+        sum.y *= 0.0625f;
+        sum.z *= 0.0625f;
+        sum.w *= 0.0625f;
+        reinterpret_cast<float4*>(out)[i] = sum;
+    }
+}
+
+hipError_t launch_avgpool(const float* in, float* out, int32_t n, hipStream_t s) {
+    const size_t total = (size_t)n * 128;
+    const int grid = (int)((total + 255) / 256);
+    hipLaunchKernelGGL(avgpool_kernel, dim3(grid), dim3(256), 0, s, in, out, n);
+    return hipGetLastError();
+}
+
+// action_sample_from_frame_middle_out (dataset_utils.py:109-138) on the device:
+// window w = (frame_num_lo + w / fighters, fighter w % fighters); slot t reads
+// frame number clamp(f -/+ delta*(mid-t)^2) and hence feature-cache row
+// (frame_num - 1) * fighters + fighter.
+__global__ void window_gather_kernel(int32_t* gather, int frame_num_lo, int count, int fighters, int seq, int delta,
+                                     int max_frames, int min_frame) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = count * fighters * seq;
+    if (i >= total) return;
+    const int t = i % seq;
+    const int w = i / seq;
+    const int fighter = w % fighters;
+    const int f = frame_num_lo + w / fighters;
+    const int mid = seq / 2;
+    int off = delta * (mid - t) * (mid - t);
+    if (off < 0) off = -off;
+    int fn;
+    if (t <= mid) {
+        fn = f - off;
+        fn = fn > min_frame ? fn : min_frame;
+    } else {
+        fn = f + off;
+        fn = fn < max_frames - 1 ? fn : max_frames - 1;
+    }
+    gather[i] = (fn - 1) * fighters + fighter;
+}
+
+hipError_t launch_window_gather(int32_t* gather, int32_t frame_num_lo, int32_t count, int32_t fighters, int32_t seq,
+                                int32_t delta, int32_t max_frames, int32_t min_frame, hipStream_t s) {
+    const int total = count * fighters * seq;
+    hipLaunchKernelGGL(window_gather_kernel, dim3((total + 255) / 256), dim3(256), 0, s, gather, frame_num_lo, count,
+                       fighters, seq, delta, max_frames, min_frame);
+    return hipGetLastError();
+}
+
+__global__ void identity_gather_kernel(int32_t* gather, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) gather[i] = i;
+}
+
+hipError_t launch_identity_gather(int32_t* gather, int32_t n, hipStream_t s) {
+    hipLaunchKernelGGL(identity_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, s, gather, n);
+    return hipGetLastError();
+}
+
+// classifier of SpatialStreamCNN (cnn_action_detector.py:27,41): Linear(512,128)
+// + ReLU + Linear(128,A), then F.log_softmax (:92), argmax and exp (ai_runner.py
+// :474-477). One workgroup per window; the 512-vector sits in LDS, each wave
+// reduces its dot products with wave64 shuffles, the A <= 64 logits live one per
+// lane of wave 0 for the softmax reductions.
+__global__ __launch_bounds__(256) void head_mlp_kernel(const HeadParams p) {
+    __shared__ float h1[512];
+    __shared__ float h2[128];
+    const int w = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    h1[tid] = p.h1[(size_t)w * 512 + tid];
+    h1[tid + 256] = p.h1[(size_t)w * 512 + tid + 256];
+    __syncthreads();
+    // 128 outputs, 32 per wave; lanes stride the 512-long dot product
+    for (int o = wave * 32; o < wave * 32 + 32; ++o) {
+        const float* wr = p.w2 + (size_t)o * 512;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += wr[lane + 64 * k] * h1[lane + 64 * k];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+        if (lane == 0) {
+            s += p.b2[o];
+            h2[o] = s > 0.f ? s : 0.f;
+        }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    const int A = p.num_actions;
+    float logit = -INFINITY;
+    if (lane < A) {
+        const float* wr = p.w3 + (size_t)lane * 128;
+        float s = 0.f;
+        for (int k = 0; k < 128; ++k) s += wr[k] * h2[k];
+        logit = s + p.b3[lane];
+    }
+    float mx = logit;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+    float ex = lane < A ? expf(logit - mx) : 0.f;
+    float se = ex;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) se += __shfl_xor(se, d, 64);
+    const float lp = logit - mx - logf(se);
+    if (p.logp && lane < A) p.logp[(size_t)w * A + lane] = lp;
+    // argmax with first-index tie break (torch.argmax)
+    float bv = lane < A ? lp : -INFINITY;
+    int bi = lane;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const float ov = __shfl_xor(bv, d, 64);
+        const int oi = __shfl_xor(bi, d, 64);
+        if (ov > bv || (ov == bv && oi < bi)) {
+            bv = ov;
+            bi = oi;
+        }
+    }
+    if (p.records && lane == 0) {
+        pa_record r;
+        const int fighter = w % p.fighters;
+        r.char_id = p.class_ids[fighter];
+        r.action_id = bi;
+        r.prob = expf(bv);
+        int st = 0;
+        if (p.crop_status && p.gather) {
+            const int row = p.gather[(size_t)w * p.seq + p.seq / 2];
+            if (row >= 0) st = p.crop_status[row];
+        }
+        r.status = st;
+        reinterpret_cast<pa_record*>(p.records)[w] = r;
+    }
+}
+
+hipError_t launch_head_mlp(const HeadParams& p, hipStream_t s) {
+    if (p.nwin <= 0) return hipSuccess;
+    if (p.num_actions > 64 || p.num_actions < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(head_mlp_kernel, dim3(p.nwin), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace pa

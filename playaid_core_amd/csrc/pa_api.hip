@@ -1,0 +1,793 @@
+// C-ABI host side of the MI355X action-recognition path (include/playaid_hip.h).
+// Owns device buffers, folds/re-lays-out the weights, sequences the kernels of
+// one forward on the caller's stream. No torch types, no hidden synchronisation
+// in the enqueue calls.
+#include "../../include/playaid_hip.h"
+#include "pa_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace pa;
+
+namespace {
+
+struct ConvLayer {
+    std::string name;
+    int cin, cout, kh, kw, stride;  // logical conv
+    int in_hw, out_hw;              // spatial size (square) of input / output interior
+    int in_pad, out_pad;            // zero-border widths of the buffers
+    int off;                        // tap origin inside the padded input
+    int taps, kw_taps, chunk;       // igemm K geometry
+    int in_px_stride;               // floats per input pixel
+    float* in = nullptr;
+    float* out = nullptr;
+    float* residual = nullptr;
+    float* wgt = nullptr;   // device [cout][taps*chunk]
+    float* bias = nullptr;  // device [cout]
+    int relu = 1;
+    GemmTile tile = TILE_128x64;
+    int splitk = 1;
+    double k_alg = 0;  // algorithmic K (unpadded) for FLOP accounting
+};
+
+struct ProfEntry {
+    int name_id;
+    hipEvent_t start, stop;
+    double flops, bytes;
+};
+
+}  // namespace
+
+struct pa_engine {
+    pa_config cfg;
+    std::string last_error;
+    int max_crops = 0;   // crops per backbone call
+    int cache_rows = 0;  // feature-cache rows
+    // clip state
+    int clip_frames = 0;
+    std::vector<char> ready;
+    // device memory (all freed in pa_destroy)
+    std::vector<void*> allocs;
+    float* x0 = nullptr;      // [max_crops][134][134][4]
+    float* pooled = nullptr;  // [max_crops][512]
+    float* feats_tmp = nullptr;  // [max_crops][1024] (b1 path)
+    float* cache = nullptr;      // [cache_rows][1024]
+    int32_t* cache_status = nullptr;  // [cache_rows]
+    float* h1 = nullptr;              // [max_crops][512]
+    int32_t* gather = nullptr;        // [max_crops][S]
+    float* slab = nullptr;
+    size_t slab_floats = 0;
+    std::vector<ConvLayer> convs;  // stem + 19 convs
+    ConvLayer fc;
+    float* c1 = nullptr;  // stem output [max_crops][66][66][64]
+    float* p1 = nullptr;  // maxpool output [max_crops][34][34][64]
+    float* layer4_out = nullptr;
+    // head weights
+    float* w1d = nullptr;  // [512][S*1024]
+    float* b1d = nullptr;
+    float *w2 = nullptr, *b2 = nullptr, *w3 = nullptr, *b3 = nullptr;
+    GemmTile head_tile = TILE_64x64;
+    int head_splitk = 16;
+    // preprocess scratch
+    CropPlan* plans = nullptr;
+    int32_t* coef = nullptr;
+    int coef_dim = 0;
+    uint8_t *t1 = nullptr, *t2 = nullptr;
+    size_t t_stride = 0;
+    int32_t* status_tmp = nullptr;
+    // profiling
+    bool profiling = false;
+    std::vector<std::string> prof_names;
+    std::vector<ProfEntry> prof_log;
+    std::vector<hipEvent_t> event_pool;
+};
+
+namespace {
+
+int fail(pa_engine* e, int code, const std::string& msg) {
+    if (e) e->last_error = msg;
+    return code;
+}
+
+#define HIPCHK(e, call)                                                                              \
+    do {                                                                                             \
+        hipError_t err__ = (call);                                                                   \
+        if (err__ != hipSuccess)                                                                     \
+            return fail((e), PA_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(err__));      \
+    } while (0)
+
+template <typename T>
+int dev_alloc(pa_engine* e, T** ptr, size_t count, bool zero) {
+    void* p = nullptr;
+    size_t bytes = count * sizeof(T);
+    if (bytes == 0) bytes = sizeof(T);
+    HIPCHK(e, hipMalloc(&p, bytes));
+    e->allocs.push_back(p);
+    if (zero) HIPCHK(e, hipMemset(p, 0, bytes));
+    *ptr = reinterpret_cast<T*>(p);
+    return PA_OK;
+}
+
+int upload(pa_engine* e, float** dst, const std::vector<float>& host) {
+    int rc = dev_alloc(e, dst, host.size(), false);
+    if (rc != PA_OK) return rc;
+    HIPCHK(e, hipMemcpy(*dst, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+    return PA_OK;
+}
+
+// --- weight blob walking -----------------------------------------------------
+struct BlobReader {
+    const float* p;
+    const float* end;
+    const float* take(size_t n) {
+        if (p + n > end) return nullptr;
+        const float* r = p;
+        p += n;
+        return r;
+    }
+};
+
+size_t blob_float_count(int S, int A) {
+    size_t n = 0;
+    auto conv = [&](int co, int ci, int k) { n += (size_t)co * ci * k * k; };
+    auto bn = [&](int c) { n += 4 * (size_t)c; };
+    conv(64, 3, 7);
+    bn(64);
+    int cin = 64;
+    const int widths[4] = {64, 128, 256, 512};
+    for (int li = 0; li < 4; ++li) {
+        const int co = widths[li];
+        for (int b = 0; b < 2; ++b) {
+            const int ci = b == 0 ? cin : co;
+            conv(co, ci, 3);
+            bn(co);
+            conv(co, co, 3);
+            bn(co);
+            if (b == 0 && li > 0) {
+                conv(co, ci, 1);
+                bn(co);
+            }
+        }
+        cin = co;
+    }
+    n += 1000 * 512 + 1000;
+    n += (size_t)512 * 1000 * S + 512;
+    n += 128 * 512 + 128;
+    n += (size_t)A * 128 + A;
+    return n;
+}
+
+// Fold eval-mode BatchNorm (eps 1e-5) into conv weights in fp64 and re-lay-out
+// OIHW -> [cout][tap][chunk] (tap = ky*kw_taps + kx, channels innermost, zero
+// padded to `chunk`). The 7x7 stem uses tap = ky and chunk = 8 px * 4 ch.
+bool fold_conv(BlobReader& br, const ConvLayer& L, std::vector<float>& w_out, std::vector<float>& b_out) {
+    const size_t wn = (size_t)L.cout * L.cin * L.kh * L.kw;
+    const float* w = br.take(wn);
+    const float* gamma = br.take(L.cout);
+    const float* beta = br.take(L.cout);
+    const float* mean = br.take(L.cout);
+    const float* var = br.take(L.cout);
+    if (!w || !gamma || !beta || !mean || !var) return false;
+    const int ktot = L.taps * L.chunk;
+    w_out.assign((size_t)L.cout * ktot, 0.f);
+    b_out.assign(L.cout, 0.f);
+    const bool stem = (L.kh == 7);
+    for (int co = 0; co < L.cout; ++co) {
+        const double scale = (double)gamma[co] / std::sqrt((double)var[co] + 1e-5);
+        b_out[co] = (float)((double)beta[co] - (double)mean[co] * scale);
+        for (int ci = 0; ci < L.cin; ++ci)
+            for (int ky = 0; ky < L.kh; ++ky)
+                for (int kx = 0; kx < L.kw; ++kx) {
+                    const double v = (double)w[(((size_t)co * L.cin + ci) * L.kh + ky) * L.kw + kx] * scale;
+                    size_t k;
+                    if (stem)
+                        k = (size_t)ky * L.chunk + kx * 4 + ci;
+                    else
+                        k = (size_t)(ky * L.kw + kx) * L.chunk + ci;
+                    w_out[(size_t)co * ktot + k] = (float)v;
+                }
+    }
+    return true;
+}
+
+void choose_tile(int M, int N, int nk, GemmTile* tile, int* splitk) {
+    // Aim for >= 2 workgroups per CU (512) so that the un-pipelined K loop of
+    // one workgroup hides behind another's; fall back to split-K when even the
+    // smallest tile cannot fill the chip.
+    const int t128x128 = (N % 128 == 0) ? ((M + 127) / 128) * (N / 128) : 0;
+    const int t128x64 = ((M + 127) / 128) * (N / 64);
+    const int t64x64 = ((M + 63) / 64) * (N / 64);
+    int tiles;
+    if (t128x128 >= 512) {
+        *tile = TILE_128x128;
+        tiles = t128x128;
+    } else if (t128x64 >= 512) {
+        *tile = TILE_128x64;
+        tiles = t128x64;
+    } else {
+        *tile = TILE_64x64;
+        tiles = t64x64;
+    }
+    int sk = 1;
+    while (tiles * sk < 512 && nk / (sk * 2) >= 8) sk *= 2;
+    *splitk = sk;
+}
+
+// --- profiling ------------------------------------------------------------------
+int prof_name_id(pa_engine* e, const char* name) {
+    for (size_t i = 0; i < e->prof_names.size(); ++i)
+        if (e->prof_names[i] == name) return (int)i;
+    e->prof_names.push_back(name);
+    return (int)e->prof_names.size() - 1;
+}
+
+hipEvent_t get_event(pa_engine* e) {
+    if (!e->event_pool.empty()) {
+        hipEvent_t ev = e->event_pool.back();
+        e->event_pool.pop_back();
+        return ev;
+    }
+    hipEvent_t ev;
+    if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+    return ev;
+}
+
+struct ProfScope {
+    pa_engine* e;
+    hipStream_t s;
+    ProfEntry ent;
+    bool on;
+    ProfScope(pa_engine* e_, hipStream_t s_, const char* name, double flops, double bytes) : e(e_), s(s_), on(e_->profiling) {
+        if (!on) return;
+        ent.name_id = prof_name_id(e, name);
+        ent.flops = flops;
+        ent.bytes = bytes;
+        ent.start = get_event(e);
+        ent.stop = get_event(e);
+        if (!ent.start || !ent.stop) {
+            on = false;
+            return;
+        }
+        hipEventRecord(ent.start, s);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        hipEventRecord(ent.stop, s);
+        e->prof_log.push_back(ent);
+    }
+};
+
+int run_conv(pa_engine* e, const ConvLayer& L, int ncrops, hipStream_t s, const char* prof_name) {
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.act = L.in;
+    p.wgt = L.wgt;
+    p.bias = L.bias;
+    p.residual = L.residual;
+    p.out = L.out;
+    p.slab = e->slab;
+    p.gather = nullptr;
+    p.M = ncrops * L.out_hw * L.out_hw;
+    p.N = L.cout;
+    p.taps = L.taps;
+    p.kw_taps = L.kw_taps;
+    p.chunk = L.chunk;
+    p.ktot = L.taps * L.chunk;
+    p.howo = L.out_hw * L.out_hw;
+    p.wo = L.out_hw;
+    const int in_w = L.in_hw + 2 * L.in_pad;
+    p.in_px_stride = L.in_px_stride;
+    p.in_row_stride = in_w * L.in_px_stride;
+    p.in_img_stride = in_w * in_w * L.in_px_stride;
+    p.stride = L.stride;
+    p.off_y = L.off;
+    p.off_x = L.off;
+    const int out_w = L.out_hw + 2 * L.out_pad;
+    p.out_px_stride = L.cout;
+    p.out_row_stride = out_w * L.cout;
+    p.out_img_stride = out_w * out_w * L.cout;
+    p.out_pad = L.out_pad;
+    p.relu = L.relu;
+    p.splitk = L.splitk;
+    if ((size_t)p.splitk * p.M * p.N > e->slab_floats) p.splitk = 1;
+    const double flops = 2.0 * p.M * p.N * L.k_alg;
+    const double bytes = 4.0 * ((double)ncrops * L.in_hw * L.in_hw * L.cin + (double)p.M * p.N * (L.residual ? 2 : 1) +
+                                (double)p.N * L.k_alg);
+    ProfScope ps(e, s, prof_name, flops, bytes);
+    HIPCHK(e, launch_igemm(p, L.tile, s));
+    return PA_OK;
+}
+
+int run_backbone(pa_engine* e, int ncrops, float* feats_out, hipStream_t s) {
+    int rc;
+    rc = run_conv(e, e->convs[0], ncrops, s, "igemm_conv7x7_stem");
+    if (rc) return rc;
+    {
+        ProfScope ps(e, s, "maxpool3x3", 0.0, 4.0 * ncrops * (64.0 * 64 * 64 + 32.0 * 32 * 64));
+        HIPCHK(e, launch_maxpool(e->c1, e->p1, ncrops, s));
+    }
+    for (size_t i = 1; i < e->convs.size(); ++i) {
+        const ConvLayer& L = e->convs[i];
+        rc = run_conv(e, L, ncrops, s, L.kh == 3 ? "igemm_conv3x3" : "igemm_conv1x1_ds");
+        if (rc) return rc;
+    }
+    {
+        ProfScope ps(e, s, "avgpool", 0.0, 4.0 * ncrops * (16.0 * 512 + 512));
+        HIPCHK(e, launch_avgpool(e->layer4_out, e->pooled, ncrops, s));
+    }
+    ConvLayer fc = e->fc;
+    fc.out = feats_out;
+    rc = run_conv(e, fc, ncrops, s, "igemm_fc");
+    return rc;
+}
+
+int run_head(pa_engine* e, int nwin, const float* feats, const int32_t* gather, const int32_t* crop_status,
+             pa_record* records, float* logp, hipStream_t s) {
+    const int S = e->cfg.sequence_length;
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.act = feats;
+    p.wgt = e->w1d;
+    p.bias = e->b1d;
+    p.out = e->h1;
+    p.slab = e->slab;
+    p.gather = gather;
+    p.M = nwin;
+    p.N = 512;
+    p.taps = S;
+    p.kw_taps = 1;
+    p.chunk = PA_FEATURE_STRIDE;
+    p.ktot = S * PA_FEATURE_STRIDE;
+    p.howo = 1;
+    p.wo = 1;
+    p.in_px_stride = PA_FEATURE_STRIDE;
+    p.out_px_stride = 512;
+    p.out_row_stride = 512;
+    p.out_img_stride = 512;
+    p.relu = 1;
+    p.splitk = e->head_splitk;
+    if ((size_t)p.splitk * p.M * p.N > e->slab_floats) p.splitk = 1;
+    {
+        ProfScope ps(e, s, "igemm_conv1d_head", 2.0 * nwin * 512.0 * 1000.0 * S,
+                     4.0 * (512.0 * 1000 * S + (double)nwin * S * 1000 + nwin * 512.0));
+        HIPCHK(e, launch_igemm(p, e->head_tile, s));
+    }
+    HeadParams h;
+    memset(&h, 0, sizeof(h));
+    h.h1 = e->h1;
+    h.w2 = e->w2;
+    h.b2 = e->b2;
+    h.w3 = e->w3;
+    h.b3 = e->b3;
+    h.logp = logp;
+    h.records = records;
+    h.crop_status = crop_status;
+    h.gather = gather;
+    h.nwin = nwin;
+    h.num_actions = e->cfg.num_actions;
+    h.fighters = e->cfg.num_fighters;
+    h.seq = S;
+    for (int i = 0; i < 4; ++i) h.class_ids[i] = e->cfg.fighter_class_ids[i];
+    {
+        ProfScope ps(e, s, "head_mlp_logsoftmax", 2.0 * nwin * (512.0 * 128 + 128.0 * e->cfg.num_actions),
+                     4.0 * (nwin * 512.0 + 512.0 * 128 + 128.0 * e->cfg.num_actions));
+        HIPCHK(e, launch_head_mlp(h, s));
+    }
+    return PA_OK;
+}
+
+int run_preprocess(pa_engine* e, const uint8_t* frames, int n, int height, int width, const double* boxes, int padding,
+                   int swap_rb, uint8_t* crops_u8, float* crops_f32, int32_t* status, hipStream_t s) {
+    PreprocParams p;
+    memset(&p, 0, sizeof(p));
+    p.frames = frames;
+    p.boxes = boxes;
+    p.n_frames = n;
+    p.height = height;
+    p.width = width;
+    p.fighters = e->cfg.num_fighters;
+    p.padding = padding;
+    p.swap_rb = swap_rb;
+    p.plans = e->plans;
+    p.coef = e->coef;
+    p.coef_dim = e->coef_dim;
+    p.t1 = e->t1;
+    p.t2 = e->t2;
+    p.t_stride = e->t_stride;
+    p.crops_u8 = crops_u8;
+    p.crops_f32 = crops_f32;
+    p.status = status;
+    const double ncrops = (double)n * e->cfg.num_fighters;
+    ProfScope ps(e, s, "preprocess_crops", 0.0, ncrops * (375.0 * 375 * 3 + 49152.0 * 5));
+    HIPCHK(e, launch_preprocess(p, s));
+    return PA_OK;
+}
+
+}  // namespace
+
+// ===============================================================================
+// C ABI
+// ===============================================================================
+
+extern "C" {
+
+int pa_abi_version(void) { return PA_ABI_VERSION; }
+
+const char* pa_status_string(int status) {
+    switch (status) {
+        case PA_OK: return "ok";
+        case PA_ERR_INVALID_ARG: return "invalid argument";
+        case PA_ERR_HIP: return "HIP runtime error";
+        case PA_ERR_BAD_WEIGHTS: return "weight blob does not match the expected layout";
+        case PA_ERR_CAPACITY: return "request exceeds the capacity the engine was created with";
+        case PA_ERR_NO_DEVICE: return "no usable HIP device";
+        case PA_ERR_NOT_READY: return "features of a required frame are not in the cache";
+        default: return "unknown status";
+    }
+}
+
+const char* pa_last_error(const pa_engine* e) { return e ? e->last_error.c_str() : "null engine"; }
+
+size_t pa_weight_blob_bytes(int S, int A) { return 8 * sizeof(int32_t) + blob_float_count(S, A) * sizeof(float); }
+
+int pa_create(const pa_config* cfg, const void* blob, size_t blob_bytes, pa_engine** out) {
+    if (!cfg || !blob || !out) return PA_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (cfg->abi_version != PA_ABI_VERSION) return PA_ERR_INVALID_ARG;
+    const int S = cfg->sequence_length, A = cfg->num_actions, F = cfg->num_fighters;
+    if (S < 1 || S % 2 == 0 || S > 15 || A < 1 || A > 64 || F < 1 || F > 4 || cfg->max_batch_frames < 1 ||
+        cfg->max_clip_frames < 1 || cfg->max_frame_height < 1 || cfg->max_frame_width < 1 || cfg->crop_padding < 0)
+        return PA_ERR_INVALID_ARG;
+    const int32_t* hdr = reinterpret_cast<const int32_t*>(blob);
+    if (blob_bytes != pa_weight_blob_bytes(S, A) || hdr[0] != PA_WEIGHT_MAGIC || hdr[1] != 1 || hdr[2] != S || hdr[3] != A)
+        return PA_ERR_BAD_WEIGHTS;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device_id < 0 || cfg->device_id >= ndev)
+        return PA_ERR_NO_DEVICE;
+    pa_engine* e = new pa_engine();
+    e->cfg = *cfg;
+    *out = e;  // handed back even on failure so the caller can read pa_last_error, then pa_destroy
+    HIPCHK(e, hipSetDevice(cfg->device_id));
+    const int NC = cfg->max_batch_frames * F;
+    e->max_crops = NC;
+    e->cache_rows = cfg->max_clip_frames * F;
+    int rc;
+#define ALLOC(ptr, count, zero)                         \
+    do {                                                \
+        rc = dev_alloc(e, &(ptr), (size_t)(count), zero); \
+        if (rc != PA_OK) return rc;                     \
+    } while (0)
+
+    ALLOC(e->x0, (size_t)NC * 134 * 134 * 4, true);
+    ALLOC(e->c1, (size_t)NC * 66 * 66 * 64, true);
+    ALLOC(e->p1, (size_t)NC * 34 * 34 * 64, true);
+    ALLOC(e->pooled, (size_t)NC * 512, true);
+    ALLOC(e->feats_tmp, (size_t)NC * PA_FEATURE_STRIDE, true);
+    ALLOC(e->cache, (size_t)e->cache_rows * PA_FEATURE_STRIDE, true);
+    ALLOC(e->cache_status, (size_t)e->cache_rows, true);
+    ALLOC(e->h1, (size_t)NC * 512, true);
+    ALLOC(e->gather, (size_t)NC * S, true);
+    ALLOC(e->status_tmp, (size_t)NC, true);
+
+    // ---- layer table + weights --------------------------------------------
+    BlobReader br{reinterpret_cast<const float*>(hdr + 8), reinterpret_cast<const float*>(hdr + 8) + blob_float_count(S, A)};
+    auto add_conv = [&](const std::string& name, int cin, int cout, int k, int stride, int in_hw, float* in, float* outb,
+                        float* residual, int relu) -> int {
+        ConvLayer L;
+        L.name = name;
+        L.cin = cin;
+        L.cout = cout;
+        L.kh = L.kw = k;
+        L.stride = stride;
+        L.in_hw = in_hw;
+        L.out_hw = in_hw / stride;
+        L.in = in;
+        L.out = outb;
+        L.residual = residual;
+        L.relu = relu;
+        if (k == 7) {
+            L.in_pad = 3; L.out_pad = 1; L.off = 0;
+            L.taps = 7; L.kw_taps = 1; L.chunk = 32; L.in_px_stride = 4;
+        } else if (k == 3) {
+            L.in_pad = 1; L.out_pad = 1; L.off = 0;
+            L.taps = 9; L.kw_taps = 3; L.chunk = cin; L.in_px_stride = cin;
+        } else {
+            L.in_pad = 1; L.out_pad = 1; L.off = 1;
+            L.taps = 1; L.kw_taps = 1; L.chunk = cin; L.in_px_stride = cin;
+        }
+        L.k_alg = (double)cin * k * k;
+        std::vector<float> w, b;
+        if (!fold_conv(br, L, w, b)) return fail(e, PA_ERR_BAD_WEIGHTS, "weight blob too short at " + name);
+        int r2 = upload(e, &L.wgt, w);
+        if (r2) return r2;
+        r2 = upload(e, &L.bias, b);
+        if (r2) return r2;
+        choose_tile(NC * L.out_hw * L.out_hw, cout, L.taps * L.chunk / 32, &L.tile, &L.splitk);
+        e->convs.push_back(L);
+        return PA_OK;
+    };
+
+    rc = add_conv("conv1", 3, 64, 7, 2, 128, e->x0, e->c1, nullptr, 1);
+    if (rc) return rc;
+    {
+        const int widths[4] = {64, 128, 256, 512};
+        const int hw_in[4] = {32, 32, 16, 8};
+        float* cur = e->p1;
+        int cin = 64;
+        for (int li = 0; li < 4; ++li) {
+            const int co = widths[li];
+            const int stride = li == 0 ? 1 : 2;
+            const int hw_out = hw_in[li] / stride;
+            const size_t buf = (size_t)NC * (hw_out + 2) * (hw_out + 2) * co;
+            float *mid, *outA, *outB, *ds = nullptr;
+            ALLOC(mid, buf, true);
+            ALLOC(outA, buf, true);
+            ALLOC(outB, buf, true);
+            if (li > 0) ALLOC(ds, buf, true);
+            const std::string pre = "layer" + std::to_string(li + 1);
+            // block 0 (blob order: conv1, bn1, conv2, bn2, downsample)
+            rc = add_conv(pre + ".0.conv1", cin, co, 3, stride, hw_in[li], cur, mid, nullptr, 1);
+            if (rc) return rc;
+            rc = add_conv(pre + ".0.conv2", co, co, 3, 1, hw_out, mid, outA, li > 0 ? ds : cur, 1);
+            if (rc) return rc;
+            if (li > 0) {
+                rc = add_conv(pre + ".0.downsample", cin, co, 1, stride, hw_in[li], cur, ds, nullptr, 0);
+                if (rc) return rc;
+                // the downsample must run before conv2 consumes it as residual
+                std::swap(e->convs[e->convs.size() - 1], e->convs[e->convs.size() - 2]);
+            }
+            rc = add_conv(pre + ".1.conv1", co, co, 3, 1, hw_out, outA, mid, nullptr, 1);
+            if (rc) return rc;
+            rc = add_conv(pre + ".1.conv2", co, co, 3, 1, hw_out, mid, outB, outA, 1);
+            if (rc) return rc;
+            cur = outB;
+            cin = co;
+        }
+        e->layer4_out = cur;
+    }
+    {  // fc 512 -> 1000 (N padded to 1024 with zero rows so cached rows are 1024 wide)
+        const float* w = br.take((size_t)1000 * 512);
+        const float* b = br.take(1000);
+        if (!w || !b) return fail(e, PA_ERR_BAD_WEIGHTS, "weight blob too short at fc");
+        std::vector<float> wp((size_t)PA_FEATURE_STRIDE * 512, 0.f), bp(PA_FEATURE_STRIDE, 0.f);
+        memcpy(wp.data(), w, sizeof(float) * 1000 * 512);
+        memcpy(bp.data(), b, sizeof(float) * 1000);
+        ConvLayer& L = e->fc;
+        L.name = "fc";
+        L.cin = 512; L.cout = PA_FEATURE_STRIDE; L.kh = L.kw = 1; L.stride = 1;
+        L.in_hw = 1; L.out_hw = 1; L.in_pad = 0; L.out_pad = 0; L.off = 0;
+        L.taps = 1; L.kw_taps = 1; L.chunk = 512; L.in_px_stride = 512;
+        L.in = e->pooled; L.out = nullptr; L.residual = nullptr; L.relu = 0;
+        L.k_alg = 512.0 * 1000.0 / 1024.0;
+        rc = upload(e, &L.wgt, wp);
+        if (rc) return rc;
+        rc = upload(e, &L.bias, bp);
+        if (rc) return rc;
+        choose_tile(NC, PA_FEATURE_STRIDE, 16, &L.tile, &L.splitk);
+    }
+    {  // Conv1d(1000 -> 512, k=S): [512][1000][S] -> [512][S][1024]
+        const float* w = br.take((size_t)512 * 1000 * S);
+        const float* b = br.take(512);
+        if (!w || !b) return fail(e, PA_ERR_BAD_WEIGHTS, "weight blob too short at cnn1d");
+        std::vector<float> wp((size_t)512 * S * PA_FEATURE_STRIDE, 0.f);
+        for (int o = 0; o < 512; ++o)
+            for (int c = 0; c < 1000; ++c)
+                for (int t = 0; t < S; ++t)
+                    wp[((size_t)o * S + t) * PA_FEATURE_STRIDE + c] = w[((size_t)o * 1000 + c) * S + t];
+        rc = upload(e, &e->w1d, wp);
+        if (rc) return rc;
+        rc = upload(e, &e->b1d, std::vector<float>(b, b + 512));
+        if (rc) return rc;
+        choose_tile(NC, 512, S * 32, &e->head_tile, &e->head_splitk);
+    }
+    {
+        const float* w2 = br.take(128 * 512);
+        const float* b2 = br.take(128);
+        const float* w3 = br.take((size_t)A * 128);
+        const float* b3 = br.take(A);
+        if (!w2 || !b2 || !w3 || !b3 || br.p != br.end) return fail(e, PA_ERR_BAD_WEIGHTS, "weight blob size mismatch at classifier");
+        if ((rc = upload(e, &e->w2, std::vector<float>(w2, w2 + 128 * 512)))) return rc;
+        if ((rc = upload(e, &e->b2, std::vector<float>(b2, b2 + 128)))) return rc;
+        if ((rc = upload(e, &e->w3, std::vector<float>(w3, w3 + (size_t)A * 128)))) return rc;
+        if ((rc = upload(e, &e->b3, std::vector<float>(b3, b3 + A)))) return rc;
+    }
+    // split-K slabs: the largest splitk*M*N over all layers
+    {
+        size_t need = 0;
+        for (const ConvLayer& L : e->convs)
+            if (L.splitk > 1) need = std::max(need, (size_t)L.splitk * NC * L.out_hw * L.out_hw * L.cout);
+        if (e->fc.splitk > 1) need = std::max(need, (size_t)e->fc.splitk * NC * PA_FEATURE_STRIDE);
+        if (e->head_splitk > 1) need = std::max(need, (size_t)e->head_splitk * NC * 512);
+        e->slab_floats = need;
+        ALLOC(e->slab, need, false);
+    }
+    // preprocess scratch
+    e->coef_dim = std::max(cfg->max_frame_height, cfg->max_frame_width);
+    e->t_stride = (size_t)cfg->max_frame_height * cfg->max_frame_width * 3;
+    ALLOC(e->plans, (size_t)NC, true);
+    ALLOC(e->coef, (size_t)NC * 2 * e->coef_dim * (2 + PA_KSIZE_MAX), false);
+    ALLOC(e->t1, (size_t)NC * e->t_stride, false);
+    ALLOC(e->t2, (size_t)NC * e->t_stride, false);
+#undef ALLOC
+    HIPCHK(e, hipDeviceSynchronize());
+    return PA_OK;
+}
+
+void pa_destroy(pa_engine* e) {
+    if (!e) return;
+    hipSetDevice(e->cfg.device_id);
+    hipDeviceSynchronize();
+    for (ProfEntry& p : e->prof_log) {
+        hipEventDestroy(p.start);
+        hipEventDestroy(p.stop);
+    }
+    for (hipEvent_t ev : e->event_pool) hipEventDestroy(ev);
+    for (void* p : e->allocs) hipFree(p);
+    delete e;
+}
+
+int pa_infer_windows(pa_engine* e, const float* x, int32_t batch, float* logp, void* stream) {
+    if (!e || !x || !logp || batch < 1) return fail(e, PA_ERR_INVALID_ARG, "pa_infer_windows: bad argument");
+    const int S = e->cfg.sequence_length;
+    hipStream_t s = (hipStream_t)stream;
+    // the backbone scratch holds max_crops crops: run the windows in groups
+    const int win_per_pass = e->max_crops / S;
+    if (win_per_pass < 1) return fail(e, PA_ERR_CAPACITY, "pa_infer_windows: engine smaller than one window");
+    for (int w0 = 0; w0 < batch; w0 += win_per_pass) {
+        const int nw = std::min(win_per_pass, batch - w0);
+        const int ncrops = nw * S;
+        {
+            ProfScope ps(e, s, "nchw_to_nhwc4", 0.0, ncrops * (49152.0 * 4 + 134.0 * 134 * 16));
+            HIPCHK(e, launch_nchw_to_padded(x + (size_t)w0 * S * 3 * 128 * 128, e->x0, ncrops, s));
+        }
+        int rc = run_backbone(e, ncrops, e->feats_tmp, s);
+        if (rc) return rc;
+        HIPCHK(e, launch_identity_gather(e->gather, ncrops, s));
+        rc = run_head(e, nw, e->feats_tmp, e->gather, nullptr, nullptr, logp + (size_t)w0 * e->cfg.num_actions, s);
+        if (rc) return rc;
+    }
+    return PA_OK;
+}
+
+int pa_square_crops(pa_engine* e, const uint8_t* frames, int32_t n, int32_t height, int32_t width, const double* boxes,
+                    int32_t padding, int32_t swap_rb, uint8_t* crops, int32_t* status, void* stream) {
+    if (!e || !frames || !boxes || !crops || n < 1 || height < 1 || width < 1 || padding < 0)
+        return fail(e, PA_ERR_INVALID_ARG, "pa_square_crops: bad argument");
+    if (n > e->cfg.max_batch_frames || height > e->cfg.max_frame_height || width > e->cfg.max_frame_width)
+        return fail(e, PA_ERR_CAPACITY, "pa_square_crops: frames exceed engine capacity");
+    return run_preprocess(e, frames, n, height, width, boxes, padding, swap_rb, crops, nullptr, status, (hipStream_t)stream);
+}
+
+int pa_clip_begin(pa_engine* e, int32_t clip_frames) {
+    if (!e || clip_frames < 1) return fail(e, PA_ERR_INVALID_ARG, "pa_clip_begin: bad argument");
+    if (clip_frames > e->cfg.max_clip_frames) return fail(e, PA_ERR_CAPACITY, "pa_clip_begin: clip longer than max_clip_frames");
+    e->clip_frames = clip_frames;
+    e->ready.assign(clip_frames, 0);
+    return PA_OK;
+}
+
+int pa_backbone_frames(pa_engine* e, const uint8_t* frames, int32_t n, int32_t height, int32_t width, const double* boxes,
+                       int32_t frame0, uint8_t* crops_rgb, int32_t* status, void* stream) {
+    if (!e || !frames || !boxes || n < 1 || height < 1 || width < 1 || frame0 < 0)
+        return fail(e, PA_ERR_INVALID_ARG, "pa_backbone_frames: bad argument");
+    if (e->clip_frames < 1) return fail(e, PA_ERR_INVALID_ARG, "pa_backbone_frames: call pa_clip_begin first");
+    if (n > e->cfg.max_batch_frames || height > e->cfg.max_frame_height || width > e->cfg.max_frame_width ||
+        frame0 + n > e->clip_frames)
+        return fail(e, PA_ERR_CAPACITY, "pa_backbone_frames: frames exceed engine / clip capacity");
+    hipStream_t s = (hipStream_t)stream;
+    const int F = e->cfg.num_fighters;
+    int32_t* st = e->cache_status + (size_t)frame0 * F;
+    int rc = run_preprocess(e, frames, n, height, width, boxes, e->cfg.crop_padding, 1, crops_rgb, e->x0, st, s);
+    if (rc) return rc;
+    if (status) HIPCHK(e, hipMemcpyAsync(status, st, sizeof(int32_t) * n * F, hipMemcpyDeviceToDevice, s));
+    rc = run_backbone(e, n * F, e->cache + (size_t)frame0 * F * PA_FEATURE_STRIDE, s);
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i) e->ready[frame0 + i] = 1;
+    return PA_OK;
+}
+
+int pa_head_frames(pa_engine* e, int32_t lo, int32_t hi, pa_record* records, float* logp, void* stream) {
+    if (!e || lo < 1 || hi <= lo) return fail(e, PA_ERR_INVALID_ARG, "pa_head_frames: bad frame range");
+    if (e->clip_frames < 1) return fail(e, PA_ERR_INVALID_ARG, "pa_head_frames: call pa_clip_begin first");
+    if (hi > e->clip_frames) return fail(e, PA_ERR_CAPACITY, "pa_head_frames: frame numbers run to max_frames - 1");
+    const int S = e->cfg.sequence_length, F = e->cfg.num_fighters, D = e->cfg.frame_delta;
+    const int mid = S / 2, reach = std::abs(D) * mid * mid;
+    // every frame a window of [lo, hi) can touch must be cached
+    {
+        const int first = std::max(1, lo - reach), last = std::min(e->clip_frames - 1, hi - 1 + reach);
+        for (int f = first; f <= last; ++f)
+            if (!e->ready[f - 1]) return fail(e, PA_ERR_NOT_READY, "pa_head_frames: features of frame " + std::to_string(f) + " missing");
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int frames_per_pass = e->max_crops / F;
+    for (int f0 = lo; f0 < hi; f0 += frames_per_pass) {
+        const int cnt = std::min(frames_per_pass, hi - f0);
+        HIPCHK(e, launch_window_gather(e->gather, f0, cnt, F, S, D, e->clip_frames, 1, s));
+        const size_t o = (size_t)(f0 - lo) * F;
+        int rc = run_head(e, cnt * F, e->cache, e->gather, e->cache_status, records ? records + o : nullptr,
+                          logp ? logp + o * e->cfg.num_actions : nullptr, s);
+        if (rc) return rc;
+    }
+    return PA_OK;
+}
+
+int pa_infer_clip(pa_engine* e, const uint8_t* frames, int32_t n, int32_t height, int32_t width, const double* boxes,
+                  pa_record* records, float* logp, uint8_t* crops_rgb, int32_t* status, void* stream) {
+    if (!e || n < 2) return fail(e, PA_ERR_INVALID_ARG, "pa_infer_clip: need at least 2 frames");
+    int rc = pa_clip_begin(e, n);
+    if (rc) return rc;
+    const int F = e->cfg.num_fighters;
+    const size_t frame_bytes = (size_t)height * width * 3;
+    for (int f0 = 0; f0 < n; f0 += e->cfg.max_batch_frames) {
+        const int cnt = std::min(e->cfg.max_batch_frames, n - f0);
+        rc = pa_backbone_frames(e, frames + (size_t)f0 * frame_bytes, cnt, height, width, boxes + (size_t)f0 * F * 4, f0,
+                                crops_rgb ? crops_rgb + (size_t)f0 * F * PA_CROP * PA_CROP * 3 : nullptr,
+                                status ? status + (size_t)f0 * F : nullptr, stream);
+        if (rc) return rc;
+    }
+    return pa_head_frames(e, 1, n, records, logp, stream);
+}
+
+int pa_features_export(pa_engine* e, int32_t frame0, int32_t n, float* feats, void* stream) {
+    if (!e || !feats || frame0 < 0 || n < 1 || frame0 + n > e->cfg.max_clip_frames)
+        return fail(e, PA_ERR_INVALID_ARG, "pa_features_export: bad range");
+    const size_t row = (size_t)e->cfg.num_fighters * PA_FEATURE_STRIDE;
+    HIPCHK(e, hipMemcpyAsync(feats, e->cache + (size_t)frame0 * row, sizeof(float) * n * row, hipMemcpyDeviceToDevice,
+                             (hipStream_t)stream));
+    return PA_OK;
+}
+
+int pa_features_import(pa_engine* e, int32_t frame0, int32_t n, const float* feats, void* stream) {
+    if (!e || !feats || frame0 < 0 || n < 1 || frame0 + n > e->clip_frames)
+        return fail(e, PA_ERR_INVALID_ARG, "pa_features_import: bad range (call pa_clip_begin first)");
+    const size_t row = (size_t)e->cfg.num_fighters * PA_FEATURE_STRIDE;
+    HIPCHK(e, hipMemcpyAsync(e->cache + (size_t)frame0 * row, feats, sizeof(float) * n * row, hipMemcpyDeviceToDevice,
+                             (hipStream_t)stream));
+    for (int i = 0; i < n; ++i) e->ready[frame0 + i] = 1;
+    return PA_OK;
+}
+
+int pa_profile_enable(pa_engine* e, int32_t on) {
+    if (!e) return PA_ERR_INVALID_ARG;
+    e->profiling = on != 0;
+    return PA_OK;
+}
+
+int pa_profile_read(pa_engine* e, pa_kernel_stat* stats, int32_t max_stats, int32_t* n_stats) {
+    if (!e || !stats || !n_stats || max_stats < 1) return fail(e, PA_ERR_INVALID_ARG, "pa_profile_read: bad argument");
+    HIPCHK(e, hipDeviceSynchronize());
+    std::vector<pa_kernel_stat> acc(e->prof_names.size());
+    for (size_t i = 0; i < acc.size(); ++i) {
+        memset(&acc[i], 0, sizeof(pa_kernel_stat));
+        snprintf(acc[i].name, sizeof(acc[i].name), "%s", e->prof_names[i].c_str());
+    }
+    for (ProfEntry& p : e->prof_log) {
+        float ms = 0.f;
+        HIPCHK(e, hipEventElapsedTime(&ms, p.start, p.stop));
+        acc[p.name_id].launches += 1;
+        acc[p.name_id].total_ms += ms;
+        acc[p.name_id].flops += p.flops;
+        acc[p.name_id].bytes += p.bytes;
+        e->event_pool.push_back(p.start);
+        e->event_pool.push_back(p.stop);
+    }
+    e->prof_log.clear();
+    int n = 0;
+    for (size_t i = 0; i < acc.size() && n < max_stats; ++i)
+        if (acc[i].launches > 0) stats[n++] = acc[i];
+    *n_stats = n;
+    return PA_OK;
+}
+
+int pa_stream_sync(pa_engine* e, void* stream) {
+    HIPCHK(e, hipStreamSynchronize((hipStream_t)stream));
+    return PA_OK;
+}
+
+}  // extern "C"

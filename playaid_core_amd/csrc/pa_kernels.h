@@ -1,0 +1,111 @@
+// Internal declarations shared by the HIP translation units and the C-ABI host
+// code. Not part of the public ABI (include/playaid_hip.h is).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pa {
+
+// ---------------------------------------------------------------------------
+// implicit-GEMM engine (igemm.hip)
+// ---------------------------------------------------------------------------
+// out[m][n] = act( sum_{tap,kc} A(m,tap,kc) * W[n][tap*chunk + kc] + bias[n] (+ residual[m][n]) )
+//
+// A(m,tap,kc) is addressed in one of two ways:
+//  * conv mode  (gather == nullptr): m -> (img, oy, ox); tap -> (ky, kx);
+//      A = act + img*in_img_stride + (oy*stride + ky + off_y)*in_row_stride
+//              + (ox*stride + kx + off_x)*in_px_stride + kc
+//    Activations are NHWC with an explicit zero border, so no bounds checks.
+//  * gather mode: row = gather[m*taps + tap]; A = act + row*in_px_stride + kc
+//    (row < 0 -> zeros). Used for the temporal Conv1d over cached features.
+struct GemmParams {
+    const float* act;
+    const float* wgt;       // [N][ktot], K contiguous
+    const float* bias;      // [N] or nullptr
+    const float* residual;  // same addressing as out, or nullptr
+    float* out;
+    float* slab;            // split-K partial sums [splitk][M][N]
+    const int32_t* gather;
+    int32_t M, N, ktot;
+    int32_t taps, kw_taps, chunk;  // ktot == taps*chunk, chunk % 32 == 0
+    int32_t howo, wo;              // output pixels per image, output width
+    int32_t in_img_stride, in_row_stride, in_px_stride, stride, off_y, off_x;
+    int32_t out_img_stride, out_row_stride, out_px_stride, out_pad;
+    int32_t relu;
+    int32_t splitk, ksteps_per_split;
+    int32_t tiles_m, tiles_n;
+};
+
+enum GemmTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x64 = 2 };
+
+hipError_t launch_igemm(const GemmParams& p, GemmTile tile, hipStream_t s);
+hipError_t launch_splitk_reduce(const GemmParams& p, hipStream_t s);
+
+// ---------------------------------------------------------------------------
+// crop preprocessing (preprocess.hip)
+// ---------------------------------------------------------------------------
+#define PA_KSIZE_MAX 15
+
+struct CropPlan {
+    int32_t status;
+    int32_t frame;
+    int32_t sx0, sy0, sw, sh;  // slice of the frame
+    int32_t d;                 // square side
+    int32_t rw, rh;            // size after ImageOps.contain
+    int32_t px, py;            // paste offset inside the d x d canvas
+    int32_t need_h, need_v;    // bicubic passes
+    int32_t ksize_h, ksize_v;
+    int32_t out_h;             // INTER_AREA destination height (width is 128)
+    int32_t area_mode;         // 0 copy, 1 fast 2x2, 2 fast integer, 3 general
+    int32_t iscale_x, iscale_y;
+    double scale_x, scale_y;
+};
+
+struct PreprocParams {
+    const uint8_t* frames;  // [n][H][W][3]
+    const double* boxes;    // [ncrops][4]
+    int32_t n_frames, height, width, fighters, padding, swap_rb;
+    CropPlan* plans;        // [ncrops]
+    int32_t* coef;          // [ncrops][2][maxdim][1 + 1 + PA_KSIZE_MAX]: xmin, count, kk[]
+    int32_t coef_dim;       // maxdim (entries per axis per crop)
+    uint8_t* t1;            // [ncrops][t_stride] horizontally resampled slice
+    uint8_t* t2;            // [ncrops][t_stride] fully resampled slice
+    size_t t_stride;
+    uint8_t* crops_u8;      // [ncrops][128][128][3] or nullptr
+    float* crops_f32;       // [ncrops][134][134][4] zero-bordered, or nullptr
+    int32_t* status;        // [ncrops] or nullptr
+};
+
+hipError_t launch_preprocess(const PreprocParams& p, hipStream_t s);
+
+// ---------------------------------------------------------------------------
+// small kernels (misc.hip)
+// ---------------------------------------------------------------------------
+// x[n][3][128][128] f32 -> zero-bordered [n][134][134][4]
+hipError_t launch_nchw_to_padded(const float* x, float* out, int32_t n, hipStream_t s);
+// 3x3/2 max pool, padded [n][66][66][64] -> padded [n][34][34][64]
+hipError_t launch_maxpool(const float* in, float* out, int32_t n, hipStream_t s);
+// global average pool, padded [n][6][6][512] -> [n][512]
+hipError_t launch_avgpool(const float* in, float* out, int32_t n, hipStream_t s);
+// window gather table: rows into the feature cache, see head_gather_kernel
+hipError_t launch_window_gather(int32_t* gather, int32_t frame_num_lo, int32_t count, int32_t fighters,
+                                int32_t seq, int32_t delta, int32_t max_frames, int32_t min_frame,
+                                hipStream_t s);
+hipError_t launch_identity_gather(int32_t* gather, int32_t n, hipStream_t s);
+
+struct HeadParams {
+    const float* h1;      // [nwin][512] post-ReLU Conv1d output
+    const float* w2;      // [128][512]
+    const float* b2;      // [128]
+    const float* w3;      // [A][128]
+    const float* b3;      // [A]
+    float* logp;          // [nwin][A] or nullptr
+    void* records;        // pa_record[nwin] or nullptr
+    const int32_t* crop_status;  // per feature row or nullptr
+    const int32_t* gather;       // [nwin][seq] (middle slot gives the window's own crop)
+    int32_t nwin, num_actions, fighters, seq;
+    int32_t class_ids[4];
+};
+hipError_t launch_head_mlp(const HeadParams& p, hipStream_t s);
+
+}  // namespace pa

@@ -1,0 +1,444 @@
+// Crop preprocessing on gfx950: frame + normalised box -> 128x128 model input.
+//
+// Device-side equivalent of YoloCrop.square_crop(frame, 128, padding=30)
+// (playaid/fighter.py:323-381) followed by the BGR2RGB + /255 of
+// playaid/ai_runner.py:448,463. The reference composes three third-party
+// resamplers; each is reproduced bit-for-bit in integer / IEEE arithmetic:
+//
+//   1. numpy slice of the padded square      (fighter.py:335-343)
+//   2. Pillow ImageOps.pad(slice, (d,d))     (fighter.py:346-357)
+//        = ImageOps.contain (aspect-preserving BICUBIC resize, 22-bit fixed
+//          point, horizontal pass then vertical pass, u8 between the passes)
+//          pasted centred on a black d x d canvas
+//   3. imutils.resize(width=128) = cv2.resize(INTER_AREA) to (128, int(d*(128/d)))
+//        (fighter.py:364) -- copy / 2x2 / integer-scale / fractional paths
+//   4. ImageOps.pad to 128x128 when step 3 produced 127 rows (fighter.py:369-373)
+//
+// This file is compiled with -ffp-contract=off: the coefficient tables are
+// computed in double precision exactly as Pillow's precompute_coeffs does, and
+// the INTER_AREA fractional path accumulates in fp32 with separate multiply
+// and add like OpenCV's generic C++ -- a fused multiply-add would change bits.
+//
+// The stage is HBM/L2 streaming work (no matrix shape): one thread per output
+// element, consecutive lanes on consecutive bytes. Five small kernels keep every
+// size general (any box, any frame); the intermediates (~0.65 MB per crop) stay
+// in L2 / Infinity Cache between them.
+#include "pa_kernels.h"
+#include "../../include/playaid_hip.h"
+
+namespace pa {
+
+#define PRECISION_BITS 22
+#define COEF_ROW (2 + PA_KSIZE_MAX)
+
+__device__ __forceinline__ bool to_int_checked(double v, int* out) {
+    if (!(v > -2.0e9 && v < 2.0e9)) return false;  // also rejects NaN
+    *out = (int)v;                                 // C cast == Python int(): truncation
+    return true;
+}
+
+// numpy basic-slice length for image[start:stop] with start >= 0.
+__device__ __forceinline__ void np_slice(int start, int stop, int size, int* s0, int* len) {
+    if (start > size) start = size;
+    if (stop < 0) {
+        stop += size;
+        if (stop < 0) stop = 0;
+    }
+    if (stop > size) stop = size;
+    *s0 = start;
+    *len = stop > start ? stop - start : 0;
+}
+
+__device__ __forceinline__ int bicubic_ksize(int in_size, int out_size) {
+    double scale = (double)(float)in_size / out_size;
+    double filterscale = scale < 1.0 ? 1.0 : scale;
+    return (int)ceil(2.0 * filterscale) * 2 + 1;
+}
+
+__global__ void crop_plan_kernel(const PreprocParams p) {
+    const int crop = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ncrops = p.n_frames * p.fighters;
+    if (crop >= ncrops) return;
+    CropPlan pl;
+    pl.status = PA_CROP_OK;
+    pl.frame = crop / p.fighters;
+    pl.sx0 = pl.sy0 = pl.sw = pl.sh = 0;
+    pl.d = pl.rw = pl.rh = pl.px = pl.py = 0;
+    pl.need_h = pl.need_v = pl.ksize_h = pl.ksize_v = 0;
+    pl.out_h = 0;
+    pl.area_mode = 0;
+    pl.iscale_x = pl.iscale_y = 1;
+    pl.scale_x = pl.scale_y = 1.0;
+    const double* b = p.boxes + (size_t)crop * 4;
+    const int W = p.width, H = p.height, pad = p.padding;
+    int cx, cy, cw, ch;
+    // YoloCrop.yolo_pixels (fighter.py:305-314)
+    if (!to_int_checked(b[0] * W, &cx) || !to_int_checked(b[1] * H, &cy) || !to_int_checked(b[2] * W, &cw) ||
+        !to_int_checked(b[3] * H, &ch)) {
+        pl.status = PA_CROP_BAD_BOX;
+    }
+    if (pl.status == PA_CROP_OK) {
+        const int d = cw > ch ? cw : ch;
+        pl.d = d;
+        if (d <= 0 || d > 16384) pl.status = PA_CROP_BAD_BOX;
+    }
+    if (pl.status == PA_CROP_OK) {
+        const int d = pl.d;
+        const int half = d / 2;  // int(square_dim / 2)
+        int y0 = cy - half - pad, y1 = cy + half + pad, x0 = cx - half - pad, x1 = cx + half + pad;
+        y0 = y0 > 0 ? y0 : 0;
+        x0 = x0 > 0 ? x0 : 0;
+        y1 = y1 < H ? y1 : H;
+        x1 = x1 < W ? x1 : W;
+        np_slice(y0, y1, H, &pl.sy0, &pl.sh);
+        np_slice(x0, x1, W, &pl.sx0, &pl.sw);
+        if (pl.sh != d || pl.sw != d) {
+            // ImageOps.pad(raw_crop, (d, d), color="black")
+            if (pl.sh == 0 || pl.sw == 0) {
+                pl.status = PA_CROP_EMPTY;
+            } else {
+                int rw = d, rh = d;
+                const double im_ratio = (double)pl.sw / (double)pl.sh;
+                if (im_ratio != 1.0) {
+                    if (im_ratio > 1.0) {
+                        const int nh = (int)rint((double)pl.sh / (double)pl.sw * (double)d);
+                        if (nh != d) rh = nh;
+                    } else {
+                        const int nw = (int)rint((double)pl.sw / (double)pl.sh * (double)d);
+                        if (nw != d) rw = nw;
+                    }
+                }
+                if (rw <= 0 || rh <= 0) {
+                    pl.status = PA_CROP_EMPTY;
+                } else {
+                    pl.rw = rw;
+                    pl.rh = rh;
+                    pl.need_h = rw != pl.sw;
+                    pl.need_v = rh != pl.sh;
+                    if (rw != d)
+                        pl.px = (int)rint((double)(d - rw) * 0.5);
+                    else if (rh != d)
+                        pl.py = (int)rint((double)(d - rh) * 0.5);
+                    if (pl.need_h) pl.ksize_h = bicubic_ksize(pl.sw, rw);
+                    if (pl.need_v) pl.ksize_v = bicubic_ksize(pl.sh, rh);
+                    if (pl.ksize_h > PA_KSIZE_MAX || pl.ksize_v > PA_KSIZE_MAX) pl.status = PA_CROP_FILTER_TOO_WIDE;
+                    if ((size_t)pl.sh * rw * 3 > p.t_stride || (size_t)rh * rw * 3 > p.t_stride || rw > p.coef_dim ||
+                        rh > p.coef_dim)
+                        pl.status = PA_CROP_FILTER_TOO_WIDE;
+                }
+            }
+        } else {
+            pl.rw = pl.rh = d;
+        }
+    }
+    if (pl.status == PA_CROP_OK) {
+        const int d = pl.d;
+        if (d < PA_CROP) {
+            pl.status = PA_CROP_UPSCALE;
+        } else {
+            // imutils.resize(width=128): dim = (128, int(h * (128 / float(w))))
+            const double r = 128.0 / (double)d;
+            pl.out_h = (int)((double)d * r);
+            const double inv_sx = 128.0 / (double)d;
+            const double inv_sy = (double)pl.out_h / (double)d;
+            pl.scale_x = 1.0 / inv_sx;
+            pl.scale_y = 1.0 / inv_sy;
+            if (d == PA_CROP && pl.out_h == PA_CROP) {
+                pl.area_mode = 0;
+            } else {
+                pl.iscale_x = (int)rint(pl.scale_x);  // saturate_cast<int>(double) == cvRound
+                pl.iscale_y = (int)rint(pl.scale_y);
+                const bool fast = fabs(pl.scale_x - pl.iscale_x) < 2.220446049250313e-16 &&
+                                  fabs(pl.scale_y - pl.iscale_y) < 2.220446049250313e-16;
+                pl.area_mode = fast ? ((pl.iscale_x == 2 && pl.iscale_y == 2) ? 1 : 2) : 3;
+            }
+        }
+    }
+    p.plans[crop] = pl;
+    if (p.status) p.status[crop] = pl.status;
+}
+
+__device__ __forceinline__ double bicubic_filter(double x) {
+    const double a = -0.5;
+    if (x < 0.0) x = -x;
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+    return 0.0;
+}
+
+// Pillow precompute_coeffs + normalize_coeffs_8bpc, one thread per output coordinate.
+__global__ void crop_coef_kernel(const PreprocParams p) {
+    const int crop = blockIdx.y >> 1;
+    const int axis = blockIdx.y & 1;
+    const int xx = blockIdx.x * blockDim.x + threadIdx.x;
+    const CropPlan pl = p.plans[crop];
+    if (pl.status != PA_CROP_OK) return;
+    const int need = axis ? pl.need_v : pl.need_h;
+    if (!need) return;
+    const int in_size = axis ? pl.sh : pl.sw;
+    const int out_size = axis ? pl.rh : pl.rw;
+    if (xx >= out_size) return;
+    const double scale = (double)(float)in_size / out_size;
+    const double filterscale = scale < 1.0 ? 1.0 : scale;
+    const double support = 2.0 * filterscale;
+    const double ss = 1.0 / filterscale;
+    const double center = 0.0 + (xx + 0.5) * scale;
+    int xmin = (int)(center - support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5);
+    if (xmax > in_size) xmax = in_size;
+    xmax -= xmin;
+    double k[PA_KSIZE_MAX];
+    double ww = 0.0;
+    for (int x = 0; x < PA_KSIZE_MAX; ++x) {
+        double w = 0.0;
+        if (x < xmax) {
+            w = bicubic_filter((x + xmin - center + 0.5) * ss);
+            ww += w;
+        }
+        k[x] = w;
+    }
+    int32_t* row = p.coef + ((size_t)(crop * 2 + axis) * p.coef_dim + xx) * COEF_ROW;
+    row[0] = xmin;
+    row[1] = xmax;
+    for (int x = 0; x < PA_KSIZE_MAX; ++x) {
+        double v = k[x];
+        if (x < xmax && ww != 0.0) v = v / ww;
+        row[2 + x] = v < 0 ? (int)(-0.5 + v * (double)(1 << PRECISION_BITS)) : (int)(0.5 + v * (double)(1 << PRECISION_BITS));
+    }
+}
+
+__device__ __forceinline__ uint8_t clip8(int v) {
+    v >>= PRECISION_BITS;
+    return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+// ImagingResampleHorizontal_8bpc over the slice rows: t1[y][xx][c].
+__global__ __launch_bounds__(256) void resample_h_kernel(const PreprocParams p) {
+    const int crop = blockIdx.y;
+    const CropPlan pl = p.plans[crop];
+    if (pl.status != PA_CROP_OK || !pl.need_h) return;
+    const int total = pl.sh * pl.rw;
+    const uint8_t* src = p.frames + ((size_t)pl.frame * p.height + pl.sy0) * p.width * 3 + (size_t)pl.sx0 * 3;
+    const size_t src_pitch = (size_t)p.width * 3;
+    uint8_t* dst = p.t1 + (size_t)crop * p.t_stride;
+    const int32_t* coef = p.coef + (size_t)(crop * 2 + 0) * p.coef_dim * COEF_ROW;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int y = i / pl.rw;
+        const int xx = i - y * pl.rw;
+        const int32_t* row = coef + (size_t)xx * COEF_ROW;
+        const int xmin = row[0], cnt = row[1];
+        const uint8_t* s = src + (size_t)y * src_pitch + (size_t)xmin * 3;
+        int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
+        for (int x = 0; x < cnt; ++x) {
+            const int k = row[2 + x];
+            a0 += s[3 * x + 0] * k;
+            a1 += s[3 * x + 1] * k;
+            a2 += s[3 * x + 2] * k;
+        }
+        uint8_t* o = dst + (size_t)i * 3;
+        o[0] = clip8(a0);
+        o[1] = clip8(a1);
+        o[2] = clip8(a2);
+    }
+}
+
+// ImagingResampleVertical_8bpc: t2[yy][x][c] from t1 (or the slice when no horizontal pass ran).
+__global__ __launch_bounds__(256) void resample_v_kernel(const PreprocParams p) {
+    const int crop = blockIdx.y;
+    const CropPlan pl = p.plans[crop];
+    if (pl.status != PA_CROP_OK || !pl.need_v) return;
+    const int total = pl.rh * pl.rw;
+    const uint8_t* src;
+    size_t src_pitch;
+    if (pl.need_h) {
+        src = p.t1 + (size_t)crop * p.t_stride;
+        src_pitch = (size_t)pl.rw * 3;
+    } else {
+        src = p.frames + ((size_t)pl.frame * p.height + pl.sy0) * p.width * 3 + (size_t)pl.sx0 * 3;
+        src_pitch = (size_t)p.width * 3;
+    }
+    uint8_t* dst = p.t2 + (size_t)crop * p.t_stride;
+    const int32_t* coef = p.coef + (size_t)(crop * 2 + 1) * p.coef_dim * COEF_ROW;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int yy = i / pl.rw;
+        const int x = i - yy * pl.rw;
+        const int32_t* row = coef + (size_t)yy * COEF_ROW;
+        const int ymin = row[0], cnt = row[1];
+        const uint8_t* s = src + (size_t)ymin * src_pitch + (size_t)x * 3;
+        int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
+        for (int y = 0; y < cnt; ++y) {
+            const int k = row[2 + y];
+            a0 += s[0] * k;
+            a1 += s[1] * k;
+            a2 += s[2] * k;
+            s += src_pitch;
+        }
+        uint8_t* o = dst + (size_t)i * 3;
+        o[0] = clip8(a0);
+        o[1] = clip8(a1);
+        o[2] = clip8(a2);
+    }
+}
+
+struct Canvas {
+    const uint8_t* src;
+    size_t pitch;
+    int px, py, rw, rh;
+    // d x d black canvas with the resized slice pasted at (px, py)
+    __device__ __forceinline__ void load(int y, int x, int& c0, int& c1, int& c2) const {
+        y -= py;
+        x -= px;
+        if ((unsigned)y < (unsigned)rh && (unsigned)x < (unsigned)rw) {
+            const uint8_t* s = src + (size_t)y * pitch + (size_t)x * 3;
+            c0 = s[0];
+            c1 = s[1];
+            c2 = s[2];
+        } else {
+            c0 = c1 = c2 = 0;
+        }
+    }
+};
+
+__device__ __forceinline__ int cv_saturate_u8(float v) {
+    const int r = (int)rintf(v);  // cvRound: round half to even
+    return r < 0 ? 0 : (r > 255 ? 255 : r);
+}
+
+// computeResizeAreaTab for one destination coordinate.
+struct AreaTab {
+    int s_first;     // source index of entry 0
+    int n;           // number of entries
+    float a_first;   // alpha of a leading partial cell (if has_first)
+    float a_mid;     // alpha of the full cells
+    float a_last;    // alpha of a trailing partial cell (if has_last)
+    int has_first, n_mid, has_last;
+};
+
+__device__ __forceinline__ AreaTab area_tab(int dx, double scale, int ssize) {
+    AreaTab t;
+    const double fsx1 = dx * scale;
+    const double fsx2 = fsx1 + scale;
+    const double cell = fmin(scale, ssize - fsx1);
+    int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
+    sx2 = sx2 < ssize - 1 ? sx2 : ssize - 1;
+    sx1 = sx1 < sx2 ? sx1 : sx2;
+    t.has_first = (sx1 - fsx1 > 1e-3) ? 1 : 0;
+    t.a_first = (float)((sx1 - fsx1) / cell);
+    t.n_mid = sx2 - sx1;
+    t.a_mid = (float)(1.0 / cell);
+    t.has_last = (fsx2 - sx2 > 1e-3) ? 1 : 0;
+    t.a_last = (float)(fmin(fmin(fsx2 - sx2, 1.0), cell) / cell);
+    t.s_first = sx1 - t.has_first;
+    t.n = t.has_first + t.n_mid + t.has_last;
+    return t;
+}
+
+__device__ __forceinline__ float area_alpha(const AreaTab& t, int k) {
+    if (k < t.has_first) return t.a_first;
+    if (k < t.has_first + t.n_mid) return t.a_mid;
+    return t.a_last;
+}
+
+// cv::resize INTER_AREA (d x d -> out_h x 128), final black pad to 128 rows,
+// channel swap, u8 crop + /255 fp32 zero-bordered NHWC4 model input.
+__global__ __launch_bounds__(256) void area_resize_kernel(const PreprocParams p) {
+    const int crop = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // 0 .. 128*128-1
+    const int dy = i >> 7, dx = i & 127;
+    const CropPlan pl = p.plans[crop];
+    int o0 = 0, o1 = 0, o2 = 0;
+    if (pl.status == PA_CROP_OK && dy < pl.out_h) {
+        Canvas cv;
+        cv.px = pl.px; cv.py = pl.py; cv.rw = pl.rw; cv.rh = pl.rh;
+        if (pl.need_v) {
+            cv.src = p.t2 + (size_t)crop * p.t_stride;
+            cv.pitch = (size_t)pl.rw * 3;
+        } else if (pl.need_h) {
+            cv.src = p.t1 + (size_t)crop * p.t_stride;
+            cv.pitch = (size_t)pl.rw * 3;
+        } else {
+            cv.src = p.frames + ((size_t)pl.frame * p.height + pl.sy0) * p.width * 3 + (size_t)pl.sx0 * 3;
+            cv.pitch = (size_t)p.width * 3;
+        }
+        if (pl.area_mode == 0) {
+            cv.load(dy, dx, o0, o1, o2);
+        } else if (pl.area_mode == 1) {
+            int s0 = 2, s1 = 2, s2 = 2;
+            for (int yy = 0; yy < 2; ++yy)
+                for (int xx = 0; xx < 2; ++xx) {
+                    int c0, c1, c2;
+                    cv.load(dy * 2 + yy, dx * 2 + xx, c0, c1, c2);
+                    s0 += c0; s1 += c1; s2 += c2;
+                }
+            o0 = s0 >> 2; o1 = s1 >> 2; o2 = s2 >> 2;
+        } else if (pl.area_mode == 2) {
+            int s0 = 0, s1 = 0, s2 = 0;
+            for (int yy = 0; yy < pl.iscale_y; ++yy)
+                for (int xx = 0; xx < pl.iscale_x; ++xx) {
+                    int c0, c1, c2;
+                    cv.load(dy * pl.iscale_y + yy, dx * pl.iscale_x + xx, c0, c1, c2);
+                    s0 += c0; s1 += c1; s2 += c2;
+                }
+            const float scale = 1.f / (float)(pl.iscale_x * pl.iscale_y);
+            o0 = cv_saturate_u8((float)s0 * scale);
+            o1 = cv_saturate_u8((float)s1 * scale);
+            o2 = cv_saturate_u8((float)s2 * scale);
+        } else {
+            const AreaTab tx = area_tab(dx, pl.scale_x, pl.d);
+            const AreaTab ty = area_tab(dy, pl.scale_y, pl.d);
+            float sum0 = 0.f, sum1 = 0.f, sum2 = 0.f;
+            for (int j = 0; j < ty.n; ++j) {
+                const float beta = area_alpha(ty, j);
+                float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+                for (int k = 0; k < tx.n; ++k) {
+                    const float alpha = area_alpha(tx, k);
+                    int c0, c1, c2;
+                    cv.load(ty.s_first + j, tx.s_first + k, c0, c1, c2);
+                    b0 = b0 + (float)c0 * alpha;
+                    b1 = b1 + (float)c1 * alpha;
+                    b2 = b2 + (float)c2 * alpha;
+                }
+                sum0 = sum0 + beta * b0;
+                sum1 = sum1 + beta * b1;
+                sum2 = sum2 + beta * b2;
+            }
+            o0 = cv_saturate_u8(sum0);
+            o1 = cv_saturate_u8(sum1);
+            o2 = cv_saturate_u8(sum2);
+        }
+    }
+    if (p.swap_rb) {
+        const int t = o0;
+        o0 = o2;
+        o2 = t;
+    }
+    if (p.crops_u8) {
+        uint8_t* o = p.crops_u8 + ((size_t)crop * PA_CROP * PA_CROP + i) * 3;
+        o[0] = (uint8_t)o0;
+        o[1] = (uint8_t)o1;
+        o[2] = (uint8_t)o2;
+    }
+    if (p.crops_f32) {
+        float4 v;
+        v.x = (float)o0 / 255.0f;
+        v.y = (float)o1 / 255.0f;
+        v.z = (float)o2 / 255.0f;
+        v.w = 0.f;
+        float4* o = reinterpret_cast<float4*>(p.crops_f32) + ((size_t)crop * 134 + (dy + 3)) * 134 + (dx + 3);
+        *o = v;
+    }
+}
+
+hipError_t launch_preprocess(const PreprocParams& p, hipStream_t s) {
+    const int ncrops = p.n_frames * p.fighters;
+    if (ncrops <= 0) return hipSuccess;
+    hipLaunchKernelGGL(crop_plan_kernel, dim3((ncrops + 63) / 64), dim3(64), 0, s, p);
+    hipLaunchKernelGGL(crop_coef_kernel, dim3((p.coef_dim + 127) / 128, ncrops * 2), dim3(128), 0, s, p);
+    hipLaunchKernelGGL(resample_h_kernel, dim3(96, ncrops), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(resample_v_kernel, dim3(96, ncrops), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(area_resize_kernel, dim3(PA_CROP * PA_CROP / 256, ncrops), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace pa

@@ -1,0 +1,233 @@
+"""Python handle on the HIP engine: device memory and streams come from
+PyTorch-ROCm, every computation goes through the C ABI
+(include/playaid_hip.h). There is no eager / CPU fallback in this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Mapping, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib, constants
+from .weights import infer_geometry, pack_state_dict
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"playaid_hip error {code}: {msg}")
+        self.code = code
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class Engine:
+    """One engine per device (``pa_create`` / ``pa_destroy``)."""
+
+    def __init__(
+        self,
+        state_dict: Mapping,
+        device: str = "cuda:0",
+        num_fighters: int = 2,
+        frame_delta: int = constants.FRAME_DELTA,
+        crop_padding: int = constants.CROP_PADDING,
+        max_batch_frames: int = 64,
+        max_clip_frames: int = 8192,
+        max_frame_height: int = 1080,
+        max_frame_width: int = 1920,
+        fighter_class_ids: Tuple[int, ...] = (2, 3),
+    ):
+        self._lib = _lib.load()  # raises HipLibraryError when the .so is missing
+        if not torch.cuda.is_available():
+            raise _lib.HipLibraryError("no HIP device visible to PyTorch-ROCm; this path has no CPU fallback")
+        self.device = torch.device(device)
+        self.S, self.A = infer_geometry(state_dict)
+        self.F = num_fighters
+        self.max_batch_frames = max_batch_frames
+        self.max_clip_frames = max_clip_frames
+        cfg = _lib.pa_config()
+        cfg.abi_version = _lib.PA_ABI_VERSION
+        cfg.device_id = self.device.index or 0
+        cfg.sequence_length = self.S
+        cfg.frame_delta = frame_delta
+        cfg.num_actions = self.A
+        cfg.num_fighters = num_fighters
+        cfg.crop_padding = crop_padding
+        cfg.max_batch_frames = max_batch_frames
+        cfg.max_clip_frames = max_clip_frames
+        cfg.max_frame_height = max_frame_height
+        cfg.max_frame_width = max_frame_width
+        ids = list(fighter_class_ids) + [0] * (4 - len(fighter_class_ids))
+        for i in range(4):
+            cfg.fighter_class_ids[i] = ids[i]
+        self.cfg = cfg
+        blob = pack_state_dict(state_dict, self.S, self.A)
+        self._h = C.c_void_p(0)
+        torch.cuda.set_device(self.device)
+        rc = self._lib.pa_create(C.byref(cfg), blob.ctypes.data_as(C.c_void_p), blob.nbytes, C.byref(self._h))
+        if rc != _lib.PA_OK:
+            msg = self._lib.pa_last_error(self._h).decode() if self._h else self._lib.pa_status_string(rc).decode()
+            if self._h:
+                self._lib.pa_destroy(self._h)
+                self._h = C.c_void_p(0)
+            raise EngineError(rc, msg)
+
+    # -- plumbing ---------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pa_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != _lib.PA_OK:
+            raise EngineError(rc, self._lib.pa_last_error(self._h).decode())
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, a, dtype) -> torch.Tensor:
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=dtype).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype)
+
+    # -- b1: operator ------------------------------------------------------
+    def infer_windows(self, x: torch.Tensor) -> torch.Tensor:
+        """x float32[B,S,3,128,128] -> logp float32[B,A] (on the engine's device)."""
+        if x.dim() != 5 or x.shape[1] != self.S or tuple(x.shape[2:]) != (3, 128, 128):
+            raise ValueError(f"expected [B,{self.S},3,128,128], got {tuple(x.shape)}")
+        xd = self._dev(x, torch.float32)
+        out = torch.empty((xd.shape[0], self.A), dtype=torch.float32, device=self.device)
+        self._check(self._lib.pa_infer_windows(self._h, _ptr(xd), xd.shape[0], _ptr(out), self._stream()))
+        return out
+
+    # -- a6: crops -----------------------------------------------------------
+    def square_crops(self, frames, boxes, padding: int = constants.CROP_PADDING, swap_rb: bool = False):
+        """frames uint8[n,H,W,3], boxes float64[n,F',4] -> (crops uint8[n,F',128,128,3], status int32[n,F']) on host."""
+        fd = self._dev(frames, torch.uint8)
+        bd = self._dev(boxes, torch.float64)
+        n, h, w, _ = fd.shape
+        nf = bd.shape[1]
+        if nf != self.F:
+            # run fighter slots through F-wide calls
+            pad = torch.zeros((n, self.F, 4), dtype=torch.float64, device=self.device)
+            pad[:, :nf] = bd[:, : self.F]
+            bd_use = pad
+        else:
+            bd_use = bd
+        crops = torch.empty((n, self.F, 128, 128, 3), dtype=torch.uint8, device=self.device)
+        status = torch.empty((n, self.F), dtype=torch.int32, device=self.device)
+        self._check(
+            self._lib.pa_square_crops(
+                self._h, _ptr(fd), n, h, w, _ptr(bd_use), padding, int(swap_rb), _ptr(crops), _ptr(status), self._stream()
+            )
+        )
+        torch.cuda.synchronize(self.device)
+        return crops[:, :nf].cpu().numpy(), status[:, :nf].cpu().numpy()
+
+    # -- b2: clip ------------------------------------------------------------
+    def clip_begin(self, clip_frames: int):
+        self._check(self._lib.pa_clip_begin(self._h, clip_frames))
+
+    def backbone_frames(self, frames_dev: torch.Tensor, boxes_dev: torch.Tensor, frame0: int, crops_rgb=None, status=None):
+        n, h, w, _ = frames_dev.shape
+        self._check(
+            self._lib.pa_backbone_frames(
+                self._h, _ptr(frames_dev), n, h, w, _ptr(boxes_dev), frame0, _ptr(crops_rgb), _ptr(status), self._stream()
+            )
+        )
+
+    def head_frames(self, lo: int, hi: int, records: torch.Tensor, logp: Optional[torch.Tensor]):
+        self._check(self._lib.pa_head_frames(self._h, lo, hi, _ptr(records), _ptr(logp), self._stream()))
+
+    def infer_clip_device(self, frames_dev, boxes_dev, records, logp=None, crops_rgb=None, status=None):
+        """Enqueue a whole clip (all tensors already on the device)."""
+        n, h, w, _ = frames_dev.shape
+        self._check(
+            self._lib.pa_infer_clip(
+                self._h, _ptr(frames_dev), n, h, w, _ptr(boxes_dev), _ptr(records), _ptr(logp), _ptr(crops_rgb),
+                _ptr(status), self._stream(),
+            )
+        )
+
+    def alloc_records(self, count: int) -> torch.Tensor:
+        return torch.zeros((count, self.F, 4), dtype=torch.int32, device=self.device)
+
+    @staticmethod
+    def decode_records(records: torch.Tensor) -> Dict[str, np.ndarray]:
+        r = records.cpu().numpy()
+        return {
+            "char_id": r[..., 0].copy(),
+            "action_id": r[..., 1].copy(),
+            "prob": r[..., 2].copy().view(np.float32),
+            "status": r[..., 3].copy(),
+        }
+
+    def infer_clip(self, frames, boxes, want_crops: bool = False):
+        """Host convenience: upload, run, download. -> dict with logp[n-1,F,A],
+        action_id, prob, char_id, status[n,F] (and crops_rgb[n,F,128,128,3])."""
+        fd = self._dev(frames, torch.uint8)
+        bd = self._dev(boxes, torch.float64)
+        n = fd.shape[0]
+        records = self.alloc_records(n - 1)
+        logp = torch.empty((n - 1, self.F, self.A), dtype=torch.float32, device=self.device)
+        status = torch.empty((n, self.F), dtype=torch.int32, device=self.device)
+        crops = torch.empty((n, self.F, 128, 128, 3), dtype=torch.uint8, device=self.device) if want_crops else None
+        self.infer_clip_device(fd, bd, records, logp, crops, status)
+        torch.cuda.synchronize(self.device)
+        out = self.decode_records(records)
+        out["logp"] = logp.cpu().numpy()
+        out["crop_status"] = status.cpu().numpy()
+        if want_crops:
+            out["crops_rgb"] = crops.cpu().numpy()
+        return out
+
+    def features_export(self, frame0: int, n: int) -> torch.Tensor:
+        out = torch.empty((n, self.F, _lib.PA_FEATURE_STRIDE), dtype=torch.float32, device=self.device)
+        self._check(self._lib.pa_features_export(self._h, frame0, n, _ptr(out), self._stream()))
+        return out
+
+    def features_import(self, frame0: int, feats: torch.Tensor):
+        feats = feats.to(self.device, torch.float32).contiguous()
+        self._check(self._lib.pa_features_import(self._h, frame0, feats.shape[0], _ptr(feats), self._stream()))
+
+    # -- measurement -----------------------------------------------------------
+    def profile_enable(self, on: bool):
+        self._check(self._lib.pa_profile_enable(self._h, int(on)))
+
+    def profile_read(self) -> List[Dict]:
+        arr = (_lib.pa_kernel_stat * 64)()
+        n = C.c_int32(0)
+        self._check(self._lib.pa_profile_read(self._h, arr, 64, C.byref(n)))
+        return [
+            {
+                "name": arr[i].name.decode(),
+                "launches": arr[i].launches,
+                "total_ms": arr[i].total_ms,
+                "flops": arr[i].flops,
+                "bytes": arr[i].bytes,
+            }
+            for i in range(n.value)
+        ]
+
+
+_default: Optional[Engine] = None
+
+
+def default_engine() -> Engine:
+    """Process-wide engine on cuda:0 with seeded synthetic weights, for the
+    ``YoloCrop.square_crop`` mirror (which needs no trained weights)."""
+    global _default
+    if _default is None:
+        from . import synth
+
+        _default = Engine(synth.make_state_dict(), max_batch_frames=8, max_clip_frames=64)
+    return _default

@@ -1,0 +1,282 @@
+"""Seeded synthetic inputs for the action-recognition hot path.
+
+Everything here is derived from a build-owned 32-bit integer hash (not
+``torch.manual_seed``, which is not stable across versions/devices), so the
+same seeds give bit-identical frames, boxes and weights in this container, on
+the GPU box and inside the CPU oracle.
+
+What is synthesised, and the reference shape it stands in for:
+
+* frames   -- ``uint8[N,H,W,3]`` BGR, HWC: what ``cv2.VideoCapture.read`` hands
+  to the reference (``playaid/ai_runner.py:404-405``).
+* boxes    -- normalised ``cx cy w h`` per (frame, fighter): the content of the
+  YOLO label lines ``"cls cx cy w h conf"`` (``playaid/ai_runner.py:53-71``).
+* weights  -- a Lightning-layout ``state_dict`` for ``CNNActionDetector``
+  (``playaid/models/cnn_action_detector.py:14-27``; torchvision resnet18 keys).
+* stub log -- JSON-lines game log with every key ``Fighter.set_from_json``
+  indexes (``playaid/fighter.py:458-555``), for the manuscript plumbing config.
+"""
+from __future__ import annotations
+
+import json
+import math
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+from . import constants
+
+_M32 = np.uint64(0xFFFFFFFF)
+
+
+def hash_u32(idx, seed: int) -> np.ndarray:
+    """lowbias32-style avalanche of (idx, seed) -> uint32. Vectorised, exact."""
+    x = (np.asarray(idx, dtype=np.uint64) + np.uint64((seed * 0x9E3779B1) & 0xFFFFFFFF)) & _M32
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x7FEB352D)) & _M32
+    x ^= x >> np.uint64(15)
+    x = (x * np.uint64(0x846CA68B)) & _M32
+    x ^= x >> np.uint64(16)
+    return x.astype(np.uint32)
+
+
+def uniform(shape, seed: int, lo: float, hi: float) -> np.ndarray:
+    """float32 array of U[lo, hi) from the integer hash (24 random bits each)."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    h = hash_u32(np.arange(n, dtype=np.uint64), seed)
+    u = (h >> np.uint32(8)).astype(np.float64) * (1.0 / 16777216.0)
+    return (lo + u * (hi - lo)).astype(np.float32).reshape(shape)
+
+
+def _name_seed(name: str, seed: int) -> int:
+    s = seed & 0xFFFFFFFF
+    for ch in name.encode():
+        s = (s * 16777619) ^ ch
+        s &= 0xFFFFFFFF
+    return s
+
+
+# ----------------------------------------------------------------------------
+# weights
+# ----------------------------------------------------------------------------
+
+def resnet18_param_shapes() -> List[Tuple[str, Tuple[int, ...]]]:
+    """(key, shape) of torchvision-0.15.2 ``resnet18`` parameters and buffers,
+    in module order (the graph the reference instantiates at
+    ``playaid/models/cnn_action_detector.py:16``)."""
+    out: List[Tuple[str, Tuple[int, ...]]] = []
+
+    def bn(prefix, c):
+        out.extend(
+            [
+                (prefix + ".weight", (c,)),
+                (prefix + ".bias", (c,)),
+                (prefix + ".running_mean", (c,)),
+                (prefix + ".running_var", (c,)),
+            ]
+        )
+
+    out.append(("conv1.weight", (64, 3, 7, 7)))
+    bn("bn1", 64)
+    cin = 64
+    for li, cout in enumerate([64, 128, 256, 512], start=1):
+        for b in range(2):
+            p = f"layer{li}.{b}"
+            c_in = cin if b == 0 else cout
+            out.append((p + ".conv1.weight", (cout, c_in, 3, 3)))
+            bn(p + ".bn1", cout)
+            out.append((p + ".conv2.weight", (cout, cout, 3, 3)))
+            bn(p + ".bn2", cout)
+            if b == 0 and li > 1:
+                out.append((p + ".downsample.0.weight", (cout, c_in, 1, 1)))
+                bn(p + ".downsample.1", cout)
+        cin = cout
+    out.append(("fc.weight", (1000, 512)))
+    out.append(("fc.bias", (1000,)))
+    return out
+
+
+def make_state_dict(seed: int = 1234, num_actions: int = 63, sequence_length: int = 7) -> Dict[str, np.ndarray]:
+    """Seeded fp32 weights in the Lightning ``state_dict`` key layout
+    (``model.cnn2d.*``, ``model.cnn1d.0.*``, ``model.classifier.{0,2}.*``;
+    SURVEY.md section 8b). conv/linear ~ U(+-sqrt(3/fan_in)); BN gamma in
+    U(0.5,1.5), beta/mean in U(-0.1,0.1), var in U(0.5,1.5)."""
+    sd: Dict[str, np.ndarray] = {}
+
+    def dense(key, shape):
+        fan_in = int(np.prod(shape[1:]))
+        a = math.sqrt(3.0 / fan_in)
+        sd[key] = uniform(shape, _name_seed(key, seed), -a, a)
+
+    for key, shape in resnet18_param_shapes():
+        full = "model.cnn2d." + key
+        if key.endswith("running_var") or (key.endswith(".weight") and len(shape) == 1):
+            sd[full] = uniform(shape, _name_seed(full, seed), 0.5, 1.5)
+        elif len(shape) == 1 and not key.startswith("fc"):
+            sd[full] = uniform(shape, _name_seed(full, seed), -0.1, 0.1)
+        elif key == "fc.bias":
+            sd[full] = uniform(shape, _name_seed(full, seed), -0.05, 0.05)
+        else:
+            dense(full, shape)
+    dense("model.cnn1d.0.weight", (512, 1000, sequence_length))
+    sd["model.cnn1d.0.bias"] = uniform((512,), _name_seed("model.cnn1d.0.bias", seed), -0.05, 0.05)
+    dense("model.classifier.0.weight", (128, 512))
+    sd["model.classifier.0.bias"] = uniform((128,), _name_seed("model.classifier.0.bias", seed), -0.05, 0.05)
+    # last layer a little wider so the 63 logits are well separated (argmax
+    # stable under 1e-4 noise)
+    fan_in = 128
+    a = 4.0 * math.sqrt(3.0 / fan_in)
+    sd["model.classifier.2.weight"] = uniform(
+        (num_actions, 128), _name_seed("model.classifier.2.weight", seed), -a, a
+    )
+    sd["model.classifier.2.bias"] = uniform(
+        (num_actions,), _name_seed("model.classifier.2.bias", seed), -0.5, 0.5
+    )
+    return sd
+
+
+def save_checkpoint(path: str, seed: int = 1234, num_actions: int = 63, sequence_length: int = 7) -> None:
+    """Write a Lightning-1.6.5-shaped ``.ckpt`` (``state_dict`` +
+    ``hyper_parameters``) holding the seeded weights, so
+    ``CNNActionDetector.load_from_checkpoint`` can be exercised offline."""
+    import torch
+
+    sd = {k: torch.from_numpy(v.copy()) for k, v in make_state_dict(seed, num_actions, sequence_length).items()}
+    torch.save(
+        {
+            "state_dict": sd,
+            "hyper_parameters": {
+                "batch_size": 64,
+                "sequence_length": sequence_length,
+                "learning_rate": 2e-4,
+                "num_samples": 1024,
+                "freeze_encoder": False,
+            },
+            "pytorch-lightning_version": "1.6.5",
+            "epoch": 0,
+            "global_step": 0,
+        },
+        path,
+    )
+
+
+# ----------------------------------------------------------------------------
+# frames + boxes
+# ----------------------------------------------------------------------------
+
+def _tri(t: int, period: int) -> float:
+    """Integer triangle wave in [0,1] (exact rational, no libm)."""
+    t %= 2 * period
+    return (t if t <= period else 2 * period - t) / period
+
+
+def fighter_box(frame_idx: int, fighter: int, height: int, width: int) -> Tuple[float, float, float, float]:
+    """Normalised (cx, cy, w, h) of synthetic fighter ``fighter`` (0/1) at
+    0-based frame ``frame_idx``. Boxes are about 275x315 px at 1080p (the
+    projected fighter box of ``playaid/fighter.py:507-526`` scaled from 720p),
+    wander so that some square crops clip the frame edge, and stay >= 128 px on
+    the long side (decimation branch of INTER_AREA only)."""
+    f = frame_idx
+    if fighter == 0:
+        cx = 0.04 + 0.92 * _tri(7 * f + 13, 97)
+        cy = 0.10 + 0.82 * _tri(5 * f + 40, 61)
+        ws = 0.90 + 0.25 * _tri(3 * f, 37)
+        hs = 0.92 + 0.20 * _tri(2 * f + 5, 29)
+    else:
+        cx = 0.04 + 0.92 * _tri(11 * f + 70, 113)
+        cy = 0.10 + 0.82 * _tri(3 * f + 9, 43)
+        ws = 0.88 + 0.30 * _tri(5 * f + 11, 41)
+        hs = 0.90 + 0.24 * _tri(4 * f + 2, 31)
+    w = (275.0 / 1920.0) * ws
+    h = (315.0 / 1080.0) * hs
+    return (cx, cy, w, h)
+
+
+def make_boxes(n: int, height: int, width: int, first_frame: int = 0) -> np.ndarray:
+    """float64[n,2,4] normalised boxes for frames first_frame .. first_frame+n-1."""
+    out = np.zeros((n, 2, 4), dtype=np.float64)
+    for i in range(n):
+        for p in range(2):
+            out[i, p] = fighter_box(first_frame + i, p, height, width)
+    return out
+
+
+FIGHTER_CLASS_IDS = (2, 3)  # Pikachu, Joker: the "--classes 2 3" of ai_runner.py:215-217
+FIGHTER_NAMES = tuple(constants.CHAR_LIST[c] for c in FIGHTER_CLASS_IDS)
+
+
+def make_frame(frame_idx: int, height: int, width: int, seed: int = 7) -> np.ndarray:
+    """One ``uint8[H,W,3]`` BGR frame: smooth gradient + hash noise + two
+    textured fighter rectangles at ``fighter_box`` positions."""
+    ys = np.arange(height, dtype=np.uint64)[:, None]
+    xs = np.arange(width, dtype=np.uint64)[None, :]
+    pix = ys * np.uint64(width) + xs  # [H,W]
+    img = np.empty((height, width, 3), dtype=np.int32)
+    g0 = (xs * np.uint64(200) // np.uint64(width)).astype(np.int32)
+    g1 = (ys * np.uint64(200) // np.uint64(height)).astype(np.int32)
+    g2 = (((xs + ys + np.uint64(3 * frame_idx)) % np.uint64(512)) * np.uint64(200) // np.uint64(512)).astype(np.int32)
+    for c, g in enumerate((g0, g1, g2)):
+        noise = hash_u32(pix * np.uint64(3) + np.uint64(c), seed * 7919 + frame_idx) & np.uint32(31)
+        img[:, :, c] = g + noise.astype(np.int32)
+    for p in range(2):
+        cx, cy, w, h = fighter_box(frame_idx, p, height, width)
+        x0 = int((cx - w / 2) * width)
+        x1 = int((cx + w / 2) * width)
+        y0 = int((cy - h / 2) * height)
+        y1 = int((cy + h / 2) * height)
+        x0c, x1c = max(x0, 0), min(x1, width)
+        y0c, y1c = max(y0, 0), min(y1, height)
+        if x1c <= x0c or y1c <= y0c:
+            continue
+        yy = np.arange(y0c, y1c, dtype=np.int64)[:, None] - y0
+        xx = np.arange(x0c, x1c, dtype=np.int64)[None, :] - x0
+        # 12x12 px blocks whose colours change every 4 frames (an "animation")
+        blk = ((yy // 12) * 64 + (xx // 12)).astype(np.uint64)
+        phase = frame_idx // 4
+        for c in range(3):
+            base = hash_u32(blk * np.uint64(3) + np.uint64(c), seed * 131 + p * 17 + phase * 1009) & np.uint32(127)
+            fine = hash_u32((yy * 4096 + xx).astype(np.uint64) * np.uint64(3) + np.uint64(c), seed + p) & np.uint32(15)
+            val = 96 + base.astype(np.int32) + fine.astype(np.int32)
+            img[y0c:y1c, x0c:x1c, c] = val
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def make_frames(n: int, height: int, width: int, seed: int = 7, first_frame: int = 0) -> np.ndarray:
+    out = np.empty((n, height, width, 3), dtype=np.uint8)
+    for i in range(n):
+        out[i] = make_frame(first_frame + i, height, width, seed)
+    return out
+
+
+# ----------------------------------------------------------------------------
+# stub game log (manuscript plumbing config)
+# ----------------------------------------------------------------------------
+
+def make_stub_log(path: str, n_frames: int) -> None:
+    """JSON-lines log, 2 lines per frame, with every key that
+    ``Fighter.set_from_json`` indexes (``playaid/fighter.py:461-477,485,492-493,554``)
+    and ``num_frames_left`` decreasing by one per frame so the gap fill of
+    ``playaid/timeline.py:249-255`` is inert."""
+    with open(path, "w") as f:
+        for i in range(n_frames):
+            for p in range(2):
+                rec = {
+                    "pos_x": -50.0 + 100.0 * p + 0.25 * i,
+                    "pos_y": 0.25 * (i % 8),
+                    "damage": 0.5 * (i // 16),
+                    "facing": 1.0 if p == 0 else -1.0,
+                    "fighter_id": p,
+                    "motion_kind": 19292652517,
+                    "num_frames_left": 25200 - i,
+                    "shield_size": 50.0,
+                    "status_kind": 0,
+                    "stock_count": 3,
+                    "attack_connected": False,
+                    "stage_id": 86,
+                    "fighter_name": 8 if p == 0 else 82,
+                    "camera_position": {"x": 0.0, "y": 15.0, "z": 150.0},
+                    "camera_target_position": {"x": 0.0, "y": 11.0, "z": 0.0},
+                    "hitstun_left": 0.0,
+                    "can_act": True,
+                }
+                f.write(json.dumps(rec) + "\n")
