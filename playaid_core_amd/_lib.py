@@ -100,6 +100,12 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own libamdhip64.so.7; import it FIRST so that this
+    # library's NEEDED libamdhip64.so.7 resolves to that same runtime instance.
+    # Two HIP/HSA runtimes in one process cannot both open the device, and
+    # streams / device pointers are only meaningful inside one of them.
+    import torch  # noqa: F401
+
     if not os.path.exists(LIB_PATH):
         raise HipLibraryError(
             f"{LIB_PATH} not found: build it with `python -m playaid_core_amd._build` "

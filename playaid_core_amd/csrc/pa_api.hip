@@ -254,11 +254,11 @@ struct ProfScope {
             on = false;
             return;
         }
-        hipEventRecord(ent.start, s);
+        (void)hipEventRecord(ent.start, s);
     }
     ~ProfScope() {
         if (!on) return;
-        hipEventRecord(ent.stop, s);
+        (void)hipEventRecord(ent.stop, s);
         e->prof_log.push_back(ent);
     }
 };
@@ -447,12 +447,17 @@ int pa_create(const pa_config* cfg, const void* blob, size_t blob_bytes, pa_engi
     const int32_t* hdr = reinterpret_cast<const int32_t*>(blob);
     if (blob_bytes != pa_weight_blob_bytes(S, A) || hdr[0] != PA_WEIGHT_MAGIC || hdr[1] != 1 || hdr[2] != S || hdr[3] != A)
         return PA_ERR_BAD_WEIGHTS;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device_id < 0 || cfg->device_id >= ndev)
-        return PA_ERR_NO_DEVICE;
     pa_engine* e = new pa_engine();
     e->cfg = *cfg;
     *out = e;  // handed back even on failure so the caller can read pa_last_error, then pa_destroy
+    {
+        int ndev = 0;
+        const hipError_t derr = hipGetDeviceCount(&ndev);
+        if (derr != hipSuccess || ndev <= 0 || cfg->device_id < 0 || cfg->device_id >= ndev)
+            return fail(e, PA_ERR_NO_DEVICE,
+                        std::string("hipGetDeviceCount: ") + hipGetErrorString(derr) + ", devices=" + std::to_string(ndev) +
+                            ", requested device " + std::to_string(cfg->device_id));
+    }
     HIPCHK(e, hipSetDevice(cfg->device_id));
     const int NC = cfg->max_batch_frames * F;
     e->max_crops = NC;
@@ -621,14 +626,14 @@ int pa_create(const pa_config* cfg, const void* blob, size_t blob_bytes, pa_engi
 
 void pa_destroy(pa_engine* e) {
     if (!e) return;
-    hipSetDevice(e->cfg.device_id);
-    hipDeviceSynchronize();
+    (void)hipSetDevice(e->cfg.device_id);
+    (void)hipDeviceSynchronize();
     for (ProfEntry& p : e->prof_log) {
-        hipEventDestroy(p.start);
-        hipEventDestroy(p.stop);
+        (void)hipEventDestroy(p.start);
+        (void)hipEventDestroy(p.stop);
     }
-    for (hipEvent_t ev : e->event_pool) hipEventDestroy(ev);
-    for (void* p : e->allocs) hipFree(p);
+    for (hipEvent_t ev : e->event_pool) (void)hipEventDestroy(ev);
+    for (void* p : e->allocs) (void)hipFree(p);
     delete e;
 }
 
