@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 1080p frames/s, raw BGR frame -> per-frame labels, on N
+MI355X (BASELINE.json `metric`, config[1]: batch = 64 x 1080p frames, fp32).
+
+A "step" is one pass of the hot path over one 64-frame clip per GPU, inputs
+already resident in HBM: square-crop + resample + /255 (HIP), ResNet-18 on the
+128 crops (fp32 MFMA implicit GEMM), temporal Conv1d/MLP head + log-softmax +
+argmax (HIP) -> pa_record per (frame, fighter). At N > 1 the N*64-frame clip is
+sharded frame-parallel: one process per GPU, the only data-path exchange is the
+27-frame feature halo (RCCL send/recv) plus the record gather.
+
+Prints ONE JSON line on rank 0 (contract in the task prompt) with `roofline`
+(dominant kernel, timed with HIP events on the launch stream inside the timed
+region) and `cpu_baseline` (the CPU oracle, reference-literal shape, on a
+bounded sample, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from playaid_core_amd import synth
+from playaid_core_amd.engine import Engine
+from playaid_core_amd.parallel import FrameParallelClip, broadcast_blob, shard_range
+from playaid_core_amd.weights import pack_state_dict
+
+PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, = fp32 vector peak
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(sd, height, width, sample_frames):
+    """Reference-literal CPU path (oracle = "port"): batch 1 per (frame,
+    fighter), 7 backbone forwards per window, crops through the PIL/cv
+    restatement -- the shape of ai_runner.py:493-520."""
+    from oracle import pipeline  # checker / baseline only
+
+    frames = synth.make_frames(sample_frames, height, width)
+    boxes = synth.make_boxes(sample_frames, height, width)
+    t0 = time.perf_counter()
+    crops, ok = pipeline.crops_for_clip(frames, boxes)
+    pipeline.run_action_recognition(frames, boxes, sd, mode="literal", crops_rgb=crops)
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(sample_frames / dt, 3),
+        "unit": "frames/s",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"{sample_frames} synthetic {height}x{width} frames ({2 * (sample_frames - 1)} windows, "
+        f"reference-literal: batch 1, 7 ResNet-18 forwards per window), {dt:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--cpu-sample-frames", type=int, default=12)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    F, S, A, DELTA = 2, 7, 63, 3
+    n_local = args.frames
+    n_total = n_local * world
+    lo, hi = shard_range(n_total, world, rank)
+
+    # weights: rank 0 packs, one RCCL broadcast
+    nbytes = None
+    if rank == 0:
+        sd = synth.make_state_dict(seed=1234)
+        blob = pack_state_dict(sd, S, A)
+        nbytes = blob.nbytes
+    if world > 1:
+        nb = torch.tensor([nbytes if rank == 0 else 0], dtype=torch.int64, device=device)
+        dist.broadcast(nb, src=0)
+        blob = broadcast_blob(blob if rank == 0 else None, int(nb.item()), device)
+    eng = Engine(
+        blob,
+        device=str(device),
+        max_batch_frames=n_local,
+        max_clip_frames=max(n_total, 64),
+        max_frame_height=args.height,
+        max_frame_width=args.width,
+    )
+    # this rank's shard of the synthetic clip, resident in HBM before timing
+    frames = torch.from_numpy(synth.make_frames(hi - lo, args.height, args.width, first_frame=lo)).to(device)
+    boxes = torch.from_numpy(synth.make_boxes(hi - lo, args.height, args.width, first_frame=lo)).to(device)
+    runner = FrameParallelClip(eng, S, DELTA)
+
+    def step():
+        return runner.run(frames, boxes, n_total, gather=True)
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    if not args.no_profile:
+        eng.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rec, lp = step()
+    fence()
+    dt = time.perf_counter() - t0
+    eng.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    stats = [] if args.no_profile else eng.profile_read()
+
+    if rank == 0:
+        # sanity: results are finite and complete
+        assert rec.shape[0] == n_total - 1 and torch.isfinite(lp).all()
+        fps = n_total * args.steps / dt
+        result = {
+            "metric": "1080p frames/sec end-to-end (decode->labels)",
+            "value": round(fps, 2),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1000.0 * dt / args.steps, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"configs[1]: {n_local} x {args.height}x{args.width} BGR frames per GPU per step, 2 fighters/frame, "
+                f"S=7 delta=3 window, fp32 CNNActionDetector (ResNet-18 + Conv1d/MLP head, 63 actions), seeded weights",
+                "frames_per_gpu_per_step": n_local,
+                "crops_per_gpu_per_step": n_local * F,
+                "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU",
+            },
+        }
+        if stats:
+            by = {s["name"]: s for s in stats}
+            dom = max(stats, key=lambda s: s["total_ms"])
+            tf = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12 if dom["total_ms"] > 0 else 0.0
+            result["roofline"] = {
+                "kernel": dom["name"],
+                "bound": "mfma",
+                "achieved": round(tf, 3),
+                "peak": PEAK_FP32_MATRIX_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(tf / PEAK_FP32_MATRIX_TFLOPS, 4),
+                "traffic": None,
+                "launches": dom["launches"],
+                "avg_launch_ms": round(dom["total_ms"] / max(dom["launches"], 1), 5),
+            }
+            total_ms = sum(s["total_ms"] for s in stats)
+            result["kernels"] = {
+                s["name"]: {
+                    "launches_per_step": s["launches"] / args.steps,
+                    "ms_per_step": round(s["total_ms"] / args.steps, 4),
+                    "share": round(s["total_ms"] / total_ms, 4),
+                    "tflops": round(s["flops"] / (s["total_ms"] * 1e-3) / 1e12, 2) if s["flops"] and s["total_ms"] else None,
+                    "algo_GBs": round(s["bytes"] / (s["total_ms"] * 1e-3) / 1e9, 1) if s["total_ms"] else None,
+                }
+                for s in stats
+            }
+            pre = by.get("preprocess_crops")
+            if pre and pre["total_ms"] > 0:
+                gbs = pre["bytes"] / (pre["total_ms"] * 1e-3) / 1e9
+                result["roofline_preprocess"] = {
+                    "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(gbs / PEAK_HBM_GBS, 4),
+                }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(sd, args.height, args.width, args.cpu_sample_frames)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -44,7 +44,11 @@ class Engine:
         if not torch.cuda.is_available():
             raise _lib.HipLibraryError("no HIP device visible to PyTorch-ROCm; this path has no CPU fallback")
         self.device = torch.device(device)
-        self.S, self.A = infer_geometry(state_dict)
+        if isinstance(state_dict, np.ndarray):  # already-packed blob (e.g. received by RCCL broadcast)
+            hdr = state_dict[:32].view(np.int32)
+            self.S, self.A = int(hdr[2]), int(hdr[3])
+        else:
+            self.S, self.A = infer_geometry(state_dict)
         self.F = num_fighters
         self.max_batch_frames = max_batch_frames
         self.max_clip_frames = max_clip_frames
@@ -64,7 +68,10 @@ class Engine:
         for i in range(4):
             cfg.fighter_class_ids[i] = ids[i]
         self.cfg = cfg
-        blob = pack_state_dict(state_dict, self.S, self.A)
+        if isinstance(state_dict, np.ndarray):
+            blob = np.ascontiguousarray(state_dict, dtype=np.uint8)
+        else:
+            blob = pack_state_dict(state_dict, self.S, self.A)
         self._h = C.c_void_p(0)
         torch.cuda.set_device(self.device)
         rc = self._lib.pa_create(C.byref(cfg), blob.ctypes.data_as(C.c_void_p), blob.nbytes, C.byref(self._h))
@@ -160,6 +167,12 @@ class Engine:
 
     def alloc_records(self, count: int) -> torch.Tensor:
         return torch.zeros((count, self.F, 4), dtype=torch.int32, device=self.device)
+
+    def alloc_logp(self, count: int) -> torch.Tensor:
+        return torch.zeros((count, self.F, self.A), dtype=torch.float32, device=self.device)
+
+    def features_buffer(self, n: int) -> torch.Tensor:
+        return torch.empty((n, self.F, _lib.PA_FEATURE_STRIDE), dtype=torch.float32, device=self.device)
 
     @staticmethod
     def decode_records(records: torch.Tensor) -> Dict[str, np.ndarray]:
