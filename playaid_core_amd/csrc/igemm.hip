@@ -31,6 +31,7 @@
 namespace pa {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: stays in VGPRs (HIP's float4 class did not)
 
 constexpr int BK = 32;
 constexpr int LDS_STRIDE = 36;  // floats per LDS row (32 + 4 pad)
@@ -86,34 +87,36 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const GemmParams p) {
     int ks_end = ks_begin + p.ksteps_per_split;
     ks_end = ks_end < nk ? ks_end : nk;
 
-    float4 a_reg[A_ROWS];
-    float4 b_reg[B_ROWS];
+    f32x4 a_reg[A_ROWS];
+    f32x4 b_reg[B_ROWS];
 
-    auto prefetch = [&](int ks) {
-        const int tap = ks / cpt;
-        const int kc = (ks - tap * cpt) * BK;
-        if (GATHER) {
-#pragma unroll
-            for (int i = 0; i < A_ROWS; ++i) {
-                const int row = p.gather[a_off[i] + tap];
-                if (row >= 0) {
-                    a_reg[i] = *reinterpret_cast<const float4*>(p.act + (size_t)row * p.in_px_stride + kc + colq * 4);
-                } else {
-                    a_reg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            }
-        } else {
-            const int ky = tap / p.kw_taps;
-            const int kx = tap - ky * p.kw_taps;
-            const int tapoff = (ky + p.off_y) * p.in_row_stride + (kx + p.off_x) * p.in_px_stride + kc;
-#pragma unroll
-            for (int i = 0; i < A_ROWS; ++i)
-                a_reg[i] = *reinterpret_cast<const float4*>(p.act + a_off[i] + tapoff);
-        }
-        const int koff = tap * p.chunk + kc;
-#pragma unroll
-        for (int i = 0; i < B_ROWS; ++i) b_reg[i] = *reinterpret_cast<const float4*>(p.wgt + b_off[i] + koff);
-    };
+    // Global -> register stage of k-step `ks` (kept as a macro, not a lambda:
+    // hipcc demotes arrays captured by a lambda to scratch memory, which puts a
+    // vmcnt(0) right behind the loads and defeats the prefetch).
+#define PA_PREFETCH(KS)                                                                                       \
+    {                                                                                                         \
+        const int ks__ = (KS);                                                                                \
+        const int tap = ks__ / cpt;                                                                           \
+        const int kc = (ks__ - tap * cpt) * BK;                                                               \
+        if (GATHER) {                                                                                         \
+            _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i) {                                              \
+                const int row = p.gather[a_off[i] + tap];                                                     \
+                const int rowc = row >= 0 ? row : 0;                                                          \
+                f32x4 v = *reinterpret_cast<const f32x4*>(p.act + (size_t)rowc * p.in_px_stride + kc + colq * 4); \
+                if (row < 0) v = (f32x4)(0.f);                                                                \
+                a_reg[i] = v;                                                                                 \
+            }                                                                                                 \
+        } else {                                                                                              \
+            const int ky = tap / p.kw_taps;                                                                   \
+            const int kx = tap - ky * p.kw_taps;                                                              \
+            const int tapoff = (ky + p.off_y) * p.in_row_stride + (kx + p.off_x) * p.in_px_stride + kc;       \
+            _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i)                                                \
+                a_reg[i] = *reinterpret_cast<const f32x4*>(p.act + a_off[i] + tapoff);                        \
+        }                                                                                                     \
+        const int koff = tap * p.chunk + kc;                                                                  \
+        _Pragma("unroll") for (int i = 0; i < B_ROWS; ++i)                                                    \
+            b_reg[i] = *reinterpret_cast<const f32x4*>(p.wgt + b_off[i] + koff);                              \
+    }
 
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -132,25 +135,26 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const GemmParams p) {
     const float* a_rd = As + (wm * (BM / 2) + lr) * LDS_STRIDE + 4 * lh;
     const float* b_rd = Bs + (wn * (BN / 2) + lr) * LDS_STRIDE + 4 * lh;
 
-    if (ks_begin < ks_end) prefetch(ks_begin);
+    if (ks_begin < ks_end) PA_PREFETCH(ks_begin);
     for (int ks = ks_begin; ks < ks_end; ++ks) {
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i)
-            *reinterpret_cast<float4*>(As + (row0 + 32 * i) * LDS_STRIDE + colq * 4) = a_reg[i];
+            *reinterpret_cast<f32x4*>(As + (row0 + 32 * i) * LDS_STRIDE + colq * 4) = a_reg[i];
 #pragma unroll
         for (int i = 0; i < B_ROWS; ++i)
-            *reinterpret_cast<float4*>(Bs + (row0 + 32 * i) * LDS_STRIDE + colq * 4) = b_reg[i];
+            *reinterpret_cast<f32x4*>(Bs + (row0 + 32 * i) * LDS_STRIDE + colq * 4) = b_reg[i];
         __syncthreads();
-        if (ks + 1 < ks_end) prefetch(ks + 1);
+        // prefetch the next k-step (the last iteration re-loads its own tile: harmless, branch-free)
+        PA_PREFETCH(ks + 1 < ks_end ? ks + 1 : ks);
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
-            float4 af[MI], bf[NI];
+            f32x4 af[MI], bf[NI];
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
-                af[mi] = *reinterpret_cast<const float4*>(a_rd + mi * 32 * LDS_STRIDE + kk * 8);
+                af[mi] = *reinterpret_cast<const f32x4*>(a_rd + mi * 32 * LDS_STRIDE + kk * 8);
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
-                bf[ni] = *reinterpret_cast<const float4*>(b_rd + ni * 32 * LDS_STRIDE + kk * 8);
+                bf[ni] = *reinterpret_cast<const f32x4*>(b_rd + ni * 32 * LDS_STRIDE + kk * 8);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -164,6 +168,7 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const GemmParams p) {
         __syncthreads();
     }
 
+#undef PA_PREFETCH
     // Epilogue. 32x32 C/D map: col = lane & 31, row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5).
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {

@@ -83,6 +83,7 @@ struct pa_engine {
     int32_t* status_tmp = nullptr;
     // profiling
     bool profiling = false;
+    bool profile_layers = false;  // PA_PROFILE_LAYERS=1: one row per conv layer instead of per kernel family
     std::vector<std::string> prof_names;
     std::vector<ProfEntry> prof_log;
     std::vector<hipEvent_t> event_pool;
@@ -314,7 +315,7 @@ int run_backbone(pa_engine* e, int ncrops, float* feats_out, hipStream_t s) {
     }
     for (size_t i = 1; i < e->convs.size(); ++i) {
         const ConvLayer& L = e->convs[i];
-        rc = run_conv(e, L, ncrops, s, L.kh == 3 ? "igemm_conv3x3" : "igemm_conv1x1_ds");
+        rc = run_conv(e, L, ncrops, s, e->profile_layers ? L.name.c_str() : (L.kh == 3 ? "igemm_conv3x3" : "igemm_conv1x1_ds"));
         if (rc) return rc;
     }
     {
@@ -449,6 +450,10 @@ int pa_create(const pa_config* cfg, const void* blob, size_t blob_bytes, pa_engi
         return PA_ERR_BAD_WEIGHTS;
     pa_engine* e = new pa_engine();
     e->cfg = *cfg;
+    {
+        const char* pl = getenv("PA_PROFILE_LAYERS");
+        e->profile_layers = pl && pl[0] == '1';
+    }
     *out = e;  // handed back even on failure so the caller can read pa_last_error, then pa_destroy
     {
         int ndev = 0;
