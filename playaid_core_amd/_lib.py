@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libplayaid_hip.so")
+# PA_LIB_PATH: load a differently built library (e.g. the ablation build used by scripts/)
+LIB_PATH = os.environ.get("PA_LIB_PATH") or os.path.join(HERE, "libplayaid_hip.so")
 
 PA_ABI_VERSION = 1
 PA_WEIGHT_MAGIC = 0x31574150

@@ -10,12 +10,17 @@
 // Structure (CDNA4):
 //   * workgroup = 256 threads = 4 wave64 arranged 2x2 over a BM x BN tile;
 //   * the im2col A-tile (BM output pixels x 32 k-values) and the weight B-tile
-//     (BN channels x 32 k-values) are staged global -> registers -> LDS with
-//     16-byte accesses; NHWC activations carry an explicit zero border so the
-//     gather is pure address arithmetic (no predicates); next tile's global
-//     loads are issued before the current tile's MFMAs (register prefetch);
-//   * LDS rows are padded to 36 floats so that the ds_read_b128 operand reads
-//     (16-lane groups, bank = dword % 64) are conflict-free;
+//     (BN channels x 32 k-values) go global -> LDS directly with
+//     global_load_lds_dwordx4 (no VGPR round trip, no ds_write: measured 15-18 %
+//     of the loop in the register-staged version); NHWC activations carry an
+//     explicit zero border so the gather is pure address arithmetic (no
+//     predicates); two LDS stages, the loads of k-step k+1 are issued before
+//     the MFMAs of step k, one barrier per step;
+//   * an LDS-DMA wave instruction writes 1 KiB lane-linear (8 rows x 128 B), so
+//     rows cannot be padded; bank conflicts are removed by an XOR swizzle on
+//     the SOURCE address instead: LDS chunk c of row r holds logical 16-byte
+//     chunk c ^ ((r >> 1) & 7), and the ds_read_b128 operand reads apply the
+//     same XOR (16-lane groups, bank = dword % 64: conflict-free);
 //   * the inner product runs on v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate,
 //     bit-identical to an fmaf chain, at the same peak as the f32 VALU but with
 //     one operand VGPR per lane (guide: cdna_hip_programming.md section 3,
@@ -27,24 +32,50 @@
 //     XCD's private L2;
 //   * deterministic split-K (slabs + ordered reduce) for the small-M layers.
 #include "pa_kernels.h"
+#include <cstdlib>
 
 namespace pa {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: stays in VGPRs (HIP's float4 class did not)
 
-constexpr int BK = 32;
-constexpr int LDS_STRIDE = 36;  // floats per LDS row (32 + 4 pad)
 
-template <int BM, int BN, bool GATHER>
+// 16-byte global -> LDS DMA. LDS destination = wave-uniform `lds_base` + lane*16.
+__device__ __forceinline__ void glds16(const float* gsrc, float* lds_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
+
+// m -> (img, oy, ox) with shifts when the output plane is a power of two
+// (every layer of this network), integer division otherwise.
+__device__ __forceinline__ void split_m(const GemmParams& p, int m, int& img, int& oy, int& ox) {
+    if (p.howo_shift >= 0) {
+        img = m >> p.howo_shift;
+        const int rem = m & (p.howo - 1);
+        oy = rem >> p.wo_shift;
+        ox = rem & (p.wo - 1);
+    } else {
+        img = m / p.howo;
+        const int rem = m - img * p.howo;
+        oy = rem / p.wo;
+        ox = rem - oy * p.wo;
+    }
+}
+
+// ABL: timing-only ablation bits for scripts/ablate_igemm.sh (results are wrong when != 0):
+//   1 no global->LDS loads, 4 no barriers in the loop, 8 no MFMAs.
+template <int BM, int BN, int BK, bool GATHER, int ABL = 0>
 __global__ __launch_bounds__(256) void igemm_f32_kernel(const GemmParams p) {
     constexpr int MI = BM / 64;  // 32x32 MFMA tiles per wave along M
     constexpr int NI = BN / 64;
-    constexpr int A_ROWS = BM / 32;  // staging rows per thread
-    constexpr int B_ROWS = BN / 32;
-    __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDS_STRIDE];
-    float* As = lds;
-    float* Bs = lds + BM * LDS_STRIDE;
+    constexpr int LDS_STRIDE = BK;       // floats per LDS row (unpadded: LDS-DMA writes are lane-linear)
+    constexpr int CH = BK / 4;           // 16-byte chunks per row (8 or 16)
+    constexpr int PASS_ROWS = 256 / CH;  // rows staged by one pass of the 256 threads (32 or 16)
+    constexpr int WAVE_ROWS = 64 / CH;   // rows written by one LDS-DMA wave instruction (8 or 4)
+    constexpr int A_ROWS = BM / PASS_ROWS;  // staging rows per thread
+    constexpr int B_ROWS = BN / PASS_ROWS;
+    constexpr int STAGE = (BM + BN) * LDS_STRIDE;  // floats per LDS stage
+    __shared__ __attribute__((aligned(16))) float lds[3 * STAGE];
 
     // XCD-aware (bijective) remap: blocks with equal b % 8 share an XCD.
     const int nwg = gridDim.x;
@@ -58,64 +89,75 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const GemmParams p) {
     const int tile_n = t_id - tile_m * p.tiles_n;
 
     const int tid = threadIdx.x;
-    const int colq = tid & 7;   // which float4 of the 32-wide k chunk
-    const int row0 = tid >> 3;  // 0..31
+    const int row0 = tid / CH;  // staging row of this thread within a pass
+    // LDS chunk c of staging row r receives logical chunk c ^ swz(r), swz(r) = (r>>1)&7 for
+    // 128-byte rows (BK 32) and r&15 for 256-byte rows (BK 64); r = row0 + PASS_ROWS*i, so the
+    // term only depends on row0.
+    const int colq = (tid & (CH - 1)) ^ (BK == 32 ? ((row0 >> 1) & 7) : (row0 & 15));
 
     int a_off[A_ROWS];
     int b_off[B_ROWS];
 #pragma unroll
     for (int i = 0; i < A_ROWS; ++i) {
-        int m = tile_m * BM + row0 + 32 * i;
+        int m = tile_m * BM + row0 + PASS_ROWS * i;
         m = m < p.M ? m : p.M - 1;
         if (GATHER) {
             a_off[i] = m * p.taps;
         } else {
-            const int img = m / p.howo;
-            const int rem = m - img * p.howo;
-            const int oy = rem / p.wo;
-            const int ox = rem - oy * p.wo;
+            int img, oy, ox;
+            split_m(p, m, img, oy, ox);
             a_off[i] = img * p.in_img_stride + oy * p.stride * p.in_row_stride +
                        ox * p.stride * p.in_px_stride + colq * 4;
         }
     }
 #pragma unroll
-    for (int i = 0; i < B_ROWS; ++i) b_off[i] = (tile_n * BN + row0 + 32 * i) * p.ktot + colq * 4;
+    for (int i = 0; i < B_ROWS; ++i) b_off[i] = (tile_n * BN + row0 + PASS_ROWS * i) * p.ktot + colq * 4;
 
     const int nk = p.ktot / BK;
-    const int cpt = p.chunk / BK;  // k-steps per tap
     const int ks_begin = z * p.ksteps_per_split;
     int ks_end = ks_begin + p.ksteps_per_split;
     ks_end = ks_end < nk ? ks_end : nk;
 
-    f32x4 a_reg[A_ROWS];
-    f32x4 b_reg[B_ROWS];
+    // k-step cursor, advanced incrementally (one division at entry only)
+    int cur_kc, cur_kx, cur_ky;
+    {
+        const int cpt = p.chunk / BK;
+        const int tap = ks_begin / cpt;
+        cur_kc = (ks_begin - tap * cpt) * BK;
+        cur_ky = tap / p.kw_taps;
+        cur_kx = tap - cur_ky * p.kw_taps;
+    }
 
-    // Global -> register stage of k-step `ks` (kept as a macro, not a lambda:
-    // hipcc demotes arrays captured by a lambda to scratch memory, which puts a
-    // vmcnt(0) right behind the loads and defeats the prefetch).
-#define PA_PREFETCH(KS)                                                                                       \
+    const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // Issue the LDS-DMA loads of the k-step under the cursor into stage BUF, then
+    // advance the cursor. Each wave instruction fills WAVE_ROWS rows (1 KiB).
+#define PA_ISSUE_STAGE(BUF)                                                                                   \
     {                                                                                                         \
-        const int ks__ = (KS);                                                                                \
-        const int tap = ks__ / cpt;                                                                           \
-        const int kc = (ks__ - tap * cpt) * BK;                                                               \
+        float* As_w = lds + (BUF) * STAGE + wave_id * 256;                                                    \
+        float* Bs_w = As_w + BM * LDS_STRIDE;                                                                 \
+        const int tap = cur_ky * p.kw_taps + cur_kx;                                                          \
         if (GATHER) {                                                                                         \
             _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i) {                                              \
                 const int row = p.gather[a_off[i] + tap];                                                     \
-                const int rowc = row >= 0 ? row : 0;                                                          \
-                f32x4 v = *reinterpret_cast<const f32x4*>(p.act + (size_t)rowc * p.in_px_stride + kc + colq * 4); \
-                if (row < 0) v = (f32x4)(0.f);                                                                \
-                a_reg[i] = v;                                                                                 \
+                glds16(p.act + (size_t)row * p.in_px_stride + cur_kc + colq * 4, As_w + i * 1024);            \
             }                                                                                                 \
         } else {                                                                                              \
-            const int ky = tap / p.kw_taps;                                                                   \
-            const int kx = tap - ky * p.kw_taps;                                                              \
-            const int tapoff = (ky + p.off_y) * p.in_row_stride + (kx + p.off_x) * p.in_px_stride + kc;       \
+            const int tapoff = (cur_ky + p.off_y) * p.in_row_stride + (cur_kx + p.off_x) * p.in_px_stride + cur_kc; \
             _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i)                                                \
-                a_reg[i] = *reinterpret_cast<const f32x4*>(p.act + a_off[i] + tapoff);                        \
+                glds16(p.act + a_off[i] + tapoff, As_w + i * 1024);                                           \
         }                                                                                                     \
-        const int koff = tap * p.chunk + kc;                                                                  \
+        const int koff = tap * p.chunk + cur_kc;                                                              \
         _Pragma("unroll") for (int i = 0; i < B_ROWS; ++i)                                                    \
-            b_reg[i] = *reinterpret_cast<const f32x4*>(p.wgt + b_off[i] + koff);                              \
+            glds16(p.wgt + b_off[i] + koff, Bs_w + i * 1024);                                                 \
+        cur_kc += BK;                                                                                         \
+        if (cur_kc == p.chunk) {                                                                              \
+            cur_kc = 0;                                                                                       \
+            if (++cur_kx == p.kw_taps) {                                                                      \
+                cur_kx = 0;                                                                                   \
+                ++cur_ky;                                                                                     \
+            }                                                                                                 \
+        }                                                                                                     \
     }
 
     const int lane = tid & 63;
@@ -132,43 +174,107 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const GemmParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-    const float* a_rd = As + (wm * (BM / 2) + lr) * LDS_STRIDE + 4 * lh;
-    const float* b_rd = Bs + (wn * (BN / 2) + lr) * LDS_STRIDE + 4 * lh;
+    const int a_rd_off = (wm * (BM / 2) + lr) * LDS_STRIDE;
+    const int b_rd_off = BM * LDS_STRIDE + (wn * (BN / 2) + lr) * LDS_STRIDE;
+    const int swz = BK == 32 ? ((lr >> 1) & 7) : (lr & 15);  // row-dependent chunk XOR (same for every 32-row MFMA tile)
 
-    if (ks_begin < ks_end) PA_PREFETCH(ks_begin);
-    for (int ks = ks_begin; ks < ks_end; ++ks) {
+    // The epilogue's bias / residual operands are fetched now, so their latency
+    // hides under the whole k loop instead of sitting at the end of the workgroup.
+    float bias_r[NI];
+    float res_r[MI][NI][16];
+    const bool direct_out = p.splitk <= 1;
 #pragma unroll
-        for (int i = 0; i < A_ROWS; ++i)
-            *reinterpret_cast<f32x4*>(As + (row0 + 32 * i) * LDS_STRIDE + colq * 4) = a_reg[i];
+    for (int ni = 0; ni < NI; ++ni)
+        bias_r[ni] = (direct_out && p.bias) ? p.bias[tile_n * BN + wn * (BN / 2) + ni * 32 + lr] : 0.f;
 #pragma unroll
-        for (int i = 0; i < B_ROWS; ++i)
-            *reinterpret_cast<f32x4*>(Bs + (row0 + 32 * i) * LDS_STRIDE + colq * 4) = b_reg[i];
-        __syncthreads();
-        // prefetch the next k-step (the last iteration re-loads its own tile: harmless, branch-free)
-        PA_PREFETCH(ks + 1 < ks_end ? ks + 1 : ks);
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk) {
-            f32x4 af[MI], bf[NI];
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-                af[mi] = *reinterpret_cast<const f32x4*>(a_rd + mi * 32 * LDS_STRIDE + kk * 8);
+        for (int e = 0; e < 16; ++e) {
+            const int m = tile_m * BM + wm * (BM / 2) + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            size_t o = 0;
+            const bool ok = direct_out && p.residual && m < p.M;
+            if (ok) {
+                int img, oy, ox;
+                split_m(p, m, img, oy, ox);
+                o = (size_t)img * p.out_img_stride + (size_t)(oy + p.out_pad) * p.out_row_stride +
+                    (size_t)(ox + p.out_pad) * p.out_px_stride;
+            }
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
-                bf[ni] = *reinterpret_cast<const f32x4*>(b_rd + ni * 32 * LDS_STRIDE + kk * 8);
+                res_r[mi][ni][e] = ok ? p.residual[o + tile_n * BN + wn * (BN / 2) + ni * 32 + lr] : 0.f;
+        }
+
+    // Three-stage LDS ring, one barrier per k-step, no post-barrier bubble:
+    //   step k: issue LDS-DMA of step k+2 into stage (k+2)%3
+    //           MFMAs of step k from stage k%3; operand fragments are read one
+    //           8-wide k group ahead, and the LAST group of the step already
+    //           reads the first fragments of step k+1 from stage (k+1)%3
+    //           __syncthreads()  (hipcc drains the DMA with vmcnt(0) first)
+    // RAW: stage (k+1)%3 was drained + barriered at the end of step k-1, so it is
+    //      visible to every wave during step k.
+    // WAR: the DMA of step k+3 (issued in step k+1) overwrites stage k%3, whose
+    //      last reads every wave completed before the barrier that ends step k.
+    f32x4 af[2][MI], bf[2][NI];
+#define PA_LOAD_FRAGS(SET, STAGE_PTR, KK)                                                                     \
+    {                                                                                                         \
+        const int ch = (((KK) * 2 + lh) ^ swz) * 4;                                                           \
+        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                     \
+            af[SET][mi] = *reinterpret_cast<const f32x4*>((STAGE_PTR) + a_rd_off + mi * 32 * LDS_STRIDE + ch); \
+        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                     \
+            bf[SET][ni] = *reinterpret_cast<const f32x4*>((STAGE_PTR) + b_rd_off + ni * 32 * LDS_STRIDE + ch); \
+    }
+    if (ks_begin < ks_end) PA_ISSUE_STAGE(0);
+    if (ks_begin + 1 < ks_end) PA_ISSUE_STAGE(1);
+    __syncthreads();
+    if (ks_begin < ks_end) PA_LOAD_FRAGS(0, lds, 0);
+    int buf = 0;
+    for (int ks = ks_begin; ks < ks_end; ++ks) {
+        const int buf1 = buf == 2 ? 0 : buf + 1;
+        const int buf2 = buf1 == 2 ? 0 : buf1 + 1;
+        if (ks + 2 < ks_end && !(ABL & 1)) PA_ISSUE_STAGE(buf2);
+        const bool has_next = ks + 1 < ks_end;
+        // pin the issue order: hipcc otherwise sinks the loads below the MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        const float* st_cur = lds + buf * STAGE;
+        const float* st_next = lds + buf1 * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            // The next group's reads are issued after the first two MFMAs of this
+            // group (pinned with sched_barrier): >= 128 cycles of MFMA pipe time
+            // remain to cover the LDS latency, and the lgkmcnt(0) hipcc puts in
+            // front of the next group never waits on a read that was just issued.
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].x, bf[ni].x, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].y, bf[ni].y, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].z, bf[ni].z, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].w, bf[ni].w, acc[mi][ni], 0, 0, 0);
+                    const f32x4 a4 = af[kk & 1][mi], b4 = bf[kk & 1][ni];
+                    if (!(ABL & 8)) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[mi][ni], 0, 0, 0);
+                    } else {
+                        acc[mi][ni][0] += a4.x * b4.x + a4.y * b4.y + a4.z * b4.z + a4.w * b4.w;
+                    }
+                    if (mi == 0 && ni == 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (kk + 1 < BK / 8) {
+                            PA_LOAD_FRAGS((kk + 1) & 1, st_cur, kk + 1);
+                        } else if (has_next) {
+                            PA_LOAD_FRAGS(0, st_next, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (!(ABL & 8)) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[mi][ni], 0, 0, 0);
+                    }
                 }
         }
-        __syncthreads();
+        if (!(ABL & 4)) __syncthreads();
+        buf = buf1;
     }
+#undef PA_LOAD_FRAGS
+#undef PA_ISSUE_STAGE
 
-#undef PA_PREFETCH
     // Epilogue. 32x32 C/D map: col = lane & 31, row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5).
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
@@ -182,18 +288,15 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const GemmParams p) {
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) dst[tile_n * BN + wn * (BN / 2) + ni * 32 + lr] = acc[mi][ni][e];
             } else {
-                const int img = m / p.howo;
-                const int rem = m - img * p.howo;
-                const int oy = rem / p.wo;
-                const int ox = rem - oy * p.wo;
+                int img, oy, ox;
+                split_m(p, m, img, oy, ox);
                 const size_t o = (size_t)img * p.out_img_stride + (size_t)(oy + p.out_pad) * p.out_row_stride +
                                  (size_t)(ox + p.out_pad) * p.out_px_stride;
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
                     const int n = tile_n * BN + wn * (BN / 2) + ni * 32 + lr;
-                    float v = acc[mi][ni][e];
-                    if (p.bias) v += p.bias[n];
-                    if (p.residual) v += p.residual[o + n];
+                    float v = acc[mi][ni][e] + bias_r[ni];
+                    v += res_r[mi][ni][e];
                     if (p.relu) v = v > 0.f ? v : 0.f;
                     p.out[o + n] = v;
                 }
@@ -214,10 +317,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
             const float4 v = *reinterpret_cast<const float4*>(p.slab + ((size_t)z * p.M + m) * p.N + n);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
-        const int img = m / p.howo;
-        const int rem = m - img * p.howo;
-        const int oy = rem / p.wo;
-        const int ox = rem - oy * p.wo;
+        int img, oy, ox;
+        split_m(p, m, img, oy, ox);
         const size_t o = (size_t)img * p.out_img_stride + (size_t)(oy + p.out_pad) * p.out_row_stride +
                          (size_t)(ox + p.out_pad) * p.out_px_stride + n;
         if (p.bias) {
@@ -236,33 +337,60 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int BK>
 static hipError_t launch_tile(const GemmParams& p, hipStream_t s) {
     const int grid = p.tiles_m * p.tiles_n * p.splitk;
+#ifdef PA_ABLATION_BUILD
+    static const int abl = getenv("PA_ABLATE") ? atoi(getenv("PA_ABLATE")) : 0;
+    if (!p.gather && abl) {
+#define PA_ABL_CASE(V) case V: hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, BK, false, V>), dim3(grid), dim3(256), 0, s, p); return hipGetLastError();
+        switch (abl) { PA_ABL_CASE(1) PA_ABL_CASE(4) PA_ABL_CASE(5) PA_ABL_CASE(8) PA_ABL_CASE(9) PA_ABL_CASE(12) default: break; }
+    }
+#endif
     if (p.gather)
-        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, true>), dim3(grid), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, BK, true>), dim3(grid), dim3(256), 0, s, p);
     else
-        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, false>), dim3(grid), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, BK, false>), dim3(grid), dim3(256), 0, s, p);
     return hipGetLastError();
+}
+
+static void tile_dims(GemmTile tile, int* bm, int* bn, int* bk) {
+    switch (tile) {
+        case TILE_128x128: *bm = 128; *bn = 128; *bk = 32; break;
+        case TILE_128x64: *bm = 128; *bn = 64; *bk = 32; break;
+        case TILE_64x64: *bm = 64; *bn = 64; *bk = 32; break;
+        case TILE_128x64_K64: *bm = 128; *bn = 64; *bk = 64; break;
+        default: *bm = 64; *bn = 64; *bk = 64; break;
+    }
 }
 
 hipError_t launch_igemm(const GemmParams& p_in, GemmTile tile, hipStream_t s) {
     GemmParams p = p_in;
-    const int bm = tile == TILE_64x64 ? 64 : 128;
-    const int bn = tile == TILE_128x128 ? 128 : 64;
-    if (p.N % bn != 0 || p.chunk % BK != 0 || p.ktot != p.taps * p.chunk || p.M <= 0) return hipErrorInvalidValue;
+    int bm, bn, bk;
+    tile_dims(tile, &bm, &bn, &bk);
+    if (p.chunk % bk != 0) {  // the 7x7 stem has 32-wide taps: fall back to the BK=32 shape
+        tile = tile == TILE_128x64_K64 ? TILE_128x64 : TILE_64x64;
+        tile_dims(tile, &bm, &bn, &bk);
+    }
+    if (p.N % bn != 0 || p.chunk % bk != 0 || p.ktot != p.taps * p.chunk || p.M <= 0) return hipErrorInvalidValue;
+    auto ilog2 = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
+    p.howo_shift = ilog2(p.howo);
+    p.wo_shift = ilog2(p.wo);
+    if (p.howo_shift < 0 || p.wo_shift < 0) p.howo_shift = p.wo_shift = -1;
     p.tiles_m = (p.M + bm - 1) / bm;
     p.tiles_n = p.N / bn;
-    const int nk = p.ktot / BK;
+    const int nk = p.ktot / bk;
     if (p.splitk < 1) p.splitk = 1;
     if (p.splitk > nk) p.splitk = nk;
     p.ksteps_per_split = (nk + p.splitk - 1) / p.splitk;
     p.splitk = (nk + p.ksteps_per_split - 1) / p.ksteps_per_split;  // no empty splits
     hipError_t err;
     switch (tile) {
-        case TILE_128x128: err = launch_tile<128, 128>(p, s); break;
-        case TILE_128x64: err = launch_tile<128, 64>(p, s); break;
-        default: err = launch_tile<64, 64>(p, s); break;
+        case TILE_128x128: err = launch_tile<128, 128, 32>(p, s); break;
+        case TILE_128x64: err = launch_tile<128, 64, 32>(p, s); break;
+        case TILE_64x64: err = launch_tile<64, 64, 32>(p, s); break;
+        case TILE_128x64_K64: err = launch_tile<128, 64, 64>(p, s); break;
+        default: err = launch_tile<64, 64, 64>(p, s); break;
     }
     if (err != hipSuccess) return err;
     if (p.splitk > 1) return launch_splitk_reduce(p, s);

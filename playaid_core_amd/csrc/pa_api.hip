@@ -519,6 +519,12 @@ int pa_create(const pa_config* cfg, const void* blob, size_t blob_bytes, pa_engi
         r2 = upload(e, &L.bias, b);
         if (r2) return r2;
         choose_tile(NC * L.out_hw * L.out_hw, cout, L.taps * L.chunk / 32, &L.tile, &L.splitk);
+        // tuning knobs (scripts/tune_tiles.py): PA_FORCE_TILE=0|1|2, PA_FORCE_SPLITK=n
+        if (const char* ft = getenv("PA_FORCE_TILE")) {
+            const int t = atoi(ft);
+            if (t >= 0 && t <= 4 && !(t == 0 && cout % 128 != 0)) L.tile = (GemmTile)t;
+        }
+        if (const char* fs = getenv("PA_FORCE_SPLITK")) L.splitk = std::max(1, atoi(fs));
         e->convs.push_back(L);
         return PA_OK;
     };

@@ -29,6 +29,7 @@ struct GemmParams {
     int32_t M, N, ktot;
     int32_t taps, kw_taps, chunk;  // ktot == taps*chunk, chunk % 32 == 0
     int32_t howo, wo;              // output pixels per image, output width
+    int32_t howo_shift, wo_shift;  // log2 of the above when both are powers of two, else -1 (set by the launcher)
     int32_t in_img_stride, in_row_stride, in_px_stride, stride, off_y, off_x;
     int32_t out_img_stride, out_row_stride, out_px_stride, out_pad;
     int32_t relu;
@@ -36,7 +37,8 @@ struct GemmParams {
     int32_t tiles_m, tiles_n;
 };
 
-enum GemmTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x64 = 2 };
+// BM x BN (x BK; 32 unless named)
+enum GemmTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x64 = 2, TILE_128x64_K64 = 3, TILE_64x64_K64 = 4 };
 
 hipError_t launch_igemm(const GemmParams& p, GemmTile tile, hipStream_t s);
 hipError_t launch_splitk_reduce(const GemmParams& p, hipStream_t s);
