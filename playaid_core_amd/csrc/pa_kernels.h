@@ -47,6 +47,7 @@ hipError_t launch_splitk_reduce(const GemmParams& p, hipStream_t s);
 // crop preprocessing (preprocess.hip)
 // ---------------------------------------------------------------------------
 #define PA_KSIZE_MAX 15
+#define PA_FUSED_LDS_BYTES 65536  // LDS budget of crop_fused_kernel (2 workgroups per CU)
 
 struct CropPlan {
     int32_t status;
@@ -60,6 +61,8 @@ struct CropPlan {
     int32_t out_h;             // INTER_AREA destination height (width is 128)
     int32_t area_mode;         // 0 copy, 1 fast 2x2, 2 fast integer, 3 general
     int32_t iscale_x, iscale_y;
+    int32_t fused_rb;          // output rows per LDS sub-band of the fused kernel (8/4/2/1), 0 = multi-kernel fallback
+    int32_t pad_;
     double scale_x, scale_y;
 };
 
@@ -76,6 +79,9 @@ struct PreprocParams {
     uint8_t* crops_u8;      // [ncrops][128][128][3] or nullptr
     float* crops_f32;       // [ncrops][134][134][4] zero-bordered, or nullptr
     int32_t* status;        // [ncrops] or nullptr
+    int32_t fused_lds;      // LDS budget of the fused kernel (set by the launcher; 0 forces the fallback)
+    uint8_t* dbg;           // debug builds only (PA_DEBUG_DUMP)
+    int32_t dbg_crop, dbg_row;
 };
 
 hipError_t launch_preprocess(const PreprocParams& p, hipStream_t s);

@@ -25,6 +25,7 @@
 // in L2 / Infinity Cache between them.
 #include "pa_kernels.h"
 #include "../../include/playaid_hip.h"
+#include <cstdlib>
 
 namespace pa {
 
@@ -55,6 +56,124 @@ __device__ __forceinline__ int bicubic_ksize(int in_size, int out_size) {
     return (int)ceil(2.0 * filterscale) * 2 + 1;
 }
 
+
+// Pillow precompute_coeffs bounds (first tap, tap count) of output coordinate
+// xx for a pass in_size -> out_size: the same arithmetic as crop_coef_kernel.
+__device__ __forceinline__ void bicubic_bounds(int in_size, int out_size, int xx, int* xmin, int* cnt) {
+    const double scale = (double)(float)in_size / out_size;
+    const double filterscale = scale < 1.0 ? 1.0 : scale;
+    const double support = 2.0 * filterscale;
+    const double center = 0.0 + (xx + 0.5) * scale;
+    int lo = (int)(center - support + 0.5);
+    if (lo < 0) lo = 0;
+    int hi = (int)(center + support + 0.5);
+    if (hi > in_size) hi = in_size;
+    *xmin = lo;
+    *cnt = hi - lo;
+}
+
+// computeResizeAreaTab for one destination coordinate.
+struct AreaTab {
+    int s_first;     // source index of entry 0
+    int n;           // number of entries
+    float a_first;   // alpha of a leading partial cell (if has_first)
+    float a_mid;     // alpha of the full cells
+    float a_last;    // alpha of a trailing partial cell (if has_last)
+    int has_first, n_mid, has_last;
+};
+
+__device__ __forceinline__ AreaTab area_tab(int dx, double scale, int ssize) {
+    AreaTab t;
+    const double fsx1 = dx * scale;
+    const double fsx2 = fsx1 + scale;
+    const double cell = fmin(scale, ssize - fsx1);
+    int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
+    sx2 = sx2 < ssize - 1 ? sx2 : ssize - 1;
+    sx1 = sx1 < sx2 ? sx1 : sx2;
+    t.has_first = (sx1 - fsx1 > 1e-3) ? 1 : 0;
+    t.a_first = (float)((sx1 - fsx1) / cell);
+    t.n_mid = sx2 - sx1;
+    t.a_mid = (float)(1.0 / cell);
+    t.has_last = (fsx2 - sx2 > 1e-3) ? 1 : 0;
+    t.a_last = (float)(fmin(fmin(fsx2 - sx2, 1.0), cell) / cell);
+    t.s_first = sx1 - t.has_first;
+    t.n = t.has_first + t.n_mid + t.has_last;
+    return t;
+}
+
+__device__ __forceinline__ float area_alpha(const AreaTab& t, int k) {
+    if (k < t.has_first) return t.a_first;
+    if (k < t.has_first + t.n_mid) return t.a_mid;
+    return t.a_last;
+}
+
+
+// Rows each stage must hold in LDS to produce output rows [r0, r1) of the
+// 128-row crop: canvas rows [dy0,dy1) -> resized rows [ry0,ry1) -> slice rows
+// [ty0,ty1) (the vertical pass's taps).
+struct BandRows {
+    int dy0, dy1, ry0, ry1, ty0, ty1;
+};
+
+__device__ __forceinline__ BandRows band_rows(const CropPlan& pl, int r0, int r1) {
+    BandRows b;
+    b.dy0 = b.dy1 = b.ry0 = b.ry1 = b.ty0 = b.ty1 = 0;
+    if (r1 > pl.out_h) r1 = pl.out_h;
+    if (r0 >= r1) return b;
+    if (pl.area_mode == 0) {
+        b.dy0 = r0;
+        b.dy1 = r1;
+    } else if (pl.area_mode == 1) {
+        b.dy0 = 2 * r0;
+        b.dy1 = 2 * r1;
+    } else if (pl.area_mode == 2) {
+        b.dy0 = r0 * pl.iscale_y;
+        b.dy1 = r1 * pl.iscale_y;
+    } else {
+        const AreaTab t0 = area_tab(r0, pl.scale_y, pl.d);
+        const AreaTab t1 = area_tab(r1 - 1, pl.scale_y, pl.d);
+        b.dy0 = t0.s_first;
+        b.dy1 = t1.s_first + t1.n;
+    }
+    int ry0 = b.dy0 - pl.py, ry1 = b.dy1 - pl.py;
+    ry0 = ry0 < 0 ? 0 : (ry0 > pl.rh ? pl.rh : ry0);
+    ry1 = ry1 < 0 ? 0 : (ry1 > pl.rh ? pl.rh : ry1);
+    b.ry0 = ry0;
+    b.ry1 = ry1;
+    if (ry1 <= ry0) return b;
+    if (pl.need_v) {
+        int ymin, cnt;
+        bicubic_bounds(pl.sh, pl.rh, ry0, &ymin, &cnt);
+        b.ty0 = ymin;
+        bicubic_bounds(pl.sh, pl.rh, ry1 - 1, &ymin, &cnt);
+        b.ty1 = ymin + cnt;
+    } else {
+        b.ty0 = ry0;
+        b.ty1 = ry1;
+    }
+    return b;
+}
+
+__device__ __forceinline__ int kk_dbg(const int32_t* row, int t) { return row[2 + t]; }
+__device__ __forceinline__ int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+// LDS layout of one sub-band: B0 source rows | B1 after the horizontal pass | B2 after the vertical pass.
+struct BandLds {
+    int p0, p1;          // row pitches in bytes (multiples of 4)
+    int off1, off2, total;
+};
+
+__device__ __forceinline__ BandLds band_lds(const CropPlan& pl, const BandRows& b) {
+    BandLds l;
+    l.p0 = align_up(pl.sw * 3, 4) + 4;
+    l.p1 = align_up(pl.rw * 3, 4) + 4;
+    const int n0 = b.ty1 - b.ty0, n2 = b.ry1 - b.ry0;
+    l.off1 = align_up(n0 * l.p0, 16);
+    l.off2 = l.off1 + (pl.need_h ? align_up(n0 * l.p1, 16) : 0);
+    l.total = l.off2 + (pl.need_v ? align_up(n2 * l.p1, 16) : 0);
+    return l;
+}
+
 __global__ void crop_plan_kernel(const PreprocParams p) {
     const int crop = blockIdx.x * blockDim.x + threadIdx.x;
     const int ncrops = p.n_frames * p.fighters;
@@ -68,6 +187,8 @@ __global__ void crop_plan_kernel(const PreprocParams p) {
     pl.out_h = 0;
     pl.area_mode = 0;
     pl.iscale_x = pl.iscale_y = 1;
+    pl.fused_rb = 0;
+    pl.pad_ = 0;
     pl.scale_x = pl.scale_y = 1.0;
     const double* b = p.boxes + (size_t)crop * 4;
     const int W = p.width, H = p.height, pad = p.padding;
@@ -154,6 +275,18 @@ __global__ void crop_plan_kernel(const PreprocParams p) {
             }
         }
     }
+    if (pl.status == PA_CROP_OK) {
+        // largest sub-band height whose three LDS stages fit the fused kernel's budget
+        for (int rb = 8; rb >= 1 && pl.fused_rb == 0; rb >>= 1) {
+            int worst = 0;
+            for (int r0 = 0; r0 < PA_CROP; r0 += rb) {
+                const BandRows b = band_rows(pl, r0, r0 + rb);
+                const int need = band_lds(pl, b).total;
+                worst = need > worst ? need : worst;
+            }
+            if (worst <= p.fused_lds) pl.fused_rb = rb;
+        }
+    }
     p.plans[crop] = pl;
     if (p.status) p.status[crop] = pl.status;
 }
@@ -208,16 +341,19 @@ __global__ void crop_coef_kernel(const PreprocParams p) {
     }
 }
 
-__device__ __forceinline__ uint8_t clip8(int v) {
+// Pillow clip8: (acc >> 22) clamped to 0..255. Returns a 32-bit value on purpose: with a
+// uint8_t return type hipcc 7.2 packed the four bytes of the vertical pass through 16-bit
+// v_bitop3_b16 operations and bytes 2/3 of each dword came out wrong on gfx950.
+__device__ __forceinline__ uint32_t clip8(int v) {
     v >>= PRECISION_BITS;
-    return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    return (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
 }
 
 // ImagingResampleHorizontal_8bpc over the slice rows: t1[y][xx][c].
 __global__ __launch_bounds__(256) void resample_h_kernel(const PreprocParams p) {
     const int crop = blockIdx.y;
     const CropPlan pl = p.plans[crop];
-    if (pl.status != PA_CROP_OK || !pl.need_h) return;
+    if (pl.status != PA_CROP_OK || !pl.need_h || pl.fused_rb) return;
     const int total = pl.sh * pl.rw;
     const uint8_t* src = p.frames + ((size_t)pl.frame * p.height + pl.sy0) * p.width * 3 + (size_t)pl.sx0 * 3;
     const size_t src_pitch = (size_t)p.width * 3;
@@ -237,9 +373,9 @@ __global__ __launch_bounds__(256) void resample_h_kernel(const PreprocParams p) 
             a2 += s[3 * x + 2] * k;
         }
         uint8_t* o = dst + (size_t)i * 3;
-        o[0] = clip8(a0);
-        o[1] = clip8(a1);
-        o[2] = clip8(a2);
+        o[0] = (uint8_t)clip8(a0);
+        o[1] = (uint8_t)clip8(a1);
+        o[2] = (uint8_t)clip8(a2);
     }
 }
 
@@ -247,7 +383,7 @@ __global__ __launch_bounds__(256) void resample_h_kernel(const PreprocParams p) 
 __global__ __launch_bounds__(256) void resample_v_kernel(const PreprocParams p) {
     const int crop = blockIdx.y;
     const CropPlan pl = p.plans[crop];
-    if (pl.status != PA_CROP_OK || !pl.need_v) return;
+    if (pl.status != PA_CROP_OK || !pl.need_v || pl.fused_rb) return;
     const int total = pl.rh * pl.rw;
     const uint8_t* src;
     size_t src_pitch;
@@ -275,9 +411,9 @@ __global__ __launch_bounds__(256) void resample_v_kernel(const PreprocParams p) 
             s += src_pitch;
         }
         uint8_t* o = dst + (size_t)i * 3;
-        o[0] = clip8(a0);
-        o[1] = clip8(a1);
-        o[2] = clip8(a2);
+        o[0] = (uint8_t)clip8(a0);
+        o[1] = (uint8_t)clip8(a1);
+        o[2] = (uint8_t)clip8(a2);
     }
 }
 
@@ -305,109 +441,60 @@ __device__ __forceinline__ int cv_saturate_u8(float v) {
     return r < 0 ? 0 : (r > 255 ? 255 : r);
 }
 
-// computeResizeAreaTab for one destination coordinate.
-struct AreaTab {
-    int s_first;     // source index of entry 0
-    int n;           // number of entries
-    float a_first;   // alpha of a leading partial cell (if has_first)
-    float a_mid;     // alpha of the full cells
-    float a_last;    // alpha of a trailing partial cell (if has_last)
-    int has_first, n_mid, has_last;
-};
-
-__device__ __forceinline__ AreaTab area_tab(int dx, double scale, int ssize) {
-    AreaTab t;
-    const double fsx1 = dx * scale;
-    const double fsx2 = fsx1 + scale;
-    const double cell = fmin(scale, ssize - fsx1);
-    int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
-    sx2 = sx2 < ssize - 1 ? sx2 : ssize - 1;
-    sx1 = sx1 < sx2 ? sx1 : sx2;
-    t.has_first = (sx1 - fsx1 > 1e-3) ? 1 : 0;
-    t.a_first = (float)((sx1 - fsx1) / cell);
-    t.n_mid = sx2 - sx1;
-    t.a_mid = (float)(1.0 / cell);
-    t.has_last = (fsx2 - sx2 > 1e-3) ? 1 : 0;
-    t.a_last = (float)(fmin(fmin(fsx2 - sx2, 1.0), cell) / cell);
-    t.s_first = sx1 - t.has_first;
-    t.n = t.has_first + t.n_mid + t.has_last;
-    return t;
-}
-
-__device__ __forceinline__ float area_alpha(const AreaTab& t, int k) {
-    if (k < t.has_first) return t.a_first;
-    if (k < t.has_first + t.n_mid) return t.a_mid;
-    return t.a_last;
-}
-
-// cv::resize INTER_AREA (d x d -> out_h x 128), final black pad to 128 rows,
-// channel swap, u8 crop + /255 fp32 zero-bordered NHWC4 model input.
-__global__ __launch_bounds__(256) void area_resize_kernel(const PreprocParams p) {
-    const int crop = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // 0 .. 128*128-1
-    const int dy = i >> 7, dx = i & 127;
-    const CropPlan pl = p.plans[crop];
-    int o0 = 0, o1 = 0, o2 = 0;
-    if (pl.status == PA_CROP_OK && dy < pl.out_h) {
-        Canvas cv;
-        cv.px = pl.px; cv.py = pl.py; cv.rw = pl.rw; cv.rh = pl.rh;
-        if (pl.need_v) {
-            cv.src = p.t2 + (size_t)crop * p.t_stride;
-            cv.pitch = (size_t)pl.rw * 3;
-        } else if (pl.need_h) {
-            cv.src = p.t1 + (size_t)crop * p.t_stride;
-            cv.pitch = (size_t)pl.rw * 3;
-        } else {
-            cv.src = p.frames + ((size_t)pl.frame * p.height + pl.sy0) * p.width * 3 + (size_t)pl.sx0 * 3;
-            cv.pitch = (size_t)p.width * 3;
-        }
-        if (pl.area_mode == 0) {
-            cv.load(dy, dx, o0, o1, o2);
-        } else if (pl.area_mode == 1) {
-            int s0 = 2, s1 = 2, s2 = 2;
-            for (int yy = 0; yy < 2; ++yy)
-                for (int xx = 0; xx < 2; ++xx) {
-                    int c0, c1, c2;
-                    cv.load(dy * 2 + yy, dx * 2 + xx, c0, c1, c2);
-                    s0 += c0; s1 += c1; s2 += c2;
-                }
-            o0 = s0 >> 2; o1 = s1 >> 2; o2 = s2 >> 2;
-        } else if (pl.area_mode == 2) {
-            int s0 = 0, s1 = 0, s2 = 0;
-            for (int yy = 0; yy < pl.iscale_y; ++yy)
-                for (int xx = 0; xx < pl.iscale_x; ++xx) {
-                    int c0, c1, c2;
-                    cv.load(dy * pl.iscale_y + yy, dx * pl.iscale_x + xx, c0, c1, c2);
-                    s0 += c0; s1 += c1; s2 += c2;
-                }
-            const float scale = 1.f / (float)(pl.iscale_x * pl.iscale_y);
-            o0 = cv_saturate_u8((float)s0 * scale);
-            o1 = cv_saturate_u8((float)s1 * scale);
-            o2 = cv_saturate_u8((float)s2 * scale);
-        } else {
-            const AreaTab tx = area_tab(dx, pl.scale_x, pl.d);
-            const AreaTab ty = area_tab(dy, pl.scale_y, pl.d);
-            float sum0 = 0.f, sum1 = 0.f, sum2 = 0.f;
-            for (int j = 0; j < ty.n; ++j) {
-                const float beta = area_alpha(ty, j);
-                float b0 = 0.f, b1 = 0.f, b2 = 0.f;
-                for (int k = 0; k < tx.n; ++k) {
-                    const float alpha = area_alpha(tx, k);
-                    int c0, c1, c2;
-                    cv.load(ty.s_first + j, tx.s_first + k, c0, c1, c2);
-                    b0 = b0 + (float)c0 * alpha;
-                    b1 = b1 + (float)c1 * alpha;
-                    b2 = b2 + (float)c2 * alpha;
-                }
-                sum0 = sum0 + beta * b0;
-                sum1 = sum1 + beta * b1;
-                sum2 = sum2 + beta * b2;
+// One destination pixel of cv::resize INTER_AREA (d x d canvas -> out_h x 128).
+// CV::load(y, x, c0, c1, c2) returns the canvas pixel (black outside the paste).
+template <class CV>
+__device__ __forceinline__ void area_pixel(const CropPlan& pl, const CV& cv, int dy, int dx, int& o0, int& o1, int& o2) {
+    if (pl.area_mode == 0) {
+        cv.load(dy, dx, o0, o1, o2);
+    } else if (pl.area_mode == 1) {
+        int s0 = 2, s1 = 2, s2 = 2;
+        for (int yy = 0; yy < 2; ++yy)
+            for (int xx = 0; xx < 2; ++xx) {
+                int c0, c1, c2;
+                cv.load(dy * 2 + yy, dx * 2 + xx, c0, c1, c2);
+                s0 += c0; s1 += c1; s2 += c2;
             }
-            o0 = cv_saturate_u8(sum0);
-            o1 = cv_saturate_u8(sum1);
-            o2 = cv_saturate_u8(sum2);
+        o0 = s0 >> 2; o1 = s1 >> 2; o2 = s2 >> 2;
+    } else if (pl.area_mode == 2) {
+        int s0 = 0, s1 = 0, s2 = 0;
+        for (int yy = 0; yy < pl.iscale_y; ++yy)
+            for (int xx = 0; xx < pl.iscale_x; ++xx) {
+                int c0, c1, c2;
+                cv.load(dy * pl.iscale_y + yy, dx * pl.iscale_x + xx, c0, c1, c2);
+                s0 += c0; s1 += c1; s2 += c2;
+            }
+        const float scale = 1.f / (float)(pl.iscale_x * pl.iscale_y);
+        o0 = cv_saturate_u8((float)s0 * scale);
+        o1 = cv_saturate_u8((float)s1 * scale);
+        o2 = cv_saturate_u8((float)s2 * scale);
+    } else {
+        const AreaTab tx = area_tab(dx, pl.scale_x, pl.d);
+        const AreaTab ty = area_tab(dy, pl.scale_y, pl.d);
+        float sum0 = 0.f, sum1 = 0.f, sum2 = 0.f;
+        for (int j = 0; j < ty.n; ++j) {
+            const float beta = area_alpha(ty, j);
+            float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+            for (int k = 0; k < tx.n; ++k) {
+                const float alpha = area_alpha(tx, k);
+                int c0, c1, c2;
+                cv.load(ty.s_first + j, tx.s_first + k, c0, c1, c2);
+                b0 = b0 + (float)c0 * alpha;
+                b1 = b1 + (float)c1 * alpha;
+                b2 = b2 + (float)c2 * alpha;
+            }
+            sum0 = sum0 + beta * b0;
+            sum1 = sum1 + beta * b1;
+            sum2 = sum2 + beta * b2;
         }
+        o0 = cv_saturate_u8(sum0);
+        o1 = cv_saturate_u8(sum1);
+        o2 = cv_saturate_u8(sum2);
     }
+}
+
+// channel swap + u8 crop + /255 fp32 zero-bordered NHWC4 model input for pixel i of `crop`
+__device__ __forceinline__ void write_crop_pixel(const PreprocParams& p, int crop, int i, int o0, int o1, int o2) {
     if (p.swap_rb) {
         const int t = o0;
         o0 = o2;
@@ -425,16 +512,228 @@ __global__ __launch_bounds__(256) void area_resize_kernel(const PreprocParams p)
         v.y = (float)o1 / 255.0f;
         v.z = (float)o2 / 255.0f;
         v.w = 0.f;
+        const int dy = i >> 7, dx = i & 127;
         float4* o = reinterpret_cast<float4*>(p.crops_f32) + ((size_t)crop * 134 + (dy + 3)) * 134 + (dx + 3);
         *o = v;
     }
 }
 
-hipError_t launch_preprocess(const PreprocParams& p, hipStream_t s) {
+// Fallback for crops whose bands do not fit the fused kernel's LDS: INTER_AREA
+// from the global-memory intermediates, final black pad to 128 rows.
+__global__ __launch_bounds__(256) void area_resize_kernel(const PreprocParams p) {
+    const int crop = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // 0 .. 128*128-1
+    const int dy = i >> 7, dx = i & 127;
+    const CropPlan pl = p.plans[crop];
+    if (pl.status == PA_CROP_OK && pl.fused_rb) return;  // done by crop_fused_kernel
+    int o0 = 0, o1 = 0, o2 = 0;
+    if (pl.status == PA_CROP_OK && dy < pl.out_h) {
+        Canvas cv;
+        cv.px = pl.px; cv.py = pl.py; cv.rw = pl.rw; cv.rh = pl.rh;
+        if (pl.need_v) {
+            cv.src = p.t2 + (size_t)crop * p.t_stride;
+            cv.pitch = (size_t)pl.rw * 3;
+        } else if (pl.need_h) {
+            cv.src = p.t1 + (size_t)crop * p.t_stride;
+            cv.pitch = (size_t)pl.rw * 3;
+        } else {
+            cv.src = p.frames + ((size_t)pl.frame * p.height + pl.sy0) * p.width * 3 + (size_t)pl.sx0 * 3;
+            cv.pitch = (size_t)p.width * 3;
+        }
+        area_pixel(pl, cv, dy, dx, o0, o1, o2);
+    }
+    write_crop_pixel(p, crop, i, o0, o1, o2);
+}
+
+// ---------------------------------------------------------------------------
+// Fused path: one workgroup = 8 output rows of one crop, every intermediate in
+// LDS. Per sub-band of fused_rb rows:
+//   stage 0  slice rows [ty0,ty1) -> B0, dword loads, re-aligned with
+//            v_alignbyte so every LDS row starts on a 4-byte boundary
+//   stage H  Pillow horizontal pass B0 -> B1 (thread = output column, its
+//            <= 15 fixed-point coefficients live in registers across the rows)
+//   stage V  Pillow vertical pass B1 -> B2 (thread = 4 output bytes: one
+//            ds_read_b32 per tap row feeds four accumulators)
+//   stage A  INTER_AREA from B2 (black outside the paste) -> u8 crop + fp32 input
+// The frame is read from HBM exactly once (about 0.42 MB per crop at 1080p).
+extern __shared__ __attribute__((aligned(16))) uint8_t pa_smem[];
+
+struct LdsCanvas {
+    int base, pitch;  // byte offset of resized row ry0 in pa_smem, row pitch
+    int px, py, rw, ry0, ry1;
+    __device__ __forceinline__ void load(int y, int x, int& c0, int& c1, int& c2) const {
+        y -= py;
+        x -= px;
+        if (y >= ry0 && y < ry1 && (unsigned)x < (unsigned)rw) {
+            const int o = base + (y - ry0) * pitch + x * 3;
+            c0 = pa_smem[o];
+            c1 = pa_smem[o + 1];
+            c2 = pa_smem[o + 2];
+        } else {
+            c0 = c1 = c2 = 0;
+        }
+    }
+};
+
+__global__ __launch_bounds__(256) void crop_fused_kernel(const PreprocParams p) {
+    const int crop = blockIdx.y;
+    const int band0 = blockIdx.x * 8;  // first of this workgroup's 8 output rows
+    const int tid = threadIdx.x;
+    const CropPlan pl = p.plans[crop];
+    if (pl.status != PA_CROP_OK) {
+        // failed crop: all-zero rows (the fallback kernels skip it as well)
+        for (int i = tid; i < 8 * PA_CROP; i += 256) write_crop_pixel(p, crop, band0 * PA_CROP + i, 0, 0, 0);
+        return;
+    }
+    if (!pl.fused_rb) return;
+    const uint8_t* slice = p.frames + ((size_t)pl.frame * p.height + pl.sy0) * p.width * 3 + (size_t)pl.sx0 * 3;
+    const size_t frame_pitch = (size_t)p.width * 3;
+    const int32_t* coef_h = p.coef + (size_t)(crop * 2 + 0) * p.coef_dim * COEF_ROW;
+    const int32_t* coef_v = p.coef + (size_t)(crop * 2 + 1) * p.coef_dim * COEF_ROW;
+    const int rb = pl.fused_rb;
+    for (int r0 = band0; r0 < band0 + 8; r0 += rb) {
+        const BandRows b = band_rows(pl, r0, r0 + rb);
+        const BandLds L = band_lds(pl, b);
+        const int n0 = b.ty1 - b.ty0, n2 = b.ry1 - b.ry0;
+        // ---- stage 0: slice rows -> B0 (aligned dwords) ----------------------
+        {
+            const int row_dwords = (pl.sw * 3 + 3) >> 2;
+            const int total = n0 * row_dwords;
+            for (int i = tid; i < total; i += 256) {
+                const int y = i / row_dwords, j = i - y * row_dwords;
+                const uint8_t* g = slice + (size_t)(b.ty0 + y) * frame_pitch;
+                const uintptr_t ga = (uintptr_t)g;
+                const uint32_t* ga4 = reinterpret_cast<const uint32_t*>(ga & ~(uintptr_t)3) + j;
+                const uint32_t sh = (uint32_t)(ga & 3);
+                const uint32_t lo = ga4[0];
+                // the second dword is only dereferenced when the row really straddles it
+                const uint32_t hi = (sh && 4 * (j + 1) < (int)sh + pl.sw * 3) ? ga4[1] : 0u;
+                *reinterpret_cast<uint32_t*>(pa_smem + y * L.p0 + j * 4) = __builtin_amdgcn_alignbyte(hi, lo, sh);
+            }
+        }
+        __syncthreads();
+        // ---- stage H: B0 -> B1 ----------------------------------------------
+        int in_base = 0, in_pitch = L.p0;
+        if (pl.need_h) {
+            for (int xx = tid; xx < pl.rw; xx += 256) {
+                const int32_t* row = coef_h + (size_t)xx * COEF_ROW;
+                const int xmin = row[0], cnt = row[1];
+                const int src0 = xmin * 3, dst0 = L.off1 + xx * 3;
+                for (int y = 0; y < n0; ++y) {
+                    int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
+                    const int s = y * L.p0 + src0;
+                    for (int t = 0; t < cnt; ++t) {
+                        const int kt = row[2 + t];
+                        a0 += pa_smem[s + 3 * t + 0] * kt;
+                        a1 += pa_smem[s + 3 * t + 1] * kt;
+                        a2 += pa_smem[s + 3 * t + 2] * kt;
+                    }
+                    const int d = dst0 + y * L.p1;
+                    pa_smem[d + 0] = (uint8_t)clip8(a0);
+                    pa_smem[d + 1] = (uint8_t)clip8(a1);
+                    pa_smem[d + 2] = (uint8_t)clip8(a2);
+                }
+            }
+            in_base = L.off1;
+            in_pitch = L.p1;
+            __syncthreads();
+#ifdef PA_EXTRA_SYNC
+            __threadfence_block();
+            __syncthreads();
+            __builtin_amdgcn_s_sleep(100);
+            __syncthreads();
+#endif
+        }
+        // ---- stage V: (B1 | B0) -> B2 ------------------------------------------
+        if (pl.need_v) {
+            const int row_dwords = (pl.rw * 3 + 3) >> 2;
+            const int total = n2 * row_dwords;
+            for (int i = tid; i < total; i += 256) {
+                const int yy = i / row_dwords, j = i - yy * row_dwords;
+                const int32_t* row = coef_v + (size_t)(b.ry0 + yy) * COEF_ROW;
+                const int ymin = row[0], cnt = row[1];
+                int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0, a3 = a0;
+                // (dword index arithmetic on the uint32 view: the byte-pointer form of this
+                // loop was mis-compiled by hipcc 7.2 -- second unrolled row read at +1 byte)
+                const uint32_t* lds32 = reinterpret_cast<const uint32_t*>(pa_smem);
+                const int pitch_dw = in_pitch >> 2;
+                const int s0 = (in_base >> 2) + (ymin - b.ty0) * pitch_dw + j;
+                for (int t = 0; t < cnt; ++t) {
+#ifdef PA_V_BYTES
+                    const int bo = (s0 + t * pitch_dw) * 4;
+                    const uint32_t v = pa_smem[bo] | (pa_smem[bo + 1] << 8) | (pa_smem[bo + 2] << 16) | (pa_smem[bo + 3] << 24);
+#else
+                    const uint32_t v = lds32[s0 + t * pitch_dw];
+#endif
+#ifdef PA_DEBUG_DUMP
+                    if (p.dbg && crop == p.dbg_crop && r0 == p.dbg_row && i == 1) {
+                        reinterpret_cast<uint32_t*>(p.dbg)[32 + t * 4 + 0] = v;
+                        reinterpret_cast<uint32_t*>(p.dbg)[32 + t * 4 + 1] = (uint32_t)kk_dbg(row, t);
+                        reinterpret_cast<uint32_t*>(p.dbg)[32 + t * 4 + 2] = (uint32_t)(s0 + t * pitch_dw);
+                        reinterpret_cast<uint32_t*>(p.dbg)[32 + t * 4 + 3] = (uint32_t)cnt;
+                    }
+#endif
+                    const int kk = row[2 + t];
+                    a0 += (int)(v & 0xff) * kk;
+                    a1 += (int)((v >> 8) & 0xff) * kk;
+                    a2 += (int)((v >> 16) & 0xff) * kk;
+                    a3 += (int)(v >> 24) * kk;
+                }
+                // hipcc 7.2 fuses "two (x >> 22) clamped to u8, packed" into v_ashr_pk_u8_i32 and
+                // then ORs its result as if bits 16..31 were zero; on gfx950 they are not, which
+                // corrupted bytes 2 and 3 of every dword. The empty asm keeps the four clamped
+                // values opaque so the pack is plain shifts and ORs.
+                uint32_t c0 = clip8(a0), c1 = clip8(a1), c2 = clip8(a2), c3 = clip8(a3);
+                asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
+                const uint32_t o = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+                *reinterpret_cast<uint32_t*>(pa_smem + L.off2 + yy * L.p1 + j * 4) = o;
+            }
+            in_base = L.off2;
+            in_pitch = L.p1;
+            __syncthreads();
+        }
+#ifdef PA_DEBUG_DUMP
+        if (p.dbg && crop == p.dbg_crop && r0 == p.dbg_row) {
+            int* meta = reinterpret_cast<int*>(p.dbg);
+            if (tid == 0) {
+                meta[0] = b.dy0; meta[1] = b.dy1; meta[2] = b.ry0; meta[3] = b.ry1; meta[4] = b.ty0; meta[5] = b.ty1;
+                meta[6] = L.p0; meta[7] = L.p1; meta[8] = L.off1; meta[9] = L.off2; meta[10] = L.total; meta[11] = rb;
+                meta[12] = pl.sw; meta[13] = pl.sh; meta[14] = pl.rw; meta[15] = pl.rh; meta[16] = pl.px; meta[17] = pl.py;
+                meta[18] = pl.need_h; meta[19] = pl.need_v; meta[20] = pl.d; meta[21] = pl.area_mode; meta[22] = pl.sx0; meta[23] = pl.sy0;
+            }
+            for (int i = tid; i < L.total; i += 256) p.dbg[256 + i] = pa_smem[i];
+        }
+#endif
+        // ---- stage A: INTER_AREA + pad + outputs --------------------------------
+        {
+            LdsCanvas cv;
+            cv.base = in_base;
+            cv.pitch = in_pitch;
+            cv.px = pl.px; cv.py = pl.py; cv.rw = pl.rw;
+            cv.ry0 = b.ry0; cv.ry1 = b.ry1;
+            for (int i = tid; i < rb * PA_CROP; i += 256) {
+                const int dy = r0 + (i >> 7), dx = i & 127;
+                int o0 = 0, o1 = 0, o2 = 0;
+                if (dy < pl.out_h) area_pixel(pl, cv, dy, dx, o0, o1, o2);
+                write_crop_pixel(p, crop, dy * PA_CROP + dx, o0, o1, o2);
+            }
+        }
+        __syncthreads();  // the next sub-band reuses the LDS stages
+    }
+}
+
+hipError_t launch_preprocess(const PreprocParams& p_in, hipStream_t s) {
+    PreprocParams p = p_in;
+    static const int budget = getenv("PA_FUSED_LDS") ? atoi(getenv("PA_FUSED_LDS")) : PA_FUSED_LDS_BYTES;
+    p.fused_lds = budget;
     const int ncrops = p.n_frames * p.fighters;
     if (ncrops <= 0) return hipSuccess;
     hipLaunchKernelGGL(crop_plan_kernel, dim3((ncrops + 63) / 64), dim3(64), 0, s, p);
     hipLaunchKernelGGL(crop_coef_kernel, dim3((p.coef_dim + 127) / 128, ncrops * 2), dim3(128), 0, s, p);
+    hipLaunchKernelGGL(crop_fused_kernel, dim3(PA_CROP / 8, ncrops), dim3(256), PA_FUSED_LDS_BYTES, s, p);
+    { hipError_t e1 = hipGetLastError(); if (e1 != hipSuccess) return e1; }
+    // multi-kernel fallback for crops whose bands exceed the LDS budget (its
+    // workgroups exit at once for every crop the fused kernel handled)
     hipLaunchKernelGGL(resample_h_kernel, dim3(96, ncrops), dim3(256), 0, s, p);
     hipLaunchKernelGGL(resample_v_kernel, dim3(96, ncrops), dim3(256), 0, s, p);
     hipLaunchKernelGGL(area_resize_kernel, dim3(PA_CROP * PA_CROP / 256, ncrops), dim3(256), 0, s, p);
