@@ -1,0 +1,253 @@
+"""``AIRunner`` -- the runner boundary (b2 in SURVEY.md section 8b).
+
+Mirror of the hot loop of ``playaid/ai_runner.py:136-608``:
+``action_recognition(frame_num, fighter)`` (``:466-491``),
+``run_action_recognition(overwrite=False)`` (``:493-520``), ``write_output()``
+(``:606-608``) and ``load_ai_output()`` (``:592-604``), with the same names,
+argument meaning, 1-indexed frame numbers and result layout.
+
+What differs, and why:
+
+* Input. The reference opens a video with OpenCV and shells out to a YOLOv5
+  checkout (``:153,191-224``); neither exists in this build (SURVEY.md section
+  8c). ``input_video_path`` here names a clip archive (``.npz`` with ``frames``
+  uint8[N,H,W,3] BGR and ``labels``: one YOLO text block per frame, lines
+  ``"cls cx cy w h conf"`` exactly as ``detect.py --save-txt --save-conf``
+  writes them) or is a ``ClipSource`` already in memory.
+* Work. Crops, backbone, head and argmax run on the MI355X for the whole clip
+  at once (each crop through ResNet-18 once, not once per window);
+  ``action_recognition`` then serves single (frame, fighter) queries from
+  those results. Numerically this equals the reference's per-call path to
+  fp32 rounding (eval-mode BatchNorm makes crops independent).
+* ``run_damage_detection`` (PaddleOCR) and ``clean_yolo_crops`` (file repair)
+  are out of scope.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import yaml
+
+from . import constants
+from .anim_ontology import MOVE_TO_CLASS_ID
+from .cnn_action_detector import CNNActionDetector
+from .dataset_utils import action_sample_from_frame_middle_out
+from .fighter import YoloCrop
+
+
+def read_fighter_yolo_crop_text(label_text: str, fighter: str, where: str = "<memory>") -> Optional[YoloCrop]:
+    """``read_fighter_yolo_crop`` (``ai_runner.py:53-71``) on the text of one label file."""
+    for line in label_text.splitlines():
+        if not line:
+            continue
+        assert len(line.split(" ")) == 6, f"Too much data for line: {line} in label {where}"
+        class_id, center_x, center_y, width, height, confidence = line.split(" ")
+        if int(class_id) == constants.CHAR_LIST.index(fighter):
+            return YoloCrop(
+                float(center_x), float(center_y), float(width), float(height),
+                confidence=float(confidence), class_id=int(class_id),
+            )
+    return None
+
+
+class ClipSource:
+    """Decoded frames + per-frame YOLO label text (stand-in for VideoCapture +
+    the ``labels/<video>_<n>.txt`` files, 1-indexed like them)."""
+
+    def __init__(self, frames: np.ndarray, labels: List[str], name: str = "clip"):
+        assert frames.ndim == 4 and frames.shape[3] == 3 and frames.dtype == np.uint8
+        assert len(labels) == frames.shape[0]
+        self.frames = frames
+        self.labels = list(labels)
+        self.name = name
+
+    @classmethod
+    def load(cls, path: str) -> "ClipSource":
+        z = np.load(path, allow_pickle=False)
+        name = os.path.splitext(os.path.basename(path))[0]
+        return cls(z["frames"], [str(s) for s in z["labels"]], name)
+
+    def save(self, path: str):
+        np.savez(path, frames=self.frames, labels=np.array(self.labels))
+
+    @classmethod
+    def synthetic(cls, n: int, height: int, width: int, seed: int = 7, name: str = "synthetic") -> "ClipSource":
+        from . import synth
+
+        frames = synth.make_frames(n, height, width, seed)
+        boxes = synth.make_boxes(n, height, width)
+        labels = []
+        for i in range(n):
+            lines = [
+                str(YoloCrop(*boxes[i, p], confidence=1.0, class_id=synth.FIGHTER_CLASS_IDS[p]))
+                for p in range(boxes.shape[1])
+            ]
+            labels.append("\n".join(lines) + "\n")
+        return cls(frames, labels, name)
+
+
+class _Rec(dict):
+    """Tiny stand-in for ``addict.Dict`` (attribute access, auto-vivification)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            return None
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def __missing__(self, k):
+        v = _Rec()
+        self[k] = v
+        return v
+
+    def to_dict(self):
+        return {k: (v.to_dict() if isinstance(v, _Rec) else v) for k, v in self.items()}
+
+
+class AIRunner:
+    """Runs action recognition end to end (tracking boxes come with the clip)."""
+
+    def __init__(self, input_video_path, debug: bool = False, model: CNNActionDetector = None,
+                 checkpoint_path: str = None, output_dir: str = None, **dataset_args):
+        self.clip = input_video_path if isinstance(input_video_path, ClipSource) else ClipSource.load(input_video_path)
+        self.input_video_path = getattr(input_video_path, "name", input_video_path)
+        self.video_name = self.clip.name
+        self.dataset_args = dataset_args
+        self.debug = debug
+        self.yolo_output_dir = output_dir or os.path.join(constants.AI_CACHE, self.video_name)
+        self.ai_output_file = os.path.join(self.yolo_output_dir, "ai_output.yaml")
+        if model is None:
+            path = checkpoint_path or os.path.join(constants.SAVED_ACTION_MODELS, "four-chars-aug-4.ckpt")
+            model = CNNActionDetector.load_from_checkpoint(path, actions=list(MOVE_TO_CLASS_ID.keys()))
+        self.model = model
+        self.model.eval()
+        # ai_runner.py:244-245: max_frames is the number of the last label file
+        self.max_frames = len(self.clip.labels)
+        class_ids = sorted({int(l.split(" ")[0]) for t in self.clip.labels for l in t.splitlines() if l})
+        if len(class_ids) != 2:
+            # ai_runner.py:240-242 prints and exit()s here
+            raise ValueError(f"expected exactly 2 fighters in the labels, found class ids {class_ids}")
+        self.fighters = [constants.CHAR_LIST[c] for c in class_ids]
+        self._class_ids = class_ids
+        res, self.ai_output_data = self.load_ai_output()
+        self._results = None
+
+    # -- geometry of the window (ai_runner.py:430-439) ---------------------------
+    @property
+    def num_frames_per_sample(self) -> int:
+        return self.dataset_args.get("num_frames_per_sample", constants.NUM_FRAMES_PER_SAMPLE)
+
+    @property
+    def frame_delta(self) -> int:
+        fd = self.dataset_args.get("frame_delta", constants.FRAME_DELTA)
+        if isinstance(fd, (list, tuple)):
+            if len(fd) != 1:
+                raise ValueError("the batched path needs one frame_delta (the reference draws random.choice per call)")
+            fd = fd[0]
+        return int(fd)
+
+    def _boxes(self) -> np.ndarray:
+        n = self.max_frames
+        boxes = np.zeros((n, 2, 4), dtype=np.float64)
+        self._crops: List[List[Optional[YoloCrop]]] = []
+        for i, text in enumerate(self.clip.labels):
+            row = []
+            for p, fighter in enumerate(self.fighters):
+                crop = read_fighter_yolo_crop_text(text, fighter, f"{self.video_name}_{i + 1}.txt")
+                assert crop is not None, f"Failed to get crop for {fighter} in frame {i + 1}"
+                boxes[i, p] = crop.yolo_crop()
+                row.append(crop)
+            self._crops.append(row)
+        return boxes
+
+    def _run_clip(self):
+        if self._results is not None:
+            return self._results
+        eng = self.model.engine
+        if eng.S != self.num_frames_per_sample:
+            raise ValueError(f"model was trained with sequence_length {eng.S}, runner asked for {self.num_frames_per_sample}")
+        if eng.cfg.frame_delta != self.frame_delta or list(eng.cfg.fighter_class_ids)[:2] != self._class_ids:
+            eng = eng.reconfigured(frame_delta=self.frame_delta, fighter_class_ids=tuple(self._class_ids),
+                                   max_clip_frames=max(self.max_frames, 64),
+                                   max_frame_height=self.clip.frames.shape[1], max_frame_width=self.clip.frames.shape[2])
+        out = eng.infer_clip(self.clip.frames, self._boxes(), want_crops=True)
+        bad = np.argwhere(out["crop_status"] != 0)
+        assert len(bad) == 0, f"Failed to get square crop from frame {bad[0][0] + 1}"  # ai_runner.py:418
+        self._results = out
+        return out
+
+    def get_action_recognition_input_for_frame(self, frame: int, fighter: str):
+        """``ai_runner.py:426-464``: -> (float32[1,S,3,128,128] /255, list of S uint8[128,128,3] RGB)."""
+        res = self._run_clip()
+        frame_nums = action_sample_from_frame_middle_out(
+            frame, num_frames_per_sample=self.num_frames_per_sample, frame_delta=self.frame_delta,
+            max_frames=self.max_frames, min_frame=1,
+        )
+        p = self.fighters.index(fighter)
+        frames = [res["crops_rgb"][f - 1, p] for f in frame_nums]
+        input_frames = torch.tensor(np.array(frames)).permute(0, 3, 1, 2).unsqueeze(0).float() / 255.0
+        return input_frames, frames
+
+    def action_recognition(self, frame_num: int, fighter: str):
+        """``ai_runner.py:466-491``: frame_num is 1-indexed, in [1, max_frames)."""
+        if not 1 <= frame_num < self.max_frames:
+            raise IndexError(f"frame_num {frame_num} outside [1, {self.max_frames})")
+        res = self._run_clip()
+        p = self.fighters.index(fighter)
+        input_frames, frames = self.get_action_recognition_input_for_frame(frame_num, fighter)
+        predicted_action_id = int(res["action_id"][frame_num - 1, p])
+        predicted_action = self.model.actions[predicted_action_id]
+        confidence = float(res["prob"][frame_num - 1, p]) * 100.0
+        crop = self._crops[frame_num - 1][p]
+        return (
+            input_frames,
+            constants.CHAR_LIST.index(fighter),
+            torch.tensor(predicted_action_id),
+            {
+                "char": fighter,
+                "predicted_action": predicted_action,
+                "confidence": confidence,
+                "crop": crop,
+                "frames": [np.array(f) for f in frames],
+            },
+        )
+
+    def run_action_recognition(self, overwrite=False):
+        """``ai_runner.py:493-520``."""
+        res = self._run_clip()
+        for p, fighter in enumerate(self.fighters):
+            if not overwrite and self.ai_output_data[fighter][0].action:
+                print(f"Already performed action recognition for {fighter}")
+                continue
+            for frame_num in range(1, self.max_frames):
+                predicted_action = self.model.actions[int(res["action_id"][frame_num - 1, p])]
+                confidence = float(res["prob"][frame_num - 1, p]) * 100.0
+                frame_data = self.ai_output_data[fighter][frame_num - 1]  # YOLO is 1-indexed -> 0-indexed
+                frame_data.crop = str(self._crops[frame_num - 1][p])
+                frame_data.action = predicted_action
+                frame_data.predicted_action_confidence = confidence
+
+    def load_ai_output(self):
+        if not os.path.exists(self.ai_output_file):
+            return False, _Rec()
+        with open(self.ai_output_file, "r") as f:
+            try:
+                data = yaml.safe_load(f)
+            except Exception:
+                return False, _Rec()
+        out = _Rec()
+        for fighter, frames in (data or {}).items():
+            for idx, rec in frames.items():
+                out[fighter][idx] = _Rec(rec)
+        return True, out
+
+    def write_output(self):
+        os.makedirs(os.path.dirname(self.ai_output_file), exist_ok=True)
+        with open(self.ai_output_file, "w") as f:
+            yaml.dump(self.ai_output_data.to_dict(), f)

@@ -80,6 +80,7 @@ struct PreprocParams {
     float* crops_f32;       // [ncrops][134][134][4] zero-bordered, or nullptr
     int32_t* status;        // [ncrops] or nullptr
     int32_t fused_lds;      // LDS budget of the fused kernel (set by the launcher; 0 forces the fallback)
+    int32_t ablate;         // timing experiments: skip stages of the fused kernel (results wrong when != 0)
     uint8_t* dbg;           // debug builds only (PA_DEBUG_DUMP)
     int32_t dbg_crop, dbg_row;
 };

@@ -368,9 +368,9 @@ __global__ __launch_bounds__(256) void resample_h_kernel(const PreprocParams p) 
         int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
         for (int x = 0; x < cnt; ++x) {
             const int k = row[2 + x];
-            a0 += s[3 * x + 0] * k;
-            a1 += s[3 * x + 1] * k;
-            a2 += s[3 * x + 2] * k;
+            a0 += __mul24((int)s[3 * x + 0], k);  // u8 x 22-bit fixed point: fits v_mad_i32_i24
+            a1 += __mul24((int)s[3 * x + 1], k);
+            a2 += __mul24((int)s[3 * x + 2], k);
         }
         uint8_t* o = dst + (size_t)i * 3;
         o[0] = (uint8_t)clip8(a0);
@@ -405,9 +405,9 @@ __global__ __launch_bounds__(256) void resample_v_kernel(const PreprocParams p) 
         int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
         for (int y = 0; y < cnt; ++y) {
             const int k = row[2 + y];
-            a0 += s[0] * k;
-            a1 += s[1] * k;
-            a2 += s[2] * k;
+            a0 += __mul24((int)s[0], k);
+            a1 += __mul24((int)s[1], k);
+            a2 += __mul24((int)s[2], k);
             s += src_pitch;
         }
         uint8_t* o = dst + (size_t)i * 3;
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(256) void crop_fused_kernel(const PreprocParams p) 
         const BandLds L = band_lds(pl, b);
         const int n0 = b.ty1 - b.ty0, n2 = b.ry1 - b.ry0;
         // ---- stage 0: slice rows -> B0 (aligned dwords) ----------------------
-        {
+        if (!(p.ablate & 1)) {
             const int row_dwords = (pl.sw * 3 + 3) >> 2;
             const int total = n0 * row_dwords;
             for (int i = tid; i < total; i += 256) {
@@ -614,24 +614,52 @@ __global__ __launch_bounds__(256) void crop_fused_kernel(const PreprocParams p) 
         __syncthreads();
         // ---- stage H: B0 -> B1 ----------------------------------------------
         int in_base = 0, in_pitch = L.p0;
-        if (pl.need_h) {
-            for (int xx = tid; xx < pl.rw; xx += 256) {
+        if (pl.need_h && !(p.ablate & 2)) {
+            // work item = (output column, chunk of 4 rows): the column's <= 15 coefficients are
+            // fetched once per item and reused for its rows; ~6 items per thread keeps all 256
+            // threads busy (one item per column would leave the second pass 3/4 empty).
+            const int chunks = (n0 + 3) >> 2;
+            const int items = chunks * pl.rw;
+            for (int it = tid; it < items; it += 256) {
+                const int ck = it / pl.rw, xx = it - ck * pl.rw;
                 const int32_t* row = coef_h + (size_t)xx * COEF_ROW;
                 const int xmin = row[0], cnt = row[1];
-                const int src0 = xmin * 3, dst0 = L.off1 + xx * 3;
-                for (int y = 0; y < n0; ++y) {
-                    int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
-                    const int s = y * L.p0 + src0;
-                    for (int t = 0; t < cnt; ++t) {
-                        const int kt = row[2 + t];
-                        a0 += pa_smem[s + 3 * t + 0] * kt;
-                        a1 += pa_smem[s + 3 * t + 1] * kt;
-                        a2 += pa_smem[s + 3 * t + 2] * kt;
+                const int y_end = (ck * 4 + 4) < n0 ? (ck * 4 + 4) : n0;
+                if (pl.ksize_h <= 7) {
+                    // common case (scale <= 1.5): 7 taps fully unrolled; coefficients beyond cnt are
+                    // zero, so the extra byte reads (still inside the LDS allocation) add nothing
+                    int k[7];
+#pragma unroll
+                    for (int t = 0; t < 7; ++t) k[t] = t < cnt ? row[2 + t] : 0;
+                    for (int y = ck * 4; y < y_end; ++y) {
+                        int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
+                        const int s = y * L.p0 + xmin * 3;
+#pragma unroll
+                        for (int t = 0; t < 7; ++t) {
+                            a0 += __mul24((int)pa_smem[s + 3 * t + 0], k[t]);
+                            a1 += __mul24((int)pa_smem[s + 3 * t + 1], k[t]);
+                            a2 += __mul24((int)pa_smem[s + 3 * t + 2], k[t]);
+                        }
+                        const int d = L.off1 + y * L.p1 + xx * 3;
+                        pa_smem[d + 0] = (uint8_t)clip8(a0);
+                        pa_smem[d + 1] = (uint8_t)clip8(a1);
+                        pa_smem[d + 2] = (uint8_t)clip8(a2);
                     }
-                    const int d = dst0 + y * L.p1;
-                    pa_smem[d + 0] = (uint8_t)clip8(a0);
-                    pa_smem[d + 1] = (uint8_t)clip8(a1);
-                    pa_smem[d + 2] = (uint8_t)clip8(a2);
+                } else {
+                    for (int y = ck * 4; y < y_end; ++y) {
+                        int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
+                        const int s = y * L.p0 + xmin * 3;
+                        for (int t = 0; t < cnt; ++t) {
+                            const int kt = row[2 + t];
+                            a0 += __mul24((int)pa_smem[s + 3 * t + 0], kt);
+                            a1 += __mul24((int)pa_smem[s + 3 * t + 1], kt);
+                            a2 += __mul24((int)pa_smem[s + 3 * t + 2], kt);
+                        }
+                        const int d = L.off1 + y * L.p1 + xx * 3;
+                        pa_smem[d + 0] = (uint8_t)clip8(a0);
+                        pa_smem[d + 1] = (uint8_t)clip8(a1);
+                        pa_smem[d + 2] = (uint8_t)clip8(a2);
+                    }
                 }
             }
             in_base = L.off1;
@@ -645,7 +673,7 @@ __global__ __launch_bounds__(256) void crop_fused_kernel(const PreprocParams p) 
 #endif
         }
         // ---- stage V: (B1 | B0) -> B2 ------------------------------------------
-        if (pl.need_v) {
+        if (pl.need_v && !(p.ablate & 4)) {
             const int row_dwords = (pl.rw * 3 + 3) >> 2;
             const int total = n2 * row_dwords;
             for (int i = tid; i < total; i += 256) {
@@ -674,10 +702,10 @@ __global__ __launch_bounds__(256) void crop_fused_kernel(const PreprocParams p) 
                     }
 #endif
                     const int kk = row[2 + t];
-                    a0 += (int)(v & 0xff) * kk;
-                    a1 += (int)((v >> 8) & 0xff) * kk;
-                    a2 += (int)((v >> 16) & 0xff) * kk;
-                    a3 += (int)(v >> 24) * kk;
+                    a0 += __mul24((int)(v & 0xff), kk);
+                    a1 += __mul24((int)((v >> 8) & 0xff), kk);
+                    a2 += __mul24((int)((v >> 16) & 0xff), kk);
+                    a3 += __mul24((int)(v >> 24), kk);
                 }
                 // hipcc 7.2 fuses "two (x >> 22) clamped to u8, packed" into v_ashr_pk_u8_i32 and
                 // then ORs its result as if bits 16..31 were zero; on gfx950 they are not, which
@@ -705,7 +733,7 @@ __global__ __launch_bounds__(256) void crop_fused_kernel(const PreprocParams p) 
         }
 #endif
         // ---- stage A: INTER_AREA + pad + outputs --------------------------------
-        {
+        if (!(p.ablate & 8)) {
             LdsCanvas cv;
             cv.base = in_base;
             cv.pitch = in_pitch;
@@ -726,6 +754,8 @@ hipError_t launch_preprocess(const PreprocParams& p_in, hipStream_t s) {
     PreprocParams p = p_in;
     static const int budget = getenv("PA_FUSED_LDS") ? atoi(getenv("PA_FUSED_LDS")) : PA_FUSED_LDS_BYTES;
     p.fused_lds = budget;
+    static const int ablate = getenv("PA_PRE_ABLATE") ? atoi(getenv("PA_PRE_ABLATE")) : 0;  // timing experiments only
+    p.ablate = ablate;
     const int ncrops = p.n_frames * p.fighters;
     if (ncrops <= 0) return hipSuccess;
     hipLaunchKernelGGL(crop_plan_kernel, dim3((ncrops + 63) / 64), dim3(64), 0, s, p);

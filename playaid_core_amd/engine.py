@@ -41,6 +41,12 @@ class Engine:
         fighter_class_ids: Tuple[int, ...] = (2, 3),
     ):
         self._lib = _lib.load()  # raises HipLibraryError when the .so is missing
+        self._weights = state_dict
+        self._ctor_kwargs = dict(
+            device=device, num_fighters=num_fighters, frame_delta=frame_delta, crop_padding=crop_padding,
+            max_batch_frames=max_batch_frames, max_clip_frames=max_clip_frames, max_frame_height=max_frame_height,
+            max_frame_width=max_frame_width, fighter_class_ids=tuple(fighter_class_ids),
+        )
         if not torch.cuda.is_available():
             raise _lib.HipLibraryError("no HIP device visible to PyTorch-ROCm; this path has no CPU fallback")
         self.device = torch.device(device)
@@ -81,6 +87,12 @@ class Engine:
                 self._lib.pa_destroy(self._h)
                 self._h = C.c_void_p(0)
             raise EngineError(rc, msg)
+
+    def reconfigured(self, **overrides) -> "Engine":
+        """A new engine on the same device and weights with some geometry changed."""
+        kw = dict(self._ctor_kwargs)
+        kw.update(overrides)
+        return Engine(self._weights, **kw)
 
     # -- plumbing ---------------------------------------------------------
     def close(self):
