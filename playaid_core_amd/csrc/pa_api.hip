@@ -81,6 +81,7 @@ struct pa_engine {
     uint8_t *t1 = nullptr, *t2 = nullptr;
     size_t t_stride = 0;
     int32_t* status_tmp = nullptr;
+    int32_t* fallback = nullptr;  // [1 + max_crops]: count, then crop indices
     // profiling
     bool profiling = false;
     bool profile_layers = false;  // PA_PROFILE_LAYERS=1: one row per conv layer instead of per kernel family
@@ -404,6 +405,8 @@ int run_preprocess(pa_engine* e, const uint8_t* frames, int n, int height, int w
     p.crops_u8 = crops_u8;
     p.crops_f32 = crops_f32;
     p.status = status;
+    p.fallback_count = e->fallback;
+    p.fallback_list = e->fallback + 4;
     const double ncrops = (double)n * e->cfg.num_fighters;
     ProfScope ps(e, s, "preprocess_crops", 0.0, ncrops * (375.0 * 375 * 3 + 49152.0 * 5));
     HIPCHK(e, launch_preprocess(p, s));
@@ -627,6 +630,7 @@ int pa_create(const pa_config* cfg, const void* blob, size_t blob_bytes, pa_engi
     e->coef_dim = std::max(cfg->max_frame_height, cfg->max_frame_width);
     e->t_stride = (size_t)cfg->max_frame_height * cfg->max_frame_width * 3;
     ALLOC(e->plans, (size_t)NC, true);
+    ALLOC(e->fallback, (size_t)NC + 4, true);
     ALLOC(e->coef, (size_t)NC * 2 * e->coef_dim * (2 + PA_KSIZE_MAX), false);
     ALLOC(e->t1, (size_t)NC * e->t_stride, false);
     ALLOC(e->t2, (size_t)NC * e->t_stride, false);

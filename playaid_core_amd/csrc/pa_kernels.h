@@ -79,6 +79,8 @@ struct PreprocParams {
     uint8_t* crops_u8;      // [ncrops][128][128][3] or nullptr
     float* crops_f32;       // [ncrops][134][134][4] zero-bordered, or nullptr
     int32_t* status;        // [ncrops] or nullptr
+    int32_t* fallback_count;  // [1] number of crops routed to the multi-kernel fallback (zeroed per call)
+    int32_t* fallback_list;   // [ncrops] their indices
     int32_t fused_lds;      // LDS budget of the fused kernel (set by the launcher; 0 forces the fallback)
     int32_t ablate;         // timing experiments: skip stages of the fused kernel (results wrong when != 0)
     uint8_t* dbg;           // debug builds only (PA_DEBUG_DUMP)

@@ -157,7 +157,8 @@ __device__ __forceinline__ BandRows band_rows(const CropPlan& pl, int r0, int r1
 __device__ __forceinline__ int kk_dbg(const int32_t* row, int t) { return row[2 + t]; }
 __device__ __forceinline__ int align_up(int v, int a) { return (v + a - 1) / a * a; }
 
-// LDS layout of one sub-band: B0 source rows | B1 after the horizontal pass | B2 after the vertical pass.
+// LDS layout of one sub-band: B0 source rows | B1 after the horizontal pass; B2 (after the
+// vertical pass) reuses B0's space when both passes run (B0 is dead once H is done).
 struct BandLds {
     int p0, p1;          // row pitches in bytes (multiples of 4)
     int off1, off2, total;
@@ -168,16 +169,29 @@ __device__ __forceinline__ BandLds band_lds(const CropPlan& pl, const BandRows& 
     l.p0 = align_up(pl.sw * 3, 4) + 4;
     l.p1 = align_up(pl.rw * 3, 4) + 4;
     const int n0 = b.ty1 - b.ty0, n2 = b.ry1 - b.ry0;
-    l.off1 = align_up(n0 * l.p0, 16);
-    l.off2 = l.off1 + (pl.need_h ? align_up(n0 * l.p1, 16) : 0);
-    l.total = l.off2 + (pl.need_v ? align_up(n2 * l.p1, 16) : 0);
+    const int s0 = align_up(n0 * l.p0, 16), s1 = align_up(n0 * l.p1, 16), s2 = align_up(n2 * l.p1, 16);
+    l.off1 = s0;
+    if (pl.need_h && pl.need_v) {
+        l.off2 = 0;
+        l.total = s0 + s1 > s2 ? s0 + s1 : s2;
+    } else if (pl.need_h) {
+        l.off2 = 0;  // unused
+        l.total = s0 + s1;
+    } else if (pl.need_v) {
+        l.off2 = s0;
+        l.total = s0 + s2;
+    } else {
+        l.off2 = 0;
+        l.total = s0;
+    }
     return l;
 }
 
-__global__ void crop_plan_kernel(const PreprocParams p) {
-    const int crop = blockIdx.x * blockDim.x + threadIdx.x;
-    const int ncrops = p.n_frames * p.fighters;
-    if (crop >= ncrops) return;
+// One wave per crop: every lane derives the geometry (cheap, identical), then the lanes
+// share the search for the largest LDS sub-band (128 candidate sub-bands in parallel).
+__global__ __launch_bounds__(64) void crop_plan_kernel(const PreprocParams p) {
+    const int crop = blockIdx.x;
+    const int lane = threadIdx.x;
     CropPlan pl;
     pl.status = PA_CROP_OK;
     pl.frame = crop / p.fighters;
@@ -276,16 +290,26 @@ __global__ void crop_plan_kernel(const PreprocParams p) {
         }
     }
     if (pl.status == PA_CROP_OK) {
-        // largest sub-band height whose three LDS stages fit the fused kernel's budget
+        // largest sub-band height whose LDS stages fit the fused kernel's budget
         for (int rb = 8; rb >= 1 && pl.fused_rb == 0; rb >>= 1) {
             int worst = 0;
-            for (int r0 = 0; r0 < PA_CROP; r0 += rb) {
+            for (int r0 = lane * rb; r0 < PA_CROP; r0 += 64 * rb) {
                 const BandRows b = band_rows(pl, r0, r0 + rb);
                 const int need = band_lds(pl, b).total;
                 worst = need > worst ? need : worst;
             }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const int o = __shfl_xor(worst, d, 64);
+                worst = o > worst ? o : worst;
+            }
             if (worst <= p.fused_lds) pl.fused_rb = rb;
         }
+    }
+    if (lane != 0) return;
+    if (pl.status == PA_CROP_OK && pl.fused_rb == 0) {
+        const int slot = atomicAdd(p.fallback_count, 1);
+        p.fallback_list[slot] = crop;
     }
     p.plans[crop] = pl;
     if (p.status) p.status[crop] = pl.status;
@@ -351,9 +375,10 @@ __device__ __forceinline__ uint32_t clip8(int v) {
 
 // ImagingResampleHorizontal_8bpc over the slice rows: t1[y][xx][c].
 __global__ __launch_bounds__(256) void resample_h_kernel(const PreprocParams p) {
-    const int crop = blockIdx.y;
+  for (int fb = blockIdx.y; fb < *p.fallback_count; fb += gridDim.y) {
+    const int crop = p.fallback_list[fb];
     const CropPlan pl = p.plans[crop];
-    if (pl.status != PA_CROP_OK || !pl.need_h || pl.fused_rb) return;
+    if (pl.status != PA_CROP_OK || !pl.need_h || pl.fused_rb) continue;
     const int total = pl.sh * pl.rw;
     const uint8_t* src = p.frames + ((size_t)pl.frame * p.height + pl.sy0) * p.width * 3 + (size_t)pl.sx0 * 3;
     const size_t src_pitch = (size_t)p.width * 3;
@@ -377,13 +402,15 @@ __global__ __launch_bounds__(256) void resample_h_kernel(const PreprocParams p) 
         o[1] = (uint8_t)clip8(a1);
         o[2] = (uint8_t)clip8(a2);
     }
+  }
 }
 
 // ImagingResampleVertical_8bpc: t2[yy][x][c] from t1 (or the slice when no horizontal pass ran).
 __global__ __launch_bounds__(256) void resample_v_kernel(const PreprocParams p) {
-    const int crop = blockIdx.y;
+  for (int fb = blockIdx.y; fb < *p.fallback_count; fb += gridDim.y) {
+    const int crop = p.fallback_list[fb];
     const CropPlan pl = p.plans[crop];
-    if (pl.status != PA_CROP_OK || !pl.need_v || pl.fused_rb) return;
+    if (pl.status != PA_CROP_OK || !pl.need_v || pl.fused_rb) continue;
     const int total = pl.rh * pl.rw;
     const uint8_t* src;
     size_t src_pitch;
@@ -415,6 +442,7 @@ __global__ __launch_bounds__(256) void resample_v_kernel(const PreprocParams p) 
         o[1] = (uint8_t)clip8(a1);
         o[2] = (uint8_t)clip8(a2);
     }
+  }
 }
 
 struct Canvas {
@@ -521,28 +549,29 @@ __device__ __forceinline__ void write_crop_pixel(const PreprocParams& p, int cro
 // Fallback for crops whose bands do not fit the fused kernel's LDS: INTER_AREA
 // from the global-memory intermediates, final black pad to 128 rows.
 __global__ __launch_bounds__(256) void area_resize_kernel(const PreprocParams p) {
-    const int crop = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // 0 .. 128*128-1
-    const int dy = i >> 7, dx = i & 127;
-    const CropPlan pl = p.plans[crop];
-    if (pl.status == PA_CROP_OK && pl.fused_rb) return;  // done by crop_fused_kernel
-    int o0 = 0, o1 = 0, o2 = 0;
-    if (pl.status == PA_CROP_OK && dy < pl.out_h) {
-        Canvas cv;
-        cv.px = pl.px; cv.py = pl.py; cv.rw = pl.rw; cv.rh = pl.rh;
-        if (pl.need_v) {
-            cv.src = p.t2 + (size_t)crop * p.t_stride;
-            cv.pitch = (size_t)pl.rw * 3;
-        } else if (pl.need_h) {
-            cv.src = p.t1 + (size_t)crop * p.t_stride;
-            cv.pitch = (size_t)pl.rw * 3;
-        } else {
-            cv.src = p.frames + ((size_t)pl.frame * p.height + pl.sy0) * p.width * 3 + (size_t)pl.sx0 * 3;
-            cv.pitch = (size_t)p.width * 3;
+    for (int fb = blockIdx.y; fb < *p.fallback_count; fb += gridDim.y) {
+        const int crop = p.fallback_list[fb];
+        const int i = blockIdx.x * blockDim.x + threadIdx.x;  // 0 .. 128*128-1
+        const int dy = i >> 7, dx = i & 127;
+        const CropPlan pl = p.plans[crop];
+        int o0 = 0, o1 = 0, o2 = 0;
+        if (dy < pl.out_h) {
+            Canvas cv;
+            cv.px = pl.px; cv.py = pl.py; cv.rw = pl.rw; cv.rh = pl.rh;
+            if (pl.need_v) {
+                cv.src = p.t2 + (size_t)crop * p.t_stride;
+                cv.pitch = (size_t)pl.rw * 3;
+            } else if (pl.need_h) {
+                cv.src = p.t1 + (size_t)crop * p.t_stride;
+                cv.pitch = (size_t)pl.rw * 3;
+            } else {
+                cv.src = p.frames + ((size_t)pl.frame * p.height + pl.sy0) * p.width * 3 + (size_t)pl.sx0 * 3;
+                cv.pitch = (size_t)p.width * 3;
+            }
+            area_pixel(pl, cv, dy, dx, o0, o1, o2);
         }
-        area_pixel(pl, cv, dy, dx, o0, o1, o2);
+        write_crop_pixel(p, crop, i, o0, o1, o2);
     }
-    write_crop_pixel(p, crop, i, o0, o1, o2);
 }
 
 // ---------------------------------------------------------------------------
@@ -591,24 +620,38 @@ __global__ __launch_bounds__(256) void crop_fused_kernel(const PreprocParams p) 
     const int32_t* coef_h = p.coef + (size_t)(crop * 2 + 0) * p.coef_dim * COEF_ROW;
     const int32_t* coef_v = p.coef + (size_t)(crop * 2 + 1) * p.coef_dim * COEF_ROW;
     const int rb = pl.fused_rb;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int r0 = band0; r0 < band0 + 8; r0 += rb) {
         const BandRows b = band_rows(pl, r0, r0 + rb);
         const BandLds L = band_lds(pl, b);
         const int n0 = b.ty1 - b.ty0, n2 = b.ry1 - b.ry0;
         // ---- stage 0: slice rows -> B0 (aligned dwords) ----------------------
+        // wave w takes rows w, w+4, ...; its lanes take consecutive dwords of the row, four
+        // independent 256-byte segments in flight per iteration (the loop is latency-bound).
         if (!(p.ablate & 1)) {
             const int row_dwords = (pl.sw * 3 + 3) >> 2;
-            const int total = n0 * row_dwords;
-            for (int i = tid; i < total; i += 256) {
-                const int y = i / row_dwords, j = i - y * row_dwords;
-                const uint8_t* g = slice + (size_t)(b.ty0 + y) * frame_pitch;
-                const uintptr_t ga = (uintptr_t)g;
-                const uint32_t* ga4 = reinterpret_cast<const uint32_t*>(ga & ~(uintptr_t)3) + j;
-                const uint32_t sh = (uint32_t)(ga & 3);
-                const uint32_t lo = ga4[0];
-                // the second dword is only dereferenced when the row really straddles it
-                const uint32_t hi = (sh && 4 * (j + 1) < (int)sh + pl.sw * 3) ? ga4[1] : 0u;
-                *reinterpret_cast<uint32_t*>(pa_smem + y * L.p0 + j * 4) = __builtin_amdgcn_alignbyte(hi, lo, sh);
+            const int row_bytes = pl.sw * 3;
+            for (int y = wave; y < n0; y += 4) {
+                const uintptr_t ga = (uintptr_t)(slice + (size_t)(b.ty0 + y) * frame_pitch);
+                const uint32_t* g4 = reinterpret_cast<const uint32_t*>(ga & ~(uintptr_t)3);
+                const uint32_t sh = (uint32_t)(ga & 3);  // wave-uniform misalignment of this row
+                uint32_t* dst = reinterpret_cast<uint32_t*>(pa_smem + y * L.p0);
+                for (int j0 = 0; j0 < row_dwords; j0 += 256) {
+                    uint32_t lo[4], hi[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int j = j0 + lane + 64 * u;
+                        lo[u] = j < row_dwords ? g4[j] : 0u;
+                        // the next dword is only dereferenced when the row really straddles it
+                        hi[u] = (sh && j < row_dwords && 4 * (j + 1) < (int)sh + row_bytes) ? g4[j + 1] : 0u;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int j = j0 + lane + 64 * u;
+                        if (j < row_dwords) dst[j] = __builtin_amdgcn_alignbyte(hi[u], lo[u], sh);
+                    }
+                }
             }
         }
         __syncthreads();
@@ -631,14 +674,28 @@ __global__ __launch_bounds__(256) void crop_fused_kernel(const PreprocParams p) 
                     int k[7];
 #pragma unroll
                     for (int t = 0; t < 7; ++t) k[t] = t < cnt ? row[2 + t] : 0;
+                    // the 7 taps x 3 channels are 21 consecutive bytes starting at byte 3*xmin of the
+                    // (4-byte aligned) LDS row: fetch the 6 aligned dwords that cover them (3x
+                    // ds_read2_b32 instead of 21 ds_read_u8 -- this stage is LDS-instruction bound),
+                    // funnel-shift them into place, then every byte sits at a compile-time position.
+                    const int sb = xmin * 3;
+                    const uint32_t shb = (uint32_t)(sb & 3);
+                    const int a_dw = sb >> 2;
                     for (int y = ck * 4; y < y_end; ++y) {
+                        const uint32_t* src = reinterpret_cast<const uint32_t*>(pa_smem + y * L.p0) + a_dw;
+                        uint32_t w[6], r[6];
+#pragma unroll
+                        for (int q = 0; q < 6; ++q) w[q] = src[q];
+#pragma unroll
+                        for (int q = 0; q < 5; ++q) r[q] = __builtin_amdgcn_alignbyte(w[q + 1], w[q], shb);
+                        r[5] = __builtin_amdgcn_alignbyte(0u, w[5], shb);
                         int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
-                        const int s = y * L.p0 + xmin * 3;
 #pragma unroll
                         for (int t = 0; t < 7; ++t) {
-                            a0 += __mul24((int)pa_smem[s + 3 * t + 0], k[t]);
-                            a1 += __mul24((int)pa_smem[s + 3 * t + 1], k[t]);
-                            a2 += __mul24((int)pa_smem[s + 3 * t + 2], k[t]);
+                            const int j0 = 3 * t, j1 = 3 * t + 1, j2 = 3 * t + 2;
+                            a0 += __mul24((int)((r[j0 >> 2] >> (8 * (j0 & 3))) & 0xff), k[t]);
+                            a1 += __mul24((int)((r[j1 >> 2] >> (8 * (j1 & 3))) & 0xff), k[t]);
+                            a2 += __mul24((int)((r[j2 >> 2] >> (8 * (j2 & 3))) & 0xff), k[t]);
                         }
                         const int d = L.off1 + y * L.p1 + xx * 3;
                         pa_smem[d + 0] = (uint8_t)clip8(a0);
@@ -673,48 +730,40 @@ __global__ __launch_bounds__(256) void crop_fused_kernel(const PreprocParams p) 
 #endif
         }
         // ---- stage V: (B1 | B0) -> B2 ------------------------------------------
+        // wave w takes output rows w, w+4, ...: the row's coefficients are wave-uniform (loaded
+        // once), each lane produces 4 bytes from one ds_read_b32 per tap row.
         if (pl.need_v && !(p.ablate & 4)) {
             const int row_dwords = (pl.rw * 3 + 3) >> 2;
-            const int total = n2 * row_dwords;
-            for (int i = tid; i < total; i += 256) {
-                const int yy = i / row_dwords, j = i - yy * row_dwords;
+            const uint32_t* lds32 = reinterpret_cast<const uint32_t*>(pa_smem);
+            const int pitch_dw = in_pitch >> 2;
+            for (int yy = wave; yy < n2; yy += 4) {
                 const int32_t* row = coef_v + (size_t)(b.ry0 + yy) * COEF_ROW;
                 const int ymin = row[0], cnt = row[1];
-                int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0, a3 = a0;
-                // (dword index arithmetic on the uint32 view: the byte-pointer form of this
-                // loop was mis-compiled by hipcc 7.2 -- second unrolled row read at +1 byte)
-                const uint32_t* lds32 = reinterpret_cast<const uint32_t*>(pa_smem);
-                const int pitch_dw = in_pitch >> 2;
-                const int s0 = (in_base >> 2) + (ymin - b.ty0) * pitch_dw + j;
-                for (int t = 0; t < cnt; ++t) {
-#ifdef PA_V_BYTES
-                    const int bo = (s0 + t * pitch_dw) * 4;
-                    const uint32_t v = pa_smem[bo] | (pa_smem[bo + 1] << 8) | (pa_smem[bo + 2] << 16) | (pa_smem[bo + 3] << 24);
-#else
-                    const uint32_t v = lds32[s0 + t * pitch_dw];
-#endif
-#ifdef PA_DEBUG_DUMP
-                    if (p.dbg && crop == p.dbg_crop && r0 == p.dbg_row && i == 1) {
-                        reinterpret_cast<uint32_t*>(p.dbg)[32 + t * 4 + 0] = v;
-                        reinterpret_cast<uint32_t*>(p.dbg)[32 + t * 4 + 1] = (uint32_t)kk_dbg(row, t);
-                        reinterpret_cast<uint32_t*>(p.dbg)[32 + t * 4 + 2] = (uint32_t)(s0 + t * pitch_dw);
-                        reinterpret_cast<uint32_t*>(p.dbg)[32 + t * 4 + 3] = (uint32_t)cnt;
+                int k[PA_KSIZE_MAX];
+#pragma unroll
+                for (int t = 0; t < PA_KSIZE_MAX; ++t) k[t] = row[2 + t];  // zero beyond cnt
+                const int s0 = (in_base >> 2) + (ymin - b.ty0) * pitch_dw;
+                uint32_t* dst = reinterpret_cast<uint32_t*>(pa_smem + L.off2 + yy * L.p1);
+                for (int j = lane; j < row_dwords; j += 64) {
+                    int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0, a3 = a0;
+#pragma unroll
+                    for (int t = 0; t < PA_KSIZE_MAX; ++t) {
+                        if (t < cnt) {  // wave-uniform
+                            const uint32_t v = lds32[s0 + t * pitch_dw + j];
+                            a0 += __mul24((int)(v & 0xff), k[t]);
+                            a1 += __mul24((int)((v >> 8) & 0xff), k[t]);
+                            a2 += __mul24((int)((v >> 16) & 0xff), k[t]);
+                            a3 += __mul24((int)(v >> 24), k[t]);
+                        }
                     }
-#endif
-                    const int kk = row[2 + t];
-                    a0 += __mul24((int)(v & 0xff), kk);
-                    a1 += __mul24((int)((v >> 8) & 0xff), kk);
-                    a2 += __mul24((int)((v >> 16) & 0xff), kk);
-                    a3 += __mul24((int)(v >> 24), kk);
+                    // hipcc 7.2 fuses "two (x >> 22) clamped to u8, packed" into v_ashr_pk_u8_i32 and
+                    // then ORs its result as if bits 16..31 were zero; on gfx950 they are not, which
+                    // corrupted bytes 2 and 3 of every dword. The empty asm keeps the four clamped
+                    // values opaque so the pack is plain shifts and ORs.
+                    uint32_t c0 = clip8(a0), c1 = clip8(a1), c2 = clip8(a2), c3 = clip8(a3);
+                    asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
+                    dst[j] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
                 }
-                // hipcc 7.2 fuses "two (x >> 22) clamped to u8, packed" into v_ashr_pk_u8_i32 and
-                // then ORs its result as if bits 16..31 were zero; on gfx950 they are not, which
-                // corrupted bytes 2 and 3 of every dword. The empty asm keeps the four clamped
-                // values opaque so the pack is plain shifts and ORs.
-                uint32_t c0 = clip8(a0), c1 = clip8(a1), c2 = clip8(a2), c3 = clip8(a3);
-                asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
-                const uint32_t o = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
-                *reinterpret_cast<uint32_t*>(pa_smem + L.off2 + yy * L.p1 + j * 4) = o;
             }
             in_base = L.off2;
             in_pitch = L.p1;
@@ -758,15 +807,16 @@ hipError_t launch_preprocess(const PreprocParams& p_in, hipStream_t s) {
     p.ablate = ablate;
     const int ncrops = p.n_frames * p.fighters;
     if (ncrops <= 0) return hipSuccess;
-    hipLaunchKernelGGL(crop_plan_kernel, dim3((ncrops + 63) / 64), dim3(64), 0, s, p);
+    if (hipError_t e0 = hipMemsetAsync(p.fallback_count, 0, sizeof(int32_t), s)) return e0;
+    hipLaunchKernelGGL(crop_plan_kernel, dim3(ncrops), dim3(64), 0, s, p);
     hipLaunchKernelGGL(crop_coef_kernel, dim3((p.coef_dim + 127) / 128, ncrops * 2), dim3(128), 0, s, p);
-    hipLaunchKernelGGL(crop_fused_kernel, dim3(PA_CROP / 8, ncrops), dim3(256), PA_FUSED_LDS_BYTES, s, p);
+    hipLaunchKernelGGL(crop_fused_kernel, dim3(PA_CROP / 8, ncrops), dim3(256), p.fused_lds > 0 ? p.fused_lds : 16, s, p);
     { hipError_t e1 = hipGetLastError(); if (e1 != hipSuccess) return e1; }
-    // multi-kernel fallback for crops whose bands exceed the LDS budget (its
-    // workgroups exit at once for every crop the fused kernel handled)
-    hipLaunchKernelGGL(resample_h_kernel, dim3(96, ncrops), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(resample_v_kernel, dim3(96, ncrops), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(area_resize_kernel, dim3(PA_CROP * PA_CROP / 256, ncrops), dim3(256), 0, s, p);
+    // multi-kernel fallback for the crops whose bands exceed the LDS budget: small grids that
+    // walk the compact list the plan kernel built (empty in the common case)
+    hipLaunchKernelGGL(resample_h_kernel, dim3(96, 4), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(resample_v_kernel, dim3(96, 4), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(area_resize_kernel, dim3(PA_CROP * PA_CROP / 256, 4), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 

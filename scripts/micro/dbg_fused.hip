@@ -18,6 +18,7 @@ int main(int argc, char** argv) {
     hipMalloc(&dbg, 1 << 20); hipMemset(dbg, 0, 1 << 20);
     PreprocParams p{}; p.frames = dframe; p.boxes = dbox; p.n_frames = 1; p.height = H; p.width = W; p.fighters = 2; p.padding = 30;
     p.swap_rb = 0; p.plans = plans; p.coef = coef; p.coef_dim = 1920; p.t1 = t1; p.t2 = t2; p.t_stride = frame.size();
+    int32_t* fb; hipMalloc(&fb, 64); p.fallback_count = fb; p.fallback_list = fb + 4;
     p.crops_u8 = crops; p.crops_f32 = nullptr; p.status = status; p.dbg = dbg; p.dbg_crop = atoi(argv[1]); p.dbg_row = atoi(argv[2]);
     hipError_t e = launch_preprocess(p, 0); hipDeviceSynchronize();
     printf("launch: %s\n", hipGetErrorString(e));
