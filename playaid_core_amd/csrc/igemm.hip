@@ -32,6 +32,7 @@
 //     XCD's private L2;
 //   * deterministic split-K (slabs + ordered reduce) for the small-M layers.
 #include "pa_kernels.h"
+#include <cstdio>
 #include <cstdlib>
 
 namespace pa {
@@ -223,6 +224,9 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const GemmParams p) {
         _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                     \
             bf[SET][ni] = *reinterpret_cast<const f32x4*>((STAGE_PTR) + b_rd_off + ni * 32 * LDS_STRIDE + ch); \
     }
+#ifdef PA_ABLATION_BUILD
+    const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (ks_begin < ks_end) PA_ISSUE_STAGE(0);
     if (ks_begin + 1 < ks_end) PA_ISSUE_STAGE(1);
     __syncthreads();
@@ -274,6 +278,12 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const GemmParams p) {
     }
 #undef PA_LOAD_FRAGS
 #undef PA_ISSUE_STAGE
+#ifdef PA_ABLATION_BUILD
+    if (p.clk && tid == 0 && blockIdx.x == gridDim.x / 2) {
+        p.clk[0] = __builtin_amdgcn_s_memtime() - clk_t0;
+        p.clk[1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+    }
+#endif
 
     // Epilogue. 32x32 C/D map: col = lane & 31, row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5).
 #pragma unroll
@@ -342,6 +352,20 @@ static hipError_t launch_tile(const GemmParams& p, hipStream_t s) {
     const int grid = p.tiles_m * p.tiles_n * p.splitk;
 #ifdef PA_ABLATION_BUILD
     static const int abl = getenv("PA_ABLATE") ? atoi(getenv("PA_ABLATE")) : 0;
+    static unsigned long long* clk_dev = nullptr;
+    static int clk_calls = 0;
+    if (getenv("PA_CLK") && !p.gather) {
+        if (!clk_dev) (void)hipMalloc(&clk_dev, 16);
+        GemmParams q = p;
+        q.clk = clk_dev;
+        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, BK, false, 0>), dim3(grid), dim3(256), 0, s, q);
+        if (++clk_calls % 97 == 0) {
+            unsigned long long h[2];
+            (void)hipMemcpy(h, clk_dev, 16, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[igemm clk] tile %dx%dx%d M=%d N=%d K=%d: %llu cycles / %llu x10ns -> %.3f GHz\n", BM, BN, BK, p.M, p.N, p.ktot, h[0], h[1], (double)h[0] / (double)h[1] * 0.1);
+        }
+        return hipGetLastError();
+    }
     if (!p.gather && abl) {
 #define PA_ABL_CASE(V) case V: hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, BK, false, V>), dim3(grid), dim3(256), 0, s, p); return hipGetLastError();
         switch (abl) { PA_ABL_CASE(1) PA_ABL_CASE(4) PA_ABL_CASE(5) PA_ABL_CASE(8) PA_ABL_CASE(9) PA_ABL_CASE(12) default: break; }

@@ -35,6 +35,7 @@ struct GemmParams {
     int32_t relu;
     int32_t splitk, ksteps_per_split;
     int32_t tiles_m, tiles_n;
+    unsigned long long* clk;  // ablation builds only: in-kernel clock stamps
 };
 
 // BM x BN (x BK; 32 unless named)
@@ -47,7 +48,7 @@ hipError_t launch_splitk_reduce(const GemmParams& p, hipStream_t s);
 // crop preprocessing (preprocess.hip)
 // ---------------------------------------------------------------------------
 #define PA_KSIZE_MAX 15
-#define PA_FUSED_LDS_BYTES 65536  // LDS budget of crop_fused_kernel (2 workgroups per CU)
+#define PA_FUSED_LDS_BYTES 49152  // LDS budget of crop_fused_kernel (3 workgroups per CU; measured best of 32/48/64/80 KB)
 
 struct CropPlan {
     int32_t status;
