@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--cpu-sample-frames", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--no-pipeline", action="store_true", help="crop stage and backbone on one stream (no overlap across steps)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -113,7 +114,7 @@ def main():
     runner = FrameParallelClip(eng, S, DELTA)
 
     def step():
-        return runner.run(frames, boxes, n_total, gather=True)
+        return runner.run(frames, boxes, n_total, gather=True, pipeline=not args.no_pipeline)
 
     def fence():
         torch.cuda.synchronize(device)
@@ -173,6 +174,7 @@ def main():
                 "frames_per_gpu_per_step": n_local,
                 "crops_per_gpu_per_step": n_local * F,
                 "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU",
+                "pipeline": "crop stage of step k+1 overlaps the backbone of step k (2 streams, 2 input slots)" if not args.no_pipeline else "none",
             },
         }
         if stats:

@@ -157,6 +157,21 @@ int pa_backbone_frames(pa_engine* e, const uint8_t* frames, int32_t n, int32_t h
                        const double* boxes, int32_t frame0, uint8_t* crops_rgb, int32_t* status,
                        void* stream);
 
+/* The two halves of pa_backbone_frames as separate calls, so that a host can pipeline them
+ * on two streams: crop preprocessing of chunk k+1 (VALU/LDS-bound) overlaps the backbone of
+ * chunk k (MFMA-bound) on the same GPU. `slot` (0 or 1) selects one of two model-input
+ * buffers inside the engine. Ordering is the caller's job:
+ *   - all pa_preprocess_frames / pa_square_crops calls are stream-ordered with each other
+ *     (they share scratch memory);
+ *   - pa_backbone_slot(slot) runs after the pa_preprocess_frames that filled `slot`;
+ *   - a slot is not refilled before the pa_backbone_slot that read it has passed its first
+ *     kernel (in practice: record an event after pa_backbone_slot and make the preprocess
+ *     stream wait on it; playaid_core_amd/parallel.py does exactly this). */
+int pa_preprocess_frames(pa_engine* e, const uint8_t* frames, int32_t n, int32_t height, int32_t width,
+                         const double* boxes, int32_t slot, uint8_t* crops_rgb, int32_t* status,
+                         void* stream);
+int pa_backbone_slot(pa_engine* e, int32_t slot, int32_t n, int32_t frame0, void* stream);
+
 /* Window gather + Conv1d/MLP head + log_softmax + argmax for frame numbers
  * frame_num_lo .. frame_num_hi-1 (1-based, as run_action_recognition iterates
  * range(1, max_frames), ai_runner.py:508). Replaces

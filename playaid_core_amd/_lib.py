@@ -84,6 +84,8 @@ SYMBOLS = [
     ("pa_square_crops", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     ("pa_clip_begin", C.c_int, [_P, C.c_int32]),
     ("pa_backbone_frames", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, _P]),
+    ("pa_preprocess_frames", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, _P]),
+    ("pa_backbone_slot", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P]),
     ("pa_head_frames", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P]),
     ("pa_infer_clip", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P]),
     ("pa_features_export", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),

@@ -37,6 +37,10 @@
 
 namespace pa {
 
+#ifndef PA_COUNTED_VMCNT
+#define PA_COUNTED_VMCNT 0
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: stays in VGPRs (HIP's float4 class did not)
 
@@ -233,6 +237,7 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const GemmParams p) {
     if (ks_begin < ks_end) PA_LOAD_FRAGS(0, lds, 0);
     int buf = 0;
     for (int ks = ks_begin; ks < ks_end; ++ks) {
+        if (PA_COUNTED_VMCNT && ks > ks_begin) PA_LOAD_FRAGS(0, lds + buf * STAGE, 0);
         const int buf1 = buf == 2 ? 0 : buf + 1;
         const int buf2 = buf1 == 2 ? 0 : buf1 + 1;
         if (ks + 2 < ks_end && !(ABL & 1)) PA_ISSUE_STAGE(buf2);
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const GemmParams p) {
                         __builtin_amdgcn_sched_barrier(0);
                         if (kk + 1 < BK / 8) {
                             PA_LOAD_FRAGS((kk + 1) & 1, st_cur, kk + 1);
-                        } else if (has_next) {
+                        } else if (has_next && !PA_COUNTED_VMCNT) {
                             PA_LOAD_FRAGS(0, st_next, 0);
                         }
                         __builtin_amdgcn_sched_barrier(0);
@@ -273,7 +278,18 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const GemmParams p) {
                     }
                 }
         }
-        if (!(ABL & 4)) __syncthreads();
+        if (!(ABL & 4)) {
+            if (PA_COUNTED_VMCNT) {
+                // leave the stage issued in THIS step in flight across the barrier: only the older
+                // stage (needed next step) must have landed. __syncthreads() would drain to vmcnt(0).
+                if (ks + 2 < ks_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ROWS + B_ROWS) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            } else {
+                __syncthreads();
+            }
+        }
         buf = buf1;
     }
 #undef PA_LOAD_FRAGS

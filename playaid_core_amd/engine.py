@@ -164,6 +164,21 @@ class Engine:
             )
         )
 
+    def preprocess_frames(self, frames_dev: torch.Tensor, boxes_dev: torch.Tensor, slot: int, crops_rgb=None, status=None):
+        """Crop stage only, into model-input buffer `slot` (0/1), on the current stream."""
+        n, h, w, _ = frames_dev.shape
+        self._check(
+            self._lib.pa_preprocess_frames(
+                self._h, _ptr(frames_dev), n, h, w, _ptr(boxes_dev), slot, _ptr(crops_rgb), _ptr(status), self._stream()
+            )
+        )
+
+    def backbone_slot(self, slot: int, n: int, frame0: int):
+        """Backbone over the crops in buffer `slot` -> feature cache rows of frames frame0.., current stream."""
+        self._check(self._lib.pa_backbone_slot(self._h, slot, n, frame0, self._stream()))
+
+    supports_pipelining = True
+
     def head_frames(self, lo: int, hi: int, records: torch.Tensor, logp: Optional[torch.Tensor]):
         self._check(self._lib.pa_head_frames(self._h, lo, hi, _ptr(records), _ptr(logp), self._stream()))
 

@@ -88,6 +88,47 @@ class FrameParallelClip:
         self.world = dist.get_world_size(group) if self.distributed else 1
         self.rank = dist.get_rank(group) if self.distributed else 0
         self.reach = abs(frame_delta) * (sequence_length // 2) ** 2
+        # two-stream software pipeline (see backbone_shard)
+        self._pre_stream = None
+        self._pre_done = None
+        self._slot_free = None
+        self._slot_used = [False, False]
+        self._slot = 0
+
+    def backbone_shard(self, frames_local, boxes_local, lo: int, pipeline: bool = False):
+        """Crop + backbone for this rank's frames, in chunks of the engine's batch size.
+
+        ``pipeline=True`` (HIP engine only) runs the crop stage on a second stream into
+        alternating model-input slots, so the VALU/LDS-bound crop kernels of chunk k+1 --
+        or of the next call -- overlap the MFMA-bound backbone of chunk k. The caller
+        guarantees that ``frames_local`` / ``boxes_local`` are complete in HBM before the
+        call (the crop stream does not wait for the caller's stream)."""
+        eng = self.engine
+        step = eng.max_batch_frames
+        n = frames_local.shape[0]
+        if not (pipeline and getattr(eng, "supports_pipelining", False)):
+            for f0 in range(0, n, step):
+                eng.backbone_frames(frames_local[f0 : f0 + step], boxes_local[f0 : f0 + step], lo + f0)
+            return
+        main = torch.cuda.current_stream(eng.device)
+        if self._pre_stream is None:
+            self._pre_stream = torch.cuda.Stream(eng.device)
+            self._pre_done = [torch.cuda.Event(), torch.cuda.Event()]
+            self._slot_free = [torch.cuda.Event(), torch.cuda.Event()]
+        pre = self._pre_stream
+        for f0 in range(0, n, step):
+            cnt = min(step, n - f0)
+            slot = self._slot
+            self._slot ^= 1
+            with torch.cuda.stream(pre):
+                if self._slot_used[slot]:
+                    pre.wait_event(self._slot_free[slot])  # the backbone that read this slot is done
+                eng.preprocess_frames(frames_local[f0 : f0 + cnt], boxes_local[f0 : f0 + cnt], slot)
+                self._pre_done[slot].record(pre)
+            main.wait_event(self._pre_done[slot])
+            eng.backbone_slot(slot, cnt, lo + f0)
+            self._slot_free[slot].record(main)
+            self._slot_used[slot] = True
 
     def exchange_halo(self, n_total: int):
         if self.world == 1:
@@ -107,7 +148,7 @@ class FrameParallelClip:
         for f0, t in bufs:
             self.engine.features_import(f0, t)
 
-    def run(self, frames_local, boxes_local, n_total: int, gather: bool = True):
+    def run(self, frames_local, boxes_local, n_total: int, gather: bool = True, pipeline: bool = False):
         """frames_local / boxes_local: this rank's shard (device tensors for the
         HIP engine). Returns on rank 0 (or every rank when ``gather`` is False:
         the local part) ``(records int32[count,F,4], logp float32[count,F,A])``
@@ -116,9 +157,7 @@ class FrameParallelClip:
         lo, hi = shard_range(n_total, self.world, self.rank)
         assert frames_local.shape[0] == hi - lo, "shard size mismatch"
         eng.clip_begin(n_total)
-        step = eng.max_batch_frames
-        for f0 in range(0, hi - lo, step):
-            eng.backbone_frames(frames_local[f0 : f0 + step], boxes_local[f0 : f0 + step], lo + f0)
+        self.backbone_shard(frames_local, boxes_local, lo, pipeline=pipeline)
         self.exchange_halo(n_total)
         f_lo, f_hi = owned_frame_nums(n_total, self.world, self.rank)
         count = max(f_hi - f_lo, 0)

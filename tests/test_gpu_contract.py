@@ -99,14 +99,16 @@ def test_streaming_chunks_and_feature_exchange(engine):
     engine.head_frames(1, 25, rec[:24], lp[:24])
     engine.head_frames(25, n, rec[24:], lp[24:])
     torch.cuda.synchronize()
-    assert torch.equal(lp.cpu(), torch.from_numpy(ref["logp"]))
+    # tile / split-K are chosen per launch from the batch size, so a different chunking may
+    # sum in a different order: equal to fp32 rounding, not bitwise
+    assert (lp.cpu() - torch.from_numpy(ref["logp"])).abs().max() <= 1e-5
     feats = engine.features_export(0, n)
     engine.clip_begin(n)
     engine.features_import(0, feats)
     lp2 = engine.alloc_logp(n - 1)
     engine.head_frames(1, n, engine.alloc_records(n - 1), lp2)
     torch.cuda.synchronize()
-    assert torch.equal(lp2.cpu(), torch.from_numpy(ref["logp"]))
+    assert torch.equal(lp2.cpu(), lp.cpu())  # same features, same head launches: bitwise
 
 
 def test_full_size_batch_properties(engine, state_dict):
@@ -146,3 +148,27 @@ def test_profile_rows(engine):
     assert {"preprocess_crops", "igemm_conv3x3", "igemm_conv7x7_stem", "head_mlp_logsoftmax"} <= names
     conv = next(r for r in rows if r["name"] == "igemm_conv3x3")
     assert conv["launches"] == 16 and conv["total_ms"] > 0 and conv["flops"] > 1e9
+
+
+def test_two_stream_pipeline_equals_serial(engine):
+    """Crop stage on a second stream into alternating slots (parallel.FrameParallelClip,
+    pipeline=True): several back-to-back clips give bitwise the serial results."""
+    from playaid_core_amd.parallel import FrameParallelClip
+
+    runner = FrameParallelClip(engine, 7, 3)
+    clips = []
+    for seed in (7, 8, 9):
+        n = 40
+        f = torch.from_numpy(synth.make_frames(n, 720, 1280, seed=seed)).cuda()
+        b = torch.from_numpy(synth.make_boxes(n, 720, 1280, first_frame=seed)).cuda()
+        clips.append((f, b, n))
+    torch.cuda.synchronize()
+    serial = [runner.run(f, b, n, pipeline=False)[1].clone() for f, b, n in clips]
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(2):  # reuse of both slots across calls
+        for f, b, n in clips:
+            outs.append(runner.run(f, b, n, pipeline=True)[1].clone())
+    torch.cuda.synchronize()
+    for i, o in enumerate(outs):
+        assert torch.equal(o, serial[i % 3])
