@@ -37,6 +37,18 @@ PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 
 PEAK_HBM_GBS = 8000.0
 
 
+def _pmc_traffic(kernel_name):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_traffic.json, produced by scripts/pmc_traffic.py; counters cannot be read
+    from inside this process). None when no measurement for that kernel is on file."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            t = json.load(f)
+        return t["traffic_bytes_per_launch"] if t.get("kernel") == kernel_name else None
+    except Exception:
+        return None
+
+
 def cpu_baseline(sd, height, width, sample_frames):
     """Reference-literal CPU path (oracle = "port"): batch 1 per (frame,
     fighter), 7 backbone forwards per window, crops through the PIL/cv
@@ -67,7 +79,7 @@ def main():
     ap.add_argument("--frames", type=int, default=64, help="frames per GPU per step")
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--cpu-sample-frames", type=int, default=12)
+    ap.add_argument("--cpu-sample-frames", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-pipeline", action="store_true", help="crop stage and backbone on one stream (no overlap across steps)")
@@ -113,8 +125,9 @@ def main():
     boxes = torch.from_numpy(synth.make_boxes(hi - lo, args.height, args.width, first_frame=lo)).to(device)
     runner = FrameParallelClip(eng, S, DELTA)
 
-    def step():
-        return runner.run(frames, boxes, n_total, gather=True, pipeline=not args.no_pipeline)
+    def step(pipeline=None):
+        pipeline = (not args.no_pipeline) if pipeline is None else pipeline
+        return runner.run(frames, boxes, n_total, gather=True, pipeline=pipeline)
 
     def fence():
         torch.cuda.synchronize(device)
@@ -144,7 +157,7 @@ def main():
         eng.profile_enable(True)
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            step()
+            step(pipeline=False)  # one stream: kernel durations free of cross-stream overlap
         fence()
         dt_prof = time.perf_counter() - t1
         eng.profile_enable(False)
@@ -188,7 +201,7 @@ def main():
                 "peak": PEAK_FP32_MATRIX_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(tf / PEAK_FP32_MATRIX_TFLOPS, 4),
-                "traffic": None,
+                "traffic": _pmc_traffic(dom["name"]),
                 "launches": dom["launches"],
                 "avg_launch_ms": round(dom["total_ms"] / max(dom["launches"], 1), 5),
             }

@@ -48,7 +48,7 @@ hipError_t launch_splitk_reduce(const GemmParams& p, hipStream_t s);
 // crop preprocessing (preprocess.hip)
 // ---------------------------------------------------------------------------
 #define PA_KSIZE_MAX 15
-#define PA_FUSED_LDS_BYTES 49152  // LDS budget of crop_fused_kernel (3 workgroups per CU; measured best of 32/48/64/80 KB)
+#define PA_FUSED_LDS_BYTES 50944  // stage buffers of crop_fused_kernel; + 2176 B of INTER_AREA tables = 53120 B -> 3 workgroups per CU
 
 struct CropPlan {
     int32_t status;

@@ -21,8 +21,8 @@
 //
 // The stage is HBM/L2 streaming work (no matrix shape): one thread per output
 // element, consecutive lanes on consecutive bytes. Five small kernels keep every
-// size general (any box, any frame); the intermediates (~0.65 MB per crop) stay
-// in L2 / Infinity Cache between them.
+// size general (any box, any frame): a fused LDS kernel for crops whose bands fit 48 KB,
+// a multi-pass fallback over global scratch for the rest.
 #include "pa_kernels.h"
 #include "../../include/playaid_hip.h"
 #include <cstdlib>
@@ -98,6 +98,34 @@ __device__ __forceinline__ AreaTab area_tab(int dx, double scale, int ssize) {
     t.a_last = (float)(fmin(fmin(fsx2 - sx2, 1.0), cell) / cell);
     t.s_first = sx1 - t.has_first;
     t.n = t.has_first + t.n_mid + t.has_last;
+    return t;
+}
+
+// 16-byte LDS form of an AreaTab (s_first < 2^16, n_mid < 2^8 for any square side the plan accepts)
+struct AreaTabPacked {
+    uint32_t bits;  // s_first | n_mid << 16 | has_first << 24 | has_last << 25
+    float a_first, a_mid, a_last;
+};
+
+__device__ __forceinline__ AreaTabPacked area_pack(const AreaTab& t) {
+    AreaTabPacked q;
+    q.bits = (uint32_t)t.s_first | ((uint32_t)t.n_mid << 16) | ((uint32_t)t.has_first << 24) | ((uint32_t)t.has_last << 25);
+    q.a_first = t.a_first;
+    q.a_mid = t.a_mid;
+    q.a_last = t.a_last;
+    return q;
+}
+
+__device__ __forceinline__ AreaTab area_unpack(const AreaTabPacked& q) {
+    AreaTab t;
+    t.s_first = (int)(q.bits & 0xffff);
+    t.n_mid = (int)((q.bits >> 16) & 0xff);
+    t.has_first = (int)((q.bits >> 24) & 1);
+    t.has_last = (int)((q.bits >> 25) & 1);
+    t.n = t.has_first + t.n_mid + t.has_last;
+    t.a_first = q.a_first;
+    t.a_mid = q.a_mid;
+    t.a_last = q.a_last;
     return t;
 }
 
@@ -373,18 +401,21 @@ __device__ __forceinline__ uint32_t clip8(int v) {
     return (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
 }
 
+// ---------------------------------------------------------------------------
+// Multi-pass fallback for crops whose bands exceed the fused kernel's LDS budget (very
+// large boxes): same arithmetic, intermediates in global scratch (t1, t2). One workgroup
+// walks the compact list the plan kernel built and runs the three passes of a crop back to
+// back (workgroup barrier + fence between them), so the common case -- empty list -- costs
+// one tiny launch.
 // ImagingResampleHorizontal_8bpc over the slice rows: t1[y][xx][c].
-__global__ __launch_bounds__(256) void resample_h_kernel(const PreprocParams p) {
-  for (int fb = blockIdx.y; fb < *p.fallback_count; fb += gridDim.y) {
-    const int crop = p.fallback_list[fb];
-    const CropPlan pl = p.plans[crop];
-    if (pl.status != PA_CROP_OK || !pl.need_h || pl.fused_rb) continue;
+__device__ void fallback_h(const PreprocParams& p, int crop, const CropPlan& pl) {
+    if (!pl.need_h) return;
     const int total = pl.sh * pl.rw;
     const uint8_t* src = p.frames + ((size_t)pl.frame * p.height + pl.sy0) * p.width * 3 + (size_t)pl.sx0 * 3;
     const size_t src_pitch = (size_t)p.width * 3;
     uint8_t* dst = p.t1 + (size_t)crop * p.t_stride;
     const int32_t* coef = p.coef + (size_t)(crop * 2 + 0) * p.coef_dim * COEF_ROW;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
         const int y = i / pl.rw;
         const int xx = i - y * pl.rw;
         const int32_t* row = coef + (size_t)xx * COEF_ROW;
@@ -402,15 +433,11 @@ __global__ __launch_bounds__(256) void resample_h_kernel(const PreprocParams p) 
         o[1] = (uint8_t)clip8(a1);
         o[2] = (uint8_t)clip8(a2);
     }
-  }
 }
 
 // ImagingResampleVertical_8bpc: t2[yy][x][c] from t1 (or the slice when no horizontal pass ran).
-__global__ __launch_bounds__(256) void resample_v_kernel(const PreprocParams p) {
-  for (int fb = blockIdx.y; fb < *p.fallback_count; fb += gridDim.y) {
-    const int crop = p.fallback_list[fb];
-    const CropPlan pl = p.plans[crop];
-    if (pl.status != PA_CROP_OK || !pl.need_v || pl.fused_rb) continue;
+__device__ void fallback_v(const PreprocParams& p, int crop, const CropPlan& pl) {
+    if (!pl.need_v) return;
     const int total = pl.rh * pl.rw;
     const uint8_t* src;
     size_t src_pitch;
@@ -423,7 +450,7 @@ __global__ __launch_bounds__(256) void resample_v_kernel(const PreprocParams p) 
     }
     uint8_t* dst = p.t2 + (size_t)crop * p.t_stride;
     const int32_t* coef = p.coef + (size_t)(crop * 2 + 1) * p.coef_dim * COEF_ROW;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
         const int yy = i / pl.rw;
         const int x = i - yy * pl.rw;
         const int32_t* row = coef + (size_t)yy * COEF_ROW;
@@ -442,7 +469,6 @@ __global__ __launch_bounds__(256) void resample_v_kernel(const PreprocParams p) 
         o[1] = (uint8_t)clip8(a1);
         o[2] = (uint8_t)clip8(a2);
     }
-  }
 }
 
 struct Canvas {
@@ -546,31 +572,50 @@ __device__ __forceinline__ void write_crop_pixel(const PreprocParams& p, int cro
     }
 }
 
-// Fallback for crops whose bands do not fit the fused kernel's LDS: INTER_AREA
-// from the global-memory intermediates, final black pad to 128 rows.
-__global__ __launch_bounds__(256) void area_resize_kernel(const PreprocParams p) {
-    for (int fb = blockIdx.y; fb < *p.fallback_count; fb += gridDim.y) {
-        const int crop = p.fallback_list[fb];
-        const int i = blockIdx.x * blockDim.x + threadIdx.x;  // 0 .. 128*128-1
+// INTER_AREA from the global-memory intermediates, final black pad to 128 rows.
+__device__ void fallback_area(const PreprocParams& p, int crop, const CropPlan& pl) {
+    Canvas cv;
+    cv.px = pl.px; cv.py = pl.py; cv.rw = pl.rw; cv.rh = pl.rh;
+    if (pl.need_v) {
+        cv.src = p.t2 + (size_t)crop * p.t_stride;
+        cv.pitch = (size_t)pl.rw * 3;
+    } else if (pl.need_h) {
+        cv.src = p.t1 + (size_t)crop * p.t_stride;
+        cv.pitch = (size_t)pl.rw * 3;
+    } else {
+        cv.src = p.frames + ((size_t)pl.frame * p.height + pl.sy0) * p.width * 3 + (size_t)pl.sx0 * 3;
+        cv.pitch = (size_t)p.width * 3;
+    }
+    for (int i = threadIdx.x; i < PA_CROP * PA_CROP; i += blockDim.x) {
         const int dy = i >> 7, dx = i & 127;
-        const CropPlan pl = p.plans[crop];
         int o0 = 0, o1 = 0, o2 = 0;
-        if (dy < pl.out_h) {
-            Canvas cv;
-            cv.px = pl.px; cv.py = pl.py; cv.rw = pl.rw; cv.rh = pl.rh;
-            if (pl.need_v) {
-                cv.src = p.t2 + (size_t)crop * p.t_stride;
-                cv.pitch = (size_t)pl.rw * 3;
-            } else if (pl.need_h) {
-                cv.src = p.t1 + (size_t)crop * p.t_stride;
-                cv.pitch = (size_t)pl.rw * 3;
-            } else {
-                cv.src = p.frames + ((size_t)pl.frame * p.height + pl.sy0) * p.width * 3 + (size_t)pl.sx0 * 3;
-                cv.pitch = (size_t)p.width * 3;
-            }
-            area_pixel(pl, cv, dy, dx, o0, o1, o2);
-        }
+        if (dy < pl.out_h) area_pixel(pl, cv, dy, dx, o0, o1, o2);
         write_crop_pixel(p, crop, i, o0, o1, o2);
+    }
+}
+
+__global__ __launch_bounds__(1024) void crop_fallback_kernel(const PreprocParams p) {
+    const int count = *p.fallback_count;
+    for (int fb = blockIdx.x; fb < count; fb += gridDim.x) {
+        const int crop = p.fallback_list[fb];
+        const CropPlan pl = p.plans[crop];
+        fallback_h(p, crop, pl);
+        __threadfence();
+        __syncthreads();
+        fallback_v(p, crop, pl);
+        __threadfence();
+        __syncthreads();
+        fallback_area(p, crop, pl);
+    }
+    // re-arm the list for the next call (every block has read `count`; the last one to leave resets it)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int done = atomicAdd(p.fallback_count + 1, 1) + 1;
+        if (done == (int)gridDim.x) {
+            p.fallback_count[1] = 0;
+            __threadfence();
+            p.fallback_count[0] = 0;
+        }
     }
 }
 
@@ -622,6 +667,15 @@ __global__ __launch_bounds__(256) void crop_fused_kernel(const PreprocParams p) 
     const int rb = pl.fused_rb;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // computeResizeAreaTab entries for the 128 destination columns and this workgroup's 8
+    // destination rows, computed once (fp64 with divisions) and kept behind the stage buffers
+    AreaTabPacked* tabs = reinterpret_cast<AreaTabPacked*>(pa_smem + p.fused_lds);
+    if (pl.area_mode == 3) {
+        if (tid < PA_CROP) tabs[tid] = area_pack(area_tab(tid, pl.scale_x, pl.d));
+        else if (tid < PA_CROP + 8 && band0 + (tid - PA_CROP) < pl.out_h)
+            tabs[tid] = area_pack(area_tab(band0 + (tid - PA_CROP), pl.scale_y, pl.d));
+    }
+    __syncthreads();
     for (int r0 = band0; r0 < band0 + 8; r0 += rb) {
         const BandRows b = band_rows(pl, r0, r0 + rb);
         const BandLds L = band_lds(pl, b);
@@ -681,14 +735,23 @@ __global__ __launch_bounds__(256) void crop_fused_kernel(const PreprocParams p) 
                     const int sb = xmin * 3;
                     const uint32_t shb = (uint32_t)(sb & 3);
                     const int a_dw = sb >> 2;
-                    for (int y = ck * 4; y < y_end; ++y) {
+                    // the chunk's 4 rows are independent: all 24 LDS reads are issued before the first
+                    // use (the stage is latency-bound at 3 waves per SIMD otherwise). Rows past the end
+                    // of the band are clamped for the reads and skipped for the store.
+                    uint32_t w[4][6];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int y = ck * 4 + u < n0 ? ck * 4 + u : n0 - 1;
                         const uint32_t* src = reinterpret_cast<const uint32_t*>(pa_smem + y * L.p0) + a_dw;
-                        uint32_t w[6], r[6];
 #pragma unroll
-                        for (int q = 0; q < 6; ++q) w[q] = src[q];
+                        for (int q = 0; q < 6; ++q) w[u][q] = src[q];
+                    }
 #pragma unroll
-                        for (int q = 0; q < 5; ++q) r[q] = __builtin_amdgcn_alignbyte(w[q + 1], w[q], shb);
-                        r[5] = __builtin_amdgcn_alignbyte(0u, w[5], shb);
+                    for (int u = 0; u < 4; ++u) {
+                        uint32_t r[6];
+#pragma unroll
+                        for (int q = 0; q < 5; ++q) r[q] = __builtin_amdgcn_alignbyte(w[u][q + 1], w[u][q], shb);
+                        r[5] = __builtin_amdgcn_alignbyte(0u, w[u][5], shb);
                         int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
 #pragma unroll
                         for (int t = 0; t < 7; ++t) {
@@ -697,10 +760,13 @@ __global__ __launch_bounds__(256) void crop_fused_kernel(const PreprocParams p) 
                             a1 += __mul24((int)((r[j1 >> 2] >> (8 * (j1 & 3))) & 0xff), k[t]);
                             a2 += __mul24((int)((r[j2 >> 2] >> (8 * (j2 & 3))) & 0xff), k[t]);
                         }
-                        const int d = L.off1 + y * L.p1 + xx * 3;
-                        pa_smem[d + 0] = (uint8_t)clip8(a0);
-                        pa_smem[d + 1] = (uint8_t)clip8(a1);
-                        pa_smem[d + 2] = (uint8_t)clip8(a2);
+                        const int y = ck * 4 + u;
+                        if (y < n0) {
+                            const int d = L.off1 + y * L.p1 + xx * 3;
+                            pa_smem[d + 0] = (uint8_t)clip8(a0);
+                            pa_smem[d + 1] = (uint8_t)clip8(a1);
+                            pa_smem[d + 2] = (uint8_t)clip8(a2);
+                        }
                     }
                 } else {
                     for (int y = ck * 4; y < y_end; ++y) {
@@ -739,30 +805,66 @@ __global__ __launch_bounds__(256) void crop_fused_kernel(const PreprocParams p) 
             for (int yy = wave; yy < n2; yy += 4) {
                 const int32_t* row = coef_v + (size_t)(b.ry0 + yy) * COEF_ROW;
                 const int ymin = row[0], cnt = row[1];
-                int k[PA_KSIZE_MAX];
-#pragma unroll
-                for (int t = 0; t < PA_KSIZE_MAX; ++t) k[t] = row[2 + t];  // zero beyond cnt
                 const int s0 = (in_base >> 2) + (ymin - b.ty0) * pitch_dw;
                 uint32_t* dst = reinterpret_cast<uint32_t*>(pa_smem + L.off2 + yy * L.p1);
-                for (int j = lane; j < row_dwords; j += 64) {
-                    int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0, a3 = a0;
+                if (pl.ksize_v <= 7) {
+                    // common case: 7 taps fully unrolled (a 15-way unroll spilled the coefficient
+                    // array to scratch); taps beyond cnt have zero coefficients and re-read the
+                    // last valid row
+                    int k[7];
 #pragma unroll
-                    for (int t = 0; t < PA_KSIZE_MAX; ++t) {
-                        if (t < cnt) {  // wave-uniform
-                            const uint32_t v = lds32[s0 + t * pitch_dw + j];
-                            a0 += __mul24((int)(v & 0xff), k[t]);
-                            a1 += __mul24((int)((v >> 8) & 0xff), k[t]);
-                            a2 += __mul24((int)((v >> 16) & 0xff), k[t]);
-                            a3 += __mul24((int)(v >> 24), k[t]);
+                    for (int t = 0; t < 7; ++t) k[t] = t < cnt ? row[2 + t] : 0;
+                    for (int j0 = 0; j0 < row_dwords; j0 += 256) {
+                        // four independent dwords per lane: 28 LDS reads in flight
+                        int acc[4][4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) acc[u][c] = 1 << (PRECISION_BITS - 1);
+#pragma unroll
+                        for (int t = 0; t < 7; ++t) {
+                            const int tr = t < cnt ? t : cnt - 1;
+                            uint32_t v[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int j = j0 + lane + 64 * u;
+                                v[u] = lds32[s0 + tr * pitch_dw + (j < row_dwords ? j : row_dwords - 1)];
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                acc[u][0] += __mul24((int)(v[u] & 0xff), k[t]);
+                                acc[u][1] += __mul24((int)((v[u] >> 8) & 0xff), k[t]);
+                                acc[u][2] += __mul24((int)((v[u] >> 16) & 0xff), k[t]);
+                                acc[u][3] += __mul24((int)(v[u] >> 24), k[t]);
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int j = j0 + lane + 64 * u;
+                            // hipcc 7.2 fuses "two (x >> 22) clamped to u8, packed" into v_ashr_pk_u8_i32
+                            // and then ORs its result as if bits 16..31 were zero; on gfx950 they are not,
+                            // which corrupted bytes 2 and 3 of every dword. The empty asm keeps the four
+                            // clamped values opaque so the pack is plain shifts and ORs.
+                            uint32_t c0 = clip8(acc[u][0]), c1 = clip8(acc[u][1]), c2 = clip8(acc[u][2]), c3 = clip8(acc[u][3]);
+                            asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
+                            if (j < row_dwords) dst[j] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
                         }
                     }
-                    // hipcc 7.2 fuses "two (x >> 22) clamped to u8, packed" into v_ashr_pk_u8_i32 and
-                    // then ORs its result as if bits 16..31 were zero; on gfx950 they are not, which
-                    // corrupted bytes 2 and 3 of every dword. The empty asm keeps the four clamped
-                    // values opaque so the pack is plain shifts and ORs.
-                    uint32_t c0 = clip8(a0), c1 = clip8(a1), c2 = clip8(a2), c3 = clip8(a3);
-                    asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
-                    dst[j] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+                } else {
+                    for (int j = lane; j < row_dwords; j += 64) {
+                        int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0, a3 = a0;
+                        for (int t = 0; t < cnt; ++t) {
+                            const uint32_t v = lds32[s0 + t * pitch_dw + j];
+                            const int kt = row[2 + t];
+                            a0 += __mul24((int)(v & 0xff), kt);
+                            a1 += __mul24((int)((v >> 8) & 0xff), kt);
+                            a2 += __mul24((int)((v >> 16) & 0xff), kt);
+                            a3 += __mul24((int)(v >> 24), kt);
+                        }
+                        uint32_t c0 = clip8(a0), c1 = clip8(a1), c2 = clip8(a2), c3 = clip8(a3);
+                        asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
+                        dst[j] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+                    }
                 }
             }
             in_base = L.off2;
@@ -791,7 +893,86 @@ __global__ __launch_bounds__(256) void crop_fused_kernel(const PreprocParams p) 
             for (int i = tid; i < rb * PA_CROP; i += 256) {
                 const int dy = r0 + (i >> 7), dx = i & 127;
                 int o0 = 0, o1 = 0, o2 = 0;
-                if (dy < pl.out_h) area_pixel(pl, cv, dy, dx, o0, o1, o2);
+                if (dy < pl.out_h) {
+                    if (pl.area_mode == 3) {
+                        // fractional INTER_AREA, the common case. Same fp32 operation order as
+                        // area_pixel(); taps that fall on the black canvas add +0.0f in the
+                        // reference order, so clipping the tap ranges to the pasted region is
+                        // exact. One (unaligned) 32-bit LDS read fetches the three channels.
+                        // table entries as plain scalars (passing the structs by reference made
+                        // hipcc keep them in scratch memory)
+                        const AreaTabPacked qx = tabs[dx], qy = tabs[PA_CROP + dy - band0];
+                        const int x_first = (int)(qx.bits & 0xffff), x_mid = (int)((qx.bits >> 16) & 0xff);
+                        const int x_hf = (int)((qx.bits >> 24) & 1), x_n = x_hf + x_mid + (int)((qx.bits >> 25) & 1);
+                        const int y_first = (int)(qy.bits & 0xffff), y_mid = (int)((qy.bits >> 16) & 0xff);
+                        const int y_hf = (int)((qy.bits >> 24) & 1), y_n = y_hf + y_mid + (int)((qy.bits >> 25) & 1);
+#define PA_ALPHA_X(K) ((K) < x_hf ? qx.a_first : ((K) < x_hf + x_mid ? qx.a_mid : qx.a_last))
+#define PA_ALPHA_Y(J) ((J) < y_hf ? qy.a_first : ((J) < y_hf + y_mid ? qy.a_mid : qy.a_last))
+                        int k_lo = pl.px - x_first, k_hi = pl.px + pl.rw - x_first;
+                        k_lo = k_lo > 0 ? k_lo : 0;
+                        k_hi = k_hi < x_n ? k_hi : x_n;
+                        int j_lo = pl.py - y_first, j_hi = pl.py + pl.rh - y_first;
+                        j_lo = j_lo > 0 ? j_lo : 0;
+                        j_hi = j_hi < y_n ? j_hi : y_n;
+                        float sum0 = 0.f, sum1 = 0.f, sum2 = 0.f;
+                        const int col0 = (x_first + k_lo - pl.px) * 3;
+                        const int nk = k_hi - k_lo;
+                        if (nk <= 6) {
+                            // <= 6 taps x 3 channels = <= 18 bytes per row: six aligned dwords cover them
+                            // at any alignment; funnel-shifted, every byte sits at a static position
+                            float al[6];
+#pragma unroll
+                            for (int k = 0; k < 6; ++k) al[k] = k < nk ? PA_ALPHA_X(k_lo + k) : 0.f;
+                            for (int j = j_lo; j < j_hi; ++j) {
+                                const float beta = PA_ALPHA_Y(j);
+                                const int o = in_base + (y_first + j - pl.py - b.ry0) * in_pitch + col0;
+                                const uint32_t* src = reinterpret_cast<const uint32_t*>(pa_smem + (o & ~3));
+                                const uint32_t shb = (uint32_t)(o & 3);
+                                uint32_t w[6], r[5];
+#pragma unroll
+                                for (int q = 0; q < 6; ++q) w[q] = src[q];
+#pragma unroll
+                                for (int q = 0; q < 5; ++q) r[q] = __builtin_amdgcn_alignbyte(w[q + 1], w[q], shb);
+                                float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+#pragma unroll
+                                for (int k = 0; k < 6; ++k) {
+                                    if (k < nk) {
+                                        const int q0 = 3 * k, q1 = 3 * k + 1, q2 = 3 * k + 2;
+                                        b0 = b0 + (float)((r[q0 >> 2] >> (8 * (q0 & 3))) & 0xff) * al[k];
+                                        b1 = b1 + (float)((r[q1 >> 2] >> (8 * (q1 & 3))) & 0xff) * al[k];
+                                        b2 = b2 + (float)((r[q2 >> 2] >> (8 * (q2 & 3))) & 0xff) * al[k];
+                                    }
+                                }
+                                sum0 = sum0 + beta * b0;
+                                sum1 = sum1 + beta * b1;
+                                sum2 = sum2 + beta * b2;
+                            }
+                        } else {
+                            for (int j = j_lo; j < j_hi; ++j) {
+                                const float beta = PA_ALPHA_Y(j);
+                                int o = in_base + (y_first + j - pl.py - b.ry0) * in_pitch + col0;
+                                float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+                                for (int k = k_lo; k < k_hi; ++k) {
+                                    const float alpha = PA_ALPHA_X(k);
+                                    b0 = b0 + (float)pa_smem[o] * alpha;
+                                    b1 = b1 + (float)pa_smem[o + 1] * alpha;
+                                    b2 = b2 + (float)pa_smem[o + 2] * alpha;
+                                    o += 3;
+                                }
+                                sum0 = sum0 + beta * b0;
+                                sum1 = sum1 + beta * b1;
+                                sum2 = sum2 + beta * b2;
+                            }
+                        }
+#undef PA_ALPHA_X
+#undef PA_ALPHA_Y
+                        o0 = cv_saturate_u8(sum0);
+                        o1 = cv_saturate_u8(sum1);
+                        o2 = cv_saturate_u8(sum2);
+                    } else {
+                        area_pixel(pl, cv, dy, dx, o0, o1, o2);
+                    }
+                }
                 write_crop_pixel(p, crop, dy * PA_CROP + dx, o0, o1, o2);
             }
         }
@@ -802,21 +983,16 @@ __global__ __launch_bounds__(256) void crop_fused_kernel(const PreprocParams p) 
 hipError_t launch_preprocess(const PreprocParams& p_in, hipStream_t s) {
     PreprocParams p = p_in;
     static const int budget = getenv("PA_FUSED_LDS") ? atoi(getenv("PA_FUSED_LDS")) : PA_FUSED_LDS_BYTES;
-    p.fused_lds = budget;
+    p.fused_lds = budget & ~15;
     static const int ablate = getenv("PA_PRE_ABLATE") ? atoi(getenv("PA_PRE_ABLATE")) : 0;  // timing experiments only
     p.ablate = ablate;
     const int ncrops = p.n_frames * p.fighters;
     if (ncrops <= 0) return hipSuccess;
-    if (hipError_t e0 = hipMemsetAsync(p.fallback_count, 0, sizeof(int32_t), s)) return e0;
     hipLaunchKernelGGL(crop_plan_kernel, dim3(ncrops), dim3(64), 0, s, p);
     hipLaunchKernelGGL(crop_coef_kernel, dim3((p.coef_dim + 127) / 128, ncrops * 2), dim3(128), 0, s, p);
-    hipLaunchKernelGGL(crop_fused_kernel, dim3(PA_CROP / 8, ncrops), dim3(256), p.fused_lds > 0 ? p.fused_lds : 16, s, p);
+    hipLaunchKernelGGL(crop_fused_kernel, dim3(PA_CROP / 8, ncrops), dim3(256), p.fused_lds + (PA_CROP + 8) * sizeof(AreaTabPacked), s, p);
     { hipError_t e1 = hipGetLastError(); if (e1 != hipSuccess) return e1; }
-    // multi-kernel fallback for the crops whose bands exceed the LDS budget: small grids that
-    // walk the compact list the plan kernel built (empty in the common case)
-    hipLaunchKernelGGL(resample_h_kernel, dim3(96, 4), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(resample_v_kernel, dim3(96, 4), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(area_resize_kernel, dim3(PA_CROP * PA_CROP / 256, 4), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(crop_fallback_kernel, dim3(16), dim3(1024), 0, s, p);
     return hipGetLastError();
 }
 

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""HBM traffic of the dominant kernel family from two rocprofv3 PMC passes
+(FETCH_SIZE and WRITE_SIZE collected separately, as MI355X_MICROARCH.md prescribes).
+
+  python scripts/pmc_traffic.py <dir with pmc_fetch/ and pmc_write/> <out.json>
+
+Units: both counters are in KiB. On gfx950 FETCH_SIZE reports half the bytes of a wide
+coalesced read stream (guide, section HBM), so it is doubled; WRITE_SIZE is taken as is.
+The igemm launches of one bench step come in a fixed order (stem, 4x layer1, then per
+layer 2..4: conv1, downsample, conv2, conv1, conv2, then fc, then the gather-mode head),
+which is how the sixteen 3x3 launches are told apart from the other users of the kernel."""
+import collections, csv, glob, json, sys
+
+def dispatches(path, counter):
+    rows = list(csv.DictReader(open(glob.glob(path + "/runc/*counter_collection.csv")[0])))
+    out = collections.OrderedDict()
+    for r in rows:
+        if r["Counter_Name"] == counter:
+            out[int(r["Dispatch_Id"])] = (r["Kernel_Name"], float(r["Counter_Value"]))
+    return [out[k] for k in sorted(out)]
+
+def conv3x3_values(disp):
+    ig = [v for (name, v) in disp if "igemm_f32_kernel" in name and ", true," not in name]
+    per_step = 1 + 4 + 3 * 5 + 1
+    assert len(ig) % per_step == 0, (len(ig), per_step)
+    vals = []
+    for s in range(len(ig) // per_step):
+        step = ig[s * per_step:(s + 1) * per_step]
+        idx = [1, 2, 3, 4] + [5 + 5 * l + k for l in range(3) for k in (0, 2, 3, 4)]
+        vals += [step[i] for i in idx]
+    return vals
+
+d = sys.argv[1]
+f = conv3x3_values(dispatches(d + "/pmc_fetch", "FETCH_SIZE"))
+w = conv3x3_values(dispatches(d + "/pmc_write", "WRITE_SIZE"))
+fetch = 2.0 * sum(f) / len(f) * 1024.0
+write = sum(w) / len(w) * 1024.0
+out = {
+    "kernel": "igemm_conv3x3",
+    "launches_sampled": len(f),
+    "fetch_bytes_per_launch": round(fetch),
+    "write_bytes_per_launch": round(write),
+    "traffic_bytes_per_launch": round(fetch + write),
+    "note": "FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, KiB -> bytes, mean over the 16 conv3x3 launches of each step",
+}
+json.dump(out, open(sys.argv[2], "w"), indent=1)
+print(json.dumps(out))

@@ -35,7 +35,11 @@ def test_square_crops_bit_exact(engine, hw):
     boxes[2, 1] = (0.4, 0.6, 128.5 / w, 100.5 / h)
     boxes[3, 0] = (0.5, 0.5, 384.5 / w, 300.5 / h)
     boxes[3, 1] = (0.5, -0.4, 0.15, 0.3)
+    boxes[4, 0] = (0.5, 0.5, 0.5, 0.9)  # huge box: bands exceed the fused kernel's LDS -> multi-pass fallback
+    boxes[4, 1] = (0.3, 0.6, 0.6, 0.5)
     crops, status = engine.square_crops(frames, boxes, padding=30)
+    crops2, status2 = engine.square_crops(frames, boxes, padding=30)  # fallback list re-arms itself
+    assert np.array_equal(crops, crops2) and np.array_equal(status, status2)
     n_ok = 0
     for i in range(n):
         for p in range(2):
