@@ -172,6 +172,16 @@ int pa_preprocess_frames(pa_engine* e, const uint8_t* frames, int32_t n, int32_t
                          void* stream);
 int pa_backbone_slot(pa_engine* e, int32_t slot, int32_t n, int32_t frame0, void* stream);
 
+/* pa_backbone_frames for frames that are NOT consecutive in the clip (a resolution bucket of a
+ * mixed-resolution stream, BASELINE.json configs[4]): frame_ids[n] (device, int32, 0-based)
+ * says where each frame's features go in the cache. The call does not touch host-side clip
+ * state, so it can be captured into a hipGraph and replayed with new buffer contents; tell
+ * the engine which frames are cached with pa_clip_mark_ready (host ids) before pa_head_frames. */
+int pa_backbone_frames_indexed(pa_engine* e, const uint8_t* frames, int32_t n, int32_t height, int32_t width,
+                               const double* boxes, const int32_t* frame_ids, uint8_t* crops_rgb,
+                               int32_t* status, void* stream);
+int pa_clip_mark_ready(pa_engine* e, const int32_t* frame_ids_host, int32_t n);
+
 /* Window gather + Conv1d/MLP head + log_softmax + argmax for frame numbers
  * frame_num_lo .. frame_num_hi-1 (1-based, as run_action_recognition iterates
  * range(1, max_frames), ai_runner.py:508). Replaces

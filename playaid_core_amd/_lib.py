@@ -86,6 +86,8 @@ SYMBOLS = [
     ("pa_backbone_frames", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, _P]),
     ("pa_preprocess_frames", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, _P]),
     ("pa_backbone_slot", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P]),
+    ("pa_backbone_frames_indexed", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
+    ("pa_clip_mark_ready", C.c_int, [_P, _P, C.c_int32]),
     ("pa_head_frames", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P]),
     ("pa_infer_clip", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P]),
     ("pa_features_export", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),

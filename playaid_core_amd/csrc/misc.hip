@@ -138,6 +138,26 @@ hipError_t launch_window_gather(int32_t* gather, int32_t frame_num_lo, int32_t c
     return hipGetLastError();
 }
 
+// feats[i][fighter][:] -> cache[(ids[i]*fighters + fighter)][:], status likewise: places the
+// features of a resolution bucket (non-contiguous frame numbers) into the clip's cache.
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ feats, const int32_t* __restrict__ st,
+                                                           const int32_t* __restrict__ ids, float* __restrict__ cache,
+                                                           int32_t* __restrict__ cache_st, int n, int fighters) {
+    const int row = blockIdx.x;  // 0 .. n*fighters-1
+    const int dst = ids[row / fighters] * fighters + row % fighters;
+    const float4* s4 = reinterpret_cast<const float4*>(feats + (size_t)row * PA_FEATURE_STRIDE);
+    float4* d4 = reinterpret_cast<float4*>(cache + (size_t)dst * PA_FEATURE_STRIDE);
+    d4[threadIdx.x] = s4[threadIdx.x];
+    if (threadIdx.x == 0) cache_st[dst] = st[row];
+}
+
+hipError_t launch_scatter_rows(const float* feats, const int32_t* st, const int32_t* ids, float* cache, int32_t* cache_st,
+                               int32_t n, int32_t fighters, hipStream_t s) {
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(n * fighters), dim3(PA_FEATURE_STRIDE / 4), 0, s, feats, st, ids, cache,
+                       cache_st, n, fighters);
+    return hipGetLastError();
+}
+
 __global__ void identity_gather_kernel(int32_t* gather, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) gather[i] = i;

@@ -780,6 +780,31 @@ int pa_backbone_frames(pa_engine* e, const uint8_t* frames, int32_t n, int32_t h
     return pa_backbone_slot(e, 0, n, frame0, stream);
 }
 
+int pa_backbone_frames_indexed(pa_engine* e, const uint8_t* frames, int32_t n, int32_t height, int32_t width,
+                               const double* boxes, const int32_t* frame_ids, uint8_t* crops_rgb, int32_t* status, void* stream) {
+    if (!e || !frame_ids) return fail(e, PA_ERR_INVALID_ARG, "pa_backbone_frames_indexed: bad argument");
+    if (e->clip_frames < 1) return fail(e, PA_ERR_INVALID_ARG, "pa_backbone_frames_indexed: call pa_clip_begin first");
+    int rc = pa_preprocess_frames(e, frames, n, height, width, boxes, 0, crops_rgb, status, stream);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int F = e->cfg.num_fighters;
+    rc = run_backbone(e, n * F, e->x0_slot[0], e->feats_tmp, s);
+    if (rc) return rc;
+    ProfScope ps(e, s, "scatter_features", 0.0, 2.0 * n * F * PA_FEATURE_STRIDE * 4.0);
+    HIPCHK(e, launch_scatter_rows(e->feats_tmp, e->pre_status[0], frame_ids, e->cache, e->cache_status, n, F, s));
+    return PA_OK;
+}
+
+int pa_clip_mark_ready(pa_engine* e, const int32_t* frame_ids_host, int32_t n) {
+    if (!e || !frame_ids_host || n < 0) return fail(e, PA_ERR_INVALID_ARG, "pa_clip_mark_ready: bad argument");
+    for (int i = 0; i < n; ++i) {
+        if (frame_ids_host[i] < 0 || frame_ids_host[i] >= e->clip_frames)
+            return fail(e, PA_ERR_CAPACITY, "pa_clip_mark_ready: frame id outside the clip");
+        e->ready[frame_ids_host[i]] = 1;
+    }
+    return PA_OK;
+}
+
 int pa_head_frames(pa_engine* e, int32_t lo, int32_t hi, pa_record* records, float* logp, void* stream) {
     if (!e || lo < 1 || hi <= lo) return fail(e, PA_ERR_INVALID_ARG, "pa_head_frames: bad frame range");
     if (e->clip_frames < 1) return fail(e, PA_ERR_INVALID_ARG, "pa_head_frames: call pa_clip_begin first");

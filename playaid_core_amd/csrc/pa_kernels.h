@@ -104,6 +104,8 @@ hipError_t launch_window_gather(int32_t* gather, int32_t frame_num_lo, int32_t c
                                 int32_t seq, int32_t delta, int32_t max_frames, int32_t min_frame,
                                 hipStream_t s);
 hipError_t launch_identity_gather(int32_t* gather, int32_t n, hipStream_t s);
+hipError_t launch_scatter_rows(const float* feats, const int32_t* st, const int32_t* ids, float* cache, int32_t* cache_st,
+                               int32_t n, int32_t fighters, hipStream_t s);
 
 struct HeadParams {
     const float* h1;      // [nwin][512] post-ReLU Conv1d output

@@ -179,6 +179,19 @@ class Engine:
 
     supports_pipelining = True
 
+    def backbone_frames_indexed(self, frames_dev, boxes_dev, ids_dev, crops_rgb=None, status=None):
+        """Crop + backbone for frames whose clip positions are given by ids_dev (int32, device)."""
+        n, h, w, _ = frames_dev.shape
+        self._check(
+            self._lib.pa_backbone_frames_indexed(
+                self._h, _ptr(frames_dev), n, h, w, _ptr(boxes_dev), _ptr(ids_dev), _ptr(crops_rgb), _ptr(status), self._stream()
+            )
+        )
+
+    def clip_mark_ready(self, ids_host):
+        ids = np.ascontiguousarray(ids_host, dtype=np.int32)
+        self._check(self._lib.pa_clip_mark_ready(self._h, ids.ctypes.data_as(C.c_void_p), len(ids)))
+
     def head_frames(self, lo: int, hi: int, records: torch.Tensor, logp: Optional[torch.Tensor]):
         self._check(self._lib.pa_head_frames(self._h, lo, hi, _ptr(records), _ptr(logp), self._stream()))
 

@@ -172,3 +172,32 @@ def test_two_stream_pipeline_equals_serial(engine):
     torch.cuda.synchronize()
     for i, o in enumerate(outs):
         assert torch.equal(o, serial[i % 3])
+
+
+def test_mixed_resolution_stream_with_hipgraph(engine, state_dict):
+    """BASELINE.json configs[4]: 1080p/720p interleaved, bucketed batches, hipGraph replay."""
+    from oracle import pipeline, yolo_crop
+    from playaid_core_amd.stream_runner import MixedResolutionRunner
+
+    n = 40
+    res = [(1080, 1920) if (i % 3) != 1 else (720, 1280) for i in range(n)]
+    frames = [synth.make_frame(i, h, w) for i, (h, w) in enumerate(res)]
+    boxes = np.stack([[synth.fighter_box(i, p, *res[i]) for p in range(2)] for i in range(n)]).astype(np.float64)
+    crops_ref = np.zeros((n, 2, 128, 128, 3), np.uint8)
+    for i in range(n):
+        for p in range(2):
+            ok, c = yolo_crop.square_crop(frames[i], boxes[i, p], 128, padding=30)
+            assert ok
+            crops_ref[i, p] = yolo_crop.runner_input_from_crop(c)
+    ref = pipeline.run_action_recognition(np.zeros((n, 1, 1, 3), np.uint8), boxes, state_dict, mode="cached", crops_rgb=crops_ref)
+    runner = MixedResolutionRunner(engine, batch_frames=8, use_graphs=True)
+    got = runner.run(frames, boxes, want_crops=True)
+    assert runner.captures == 2 and runner.replays == 4 + 2  # 27 frames @1080p -> 4 batches, 13 @720p -> 2
+    assert np.array_equal(got["crops_rgb"], crops_ref)
+    assert np.abs(got["logp"] - ref["logp"]).max() <= 1e-4
+    assert np.array_equal(got["action_id"], ref["action_id"])
+    # steady state: a second clip replays the captured graphs only, and eager mode agrees bitwise
+    again = runner.run(frames, boxes)
+    assert runner.captures == 2 and np.array_equal(again["logp"], got["logp"])
+    eager = MixedResolutionRunner(engine, batch_frames=8, use_graphs=False).run(frames, boxes)
+    assert np.array_equal(eager["logp"], got["logp"])
