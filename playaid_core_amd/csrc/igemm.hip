@@ -117,6 +117,22 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const GemmParams p) {
     }
 #pragma unroll
     for (int i = 0; i < B_ROWS; ++i) b_off[i] = (tile_n * BN + row0 + PASS_ROWS * i) * p.ktot + colq * 4;
+    // optional second source for the last k2_steps k-steps (the 1x1/2 downsample branch of a
+    // residual block, fused into conv2's accumulation as extra K)
+    int a_off2[A_ROWS];
+#pragma unroll
+    for (int i = 0; i < A_ROWS; ++i) {
+        a_off2[i] = 0;
+        if (!GATHER && p.act2) {
+            int m = tile_m * BM + row0 + PASS_ROWS * i;
+            m = m < p.M ? m : p.M - 1;
+            int img, oy, ox;
+            split_m(p, m, img, oy, ox);
+            a_off2[i] = img * p.in2_img_stride + (oy * p.stride2 + p.off2) * p.in2_row_stride +
+                        (ox * p.stride2 + p.off2) * p.in2_px_stride + colq * 4;
+        }
+    }
+    const int nk_main = (p.ktot - p.k2_steps * BK) / BK;
 
     const int nk = p.ktot / BK;
     const int ks_begin = z * p.ksteps_per_split;
@@ -125,10 +141,12 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const GemmParams p) {
 
     // k-step cursor, advanced incrementally (one division at entry only)
     int cur_kc, cur_kx, cur_ky;
+    int issue_ks = ks_begin;  // absolute index of the next k-step to issue
     {
         const int cpt = p.chunk / BK;
-        const int tap = ks_begin / cpt;
-        cur_kc = (ks_begin - tap * cpt) * BK;
+        const int ksm = ks_begin < nk_main ? ks_begin : nk_main;
+        const int tap = ksm / cpt;
+        cur_kc = (ksm - tap * cpt) * BK;
         cur_ky = tap / p.kw_taps;
         cur_kx = tap - cur_ky * p.kw_taps;
     }
@@ -141,28 +159,38 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const GemmParams p) {
     {                                                                                                         \
         float* As_w = lds + (BUF) * STAGE + wave_id * 256;                                                    \
         float* Bs_w = As_w + BM * LDS_STRIDE;                                                                 \
-        const int tap = cur_ky * p.kw_taps + cur_kx;                                                          \
-        if (GATHER) {                                                                                         \
-            _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i) {                                              \
-                const int row = p.gather[a_off[i] + tap];                                                     \
-                glds16(p.act + (size_t)row * p.in_px_stride + cur_kc + colq * 4, As_w + i * 1024);            \
-            }                                                                                                 \
-        } else {                                                                                              \
-            const int tapoff = (cur_ky + p.off_y) * p.in_row_stride + (cur_kx + p.off_x) * p.in_px_stride + cur_kc; \
+        if (issue_ks >= nk_main) {                                                                            \
+            const int kc2 = (issue_ks - nk_main) * BK;                                                        \
             _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i)                                                \
-                glds16(p.act + a_off[i] + tapoff, As_w + i * 1024);                                           \
-        }                                                                                                     \
-        const int koff = tap * p.chunk + cur_kc;                                                              \
-        _Pragma("unroll") for (int i = 0; i < B_ROWS; ++i)                                                    \
-            glds16(p.wgt + b_off[i] + koff, Bs_w + i * 1024);                                                 \
-        cur_kc += BK;                                                                                         \
-        if (cur_kc == p.chunk) {                                                                              \
-            cur_kc = 0;                                                                                       \
-            if (++cur_kx == p.kw_taps) {                                                                      \
-                cur_kx = 0;                                                                                   \
-                ++cur_ky;                                                                                     \
+                glds16(p.act2 + a_off2[i] + kc2, As_w + i * 1024);                                            \
+            const int koff2 = nk_main * BK + kc2;                                                             \
+            _Pragma("unroll") for (int i = 0; i < B_ROWS; ++i)                                                \
+                glds16(p.wgt + b_off[i] + koff2, Bs_w + i * 1024);                                            \
+        } else {                                                                                              \
+            const int tap = cur_ky * p.kw_taps + cur_kx;                                                      \
+            if (GATHER) {                                                                                     \
+                _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i) {                                          \
+                    const int row = p.gather[a_off[i] + tap];                                                 \
+                    glds16(p.act + (size_t)row * p.in_px_stride + cur_kc + colq * 4, As_w + i * 1024);        \
+                }                                                                                             \
+            } else {                                                                                          \
+                const int tapoff = (cur_ky + p.off_y) * p.in_row_stride + (cur_kx + p.off_x) * p.in_px_stride + cur_kc; \
+                _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i)                                            \
+                    glds16(p.act + a_off[i] + tapoff, As_w + i * 1024);                                       \
+            }                                                                                                 \
+            const int koff = tap * p.chunk + cur_kc;                                                          \
+            _Pragma("unroll") for (int i = 0; i < B_ROWS; ++i)                                                \
+                glds16(p.wgt + b_off[i] + koff, Bs_w + i * 1024);                                             \
+            cur_kc += BK;                                                                                     \
+            if (cur_kc == p.chunk) {                                                                          \
+                cur_kc = 0;                                                                                   \
+                if (++cur_kx == p.kw_taps) {                                                                  \
+                    cur_kx = 0;                                                                               \
+                    ++cur_ky;                                                                                 \
+                }                                                                                             \
             }                                                                                                 \
         }                                                                                                     \
+        ++issue_ks;                                                                                           \
     }
 
     const int lane = tid & 63;
@@ -408,11 +436,12 @@ hipError_t launch_igemm(const GemmParams& p_in, GemmTile tile, hipStream_t s) {
     GemmParams p = p_in;
     int bm, bn, bk;
     tile_dims(tile, &bm, &bn, &bk);
-    if (p.chunk % bk != 0) {  // the 7x7 stem has 32-wide taps: fall back to the BK=32 shape
+    if (p.chunk % bk != 0 || p.k2_steps) {  // 32-wide taps (stem) or a fused second source: BK=32 shapes only
         tile = tile == TILE_128x64_K64 ? TILE_128x64 : TILE_64x64;
         tile_dims(tile, &bm, &bn, &bk);
     }
-    if (p.N % bn != 0 || p.chunk % bk != 0 || p.ktot != p.taps * p.chunk || p.M <= 0) return hipErrorInvalidValue;
+    if (p.N % bn != 0 || p.chunk % bk != 0 || p.ktot != p.taps * p.chunk + p.k2_steps * 32 || p.M <= 0) return hipErrorInvalidValue;
+    if (p.k2_steps && (bk != 32 || !p.act2 || p.gather)) return hipErrorInvalidValue;
     auto ilog2 = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
     p.howo_shift = ilog2(p.howo);
     p.wo_shift = ilog2(p.wo);

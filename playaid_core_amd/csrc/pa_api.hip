@@ -34,6 +34,9 @@ struct ConvLayer {
     GemmTile tile = TILE_128x64;
     int splitk = 1;
     bool forced = false;  // tile/split-K pinned by PA_FORCE_* (tuning), else chosen per launch
+    // fused 1x1 stride-2 downsample branch (block 0 of layers 2-4): extra K read from `in2`
+    float* in2 = nullptr;
+    int in2_c = 0, in2_hw = 0, in2_stride = 1;
     double k_alg = 0;  // algorithmic K (unpadded) for FLOP accounting
 };
 
@@ -307,6 +310,17 @@ int run_conv(pa_engine* e, const ConvLayer& L, int crop0, int ncrops, size_t sla
     p.out_img_stride = (int)out_crop;
     p.out_pad = L.out_pad;
     p.relu = L.relu;
+    if (L.in2) {
+        const int w2 = L.in2_hw + 2;  // zero-bordered block input
+        p.act2 = L.in2 + (size_t)crop0 * w2 * w2 * L.in2_c;
+        p.k2_steps = L.in2_c / 32;
+        p.in2_px_stride = L.in2_c;
+        p.in2_row_stride = w2 * L.in2_c;
+        p.in2_img_stride = w2 * w2 * L.in2_c;
+        p.stride2 = L.in2_stride;
+        p.off2 = 1;
+        p.ktot += L.in2_c;
+    }
     GemmTile tile = L.tile;
     int splitk = L.splitk;
     if (!L.forced) choose_tile(p.M, p.N, p.ktot / 32, &tile, &splitk);  // per launch: M depends on the batch
@@ -315,7 +329,7 @@ int run_conv(pa_engine* e, const ConvLayer& L, int crop0, int ncrops, size_t sla
     if ((size_t)p.splitk * p.M * p.N > slab_avail) p.splitk = 1;
     const double flops = 2.0 * p.M * p.N * L.k_alg;
     const double bytes = 4.0 * ((double)ncrops * L.in_hw * L.in_hw * L.cin + (double)p.M * p.N * (L.residual ? 2 : 1) +
-                                (double)p.N * L.k_alg);
+                                (double)p.N * L.k_alg + (L.in2 ? (double)ncrops * L.in2_hw * L.in2_hw * L.in2_c : 0.0));
     ProfScope ps(e, s, prof_name, flops, bytes);
     HIPCHK(e, launch_igemm(p, tile, s));
     return PA_OK;
@@ -530,8 +544,9 @@ int pa_create(const pa_config* cfg, const void* blob, size_t blob_bytes, pa_engi
 
     // ---- layer table + weights --------------------------------------------
     BlobReader br{reinterpret_cast<const float*>(hdr + 8), reinterpret_cast<const float*>(hdr + 8) + blob_float_count(S, A)};
+    std::vector<float> keep_w, keep_b;  // host copy of the last conv added with keep=true (not uploaded yet)
     auto add_conv = [&](const std::string& name, int cin, int cout, int k, int stride, int in_hw, float* in, float* outb,
-                        float* residual, int relu) -> int {
+                        float* residual, int relu, bool keep = false) -> int {
         ConvLayer L;
         L.name = name;
         L.cin = cin;
@@ -557,10 +572,16 @@ int pa_create(const pa_config* cfg, const void* blob, size_t blob_bytes, pa_engi
         L.k_alg = (double)cin * k * k;
         std::vector<float> w, b;
         if (!fold_conv(br, L, w, b)) return fail(e, PA_ERR_BAD_WEIGHTS, "weight blob too short at " + name);
-        int r2 = upload(e, &L.wgt, w);
-        if (r2) return r2;
-        r2 = upload(e, &L.bias, b);
-        if (r2) return r2;
+        int r2 = PA_OK;
+        if (keep) {
+            keep_w.swap(w);
+            keep_b.swap(b);
+        } else {
+            r2 = upload(e, &L.wgt, w);
+            if (r2) return r2;
+            r2 = upload(e, &L.bias, b);
+            if (r2) return r2;
+        }
         choose_tile(NC * L.out_hw * L.out_hw, cout, L.taps * L.chunk / 32, &L.tile, &L.splitk);
         // tuning knobs (scripts/tune_tiles.py): PA_FORCE_TILE=0|1|2, PA_FORCE_SPLITK=n
         if (const char* ft = getenv("PA_FORCE_TILE")) {
@@ -584,22 +605,45 @@ int pa_create(const pa_config* cfg, const void* blob, size_t blob_bytes, pa_engi
             const int stride = li == 0 ? 1 : 2;
             const int hw_out = hw_in[li] / stride;
             const size_t buf = (size_t)NC * (hw_out + 2) * (hw_out + 2) * co;
-            float *mid, *outA, *outB, *ds = nullptr;
+            float *mid, *outA, *outB;
             ALLOC(mid, buf, true);
             ALLOC(outA, buf, true);
             ALLOC(outB, buf, true);
-            if (li > 0) ALLOC(ds, buf, true);
             const std::string pre = "layer" + std::to_string(li + 1);
             // block 0 (blob order: conv1, bn1, conv2, bn2, downsample)
             rc = add_conv(pre + ".0.conv1", cin, co, 3, stride, hw_in[li], cur, mid, nullptr, 1);
             if (rc) return rc;
-            rc = add_conv(pre + ".0.conv2", co, co, 3, 1, hw_out, mid, outA, li > 0 ? ds : cur, 1);
-            if (rc) return rc;
-            if (li > 0) {
-                rc = add_conv(pre + ".0.downsample", cin, co, 1, stride, hw_in[li], cur, ds, nullptr, 0);
+            if (li == 0) {
+                rc = add_conv(pre + ".0.conv2", co, co, 3, 1, hw_out, mid, outA, cur, 1);
                 if (rc) return rc;
-                // the downsample must run before conv2 consumes it as residual
-                std::swap(e->convs[e->convs.size() - 1], e->convs[e->convs.size() - 2]);
+            } else {
+                // conv2 and the 1x1/2 downsample of the block input are ONE implicit GEMM:
+                //   out = relu( [W2' | Wd'] . [im2col3x3(mid) ; x(2y,2x)] + (b2' + bd') )
+                // (K = 9*co + cin): no separate downsample launch, no residual tensor.
+                rc = add_conv(pre + ".0.conv2", co, co, 3, 1, hw_out, mid, outA, nullptr, 1, /*keep=*/true);
+                if (rc) return rc;
+                ConvLayer D;  // only used to fold the downsample weights
+                D.name = pre + ".0.downsample";
+                D.cin = cin; D.cout = co; D.kh = D.kw = 1; D.taps = 1; D.kw_taps = 1; D.chunk = cin;
+                std::vector<float> wd, bd;
+                if (!fold_conv(br, D, wd, bd)) return fail(e, PA_ERR_BAD_WEIGHTS, "weight blob too short at " + D.name);
+                ConvLayer& L = e->convs.back();
+                const int k_main = 9 * co, k_all = k_main + cin;
+                std::vector<float> wf((size_t)co * k_all), bf(co);
+                for (int o = 0; o < co; ++o) {
+                    memcpy(&wf[(size_t)o * k_all], &keep_w[(size_t)o * k_main], sizeof(float) * k_main);
+                    memcpy(&wf[(size_t)o * k_all + k_main], &wd[(size_t)o * cin], sizeof(float) * cin);
+                    bf[o] = (float)((double)keep_b[o] + (double)bd[o]);
+                }
+                rc = upload(e, &L.wgt, wf);
+                if (rc) return rc;
+                rc = upload(e, &L.bias, bf);
+                if (rc) return rc;
+                L.in2 = cur;
+                L.in2_c = cin;
+                L.in2_hw = hw_in[li];
+                L.in2_stride = stride;
+                L.k_alg += cin;
             }
             rc = add_conv(pre + ".1.conv1", co, co, 3, 1, hw_out, outA, mid, nullptr, 1);
             if (rc) return rc;

@@ -33,6 +33,10 @@ struct GemmParams {
     int32_t in_img_stride, in_row_stride, in_px_stride, stride, off_y, off_x;
     int32_t out_img_stride, out_row_stride, out_px_stride, out_pad;
     int32_t relu;
+    // optional second im2col source appended to K (k2_steps * 32 values, 1x1 taps): act2 addressed as
+    //   act2 + img*in2_img_stride + (oy*stride2 + off2)*in2_row_stride + (ox*stride2 + off2)*in2_px_stride + kc
+    const float* act2;
+    int32_t k2_steps, in2_img_stride, in2_row_stride, in2_px_stride, stride2, off2;
     int32_t splitk, ksteps_per_split;
     int32_t tiles_m, tiles_n;
     unsigned long long* clk;  // ablation builds only: in-kernel clock stamps

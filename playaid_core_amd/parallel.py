@@ -94,6 +94,7 @@ class FrameParallelClip:
         self._slot_free = None
         self._slot_used = [False, False]
         self._slot = 0
+        self._out = None
 
     def backbone_shard(self, frames_local, boxes_local, lo: int, pipeline: bool = False):
         """Crop + backbone for this rank's frames, in chunks of the engine's batch size.
@@ -161,8 +162,10 @@ class FrameParallelClip:
         self.exchange_halo(n_total)
         f_lo, f_hi = owned_frame_nums(n_total, self.world, self.rank)
         count = max(f_hi - f_lo, 0)
-        records = eng.alloc_records(max(count, 1))
-        logp = eng.alloc_logp(max(count, 1))
+        # result buffers are kept between calls (a fresh torch.zeros costs a fill kernel each)
+        if self._out is None or self._out[0].shape[0] < max(count, 1):
+            self._out = (eng.alloc_records(max(count, 1)), eng.alloc_logp(max(count, 1)))
+        records, logp = self._out
         if count > 0:
             eng.head_frames(f_lo, f_hi, records, logp)
         if not gather or self.world == 1:

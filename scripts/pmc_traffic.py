@@ -6,9 +6,9 @@
 
 Units: both counters are in KiB. On gfx950 FETCH_SIZE reports half the bytes of a wide
 coalesced read stream (guide, section HBM), so it is doubled; WRITE_SIZE is taken as is.
-The igemm launches of one bench step come in a fixed order (stem, 4x layer1, then per
-layer 2..4: conv1, downsample, conv2, conv1, conv2, then fc, then the gather-mode head),
-which is how the sixteen 3x3 launches are told apart from the other users of the kernel."""
+The igemm launches of one bench step come in a fixed order (stem, the sixteen 3x3 convs,
+fc, then the gather-mode head), which is how the 3x3 launches are told apart from the
+other users of the kernel."""
 import collections, csv, glob, json, sys
 
 def dispatches(path, counter):
@@ -21,12 +21,12 @@ def dispatches(path, counter):
 
 def conv3x3_values(disp):
     ig = [v for (name, v) in disp if "igemm_f32_kernel" in name and ", true," not in name]
-    per_step = 1 + 4 + 3 * 5 + 1
+    per_step = 1 + 16 + 1
     assert len(ig) % per_step == 0, (len(ig), per_step)
     vals = []
     for s in range(len(ig) // per_step):
         step = ig[s * per_step:(s + 1) * per_step]
-        idx = [1, 2, 3, 4] + [5 + 5 * l + k for l in range(3) for k in (0, 2, 3, 4)]
+        idx = list(range(1, 17))
         vals += [step[i] for i in idx]
     return vals
 
