@@ -36,14 +36,14 @@ int main() {
         const int grid = 256 * wpc, iters = 10000;
         for (int rep = 0; rep < 3; ++rep) {
             hipEventRecord(e0);
-            if (rnd) hipLaunchKernelGGL((mfma_loop<4, true>), dim3(grid), dim3(256), 0, 0, out, iters, clk);
-            else hipLaunchKernelGGL((mfma_loop<4, false>), dim3(grid), dim3(256), 0, 0, out, iters, clk);
+            if (rnd) hipLaunchKernelGGL((mfma_loop<1, true>), dim3(grid), dim3(256), 0, 0, out, iters * 4, clk);
+            else hipLaunchKernelGGL((mfma_loop<2, true>), dim3(grid), dim3(256), 0, 0, out, iters * 2, clk);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             std::vector<unsigned long long> h(grid * 2); hipMemcpy(h.data(), clk, grid * 16, hipMemcpyDeviceToHost);
             double flops = (double)grid * 4 * iters * 4 * 2 * 32 * 32 * 2 * 2;
             double ghz = (double)h[0] / (double)h[1] * 0.1;
-            printf("random=%d wg/CU %d: %.3f ms  %.1f TF  in-kernel clock %.3f GHz (cycles %llu)\n", rnd, wpc, ms, flops / ms / 1e9, ghz, h[0]);
+            printf("chains=%d wg/CU %d: %.3f ms  %.1f TF  in-kernel clock %.3f GHz (cycles %llu)\n", rnd ? 1 : 2, wpc, ms, flops / ms / 1e9, ghz, h[0]);
         }
     }
     return 0;
