@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--cpu-sample-frames", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse ranks > GPUs)")
     ap.add_argument("--no-pipeline", action="store_true", help="crop stage and backbone on one stream (no overlap across steps)")
     args = ap.parse_args()
 
@@ -91,11 +92,15 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)  # (== local_rank on a real N-GPU node)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:  # rehearsal of the multi-rank path on a box with fewer GPUs than ranks
+            dist.init_process_group(args.backend)
 
     F, S, A, DELTA = 2, 7, 63, 3
     n_local = args.frames
@@ -109,7 +114,8 @@ def main():
         blob = pack_state_dict(sd, S, A)
         nbytes = blob.nbytes
     if world > 1:
-        nb = torch.tensor([nbytes if rank == 0 else 0], dtype=torch.int64, device=device)
+        comm_dev = device if args.backend == "nccl" else "cpu"
+        nb = torch.tensor([nbytes if rank == 0 else 0], dtype=torch.int64, device=comm_dev)
         dist.broadcast(nb, src=0)
         blob = broadcast_blob(blob if rank == 0 else None, int(nb.item()), device)
     eng = Engine(
@@ -145,7 +151,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     # ---- kernel pass: the same K steps again with every launch bracketed by HIP events on

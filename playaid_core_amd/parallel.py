@@ -71,9 +71,16 @@ def halo_plan(n_total: int, world: int, rank: int, reach: int):
     return recvs, sends
 
 
+def _host_staged(group=None) -> bool:
+    """True when the process group cannot move device tensors (gloo): collectives then go
+    through host copies. Only used to rehearse the multi-rank path on boxes with fewer GPUs
+    than ranks; the product backend is "nccl" (RCCL), which takes device tensors directly."""
+    return dist.get_backend(group) != "nccl"
+
+
 def broadcast_blob(blob: Optional[np.ndarray], nbytes: int, device: torch.device, group=None) -> np.ndarray:
     """One broadcast of the weight blob (61.4 MB fp32) from rank 0."""
-    t = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    t = torch.empty(nbytes, dtype=torch.uint8, device="cpu" if _host_staged(group) else device)
     if dist.get_rank(group) == 0:
         t.copy_(torch.from_numpy(blob))
     dist.broadcast(t, src=0, group=group)
@@ -135,12 +142,15 @@ class FrameParallelClip:
         if self.world == 1:
             return
         recvs, sends = halo_plan(n_total, self.world, self.rank, self.reach)
+        staged = _host_staged(self.group)
         ops, bufs = [], []
         for peer, f0, cnt in sends:
             t = self.engine.features_export(f0, cnt)
-            ops.append(dist.P2POp(dist.isend, t, peer, self.group))
+            ops.append(dist.P2POp(dist.isend, t.cpu() if staged else t, peer, self.group))
         for peer, f0, cnt in recvs:
             t = self.engine.features_buffer(cnt)
+            if staged:
+                t = torch.empty(t.shape, dtype=t.dtype)
             bufs.append((f0, t))
             ops.append(dist.P2POp(dist.irecv, t, peer, self.group))
         if ops:
@@ -177,6 +187,8 @@ class FrameParallelClip:
         lp_pad = eng.alloc_logp(cap)
         rec_pad[:count] = records[:count]
         lp_pad[:count] = logp[:count]
+        if _host_staged(self.group):
+            rec_pad, lp_pad = rec_pad.cpu(), lp_pad.cpu()
         rec_all = [torch.empty_like(rec_pad) for _ in range(self.world)]
         lp_all = [torch.empty_like(lp_pad) for _ in range(self.world)]
         dist.all_gather(rec_all, rec_pad, group=self.group)
