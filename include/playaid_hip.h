@@ -138,6 +138,15 @@ int pa_square_crops(pa_engine* e, const uint8_t* frames, int32_t n, int32_t heig
                     const double* boxes, int32_t padding, int32_t swap_rb, uint8_t* crops,
                     int32_t* status, void* stream);
 
+/* Boxes from the game log instead of a detector. Replaces the
+ * projection half of Fighter.set_from_json (fighter.py:494-539: calculate_lookat_matrix,
+ * calculate_intrinsic_matrix, project_point_to_pixel on four corners, all for the
+ * reference's hard-coded 1280x720 image) + YoloCrop.from_pixel_coordinates (fighter.py:170-190).
+ * log_rows: float64[n_rows,9] = pos_x, pos_y, camera_position xyz, camera_target_position
+ * xyz, fov in degrees (STAGE_ENUM_TO_DATA[stage]["fov"], fighter.py:488); boxes:
+ * float64[n_rows,4] normalised (cx,cy,w,h), directly usable as the `boxes` of the calls below. */
+int pa_project_boxes(pa_engine* e, const double* log_rows, int32_t n_rows, double* boxes, void* stream);
+
 /* ---- b2: the runner loop ------------------------------------------------ */
 
 /* Start a clip of clip_frames frames (= the reference's max_frames,

@@ -82,6 +82,7 @@ SYMBOLS = [
     ("pa_weight_blob_bytes", C.c_size_t, [C.c_int, C.c_int]),
     ("pa_infer_windows", C.c_int, [_P, _P, C.c_int32, _P, _P]),
     ("pa_square_crops", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, _P]),
+    ("pa_project_boxes", C.c_int, [_P, _P, C.c_int32, _P, _P]),
     ("pa_clip_begin", C.c_int, [_P, C.c_int32]),
     ("pa_backbone_frames", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, _P]),
     ("pa_preprocess_frames", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, _P]),

@@ -776,6 +776,12 @@ int pa_square_crops(pa_engine* e, const uint8_t* frames, int32_t n, int32_t heig
     return run_preprocess(e, frames, n, height, width, boxes, padding, swap_rb, crops, nullptr, status, (hipStream_t)stream);
 }
 
+int pa_project_boxes(pa_engine* e, const double* log_rows, int32_t n_rows, double* boxes, void* stream) {
+    if (!e || !log_rows || !boxes || n_rows < 1) return fail(e, PA_ERR_INVALID_ARG, "pa_project_boxes: bad argument");
+    HIPCHK(e, launch_project_boxes(log_rows, boxes, n_rows, (hipStream_t)stream));
+    return PA_OK;
+}
+
 int pa_clip_begin(pa_engine* e, int32_t clip_frames) {
     if (!e || clip_frames < 1) return fail(e, PA_ERR_INVALID_ARG, "pa_clip_begin: bad argument");
     if (clip_frames > e->cfg.max_clip_frames) return fail(e, PA_ERR_CAPACITY, "pa_clip_begin: clip longer than max_clip_frames");

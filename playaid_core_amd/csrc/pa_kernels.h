@@ -93,6 +93,8 @@ struct PreprocParams {
 };
 
 hipError_t launch_preprocess(const PreprocParams& p, hipStream_t s);
+// log rows [n][9] (pos_x,pos_y,cam xyz,target xyz,fov deg) -> normalised boxes [n][4]
+hipError_t launch_project_boxes(const double* log, double* boxes, int32_t n, hipStream_t s);
 
 // ---------------------------------------------------------------------------
 // small kernels (misc.hip)

@@ -980,6 +980,60 @@ __global__ __launch_bounds__(256) void crop_fused_kernel(const PreprocParams p) 
     }
 }
 
+// ---------------------------------------------------------------------------
+// Log-projection boxes: the reference's current source of
+// fighter boxes. Fighter.set_from_json (playaid/fighter.py:494-539) projects four corners
+// around the logged world position through a look-at camera (calculate_lookat_matrix :87-121,
+// calculate_intrinsic_matrix :66-84, project_point_to_pixel :124-155, all for a hard-coded
+// 1280x720 image) and YoloCrop.from_pixel_coordinates (:170-190) turns the rounded pixels
+// into a normalised box. One thread per (frame, fighter), fp64 like numpy.
+// log row: pos_x, pos_y, cam_x, cam_y, cam_z, tgt_x, tgt_y, tgt_z, fov_degrees.
+__global__ void project_boxes_kernel(const double* __restrict__ log, double* __restrict__ boxes, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double* r = log + (size_t)i * 9;
+    const double W = 1280.0, H = 720.0;
+    // look-at basis
+    double fx = r[2] - r[5], fy = r[3] - r[6], fz = r[4] - r[7];
+    const double fn = sqrt(fx * fx + fy * fy + fz * fz);
+    fx /= fn; fy /= fn; fz /= fn;
+    double rx = 1.0 * fz - 0.0 * fy, ry = 0.0 * fx - 0.0 * fz, rz = 0.0 * fy - 1.0 * fx;  // cross(up, forward)
+    const double rn = sqrt(rx * rx + ry * ry + rz * rz);
+    rx /= rn; ry /= rn; rz /= rn;
+    const double ux = fy * rz - fz * ry, uy = fz * rx - fx * rz, uz = fx * ry - fy * rx;  // cross(forward, right)
+    const double fov_rad = r[8] * (3.141592653589793 / 180.0);
+    const double focal = W / (2.0 * tan(fov_rad / 2.0));
+    const double dxs[4] = {-10.0, 10.0, -10.0, 10.0};
+    const double dys[4] = {20.0, 20.0, -3.0, -3.0};
+    double px[4], py[4];
+    for (int c = 0; c < 4; ++c) {
+        // inverse of [R | t] with orthonormal rows R = (right, up, -forward): R^T (p - t)
+        const double dx = r[0] + dxs[c] - r[2], dy = r[1] + dys[c] - r[3], dz = 0.0 - r[4];
+        const double cxm = rx * dx + ux * dy - fx * dz;
+        const double cym = ry * dx + uy * dy - fy * dz;
+        const double czm = rz * dx + uz * dy - fz * dz;
+        const double nx = cxm / czm, ny = cym / czm;
+        const double ix = focal * nx + W / 2.0;
+        const double iy = H - (focal * ny + H / 2.0);
+        px[c] = rint(ix);  // np.round: half to even
+        py[c] = rint(iy);
+    }
+    const double cx = (px[0] + px[1] + px[2] + px[3]) / 4.0, cy = (py[0] + py[1] + py[2] + py[3]) / 4.0;
+    const double bw = fmax(fmax(px[0], px[1]), fmax(px[2], px[3])) - fmin(fmin(px[0], px[1]), fmin(px[2], px[3]));
+    const double bh = fmax(fmax(py[0], py[1]), fmax(py[2], py[3])) - fmin(fmin(py[0], py[1]), fmin(py[2], py[3]));
+    double* o = boxes + (size_t)i * 4;
+    o[0] = cx / W;
+    o[1] = cy / H;
+    o[2] = bw / W;
+    o[3] = bh / H;
+}
+
+hipError_t launch_project_boxes(const double* log, double* boxes, int32_t n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(project_boxes_kernel, dim3((n + 127) / 128), dim3(128), 0, s, log, boxes, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_preprocess(const PreprocParams& p_in, hipStream_t s) {
     PreprocParams p = p_in;
     static const int budget = getenv("PA_FUSED_LDS") ? atoi(getenv("PA_FUSED_LDS")) : PA_FUSED_LDS_BYTES;

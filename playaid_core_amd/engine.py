@@ -152,6 +152,14 @@ class Engine:
         torch.cuda.synchronize(self.device)
         return crops[:, :nf].cpu().numpy(), status[:, :nf].cpu().numpy()
 
+    # -- boxes from the game log ----------------------------------------------
+    def project_boxes(self, log_rows) -> torch.Tensor:
+        """log_rows float64[..., 9] (pos_x,pos_y,cam xyz,target xyz,fov deg) -> boxes float64[..., 4] on device."""
+        ld = self._dev(log_rows, torch.float64)
+        out = torch.empty(ld.shape[:-1] + (4,), dtype=torch.float64, device=self.device)
+        self._check(self._lib.pa_project_boxes(self._h, _ptr(ld), ld.numel() // 9, _ptr(out), self._stream()))
+        return out
+
     # -- b2: clip ------------------------------------------------------------
     def clip_begin(self, clip_frames: int):
         self._check(self._lib.pa_clip_begin(self._h, clip_frames))

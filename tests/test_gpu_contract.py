@@ -201,3 +201,34 @@ def test_mixed_resolution_stream_with_hipgraph(engine, state_dict):
     assert runner.captures == 2 and np.array_equal(again["logp"], got["logp"])
     eager = MixedResolutionRunner(engine, batch_frames=8, use_graphs=False).run(frames, boxes)
     assert np.array_equal(eager["logp"], got["logp"])
+
+
+def test_log_projection_boxes(engine, tmp_path):
+    """boxes from the game log on the device vs the literal numpy oracle."""
+    from oracle import projection as oproj
+    from playaid_core_amd import projection, timeline
+
+    rng = np.random.default_rng(5)
+    n = 400
+    rows = np.zeros((n, 2, 9))
+    rows[..., 0] = rng.uniform(-70, 70, (n, 2))          # pos_x
+    rows[..., 1] = rng.uniform(-5, 45, (n, 2))           # pos_y
+    rows[..., 2:5] = np.array([0.0, 15.8, 148.5]) + rng.normal(0, [8, 4, 25], (n, 1, 3))
+    rows[..., 5:8] = np.array([0.0, 11.2, 0.0]) + rng.normal(0, [8, 4, 0], (n, 1, 3))
+    rows[..., 8] = rng.choice([30.0, 50.0], (n, 1))
+    got = engine.project_boxes(rows).cpu().numpy()
+    for i in range(n):
+        for p in range(2):
+            r = rows[i, p]
+            ref = oproj.project_box(r[0], r[1], list(r[2:5]), list(r[5:8]), r[8])
+            assert tuple(got[i, p]) == ref, (i, p, got[i, p], ref)
+    # the stub log of the plumbing config goes through the same path
+    log = str(tmp_path / "stub.log")
+    synth.make_stub_log(log, 16)
+    tl = timeline.load_ground_truth_from_path(log)
+    lr = projection.log_rows_from_timeline(tl)
+    assert lr.shape == (16, 2, 9) and (lr[..., 8] == 50).all()
+    boxes = engine.project_boxes(lr).cpu().numpy()
+    d0 = tl[3][1]
+    assert tuple(boxes[3, 1]) == oproj.project_box(d0["pos_x"], d0["pos_y"], list(d0["camera_position"].values()),
+                                                    list(d0["camera_target_position"].values()), 50)
