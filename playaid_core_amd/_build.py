@@ -19,6 +19,7 @@ ARCH = "gfx950"
 # bit-for-bit and must not have its multiplies and adds fused.
 SOURCES = [
     ("igemm.hip", []),
+    ("stem.hip", []),
     ("misc.hip", []),
     ("preprocess.hip", ["-ffp-contract=off"]),
     ("pa_api.hip", []),

@@ -69,7 +69,9 @@ __device__ __forceinline__ void split_m(const GemmParams& p, int m, int& img, in
 
 // ABL: timing-only ablation bits for scripts/ablate_igemm.sh (results are wrong when != 0):
 //   1 no global->LDS loads, 4 no barriers in the loop, 8 no MFMAs.
-template <int BM, int BN, int BK, bool GATHER, int ABL = 0>
+// SKIPW: every 4th k carries a zero weight (the stem's channel pad, k = ky*32 + kx*4 + c with c < 3),
+// so the MFMA of each fragment's .w component is dropped -- 25 % fewer matrix instructions.
+template <int BM, int BN, int BK, bool GATHER, int ABL = 0, bool SKIPW = false>
 __global__ __launch_bounds__(256) void igemm_f32_kernel(const GemmParams p) {
     constexpr int MI = BM / 64;  // 32x32 MFMA tiles per wave along M
     constexpr int NI = BN / 64;
@@ -302,7 +304,7 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const GemmParams p) {
                     }
                     if (!(ABL & 8)) {
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[mi][ni], 0, 0, 0);
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[mi][ni], 0, 0, 0);
+                        if (!SKIPW) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[mi][ni], 0, 0, 0);
                     }
                 }
         }
@@ -417,6 +419,8 @@ static hipError_t launch_tile(const GemmParams& p, hipStream_t s) {
 #endif
     if (p.gather)
         hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, BK, true>), dim3(grid), dim3(256), 0, s, p);
+    else if (p.skip_w && BK == 32 && BN == 64)
+        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, (BN == 64 ? 32 : BK), false, 0, (BN == 64 && BK == 32)>), dim3(grid), dim3(256), 0, s, p);
     else
         hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, BK, false>), dim3(grid), dim3(256), 0, s, p);
     return hipGetLastError();

@@ -297,6 +297,7 @@ int run_conv(pa_engine* e, const ConvLayer& L, int crop0, int ncrops, size_t sla
     p.kw_taps = L.kw_taps;
     p.chunk = L.chunk;
     p.ktot = L.taps * L.chunk;
+    p.skip_w = L.kh == 7;  // stem: 3 channels in 4-float pixels
     p.howo = L.out_hw * L.out_hw;
     p.wo = L.out_hw;
     p.in_px_stride = L.in_px_stride;
@@ -339,8 +340,21 @@ int run_backbone_part(pa_engine* e, int crop0, int ncrops, const float* x_in, fl
     int rc;
     ConvLayer stem = e->convs[0];
     stem.in = const_cast<float*>(x_in);  // x_in / feats_out are the caller's bases: crop0 is applied by run_conv
-    rc = run_conv(e, stem, crop0, ncrops, slab_off, s, "igemm_conv7x7_stem");
-    if (rc) return rc;
+    static const bool stem_igemm = getenv("PA_STEM_IGEMM") && atoi(getenv("PA_STEM_IGEMM"));  // A/B knob: generic engine
+    if (stem_igemm) {
+        rc = run_conv(e, stem, crop0, ncrops, slab_off, s, "igemm_conv7x7_stem");
+        if (rc) return rc;
+    } else {
+        StemParams sp;
+        sp.x = x_in + (size_t)crop0 * 134 * 134 * 4;
+        sp.wgt = stem.wgt;
+        sp.bias = stem.bias;
+        sp.out = e->c1 + (size_t)crop0 * 66 * 66 * 64;
+        sp.tiles = ncrops * 32;
+        const double px = (double)ncrops * 64 * 64;
+        ProfScope ps(e, s, "stem_conv7x7", 2.0 * px * 64 * 147, 4.0 * ((double)ncrops * 128 * 128 * 3 + px * 64 + 64.0 * 147));
+        HIPCHK(e, launch_stem7x7(sp, s));
+    }
     {
         ProfScope ps(e, s, "maxpool3x3", 0.0, 4.0 * ncrops * (64.0 * 64 * 64 + 32.0 * 32 * 64));
         HIPCHK(e, launch_maxpool(e->c1 + (size_t)crop0 * 66 * 66 * 64, e->p1 + (size_t)crop0 * 34 * 34 * 64, ncrops, s));

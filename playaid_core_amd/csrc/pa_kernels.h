@@ -38,6 +38,7 @@ struct GemmParams {
     const float* act2;
     int32_t k2_steps, in2_img_stride, in2_row_stride, in2_px_stride, stride2, off2;
     int32_t splitk, ksteps_per_split;
+    int32_t skip_w;         // 1: k % 4 == 3 always meets a zero weight (stem channel pad): those MFMAs are skipped
     int32_t tiles_m, tiles_n;
     unsigned long long* clk;  // ablation builds only: in-kernel clock stamps
 };
@@ -46,6 +47,17 @@ struct GemmParams {
 enum GemmTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x64 = 2, TILE_128x64_K64 = 3, TILE_64x64_K64 = 4 };
 
 hipError_t launch_igemm(const GemmParams& p, GemmTile tile, hipStream_t s);
+
+// Persistent direct 7x7/2 stem (stem.hip): x = [crops][134][134][4] fp32 (3-pixel zero border,
+// channel 3 = 0), wgt = [64][7 ky][8 px][4 ch] (the igemm stem layout), out = [crops][66][66][64].
+struct StemParams {
+    const float* x;
+    const float* wgt;
+    const float* bias;
+    float* out;
+    int32_t tiles;  // crops * 32 (one tile = two output rows of one crop)
+};
+hipError_t launch_stem7x7(const StemParams& p, hipStream_t s);
 hipError_t launch_splitk_reduce(const GemmParams& p, hipStream_t s);
 
 // ---------------------------------------------------------------------------

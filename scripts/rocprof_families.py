@@ -2,8 +2,8 @@
 """Average duration per kernel FAMILY from a rocprofv3 --kernel-trace CSV of bench.py.
 
 rocprofv3 --stats groups by kernel symbol, and one symbol (igemm_f32_kernel<...>) serves the
-stem, the sixteen 3x3 convolutions and the fc. The launches of a bench step come in a fixed
-order (stem, 16 x conv3x3, fc, then the gather-mode Conv1d), which this script uses to split
+sixteen 3x3 convolutions and the fc (the stem has its own kernel, stem7x7_kernel). The launches
+of a bench step come in a fixed order (16 x conv3x3, fc, then the gather-mode Conv1d), which this script uses to split
 them, so that bench.py's roofline.avg_launch_ms can be checked against the profiler.
 
   python scripts/rocprof_families.py <dir>/runc/<pid>_kernel_trace.csv out.json"""
@@ -23,13 +23,12 @@ for r in rows:
             ig.append(dur)
     elif name.startswith("pa::") or " pa::" in name:
         fam[name.split("(")[0].replace("void ", "").replace("pa::", "")].append(dur)
-per = 18
+per = 17
 assert len(ig) % per == 0, len(ig)
 for s in range(len(ig) // per):
     step = ig[s * per:(s + 1) * per]
-    fam["igemm_conv7x7_stem"].append(step[0])
-    fam["igemm_conv3x3"] += step[1:17]
-    fam["igemm_fc"].append(step[17])
+    fam["igemm_conv3x3"] += step[0:16]
+    fam["igemm_fc"].append(step[16])
 out = {k: {"launches": len(v), "avg_us": round(sum(v) / len(v) / 1e3, 2), "total_ms": round(sum(v) / 1e6, 3)} for k, v in sorted(fam.items())}
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 for k, v in out.items():
