@@ -170,40 +170,56 @@ hipError_t launch_identity_gather(int32_t* gather, int32_t n, hipStream_t s) {
 
 // classifier of SpatialStreamCNN (cnn_action_detector.py:27,41): Linear(512,128)
 // + ReLU + Linear(128,A), then F.log_softmax (:92), argmax and exp (ai_runner.py
-// :474-477). One workgroup per window; the 512-vector sits in LDS, each wave
-// reduces its dot products with wave64 shuffles, the A <= 64 logits live one per
-// lane of wave 0 for the softmax reductions.
-__global__ __launch_bounds__(256) void head_mlp_kernel(const HeadParams p) {
+// :474-477). One workgroup (1024 threads) per window; the 512-vector sits in LDS,
+// the hidden layer is 128 outputs x 8 k-slices with coalesced k-major weight reads,
+// the A <= 64 logits live one per lane of wave 0 for the softmax reductions.
+__global__ __launch_bounds__(1024) void head_mlp_kernel(const HeadParams p) {
+    // w2 is stored transposed [512 k][128 o] and w3 as [128 k][64 (A padded)] so that the lanes
+    // of a wave (consecutive outputs) read consecutive floats; h1/h2 come from LDS broadcasts.
     __shared__ float h1[512];
+    __shared__ float part[8][128];
     __shared__ float h2[128];
     const int w = blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    h1[tid] = p.h1[(size_t)w * 512 + tid];
-    h1[tid + 256] = p.h1[(size_t)w * 512 + tid + 256];
+    if (tid < 512) h1[tid] = p.h1[(size_t)w * 512 + tid];
     __syncthreads();
-    // 128 outputs, 32 per wave; lanes stride the 512-long dot product
-    for (int o = wave * 32; o < wave * 32 + 32; ++o) {
-        const float* wr = p.w2 + (size_t)o * 512;
-        float s = 0.f;
+    {
+        // 1024 threads = 128 outputs x 8 k-slices of 64: every load is independent and coalesced
+        const int o = tid & 127, slice = tid >> 7;
+        const float* wc = p.w2 + (size_t)slice * 64 * 128 + o;
+        const float* hh = h1 + slice * 64;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s += wr[lane + 64 * k] * h1[lane + 64 * k];
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
-        if (lane == 0) {
-            s += p.b2[o];
-            h2[o] = s > 0.f ? s : 0.f;
+        for (int k = 0; k < 64; k += 4) {
+            s0 += wc[(size_t)(k + 0) * 128] * hh[k + 0];
+            s1 += wc[(size_t)(k + 1) * 128] * hh[k + 1];
+            s2 += wc[(size_t)(k + 2) * 128] * hh[k + 2];
+            s3 += wc[(size_t)(k + 3) * 128] * hh[k + 3];
         }
+        part[slice][o] = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+    if (tid < 128) {
+        float s = p.b2[tid];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += part[i][tid];
+        h2[tid] = s > 0.f ? s : 0.f;
     }
     __syncthreads();
     if (wave != 0) return;
     const int A = p.num_actions;
     float logit = -INFINITY;
-    if (lane < A) {
-        const float* wr = p.w3 + (size_t)lane * 128;
-        float s = 0.f;
-        for (int k = 0; k < 128; ++k) s += wr[k] * h2[k];
-        logit = s + p.b3[lane];
+    {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < 128; k += 4) {
+            s0 += p.w3[(k + 0) * 64 + lane] * h2[k + 0];
+            s1 += p.w3[(k + 1) * 64 + lane] * h2[k + 1];
+            s2 += p.w3[(k + 2) * 64 + lane] * h2[k + 2];
+            s3 += p.w3[(k + 3) * 64 + lane] * h2[k + 3];
+        }
+        if (lane < A) logit = (s0 + s1) + (s2 + s3) + p.b3[lane];
     }
     float mx = logit;
 #pragma unroll
@@ -245,7 +261,7 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(const HeadParams p) {
 hipError_t launch_head_mlp(const HeadParams& p, hipStream_t s) {
     if (p.nwin <= 0) return hipSuccess;
     if (p.num_actions > 64 || p.num_actions < 1) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(head_mlp_kernel, dim3(p.nwin), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(head_mlp_kernel, dim3(p.nwin), dim3(1024), 0, s, p);
     return hipGetLastError();
 }
 

@@ -709,9 +709,15 @@ int pa_create(const pa_config* cfg, const void* blob, size_t blob_bytes, pa_engi
         const float* w3 = br.take((size_t)A * 128);
         const float* b3 = br.take(A);
         if (!w2 || !b2 || !w3 || !b3 || br.p != br.end) return fail(e, PA_ERR_BAD_WEIGHTS, "weight blob size mismatch at classifier");
-        if ((rc = upload(e, &e->w2, std::vector<float>(w2, w2 + 128 * 512)))) return rc;
+        // head_mlp_kernel reads both matrices k-major (lanes = outputs): w2 -> [512][128], w3 -> [128][64]
+        std::vector<float> w2t((size_t)512 * 128), w3t((size_t)128 * 64, 0.f);
+        for (int o = 0; o < 128; ++o)
+            for (int k = 0; k < 512; ++k) w2t[(size_t)k * 128 + o] = w2[(size_t)o * 512 + k];
+        for (int a = 0; a < A; ++a)
+            for (int k = 0; k < 128; ++k) w3t[(size_t)k * 64 + a] = w3[(size_t)a * 128 + k];
+        if ((rc = upload(e, &e->w2, w2t))) return rc;
         if ((rc = upload(e, &e->b2, std::vector<float>(b2, b2 + 128)))) return rc;
-        if ((rc = upload(e, &e->w3, std::vector<float>(w3, w3 + (size_t)A * 128)))) return rc;
+        if ((rc = upload(e, &e->w3, w3t))) return rc;
         if ((rc = upload(e, &e->b3, std::vector<float>(b3, b3 + A)))) return rc;
     }
     // split-K slabs: the largest splitk*M*N over all layers
