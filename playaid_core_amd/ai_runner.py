@@ -19,8 +19,12 @@ What differs, and why:
   ``action_recognition`` then serves single (frame, fighter) queries from
   those results. Numerically this equals the reference's per-call path to
   fp32 rounding (eval-mode BatchNorm makes crops independent).
-* ``run_damage_detection`` (PaddleOCR) and ``clean_yolo_crops`` (file repair)
-  are out of scope.
+* ``clean_yolo_crops`` (``:226-424``) runs on the label text in memory
+  (``label_cleaning.py``): duplicate resolution, gap interpolation and tail
+  duplication decide which box and which decoded frame every crop is cut from;
+  the crop pixels are produced by the HIP crop stage (``square_crop`` geometry,
+  ``:417-418``) for every frame, not only for the repaired ones.
+* ``run_damage_detection`` (PaddleOCR) is out of scope.
 """
 from __future__ import annotations
 
@@ -36,6 +40,7 @@ from .anim_ontology import MOVE_TO_CLASS_ID
 from .cnn_action_detector import CNNActionDetector
 from .dataset_utils import action_sample_from_frame_middle_out
 from .fighter import YoloCrop
+from .label_cleaning import clean_yolo_labels
 
 
 def read_fighter_yolo_crop_text(label_text: str, fighter: str, where: str = "<memory>") -> Optional[YoloCrop]:
@@ -127,14 +132,19 @@ class AIRunner:
             model = CNNActionDetector.load_from_checkpoint(path, actions=list(MOVE_TO_CLASS_ID.keys()))
         self.model = model
         self.model.eval()
-        # ai_runner.py:244-245: max_frames is the number of the last label file
-        self.max_frames = len(self.clip.labels)
         class_ids = sorted({int(l.split(" ")[0]) for t in self.clip.labels for l in t.splitlines() if l})
         if len(class_ids) != 2:
             # ai_runner.py:240-242 prints and exit()s here
             raise ValueError(f"expected exactly 2 fighters in the labels, found class ids {class_ids}")
         self.fighters = [constants.CHAR_LIST[c] for c in class_ids]
         self._class_ids = class_ids
+        # ai_runner.py:226-424 (run from __init__ via run_yolo, :188-189): repair the labels;
+        # max_frames is the number of the last label file (:244-245)
+        self.cleaned = clean_yolo_labels(self.clip.labels, self.fighters, self.clip.frames.shape[0], self.video_name)
+        self.max_frames = self.cleaned.max_frames
+        if debug:
+            for line in self.cleaned.log:
+                print(line)
         res, self.ai_output_data = self.load_ai_output()
         self._results = None
 
@@ -152,19 +162,22 @@ class AIRunner:
             fd = fd[0]
         return int(fd)
 
-    def _boxes(self) -> np.ndarray:
+    def _boxes(self):
+        """-> (boxes float64[max_frames,2,4], src int32[max_frames,2], missing bool[max_frames,2]) from the
+        repaired labels. An entry without a crop gets a stand-in box (never reported: the reference
+        asserts when a window needs it, see ``_run_clip``)."""
+        cl = self.cleaned
         n = self.max_frames
-        boxes = np.zeros((n, 2, 4), dtype=np.float64)
-        self._crops: List[List[Optional[YoloCrop]]] = []
-        for i, text in enumerate(self.clip.labels):
-            row = []
-            for p, fighter in enumerate(self.fighters):
-                crop = read_fighter_yolo_crop_text(text, fighter, f"{self.video_name}_{i + 1}.txt")
-                assert crop is not None, f"Failed to get crop for {fighter} in frame {i + 1}"
-                boxes[i, p] = crop.yolo_crop()
-                row.append(crop)
-            self._crops.append(row)
-        return boxes
+        self._crops = cl.label_crop
+        missing = cl.pixel_frame < 0
+        boxes = cl.pixel_box.copy()
+        src = cl.pixel_frame.copy()
+        for p in range(len(self.fighters)):
+            ok = np.nonzero(~missing[:, p])[0]
+            for i in np.nonzero(missing[:, p])[0]:
+                boxes[i, p] = cl.pixel_box[ok[0], p]
+                src[i, p] = min(i, self.clip.frames.shape[0] - 1)
+        return boxes, src, missing
 
     def _run_clip(self):
         if self._results is not None:
@@ -176,8 +189,30 @@ class AIRunner:
             eng = eng.reconfigured(frame_delta=self.frame_delta, fighter_class_ids=tuple(self._class_ids),
                                    max_clip_frames=max(self.max_frames, 64),
                                    max_frame_height=self.clip.frames.shape[1], max_frame_width=self.clip.frames.shape[2])
-        out = eng.infer_clip(self.clip.frames, self._boxes(), want_crops=True)
-        bad = np.argwhere(out["crop_status"] != 0)
+        boxes, src, missing = self._boxes()
+        n = self.max_frames
+        for p, fighter in enumerate(self.fighters):
+            # every frame in [1, max_frames) is the middle of its own window (ai_runner.py:443-447)
+            bad = np.nonzero(missing[: n - 1, p])[0]
+            assert len(bad) == 0, f"Failed to get frame crops/{fighter}/{self.video_name}_{bad[0] + 1}.jpg"
+        own = np.arange(n, dtype=np.int32)
+        if all(np.array_equal(src[:, p], own) for p in range(src.shape[1])):
+            out = eng.infer_clip(self.clip.frames[:n], boxes, want_crops=True)
+        else:
+            # repaired gaps are cut from VideoCapture position j, not j-1 (ai_runner.py:405-406), so the
+            # two fighters may read different decoded frames: one pass per fighter, columns merged
+            # (crops are independent of each other in eval mode, so this is exact)
+            out = None
+            for p in range(src.shape[1]):
+                r = eng.infer_clip(self.clip.frames[src[:, p]], boxes, want_crops=True)
+                if out is None:
+                    out = r
+                else:
+                    for k, v in r.items():
+                        out[k][:, p] = v[:, p]
+        st = out["crop_status"].copy()
+        st[missing] = 0
+        bad = np.argwhere(st != 0)
         assert len(bad) == 0, f"Failed to get square crop from frame {bad[0][0] + 1}"  # ai_runner.py:418
         self._results = out
         return out
