@@ -53,7 +53,7 @@ typedef enum pa_status {
 #define PA_CROP_OK 0
 #define PA_CROP_EMPTY 1        /* empty / off-screen slice: reference returns (False, None), fighter.py:356-362 */
 #define PA_CROP_BAD_BOX 2      /* non-finite box or square side <= 0 (reference raises) */
-#define PA_CROP_UPSCALE 3      /* square side < 128 px: INTER_AREA enlarging branch, not implemented */
+#define PA_CROP_UPSCALE 3      /* reserved (was: square side < 128 px rejected; the enlarging branch is implemented now) */
 #define PA_CROP_FILTER_TOO_WIDE 4 /* bicubic support beyond the kernel's table size (scale > 3.5) */
 
 typedef struct pa_engine pa_engine;

@@ -205,9 +205,71 @@ def _cv_round_half_even(x: np.ndarray) -> np.ndarray:
     return np.clip(np.rint(x), 0, 255).astype(np.uint8)
 
 
+def cv_linear_area_coeffs(ssize: int, dsize: int):
+    """Offsets and 11-bit fixed-point weights of OpenCV's bilinear resizer in ``area_mode``
+    (cv::hal::resize, generic path, ``interpolation == INTER_AREA`` with a scale < 1: "true area
+    interpolation is only implemented for scale >= 1, in other cases it is emulated using some
+    variant of bilinear"): ``s = floor(d * scale)``, ``f = (d + 1) - (s + 1) * inv_scale``,
+    ``f = 0 if f <= 0 else f - floor(f)`` (float32), weights ``cvRound((1 - f) * 2048)``,
+    ``cvRound(f * 2048)``. -> (ofs int[dsize], w0 int[dsize], w1 int[dsize], first index whose
+    right neighbour would fall outside the source)."""
+    inv_scale = dsize / ssize
+    scale = 1.0 / inv_scale
+    ofs = np.zeros(dsize, dtype=np.int64)
+    w0 = np.zeros(dsize, dtype=np.int64)
+    w1 = np.zeros(dsize, dtype=np.int64)
+    dmax = dsize
+    for d in range(dsize):
+        s = int(math.floor(d * scale))
+        f = np.float32((d + 1) - (s + 1) * inv_scale)
+        f = np.float32(0.0) if f <= 0 else np.float32(f - np.float32(math.floor(float(f))))
+        if s + 1 >= ssize:
+            dmax = min(dmax, d)
+            if s >= ssize - 1:
+                f = np.float32(0.0)
+                s = ssize - 1
+        ofs[d] = s
+        w0[d] = int(np.rint(np.float32(np.float32(1.0) - f) * np.float32(2048.0)))
+        w1[d] = int(np.rint(f * np.float32(2048.0)))
+    return ofs, w0, w1, dmax
+
+
+def _cv_resize_area_enlarge(img: np.ndarray, out_w: int, out_h: int) -> np.ndarray:
+    """INTER_AREA with a destination larger than the source: the 8-bit fixed-point bilinear
+    resizer (HResizeLinear into int rows scaled by 2048, VResizeLinear
+    ``(((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2``) with the area-mode
+    coefficients above. **Parity unpinned**: restated from the OpenCV 4.5.5 sources as
+    remembered, no cv2 in the build container to check against."""
+    h, w, cn = img.shape
+    xofs, a0, a1, xmax = cv_linear_area_coeffs(w, out_w)
+    yofs, b0, b1, _ = cv_linear_area_coeffs(h, out_h)
+    src = img.astype(np.int64)
+    hbuf = np.zeros((h, out_w, cn), dtype=np.int64)
+    for dx in range(out_w):
+        sx = xofs[dx]
+        if dx < xmax:
+            hbuf[:, dx] = src[:, sx] * a0[dx] + src[:, sx + 1] * a1[dx]
+        else:
+            hbuf[:, dx] = src[:, sx] * 2048
+    out = np.zeros((out_h, out_w, cn), dtype=np.uint8)
+    for dy in range(out_h):
+        # the row coefficients are NOT zeroed at the bottom edge (only the row index is clipped)
+        inv = out_h / h
+        sy = int(math.floor(dy * (1.0 / inv)))
+        f = np.float32((dy + 1) - (sy + 1) * inv)
+        f = np.float32(0.0) if f <= 0 else np.float32(f - np.float32(math.floor(float(f))))
+        c0 = int(np.rint(np.float32(np.float32(1.0) - f) * np.float32(2048.0)))
+        c1 = int(np.rint(f * np.float32(2048.0)))
+        r0 = min(max(sy, 0), h - 1)
+        r1 = min(max(sy + 1, 0), h - 1)
+        v = (((c0 * (hbuf[r0] >> 4)) >> 16) + ((c1 * (hbuf[r1] >> 4)) >> 16) + 2) >> 2
+        out[dy] = (v & 0xFF).astype(np.uint8)
+    return out
+
+
 def cv_resize_area(img: np.ndarray, out_w: int, out_h: int) -> np.ndarray:
     """``cv2.resize(img, (out_w, out_h), interpolation=cv2.INTER_AREA)`` for a
-    uint8 HWC image with out_w <= w and out_h <= h."""
+    uint8 HWC image (shrinking: box / area-weighted paths; enlarging: the bilinear emulation)."""
     h, w, cn = img.shape
     if (w, h) == (out_w, out_h):
         return img.copy()
@@ -216,7 +278,7 @@ def cv_resize_area(img: np.ndarray, out_w: int, out_h: int) -> np.ndarray:
     scale_x = 1.0 / inv_sx
     scale_y = 1.0 / inv_sy
     if scale_x < 1.0 or scale_y < 1.0:
-        raise NotImplementedError("INTER_AREA enlarging branch is not restated (parity unpinned)")
+        return _cv_resize_area_enlarge(img, out_w, out_h)
     eps = np.finfo(np.float64).eps
     isx = int(np.rint(scale_x))  # saturate_cast<int>(double) == cvRound
     isy = int(np.rint(scale_y))

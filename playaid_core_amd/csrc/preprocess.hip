@@ -296,9 +296,7 @@ __global__ __launch_bounds__(64) void crop_plan_kernel(const PreprocParams p) {
     }
     if (pl.status == PA_CROP_OK) {
         const int d = pl.d;
-        if (d < PA_CROP) {
-            pl.status = PA_CROP_UPSCALE;
-        } else {
+        {
             // imutils.resize(width=128): dim = (128, int(h * (128 / float(w))))
             const double r = 128.0 / (double)d;
             pl.out_h = (int)((double)d * r);
@@ -306,7 +304,11 @@ __global__ __launch_bounds__(64) void crop_plan_kernel(const PreprocParams p) {
             const double inv_sy = (double)pl.out_h / (double)d;
             pl.scale_x = 1.0 / inv_sx;
             pl.scale_y = 1.0 / inv_sy;
-            if (d == PA_CROP && pl.out_h == PA_CROP) {
+            if (pl.scale_x < 1.0 || pl.scale_y < 1.0) {
+                // source smaller than 128 px: cv::resize emulates INTER_AREA with its fixed-point
+                // bilinear resizer (area_pixel mode 4); rare, served by the fallback kernel only
+                pl.area_mode = 4;
+            } else if (d == PA_CROP && pl.out_h == PA_CROP) {
                 pl.area_mode = 0;
             } else {
                 pl.iscale_x = (int)rint(pl.scale_x);  // saturate_cast<int>(double) == cvRound
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(64) void crop_plan_kernel(const PreprocParams p) {
             }
         }
     }
-    if (pl.status == PA_CROP_OK) {
+    if (pl.status == PA_CROP_OK && pl.area_mode != 4) {
         // largest sub-band height whose LDS stages fit the fused kernel's budget
         for (int rb = 8; rb >= 1 && pl.fused_rb == 0; rb >>= 1) {
             int worst = 0;
@@ -522,6 +524,46 @@ __device__ __forceinline__ void area_pixel(const CropPlan& pl, const CV& cv, int
         o0 = cv_saturate_u8((float)s0 * scale);
         o1 = cv_saturate_u8((float)s1 * scale);
         o2 = cv_saturate_u8((float)s2 * scale);
+    } else if (pl.area_mode == 4) {
+        // enlarging: cv::hal::resize runs the 8-bit bilinear resizer with area-mode coefficients
+        // (s = floor(d*scale), f = (d+1) - (s+1)*inv_scale, f <= 0 ? 0 : f - floor(f); weights
+        // cvRound(w * 2048)); HResizeLinear keeps 11 fraction bits, VResizeLinear computes
+        // (((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2. Columns whose right neighbour
+        // would leave the source use S[last]*2048; rows only clip the index.
+        const int ss = pl.d;
+        const double inv_x = 128.0 / (double)ss, inv_y = (double)pl.out_h / (double)ss;  // dsize / ssize, as cv::resize forms them
+        int sx = (int)floor((double)dx * pl.scale_x);
+        float fx = (float)((double)(dx + 1) - (double)(sx + 1) * inv_x);
+        fx = fx <= 0.f ? 0.f : fx - floorf(fx);
+        const bool plain = sx + 1 >= ss;
+        if (sx >= ss - 1) {
+            fx = 0.f;
+            sx = ss - 1;
+        }
+        const int a0 = (int)rintf((1.f - fx) * 2048.f), a1 = (int)rintf(fx * 2048.f);
+        const int sy = (int)floor((double)dy * pl.scale_y);
+        float fy = (float)((double)(dy + 1) - (double)(sy + 1) * inv_y);
+        fy = fy <= 0.f ? 0.f : fy - floorf(fy);
+        const int b0 = (int)rintf((1.f - fy) * 2048.f), b1 = (int)rintf(fy * 2048.f);
+        const int r0 = sy < ss - 1 ? sy : ss - 1;
+        const int r1 = sy + 1 < ss - 1 ? sy + 1 : ss - 1;
+        int h0[3], h1[3];
+        {
+            int c0, c1, c2, e0 = 0, e1 = 0, e2 = 0;
+            cv.load(r0, sx, c0, c1, c2);
+            if (!plain) cv.load(r0, sx + 1, e0, e1, e2);
+            h0[0] = plain ? c0 * 2048 : c0 * a0 + e0 * a1;
+            h0[1] = plain ? c1 * 2048 : c1 * a0 + e1 * a1;
+            h0[2] = plain ? c2 * 2048 : c2 * a0 + e2 * a1;
+            cv.load(r1, sx, c0, c1, c2);
+            if (!plain) cv.load(r1, sx + 1, e0, e1, e2);
+            h1[0] = plain ? c0 * 2048 : c0 * a0 + e0 * a1;
+            h1[1] = plain ? c1 * 2048 : c1 * a0 + e1 * a1;
+            h1[2] = plain ? c2 * 2048 : c2 * a0 + e2 * a1;
+        }
+        o0 = ((((b0 * (h0[0] >> 4)) >> 16) + ((b1 * (h1[0] >> 4)) >> 16) + 2) >> 2) & 0xff;
+        o1 = ((((b0 * (h0[1] >> 4)) >> 16) + ((b1 * (h1[1] >> 4)) >> 16) + 2) >> 2) & 0xff;
+        o2 = ((((b0 * (h0[2] >> 4)) >> 16) + ((b1 * (h1[2] >> 4)) >> 16) + 2) >> 2) & 0xff;
     } else {
         const AreaTab tx = area_tab(dx, pl.scale_x, pl.d);
         const AreaTab ty = area_tab(dy, pl.scale_y, pl.d);

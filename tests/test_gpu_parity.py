@@ -65,6 +65,38 @@ def test_square_crops_padding0(engine):
             assert np.array_equal(crops[i, p], ref)
 
 
+def test_square_crops_small_boxes_enlarge(engine):
+    """Square side below 128 px: cv::resize's INTER_AREA falls back to its fixed-point bilinear
+    resizer (oracle/resample.py::_cv_resize_area_enlarge -- parity unpinned, see DESIGN.md);
+    the HIP stage must agree with that restatement bit for bit, edges and clipping included."""
+    _, _, yolo_crop = _oracle()
+    h, w = 720, 1280
+    frames = synth.make_frames(5, h, w, seed=21)
+    boxes = np.zeros((5, 2, 4))
+    sides = [(40.5, 30.5), (64.5, 50.5), (97.5, 101.5), (127.5, 90.5), (100.5, 100.5),
+             (20.5, 25.5), (127.5, 127.5), (77.5, 60.5), (50.5, 120.5), (24.5, 24.5)]
+    centres = [(0.5, 0.5), (0.3, 0.6), (0.02, 0.04), (0.985, 0.97), (0.7, 0.2),
+               (0.5, 0.99), (0.4, 0.4), (0.0, 0.5), (0.6, 0.01), (0.5, 0.5)]
+    for k, ((bw, bh), (cx, cy)) in enumerate(zip(sides, centres)):
+        boxes[k // 2, k % 2] = (cx, cy, bw / w, bh / h)
+    for pad in (30, 0):
+        crops, status = engine.square_crops(frames, boxes, padding=pad)
+        n_ok = 0
+        for i in range(5):
+            for p in range(2):
+                ok, ref = yolo_crop.square_crop(frames[i], boxes[i, p], 128, padding=pad)
+                assert ok == (status[i, p] == 0), (pad, i, p, status[i, p])
+                if ok:
+                    n_ok += 1
+                    assert np.array_equal(crops[i, p], ref), (pad, i, p, np.abs(crops[i, p].astype(int) - ref.astype(int)).max())
+        assert n_ok >= 8
+    # a box so small that the (d+60) -> d BICUBIC shrink needs more than PA_KSIZE_MAX taps (scale > 3.5)
+    # is reported, not mis-computed
+    boxes[0, 0] = (0.5, 0.5, 3.5 / w, 2.5 / h)
+    _, status = engine.square_crops(frames[:1], boxes[:1], padding=30)
+    assert status[0, 0] == 4  # PA_CROP_FILTER_TOO_WIDE
+
+
 def test_infer_windows_matches_oracle(engine, state_dict):
     cnn, _, _ = _oracle()
     rng = np.random.default_rng(3)

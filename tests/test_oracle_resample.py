@@ -112,3 +112,24 @@ def test_square_crop_pil_stage_matches_live_pillow():
     raw = frame[max(cy - half - 30, 0) : min(cy + half + 30, 720), max(cx - half - 30, 0) : min(cx + half + 30, 1280)]
     ref = np.array(ImageOps.pad(Image.fromarray(raw), (d, d), color="black"))
     assert np.array_equal(R.pil_pad_black(raw, (d, d)), ref)
+
+
+def test_cv_area_enlarge_properties():
+    """INTER_AREA with a destination larger than the source (parity unpinned restatement of
+    cv::resize's bilinear emulation): an exact 2x enlargement duplicates pixels (f = 0 everywhere,
+    OpenCV's documented "similar to INTER_NEAREST"), constants stay constant, values stay inside
+    the source range, and the last column/row replicate the edge."""
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)
+    out = R.cv_resize_area(img, 128, 128)
+    assert np.array_equal(out, img.repeat(2, 0).repeat(2, 1))
+    for d in (24, 50, 97, 127):
+        img = rng.integers(0, 256, (d, d, 3), dtype=np.uint8)
+        out = R.imutils_resize_width(img, 128)
+        assert out.shape == (128, 128, 3)
+        assert out.min() >= img.min() and out.max() <= img.max()
+        assert np.array_equal(out[0, 0], img[0, 0]) and np.array_equal(out[-1, -1], img[-1, -1])
+        flat = np.full((d, d, 3), 201, np.uint8)
+        assert (R.imutils_resize_width(flat, 128) == 201).all()
+    ofs, w0, w1, xmax = R.cv_linear_area_coeffs(100, 128)
+    assert ofs[0] == 0 and w0[0] == 2048 and w1[0] == 0 and (w0 + w1 == 2048).all() and xmax == 127
