@@ -19,6 +19,7 @@ ARCH = "gfx950"
 # bit-for-bit and must not have its multiplies and adds fused.
 SOURCES = [
     ("igemm.hip", []),
+    ("igemm_bf16.hip", []),
     ("stem.hip", []),
     ("misc.hip", []),
     ("preprocess.hip", ["-ffp-contract=off"]),

@@ -12,7 +12,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # PA_LIB_PATH: load a differently built library (e.g. the ablation build used by scripts/)
 LIB_PATH = os.environ.get("PA_LIB_PATH") or os.path.join(HERE, "libplayaid_hip.so")
 
-PA_ABI_VERSION = 1
+PA_ABI_VERSION = 2
+PA_DTYPE_F32 = 0
+PA_DTYPE_BF16 = 1
 PA_WEIGHT_MAGIC = 0x31574150
 PA_FEATURE_STRIDE = 1024
 
@@ -49,6 +51,7 @@ class pa_config(C.Structure):
         ("max_frame_height", C.c_int32),
         ("max_frame_width", C.c_int32),
         ("fighter_class_ids", C.c_int32 * 4),
+        ("compute_dtype", C.c_int32),
     ]
 
 

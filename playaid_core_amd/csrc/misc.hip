@@ -69,6 +69,67 @@ hipError_t launch_maxpool(const float* in, float* out, int32_t n, hipStream_t s)
     return hipGetLastError();
 }
 
+// bf16 storage variant of the max-pool (bf16 conv path): 8 channels per thread (one 16-byte load).
+// Non-negative bf16 values order like their bit patterns, so the maximum is an integer max.
+__global__ __launch_bounds__(256) void maxpool_bf16_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int n) {
+    const size_t total = (size_t)n * 32 * 32 * 8;  // 8-channel units
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i & 7);
+        const int ox = (int)((i >> 3) & 31);
+        const int oy = (int)((i >> 8) & 31);
+        const int img = (int)(i >> 13);
+        const uint4* src = reinterpret_cast<const uint4*>(in) + (((size_t)img * 66 + oy * 2) * 66 + ox * 2) * 8 + c8;
+        uint4 m = src[0];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const uint4 v = src[((size_t)ky * 66 + kx) * 8];
+                const uint32_t mv[4] = {m.x, m.y, m.z, m.w}, vv[4] = {v.x, v.y, v.z, v.w};
+                uint32_t r[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t lo = (mv[k] & 0xffffu) > (vv[k] & 0xffffu) ? (mv[k] & 0xffffu) : (vv[k] & 0xffffu);
+                    const uint32_t hi = (mv[k] >> 16) > (vv[k] >> 16) ? (mv[k] >> 16) : (vv[k] >> 16);
+                    r[k] = lo | (hi << 16);
+                }
+                m = make_uint4(r[0], r[1], r[2], r[3]);
+            }
+        reinterpret_cast<uint4*>(out)[(((size_t)img * 34 + oy + 1) * 34 + ox + 1) * 8 + c8] = m;
+    }
+}
+
+hipError_t launch_maxpool_bf16(const void* in, void* out, int32_t n, hipStream_t s) {
+    const size_t total = (size_t)n * 32 * 32 * 8;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(maxpool_bf16_kernel, dim3(grid), dim3(256), 0, s, (const uint16_t*)in, (uint16_t*)out, n);
+    return hipGetLastError();
+}
+
+// bf16 layer4 output -> fp32 pooled features (the fc and the head stay in fp32).
+__global__ __launch_bounds__(256) void avgpool_bf16_kernel(const uint16_t* __restrict__ in, float* __restrict__ out, int n) {
+    const size_t total = (size_t)n * 512;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i & 511);
+        const int img = (int)(i >> 9);
+        const uint16_t* src = in + (size_t)img * 36 * 512 + c;
+        float sum = 0.f;
+#pragma unroll
+        for (int y = 1; y <= 4; ++y)
+#pragma unroll
+            for (int x = 1; x <= 4; ++x) sum += __uint_as_float((uint32_t)src[(size_t)(y * 6 + x) * 512] << 16);
+        out[i] = sum * 0.0625f;
+    }
+}
+
+hipError_t launch_avgpool_bf16(const void* in, float* out, int32_t n, hipStream_t s) {
+    const size_t total = (size_t)n * 512;
+    const int grid = (int)((total + 255) / 256);
+    hipLaunchKernelGGL(avgpool_bf16_kernel, dim3(grid), dim3(256), 0, s, (const uint16_t*)in, out, n);
+    return hipGetLastError();
+}
+
 // adaptive_avg_pool2d((1,1)) over the 4x4 interior of the zero-bordered
 // [n][6][6][512] layer4 output -> [n][512].
 __global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ in, float* __restrict__ out, int n) {

@@ -52,6 +52,7 @@ struct pa_engine {
     pa_config cfg;
     std::string last_error;
     int max_crops = 0;   // crops per backbone call
+    bool bf16 = false;   // cfg.compute_dtype == PA_DTYPE_BF16: the 3x3 conv stack stores bf16 (buffers keep their fp32 size)
     int cache_rows = 0;  // feature-cache rows
     // clip state
     int clip_frames = 0;
@@ -130,6 +131,24 @@ int upload(pa_engine* e, float** dst, const std::vector<float>& host) {
     int rc = dev_alloc(e, dst, host.size(), false);
     if (rc != PA_OK) return rc;
     HIPCHK(e, hipMemcpy(*dst, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+    return PA_OK;
+}
+
+// fp32 -> bf16 (round to nearest even) weights of the bf16 conv path; the device pointer keeps
+// the float* type of ConvLayer::wgt, the kernels reinterpret it.
+int upload_bf16(pa_engine* e, float** dst, const std::vector<float>& host) {
+    std::vector<uint16_t> h(host.size());
+    for (size_t i = 0; i < host.size(); ++i) {
+        uint32_t u;
+        memcpy(&u, &host[i], 4);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        h[i] = (uint16_t)(u >> 16);
+    }
+    uint16_t* d = nullptr;
+    int rc = dev_alloc(e, &d, h.size(), false);
+    if (rc != PA_OK) return rc;
+    HIPCHK(e, hipMemcpy(d, h.data(), h.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    *dst = reinterpret_cast<float*>(d);
     return PA_OK;
 }
 
@@ -284,11 +303,14 @@ int run_conv(pa_engine* e, const ConvLayer& L, int crop0, int ncrops, size_t sla
     const int out_w = L.out_hw + 2 * L.out_pad;
     const size_t in_crop = (size_t)in_w * in_w * L.in_px_stride;
     const size_t out_crop = (size_t)out_w * out_w * L.cout;
-    p.act = L.in + crop0 * in_crop;
+    const bool bf = e->bf16 && L.kh == 3;  // bf16 conv path: the 3x3 stack (buffers addressed in 2-byte elements)
+    const size_t es = bf ? 2 : 4;
+    auto at = [es](float* base, size_t elems) { return reinterpret_cast<float*>(reinterpret_cast<char*>(base) + elems * es); };
+    p.act = at(L.in, crop0 * in_crop);
     p.wgt = L.wgt;
     p.bias = L.bias;
-    p.residual = L.residual ? L.residual + crop0 * out_crop : nullptr;
-    p.out = L.out + crop0 * out_crop;
+    p.residual = L.residual ? at(L.residual, crop0 * out_crop) : nullptr;
+    p.out = at(L.out, crop0 * out_crop);
     p.slab = e->slab + slab_off;
     p.gather = nullptr;
     p.M = ncrops * L.out_hw * L.out_hw;
@@ -313,8 +335,8 @@ int run_conv(pa_engine* e, const ConvLayer& L, int crop0, int ncrops, size_t sla
     p.relu = L.relu;
     if (L.in2) {
         const int w2 = L.in2_hw + 2;  // zero-bordered block input
-        p.act2 = L.in2 + (size_t)crop0 * w2 * w2 * L.in2_c;
-        p.k2_steps = L.in2_c / 32;
+        p.act2 = at(L.in2, (size_t)crop0 * w2 * w2 * L.in2_c);
+        p.k2_steps = L.in2_c / (bf ? 64 : 32);
         p.in2_px_stride = L.in2_c;
         p.in2_row_stride = w2 * L.in2_c;
         p.in2_img_stride = w2 * w2 * L.in2_c;
@@ -324,15 +346,18 @@ int run_conv(pa_engine* e, const ConvLayer& L, int crop0, int ncrops, size_t sla
     }
     GemmTile tile = L.tile;
     int splitk = L.splitk;
-    if (!L.forced) choose_tile(p.M, p.N, p.ktot / 32, &tile, &splitk);  // per launch: M depends on the batch
+    if (!L.forced) choose_tile(p.M, p.N, p.ktot / (bf ? 64 : 32), &tile, &splitk);  // per launch: M depends on the batch
     p.splitk = splitk;
     const size_t slab_avail = e->slab_floats > slab_off ? e->slab_floats - slab_off : 0;
     if ((size_t)p.splitk * p.M * p.N > slab_avail) p.splitk = 1;
     const double flops = 2.0 * p.M * p.N * L.k_alg;
-    const double bytes = 4.0 * ((double)ncrops * L.in_hw * L.in_hw * L.cin + (double)p.M * p.N * (L.residual ? 2 : 1) +
-                                (double)p.N * L.k_alg + (L.in2 ? (double)ncrops * L.in2_hw * L.in2_hw * L.in2_c : 0.0));
+    const double bytes = (double)es * ((double)ncrops * L.in_hw * L.in_hw * L.cin + (double)p.M * p.N * (L.residual ? 2 : 1) +
+                                       (double)p.N * L.k_alg + (L.in2 ? (double)ncrops * L.in2_hw * L.in2_hw * L.in2_c : 0.0));
     ProfScope ps(e, s, prof_name, flops, bytes);
-    HIPCHK(e, launch_igemm(p, tile, s));
+    if (bf)
+        HIPCHK(e, launch_igemm_bf16(p, tile, s));
+    else
+        HIPCHK(e, launch_igemm(p, tile, s));
     return PA_OK;
 }
 
@@ -341,7 +366,7 @@ int run_backbone_part(pa_engine* e, int crop0, int ncrops, const float* x_in, fl
     ConvLayer stem = e->convs[0];
     stem.in = const_cast<float*>(x_in);  // x_in / feats_out are the caller's bases: crop0 is applied by run_conv
     static const bool stem_igemm = getenv("PA_STEM_IGEMM") && atoi(getenv("PA_STEM_IGEMM"));  // A/B knob: generic engine
-    if (stem_igemm) {
+    if (stem_igemm && !e->bf16) {
         rc = run_conv(e, stem, crop0, ncrops, slab_off, s, "igemm_conv7x7_stem");
         if (rc) return rc;
     } else {
@@ -349,15 +374,20 @@ int run_backbone_part(pa_engine* e, int crop0, int ncrops, const float* x_in, fl
         sp.x = x_in + (size_t)crop0 * 134 * 134 * 4;
         sp.wgt = stem.wgt;
         sp.bias = stem.bias;
-        sp.out = e->c1 + (size_t)crop0 * 66 * 66 * 64;
+        sp.out = reinterpret_cast<float*>(reinterpret_cast<char*>(e->c1) + (size_t)crop0 * 66 * 66 * 64 * (e->bf16 ? 2 : 4));
         sp.tiles = ncrops * 32;
+        sp.out_bf16 = e->bf16 ? 1 : 0;
         const double px = (double)ncrops * 64 * 64;
         ProfScope ps(e, s, "stem_conv7x7", 2.0 * px * 64 * 147, 4.0 * ((double)ncrops * 128 * 128 * 3 + px * 64 + 64.0 * 147));
         HIPCHK(e, launch_stem7x7(sp, s));
     }
     {
-        ProfScope ps(e, s, "maxpool3x3", 0.0, 4.0 * ncrops * (64.0 * 64 * 64 + 32.0 * 32 * 64));
-        HIPCHK(e, launch_maxpool(e->c1 + (size_t)crop0 * 66 * 66 * 64, e->p1 + (size_t)crop0 * 34 * 34 * 64, ncrops, s));
+        ProfScope ps(e, s, "maxpool3x3", 0.0, (e->bf16 ? 2.0 : 4.0) * ncrops * (64.0 * 64 * 64 + 32.0 * 32 * 64));
+        if (e->bf16)
+            HIPCHK(e, launch_maxpool_bf16(reinterpret_cast<uint16_t*>(e->c1) + (size_t)crop0 * 66 * 66 * 64,
+                                          reinterpret_cast<uint16_t*>(e->p1) + (size_t)crop0 * 34 * 34 * 64, ncrops, s));
+        else
+            HIPCHK(e, launch_maxpool(e->c1 + (size_t)crop0 * 66 * 66 * 64, e->p1 + (size_t)crop0 * 34 * 34 * 64, ncrops, s));
     }
     for (size_t i = 1; i < e->convs.size(); ++i) {
         const ConvLayer& L = e->convs[i];
@@ -366,8 +396,12 @@ int run_backbone_part(pa_engine* e, int crop0, int ncrops, const float* x_in, fl
         if (rc) return rc;
     }
     {
-        ProfScope ps(e, s, "avgpool", 0.0, 4.0 * ncrops * (16.0 * 512 + 512));
-        HIPCHK(e, launch_avgpool(e->layer4_out + (size_t)crop0 * 36 * 512, e->pooled + (size_t)crop0 * 512, ncrops, s));
+        ProfScope ps(e, s, "avgpool", 0.0, ncrops * ((e->bf16 ? 2.0 : 4.0) * 16.0 * 512 + 4.0 * 512));
+        if (e->bf16)
+            HIPCHK(e, launch_avgpool_bf16(reinterpret_cast<uint16_t*>(e->layer4_out) + (size_t)crop0 * 36 * 512,
+                                          e->pooled + (size_t)crop0 * 512, ncrops, s));
+        else
+            HIPCHK(e, launch_avgpool(e->layer4_out + (size_t)crop0 * 36 * 512, e->pooled + (size_t)crop0 * 512, ncrops, s));
     }
     ConvLayer fc = e->fc;
     fc.out = feats_out;
@@ -510,13 +544,15 @@ int pa_create(const pa_config* cfg, const void* blob, size_t blob_bytes, pa_engi
     if (cfg->abi_version != PA_ABI_VERSION) return PA_ERR_INVALID_ARG;
     const int S = cfg->sequence_length, A = cfg->num_actions, F = cfg->num_fighters;
     if (S < 1 || S % 2 == 0 || S > 15 || A < 1 || A > 64 || F < 1 || F > 4 || cfg->max_batch_frames < 1 ||
-        cfg->max_clip_frames < 1 || cfg->max_frame_height < 1 || cfg->max_frame_width < 1 || cfg->crop_padding < 0)
+        cfg->max_clip_frames < 1 || cfg->max_frame_height < 1 || cfg->max_frame_width < 1 || cfg->crop_padding < 0 ||
+        (cfg->compute_dtype != PA_DTYPE_F32 && cfg->compute_dtype != PA_DTYPE_BF16))
         return PA_ERR_INVALID_ARG;
     const int32_t* hdr = reinterpret_cast<const int32_t*>(blob);
     if (blob_bytes != pa_weight_blob_bytes(S, A) || hdr[0] != PA_WEIGHT_MAGIC || hdr[1] != 1 || hdr[2] != S || hdr[3] != A)
         return PA_ERR_BAD_WEIGHTS;
     pa_engine* e = new pa_engine();
     e->cfg = *cfg;
+    e->bf16 = cfg->compute_dtype == PA_DTYPE_BF16;
     {
         const char* pl = getenv("PA_PROFILE_LAYERS");
         e->profile_layers = pl && pl[0] == '1';
@@ -591,12 +627,12 @@ int pa_create(const pa_config* cfg, const void* blob, size_t blob_bytes, pa_engi
             keep_w.swap(w);
             keep_b.swap(b);
         } else {
-            r2 = upload(e, &L.wgt, w);
+            r2 = (e->bf16 && k == 3) ? upload_bf16(e, &L.wgt, w) : upload(e, &L.wgt, w);
             if (r2) return r2;
             r2 = upload(e, &L.bias, b);
             if (r2) return r2;
         }
-        choose_tile(NC * L.out_hw * L.out_hw, cout, L.taps * L.chunk / 32, &L.tile, &L.splitk);
+        choose_tile(NC * L.out_hw * L.out_hw, cout, L.taps * L.chunk / ((e->bf16 && k == 3) ? 64 : 32), &L.tile, &L.splitk);
         // tuning knobs (scripts/tune_tiles.py): PA_FORCE_TILE=0|1|2, PA_FORCE_SPLITK=n
         if (const char* ft = getenv("PA_FORCE_TILE")) {
             const int t = atoi(ft);
@@ -649,7 +685,7 @@ int pa_create(const pa_config* cfg, const void* blob, size_t blob_bytes, pa_engi
                     memcpy(&wf[(size_t)o * k_all + k_main], &wd[(size_t)o * cin], sizeof(float) * cin);
                     bf[o] = (float)((double)keep_b[o] + (double)bd[o]);
                 }
-                rc = upload(e, &L.wgt, wf);
+                rc = e->bf16 ? upload_bf16(e, &L.wgt, wf) : upload(e, &L.wgt, wf);
                 if (rc) return rc;
                 rc = upload(e, &L.bias, bf);
                 if (rc) return rc;

@@ -47,6 +47,9 @@ struct GemmParams {
 enum GemmTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x64 = 2, TILE_128x64_K64 = 3, TILE_64x64_K64 = 4 };
 
 hipError_t launch_igemm(const GemmParams& p, GemmTile tile, hipStream_t s);
+// bf16 activations / weights (uint16_t storage behind the float* fields, every count in elements),
+// f32 accumulate on v_mfma_f32_32x32x16_bf16; conv mode only (igemm_bf16.hip)
+hipError_t launch_igemm_bf16(const GemmParams& p, GemmTile tile, hipStream_t s);
 
 // Persistent direct 7x7/2 stem (stem.hip): x = [crops][134][134][4] fp32 (3-pixel zero border,
 // channel 3 = 0), wgt = [64][7 ky][8 px][4 ch] (the igemm stem layout), out = [crops][66][66][64].
@@ -54,8 +57,9 @@ struct StemParams {
     const float* x;
     const float* wgt;
     const float* bias;
-    float* out;
+    float* out;     // fp32, or bf16 (uint16_t storage) when out_bf16 != 0
     int32_t tiles;  // crops * 32 (one tile = two output rows of one crop)
+    int32_t out_bf16;
 };
 hipError_t launch_stem7x7(const StemParams& p, hipStream_t s);
 hipError_t launch_splitk_reduce(const GemmParams& p, hipStream_t s);
@@ -117,6 +121,8 @@ hipError_t launch_nchw_to_padded(const float* x, float* out, int32_t n, hipStrea
 hipError_t launch_maxpool(const float* in, float* out, int32_t n, hipStream_t s);
 // global average pool, padded [n][6][6][512] -> [n][512]
 hipError_t launch_avgpool(const float* in, float* out, int32_t n, hipStream_t s);
+hipError_t launch_maxpool_bf16(const void* in, void* out, int32_t n, hipStream_t s);  // bf16 storage
+hipError_t launch_avgpool_bf16(const void* in, float* out, int32_t n, hipStream_t s);  // bf16 in, fp32 out
 // window gather table: rows into the feature cache, see head_gather_kernel
 hipError_t launch_window_gather(int32_t* gather, int32_t frame_num_lo, int32_t count, int32_t fighters,
                                 int32_t seq, int32_t delta, int32_t max_frames, int32_t min_frame,

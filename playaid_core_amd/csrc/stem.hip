@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void stem7x7_kernel(const StemParams p) {
 
         // epilogue: + folded BN bias, ReLU, into the bordered NHWC map [crop][66][66][64]
         const int img = t >> 5, oy = (t & 31) * 2 + wm;
-        float* orow = p.out + ((size_t)img * OUT_W * OUT_W + (size_t)(oy + 1) * OUT_W + 1) * COUT + n;
+        const size_t obase = ((size_t)img * OUT_W * OUT_W + (size_t)(oy + 1) * OUT_W + 1) * COUT + n;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -141,7 +141,13 @@ __global__ __launch_bounds__(256, 2) void stem7x7_kernel(const StemParams p) {
                 const int ox = mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 float v = acc[mi][e] + bias;
                 v = v > 0.f ? v : 0.f;
-                orow[(size_t)ox * COUT] = v;
+                if (p.out_bf16) {  // bf16 conv path: round to nearest even
+                    uint32_t u = __float_as_uint(v);
+                    u += 0x7fffu + ((u >> 16) & 1u);
+                    reinterpret_cast<uint16_t*>(p.out)[obase + (size_t)ox * COUT] = (uint16_t)(u >> 16);
+                } else {
+                    p.out[obase + (size_t)ox * COUT] = v;
+                }
             }
         __syncthreads();  // next patch landed (vmcnt drained) and every wave is done with this one
         buf ^= 1;

@@ -39,13 +39,21 @@ class Engine:
         max_frame_height: int = 1080,
         max_frame_width: int = 1920,
         fighter_class_ids: Tuple[int, ...] = (2, 3),
+        compute_dtype: str = "f32",
     ):
+        """``compute_dtype="bf16"`` selects the bf16 conv path (BASELINE.json configs[2]): 3x3
+        convolutions on bf16 activations / weights with fp32 accumulation, everything else fp32.
+        It is outside the 1e-4 parity bar of the default fp32 path."""
+        if compute_dtype not in ("f32", "bf16"):
+            raise ValueError("compute_dtype must be 'f32' or 'bf16'")
+        self.compute_dtype = compute_dtype
         self._lib = _lib.load()  # raises HipLibraryError when the .so is missing
         self._weights = state_dict
         self._ctor_kwargs = dict(
             device=device, num_fighters=num_fighters, frame_delta=frame_delta, crop_padding=crop_padding,
             max_batch_frames=max_batch_frames, max_clip_frames=max_clip_frames, max_frame_height=max_frame_height,
             max_frame_width=max_frame_width, fighter_class_ids=tuple(fighter_class_ids),
+            compute_dtype=compute_dtype,
         )
         if not torch.cuda.is_available():
             raise _lib.HipLibraryError("no HIP device visible to PyTorch-ROCm; this path has no CPU fallback")
@@ -73,6 +81,7 @@ class Engine:
         ids = list(fighter_class_ids) + [0] * (4 - len(fighter_class_ids))
         for i in range(4):
             cfg.fighter_class_ids[i] = ids[i]
+        cfg.compute_dtype = _lib.PA_DTYPE_BF16 if compute_dtype == "bf16" else _lib.PA_DTYPE_F32
         self.cfg = cfg
         if isinstance(state_dict, np.ndarray):
             blob = np.ascontiguousarray(state_dict, dtype=np.uint8)

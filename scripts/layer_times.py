@@ -8,7 +8,7 @@ from playaid_core_amd.engine import Engine
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 sd = synth.make_state_dict()
-eng = Engine(sd, max_batch_frames=n, max_clip_frames=max(n, 64))
+eng = Engine(sd, max_batch_frames=n, max_clip_frames=max(n, 64), compute_dtype=os.environ.get("PA_DTYPE", "f32"))
 frames = torch.from_numpy(synth.make_frames(8, 1080, 1920)).cuda().repeat((n + 7) // 8, 1, 1, 1)[:n].contiguous()
 boxes = torch.from_numpy(synth.make_boxes(n, 1080, 1920)).cuda()
 rec = eng.alloc_records(n - 1)

@@ -49,7 +49,7 @@ def test_struct_layouts_match_header():
     from playaid_core_amd import _lib
 
     assert ctypes.sizeof(_lib.pa_record) == 16
-    assert ctypes.sizeof(_lib.pa_config) == 15 * 4
+    assert ctypes.sizeof(_lib.pa_config) == 16 * 4
     assert ctypes.sizeof(_lib.pa_kernel_stat) == 72
 
 
@@ -67,6 +67,8 @@ def test_create_rejects_bad_arguments_without_gpu(lib):
     cfg.max_batch_frames, cfg.max_clip_frames, cfg.max_frame_height, cfg.max_frame_width = 8, 64, 720, 1280
     assert lib.pa_create(ctypes.byref(cfg), buf, 64, ctypes.byref(h)) == _lib.PA_ERR_BAD_WEIGHTS
     cfg.sequence_length = 4  # even window
+    assert lib.pa_create(ctypes.byref(cfg), buf, 64, ctypes.byref(h)) == _lib.PA_ERR_INVALID_ARG
+    cfg.sequence_length, cfg.compute_dtype = 7, 5  # unknown arithmetic type
     assert lib.pa_create(ctypes.byref(cfg), buf, 64, ctypes.byref(h)) == _lib.PA_ERR_INVALID_ARG
 
 
