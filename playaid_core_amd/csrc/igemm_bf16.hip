@@ -170,7 +170,9 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const GemmParams p) {
     // Epilogue operands are fetched now so their latency hides under the k loop.
     const bool direct_out = p.splitk <= 1;
     float bias_r[NI];
-    uint16_t res_r[MI][NI][16];
+    // each lane fetches the aligned dword that holds its bf16 (a lane pair shares it): 2-byte loads
+    // into packed registers made hipcc wait on every single one of them
+    uint32_t res_r[MI][NI][16];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
         bias_r[ni] = (direct_out && p.bias) ? p.bias[tile_n * BN + wn * (BN / 2) + ni * 32 + lr] : 0.f;
@@ -189,7 +191,8 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const GemmParams p) {
             }
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
-                res_r[mi][ni][e] = ok ? residual[o + tile_n * BN + wn * (BN / 2) + ni * 32 + lr] : (uint16_t)0;
+                res_r[mi][ni][e] =
+                    ok ? *reinterpret_cast<const uint32_t*>(residual + o + tile_n * BN + wn * (BN / 2) + ni * 32 + (lr & ~1)) : 0u;
         }
 
     f32x4 af[2][MI], bf[2][NI];
@@ -259,7 +262,8 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const GemmParams p) {
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
                     const int n = tile_n * BN + wn * (BN / 2) + ni * 32 + lr;
-                    float v = acc[mi][ni][e] + bias_r[ni] + bf2f(res_r[mi][ni][e]);
+                    const uint32_t rw = res_r[mi][ni][e];
+                    float v = acc[mi][ni][e] + bias_r[ni] + __uint_as_float((lr & 1) ? (rw & 0xffff0000u) : (rw << 16));
                     if (p.relu) v = v > 0.f ? v : 0.f;
                     // neighbouring lanes hold neighbouring channels: pair them into one 4-byte store
                     const uint32_t mine = f2bf(v);
