@@ -37,14 +37,17 @@ PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 
 PEAK_HBM_GBS = 8000.0
 
 
-def _pmc_traffic(kernel_name):
+def _pmc_traffic(kernel_name, dtype, frames, height, width):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_traffic.json, produced by scripts/pmc_traffic.py; counters cannot be read
-    from inside this process). None when no measurement for that kernel is on file."""
+    (profiles/r01_traffic.json for the fp32 headline, profiles/r01_cfg2_bf16_traffic.json for
+    configs[2]; produced by scripts/pmc_traffic.py -- counters cannot be read from inside this
+    process). None when no measurement of that kernel on that workload shape is on file."""
+    name = "r01_traffic.json" if dtype == "f32" else "r01_cfg2_bf16_traffic.json"
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
             t = json.load(f)
-        return t["traffic_bytes_per_launch"] if t.get("kernel") == kernel_name else None
+        same = t.get("kernel") == kernel_name and t.get("workload") == {"frames": frames, "height": height, "width": width}
+        return t["traffic_bytes_per_launch"] if same else None
     except Exception:
         return None
 
@@ -183,8 +186,10 @@ def main():
         # sanity: results are finite and complete
         assert rec.shape[0] == n_total - 1 and torch.isfinite(lp).all()
         fps = n_total * args.steps / dt
+        shape = (n_local, args.height, args.width, args.dtype)
+        cfg_name = {(64, 1080, 1920, "f32"): "configs[1]", (256, 720, 1280, "bf16"): "configs[2]"}.get(shape, "custom shape")
         result = {
-            "metric": "1080p frames/sec end-to-end (decode->labels)",
+            "metric": f"{args.height}p frames/sec end-to-end (decode->labels)",
             "value": round(fps, 2),
             "unit": "frames/s",
             "n_gpus": world,
@@ -198,7 +203,7 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {
-                "workload": f"configs[1]: {n_local} x {args.height}x{args.width} BGR frames per GPU per step, 2 fighters/frame, "
+                "workload": f"{cfg_name}: {n_local} x {args.height}x{args.width} BGR frames per GPU per step, 2 fighters/frame, "
                 f"S=7 delta=3 window, {'fp32' if args.dtype == 'f32' else 'bf16-conv (3x3 stack in bf16, fp32 accumulate; stem, fc, head fp32)'} "
                 f"CNNActionDetector (ResNet-18 + Conv1d/MLP head, 63 actions), seeded weights",
                 "frames_per_gpu_per_step": n_local,
@@ -232,7 +237,7 @@ def main():
                     "peak": PEAK_FP32_MATRIX_TFLOPS,
                     "unit": "TFLOP/s",
                     "frac": round(tf / PEAK_FP32_MATRIX_TFLOPS, 4),
-                    "traffic": _pmc_traffic(dom["name"]),
+                    "traffic": _pmc_traffic(dom["name"], "f32", n_local, args.height, args.width),
                     "launches": dom["launches"],
                     "avg_launch_ms": round(dom["total_ms"] / max(dom["launches"], 1), 5),
                 }
@@ -247,7 +252,7 @@ def main():
                     "peak": PEAK_HBM_GBS,
                     "unit": "GB/s",
                     "frac": round(gbs / PEAK_HBM_GBS, 4),
-                    "traffic": None,
+                    "traffic": _pmc_traffic(dom["name"], "bf16", n_local, args.height, args.width),
                     "launches": dom["launches"],
                     "avg_launch_ms": round(dom["total_ms"] / max(dom["launches"], 1), 5),
                     "tflops": round(tf, 2),

@@ -1,42 +1,47 @@
 #!/usr/bin/env python3
-"""HBM traffic of the dominant kernel family from two rocprofv3 PMC passes
+"""HBM traffic of the conv3x3 kernel family from two rocprofv3 PMC passes
 (FETCH_SIZE and WRITE_SIZE collected separately, as MI355X_MICROARCH.md prescribes).
 
-  python scripts/pmc_traffic.py <dir with pmc_fetch/ and pmc_write/> <out.json>
+  python scripts/pmc_traffic.py <dir with pmc_fetch/ and pmc_write/> <out.json> [f32|bf16]
 
 Units: both counters are in KiB. On gfx950 FETCH_SIZE reports half the bytes of a wide
 coalesced read stream (guide, section HBM), so it is doubled; WRITE_SIZE is taken as is.
-The igemm launches of one bench step come in a fixed order (stem, the sixteen 3x3 convs,
-fc, then the gather-mode head), which is how the 3x3 launches are told apart from the
-other users of the kernel."""
+fp32: the igemm_f32_kernel launches of one bench step come in a fixed order (the sixteen 3x3
+convs, then the fc; the gather-mode head is a different instantiation), which is how the 3x3
+launches are told apart. bf16: every igemm_bf16_kernel launch is a 3x3 conv."""
 import collections, csv, glob, json, sys
 
+
 def dispatches(path, counter):
-    rows = list(csv.DictReader(open(glob.glob(path + "/runc/*counter_collection.csv")[0])))
+    rows = list(csv.DictReader(open(glob.glob(path + "/*/*counter_collection.csv")[0])))
     out = collections.OrderedDict()
     for r in rows:
         if r["Counter_Name"] == counter:
             out[int(r["Dispatch_Id"])] = (r["Kernel_Name"], float(r["Counter_Value"]))
     return [out[k] for k in sorted(out)]
 
-def conv3x3_values(disp):
+
+def conv3x3_values(disp, dtype):
+    if dtype == "bf16":
+        return [v for (name, v) in disp if "igemm_bf16_kernel" in name]
     ig = [v for (name, v) in disp if "igemm_f32_kernel" in name and ", true," not in name]
-    per_step = 1 + 16 + 1
+    per_step = 16 + 1
     assert len(ig) % per_step == 0, (len(ig), per_step)
     vals = []
     for s in range(len(ig) // per_step):
-        step = ig[s * per_step:(s + 1) * per_step]
-        idx = list(range(1, 17))
-        vals += [step[i] for i in idx]
+        vals += ig[s * per_step:s * per_step + 16]
     return vals
 
+
 d = sys.argv[1]
-f = conv3x3_values(dispatches(d + "/pmc_fetch", "FETCH_SIZE"))
-w = conv3x3_values(dispatches(d + "/pmc_write", "WRITE_SIZE"))
+dtype = sys.argv[3] if len(sys.argv) > 3 else "f32"
+f = conv3x3_values(dispatches(d + "/pmc_fetch", "FETCH_SIZE"), dtype)
+w = conv3x3_values(dispatches(d + "/pmc_write", "WRITE_SIZE"), dtype)
 fetch = 2.0 * sum(f) / len(f) * 1024.0
 write = sum(w) / len(w) * 1024.0
 out = {
     "kernel": "igemm_conv3x3",
+    "dtype": dtype,
     "launches_sampled": len(f),
     "fetch_bytes_per_launch": round(fetch),
     "write_bytes_per_launch": round(write),
