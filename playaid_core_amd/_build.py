@@ -20,6 +20,7 @@ ARCH = "gfx950"
 SOURCES = [
     ("igemm.hip", []),
     ("igemm_bf16.hip", []),
+    ("patchconv.hip", []),
     ("stem.hip", []),
     ("misc.hip", []),
     ("preprocess.hip", ["-ffp-contract=off"]),

@@ -354,10 +354,20 @@ int run_conv(pa_engine* e, const ConvLayer& L, int crop0, int ncrops, size_t sla
     const double bytes = (double)es * ((double)ncrops * L.in_hw * L.in_hw * L.cin + (double)p.M * p.N * (L.residual ? 2 : 1) +
                                        (double)p.N * L.k_alg + (L.in2 ? (double)ncrops * L.in2_hw * L.in2_hw * L.in2_c : 0.0));
     ProfScope ps(e, s, prof_name, flops, bytes);
-    if (bf)
+    // stride-1 3x3 layers: input patch resident in LDS across the nine taps (patchconv.hip);
+    // PA_PATCH=0 keeps the generic im2col engine for A/B runs
+    static const int use_patch = getenv("PA_PATCH") ? atoi(getenv("PA_PATCH")) : 1;
+    if (bf) {
         HIPCHK(e, launch_igemm_bf16(p, tile, s));
-    else
+    } else if (use_patch && L.kh == 3 && L.stride == 1 && !L.in2) {
+        int bm = tile == TILE_64x64 || tile == TILE_64x64_K64 ? 64 : 128;
+        const int howo = L.out_hw * L.out_hw, in_w2 = L.out_hw + 2;
+        const int px128 = howo >= 128 ? (128 / L.out_hw + 2) * in_w2 : (128 / howo) * in_w2 * in_w2;
+        if (bm == 128 && px128 > 224) bm = 64;  // keep two workgroups per CU (2 patch buffers + weight ring <= 80 KB)
+        HIPCHK(e, launch_conv3x3_patch(p, bm, s));
+    } else {
         HIPCHK(e, launch_igemm(p, tile, s));
+    }
     return PA_OK;
 }
 

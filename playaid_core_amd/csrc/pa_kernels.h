@@ -40,6 +40,9 @@ struct GemmParams {
     int32_t splitk, ksteps_per_split;
     int32_t skip_w;         // 1: k % 4 == 3 always meets a zero weight (stem channel pad): those MFMAs are skipped
     int32_t tiles_m, tiles_n;
+    // patch-resident 3x3 kernel (patchconv.hip), filled by its launcher: pixels per LDS patch buffer,
+    // input row pitch and image size in pixels, tile -> first patch pixel, pixels in the whole buffer
+    int32_t patch_slots, patch_pitch, img_px, tiles_per_img, p0_img, p0_row, total_px;
     unsigned long long* clk;  // ablation builds only: in-kernel clock stamps
 };
 
@@ -63,6 +66,8 @@ struct StemParams {
 };
 hipError_t launch_stem7x7(const StemParams& p, hipStream_t s);
 hipError_t launch_splitk_reduce(const GemmParams& p, hipStream_t s);
+// stride-1 3x3 convolution with the input patch resident in LDS across the nine taps (patchconv.hip); bm = 128 | 64
+hipError_t launch_conv3x3_patch(const GemmParams& p, int bm, hipStream_t s);
 
 // ---------------------------------------------------------------------------
 // crop preprocessing (preprocess.hip)

@@ -1,0 +1,364 @@
+// Stride-1 3x3 convolution with the activation patch resident in LDS and the weights in a
+// register ring (gfx950, exact fp32).
+//
+// The generic engine (igemm.hip) stages an im2col tile AND a weight tile per k-step, so every
+// activation byte of a tile travels L2 -> LDS nine times (once per tap) and the four waves meet
+// at a barrier every 32 k. Here the K loop runs channel chunk outermost: for each 32-channel
+// chunk the tile's input patch -- (rows + 2) x (W + 2) pixels x 128 B, a CONTIGUOUS pixel range
+// of the zero-bordered NHWC buffer (for the small maps: whole padded images) -- is copied to LDS
+// once with global_load_lds_dwordx4 (double buffered, one 4 KB pass per tap), and the nine taps
+// read their operand fragments from it at a per-tap pixel offset ky*(W+2)+kx. The weights skip
+// LDS: every lane fetches the 4 x 16 B of its own output channel straight into a three-deep
+// register ring two steps ahead. With no per-step stage there is no per-step barrier: ONE
+// barrier per 9 k-steps (288 MFMAs per wave at 128x64) when the patch buffers swap.
+//
+// Everything else follows igemm.hip: 2x2 waves over a BM x 64 tile, v_mfma_f32_32x32x2_f32,
+// 16-byte chunks XOR-swizzled by (pixel >> 1) & 7 on the DMA source so that ds_read_b128 of
+// consecutive pixels is conflict-free, fused bias / residual / ReLU epilogue, ordered split-K
+// over channel chunks. k is summed in (chunk, tap, channel) order -- a different rounding order
+// than igemm.hip's (tap, chunk, channel), equally deterministic. Layers with the fused 1x1/2
+// second source (block 0 conv2 of layers 2-4) and the stride-2 convs stay on igemm.hip.
+#include "pa_kernels.h"
+#ifdef PA_STAMP_BUILD
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#endif
+
+namespace pa {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ void glds16(const float* gsrc, float* lds_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ void split_m(const GemmParams& p, int m, int& img, int& oy, int& ox) {
+    if (p.howo_shift >= 0) {
+        img = m >> p.howo_shift;
+        const int rem = m & (p.howo - 1);
+        oy = rem >> p.wo_shift;
+        ox = rem & (p.wo - 1);
+    } else {
+        img = m / p.howo;
+        const int rem = m - img * p.howo;
+        oy = rem / p.wo;
+        ox = rem - oy * p.wo;
+    }
+}
+
+}  // namespace
+
+extern __shared__ __attribute__((aligned(16))) float pc_lds[];
+
+template <int BM>
+__global__ __launch_bounds__(256) void conv3x3_patch_kernel(const GemmParams p) {
+    constexpr int BN = 64;
+    constexpr int MI = BM / 64;
+    const int PP = p.patch_slots * 32;     // floats per patch buffer
+    float* const patch0 = pc_lds;
+
+    // XCD-aware (bijective) remap: blocks with equal b % 8 share an XCD.
+    const int nwg = gridDim.x;
+    const int b = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    const int tiles_mn = p.tiles_m * p.tiles_n;
+    const int z = wg / tiles_mn;
+    const int t_id = wg - z * tiles_mn;
+    const int tile_m = t_id / p.tiles_n;
+    const int tile_n = t_id - tile_m * p.tiles_n;
+
+    const int tid = threadIdx.x;
+#ifdef PA_STAMP_BUILD
+    const unsigned long long st0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = tid >> 3;                              // pixel of this thread within a DMA pass
+    const int colq = (tid & 7) ^ ((row0 >> 1) & 7);         // source chunk: slot c holds chunk c ^ ((pixel >> 1) & 7)
+
+    // first pixel of this tile's patch inside the zero-bordered input buffer
+    const int p0 = (tile_m / p.tiles_per_img) * p.p0_img + (tile_m % p.tiles_per_img) * p.p0_row;
+    const int n_ch = p.chunk >> 5;                          // 32-channel chunks
+    const int ch_begin = z * p.ksteps_per_split;            // (per split: whole chunks)
+    int ch_end = ch_begin + p.ksteps_per_split;
+    ch_end = ch_end < n_ch ? ch_end : n_ch;
+
+    // One DMA pass (32 pixels x 128 B, one piece per wave) of chunk CH's patch into buffer PB.
+#define PC_PATCH_PASS(CH, PB, Q)                                                                   \
+    {                                                                                              \
+        int px_ = p0 + row0 + 32 * (Q);                                                            \
+        px_ = px_ < p.total_px ? px_ : p.total_px - 1;                                             \
+        glds16(p.act + (size_t)px_ * p.in_px_stride + (CH) * 32 + colq * 4,                        \
+               patch0 + (PB) * PP + (Q) * 1024 + wave_id * 256);                                   \
+    }
+
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 31;
+    const int lh = lane >> 5;
+
+    // Weights never touch LDS: lane (lr, lh) of a wave needs, for its output channel n and every
+    // 8-wide k group kk of a step, the 4 floats W[n][k0 + 8 kk + 4 lh ..] -- four 16-byte global
+    // loads per step into a three-deep register ring, issued two steps ahead. No weight stage
+    // means no per-step barrier: the workgroup synchronises once per channel chunk (9 steps),
+    // when the patch buffers swap.
+    const int n_col = tile_n * BN + wn * 32 + lr;
+    const float* wrow = p.wgt + (size_t)n_col * p.ktot + lh * 4;
+    f32x4 breg[3][4];
+#define PC_LOAD_B(STAGE, CH, TAP)                                                                  \
+    {                                                                                              \
+        const float* w_ = wrow + (TAP) * p.chunk + (CH) * 32;                                      \
+        _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_)                                        \
+            breg[STAGE][kk_] = *reinterpret_cast<const f32x4*>(w_ + kk_ * 8);                      \
+    }
+
+    // patch pixel of this lane's MFMA row (tap 0,0) for each 32-row group
+    int pbase[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        int m = tile_m * BM + wm * (BM / 2) + mi * 32 + lr;
+        m = m < p.M ? m : p.M - 1;
+        int img, oy, ox;
+        split_m(p, m, img, oy, ox);
+        pbase[mi] = img * p.img_px + oy * p.patch_pitch + ox - p0;
+    }
+
+    f32x16 acc[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[mi][e] = 0.f;
+
+    const int npass = p.patch_slots >> 5;            // DMA passes per patch (<= 9); slots are a multiple of 32
+
+    // ---- prologue: first patch, weights of the first two steps ------------------------------
+    if (ch_begin < ch_end) {
+        for (int qq = 0; qq < npass; ++qq) PC_PATCH_PASS(ch_begin, 0, qq);
+        PC_LOAD_B(0, ch_begin, 0);
+        PC_LOAD_B(1, ch_begin, 1);
+    }
+    __syncthreads();
+#ifdef PA_STAMP_BUILD
+    const unsigned long long st1 = __builtin_amdgcn_s_memrealtime();
+#endif
+
+    int pb = 0;
+    for (int ch = ch_begin; ch < ch_end; ++ch) {
+        const float* patch = patch0 + pb * PP;
+        const bool more = ch + 1 < ch_end;
+        f32x4 af[2][MI];
+#define PC_LOAD_A(SET, TAP, KK)                                                                    \
+    {                                                                                              \
+        const int toff_ = ((TAP) / 3) * p.patch_pitch + ((TAP) % 3);                               \
+        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                        \
+            const int px_ = pbase[mi] + toff_;                                                     \
+            af[SET][mi] = *reinterpret_cast<const f32x4*>(patch + px_ * 32 + ((((KK) * 2 + lh) ^ ((px_ >> 1) & 7)) << 2)); \
+        }                                                                                          \
+    }
+        PC_LOAD_A(0, 0, 0);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            // loads for later steps first: weights of step +2 (ring stage (tap + 2) % 3), and one
+            // pass of the next chunk's patch per tap
+            if (tap + 2 < 9) {
+                PC_LOAD_B((tap + 2) % 3, ch, tap + 2);
+            } else if (more) {
+                PC_LOAD_B((tap + 2) % 3, ch + 1, tap + 2 - 9);
+            }
+            if (more && tap < npass) PC_PATCH_PASS(ch + 1, pb ^ 1, tap);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int g = tap * 4 + kk;  // fragment set alternates over the whole chunk
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const f32x4 a4 = af[g & 1][mi], b4 = breg[tap % 3][kk];
+                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[mi], 0, 0, 0);
+                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[mi], 0, 0, 0);
+                    if (mi == 0) {
+                        // next group's operands (next tap's first group at kk == 3): same patch
+                        // buffer, no barrier in between
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (kk + 1 < 4) {
+                            PC_LOAD_A((g + 1) & 1, tap, kk + 1);
+                        } else if (tap + 1 < 9) {
+                            PC_LOAD_A((g + 1) & 1, tap + 1, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[mi], 0, 0, 0);
+                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[mi], 0, 0, 0);
+                }
+            }
+        }
+#undef PC_LOAD_A
+        // the passes of the next patch (npass == 9: the last one was issued in tap 8) must have
+        // landed, and every wave must be done with this patch before it is overwritten
+        __syncthreads();
+        pb ^= 1;
+    }
+#undef PC_PATCH_PASS
+#undef PC_LOAD_B
+#ifdef PA_STAMP_BUILD
+    const unsigned long long st2 = __builtin_amdgcn_s_memrealtime();
+#endif
+
+    // Epilogue. The accumulators hold one output channel per lane (32x32 C/D map: col = lane & 31,
+    // row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5)), which would mean 32 four-byte stores per lane,
+    // and with every workgroup of the launch reaching its epilogue together the stores queue up
+    // (timeline stamps: 8 us median, 16 us worst, of a 46 us workgroup lifetime). So the tile is
+    // transposed through the (now idle) patch buffers: rows of 64 channels padded to 72 floats
+    // (conflict-free for the ds_write_b32 pairs 4 rows apart and for the ds_read_b128), then each
+    // thread moves 16 bytes: BM/16 residual loads + stores of dwordx4 instead of 32 of a dword.
+    constexpr int TS = 72;
+    const bool direct_out = p.splitk <= 1;
+    const int c4 = (tid & 15) * 4;  // first of this thread's 4 channels inside the tile
+    const int r_t = tid >> 4;       // its row in each 16-row slice
+    int o_t[BM / 16];
+    f32x4 res_t[BM / 16];
+#pragma unroll
+    for (int i = 0; i < BM / 16; ++i) {
+        int m = tile_m * BM + r_t + 16 * i;
+        m = m < p.M ? m : p.M - 1;
+        int img, oy, ox;
+        split_m(p, m, img, oy, ox);
+        o_t[i] = img * p.out_img_stride + (oy + p.out_pad) * p.out_row_stride + (ox + p.out_pad) * p.out_px_stride +
+                 tile_n * BN + c4;
+        res_t[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (direct_out && p.residual) {
+#pragma unroll
+        for (int i = 0; i < BM / 16; ++i) res_t[i] = *reinterpret_cast<const f32x4*>(p.residual + o_t[i]);
+    }
+    f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (direct_out && p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + tile_n * BN + c4);
+    float* const tbuf = pc_lds;  // every wave left the k loop through the final barrier
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = wm * (BM / 2) + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            tbuf[row * TS + wn * 32 + lr] = acc[mi][e];
+        }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < BM / 16; ++i) {
+        const int row = r_t + 16 * i;
+        const int m = tile_m * BM + row;
+        if (m >= p.M) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(tbuf + row * TS + c4);
+        if (!direct_out) {
+            *reinterpret_cast<f32x4*>(p.slab + ((size_t)z * p.M + m) * p.N + tile_n * BN + c4) = v;
+        } else {
+            v += bias4 + res_t[i];
+            if (p.relu) {
+                v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+                v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(p.out + o_t[i]) = v;
+        }
+    }
+#ifdef PA_STAMP_BUILD
+    if (p.clk && tid == 0) {
+        unsigned long long* o = p.clk + (size_t)blockIdx.x * 6;
+        o[0] = st0; o[1] = st1; o[2] = st2; o[3] = __builtin_amdgcn_s_memrealtime();
+        o[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
+        o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+    }
+#endif
+}
+
+// p: GemmParams as for launch_igemm (conv mode, 3x3, stride 1, chunk = Cin, ktot = 9*Cin + 32*k2_steps),
+// bm: 128 or 64. Fills the patch geometry, picks the split and launches; the ordered split-K
+// reduce is igemm.hip's.
+hipError_t launch_conv3x3_patch(const GemmParams& p_in, int bm, hipStream_t s) {
+    GemmParams p = p_in;
+    if (p.gather || p.taps != 9 || p.kw_taps != 3 || p.stride != 1 || p.chunk % 32 != 0 || p.N % 64 != 0 || p.M <= 0 ||
+        p.k2_steps != 0 || p.ktot != 9 * p.chunk || (bm != 128 && bm != 64))
+        return hipErrorInvalidValue;
+    auto ilog2 = [](int v) { int sh = 0; while ((1 << sh) < v) ++sh; return (1 << sh) == v ? sh : -1; };
+    p.howo_shift = ilog2(p.howo);
+    p.wo_shift = ilog2(p.wo);
+    if (p.howo_shift < 0 || p.wo_shift < 0) p.howo_shift = p.wo_shift = -1;
+    const int ho = p.howo / p.wo;
+    p.patch_pitch = p.in_row_stride / p.in_px_stride;  // W + 2
+    p.img_px = p.in_img_stride / p.in_px_stride;       // (H + 2) * (W + 2)
+    int patch_px;
+    if (p.howo >= bm) {  // a tile is a band of rows of one image
+        if (p.howo % bm != 0 || bm % p.wo != 0) return hipErrorInvalidValue;
+        const int rows = bm / p.wo;
+        p.tiles_per_img = p.howo / bm;
+        p.p0_img = p.img_px;
+        p.p0_row = rows * p.patch_pitch;
+        patch_px = (rows + 2) * p.patch_pitch;
+    } else {  // a tile is a run of whole images
+        if (bm % p.howo != 0) return hipErrorInvalidValue;
+        const int imgs = bm / p.howo;
+        p.tiles_per_img = 1;
+        p.p0_img = imgs * p.img_px;
+        p.p0_row = 0;
+        patch_px = imgs * p.img_px;
+    }
+    (void)ho;
+    p.patch_slots = (patch_px + 31) & ~31;  // whole 32-pixel DMA passes (no partially masked wave instruction)
+    if (p.patch_slots > 9 * 32) return hipErrorInvalidValue;
+    p.total_px = (p.M / p.howo) * p.img_px;
+    if (p.M % p.howo != 0) return hipErrorInvalidValue;
+    p.tiles_m = (p.M + bm - 1) / bm;
+    p.tiles_n = p.N / 64;
+    const int n_ch = p.chunk / 32;
+    if (p.splitk < 1) p.splitk = 1;
+    if (p.splitk > n_ch) p.splitk = n_ch;
+    p.ksteps_per_split = (n_ch + p.splitk - 1) / p.splitk;  // chunks per split
+    p.splitk = (n_ch + p.ksteps_per_split - 1) / p.ksteps_per_split;
+    size_t lds_bytes = (size_t)2 * p.patch_slots * 128;
+    if (lds_bytes < (size_t)bm * 72 * 4) lds_bytes = (size_t)bm * 72 * 4;  // the epilogue's transposed tile
+    static bool attr_set = false;
+    if (!attr_set) {  // dynamic LDS beyond the 64 KiB default
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const int grid = p.tiles_m * p.tiles_n * p.splitk;
+#ifdef PA_STAMP_BUILD
+    // timeline stamps of every workgroup of launch number PA_STAMP_CALL, written to PA_STAMP_FILE
+    static int stamp_calls = 0;
+    static unsigned long long* stamp_dev = nullptr;
+    const char* sf = getenv("PA_STAMP_FILE");
+    const bool stamp_now = sf && getenv("PA_STAMP_CALL") && stamp_calls++ == atoi(getenv("PA_STAMP_CALL"));
+    if (stamp_now) {
+        if (!stamp_dev) (void)hipMalloc(&stamp_dev, (size_t)65536 * 6 * 8);
+        p.clk = stamp_dev;
+    }
+#endif
+    if (bm == 128)
+        hipLaunchKernelGGL((conv3x3_patch_kernel<128>), dim3(grid), dim3(256), lds_bytes, s, p);
+    else
+        hipLaunchKernelGGL((conv3x3_patch_kernel<64>), dim3(grid), dim3(256), lds_bytes, s, p);
+#ifdef PA_STAMP_BUILD
+    if (stamp_now) {
+        (void)hipStreamSynchronize(s);
+        std::vector<unsigned long long> h((size_t)grid * 6);
+        (void)hipMemcpy(h.data(), stamp_dev, h.size() * 8, hipMemcpyDeviceToHost);
+        FILE* f = fopen(sf, "wb");
+        if (f) {
+            int hdr[4] = {grid, bm, p.M, p.chunk};
+            fwrite(hdr, 4, 4, f);
+            fwrite(h.data(), 8, h.size(), f);
+            fclose(f);
+        }
+    }
+#endif
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return err;
+    if (p.splitk > 1) return launch_splitk_reduce(p, s);
+    return hipSuccess;
+}
+
+}  // namespace pa
