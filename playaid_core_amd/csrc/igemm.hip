@@ -45,10 +45,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: stays in VGPRs (HIP's float4 class did not)
 
 
-// 16-byte global -> LDS DMA. LDS destination = wave-uniform `lds_base` + lane*16.
-__device__ __forceinline__ void glds16(const float* gsrc, float* lds_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+// 16-byte global -> LDS DMA, buffer form (buffer_load_dwordx4 ... offen lds). LDS destination =
+// wave-uniform `lds_base` + lane*16, source = descriptor base + `off` floats. The FLAT form
+// (global_load_lds) makes hipcc assume "a FLAT access may be pending" and turn every later wait
+// into s_waitcnt vmcnt(0) lgkmcnt(0); behind the MUBUF form the waits stay counted.
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, int off, float* lds_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_base, 16, off * 4, 0, 0, 0);
 }
 
 // m -> (img, oy, ox) with shifts when the output plane is a power of two
@@ -154,6 +156,10 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const GemmParams p) {
     }
 
     const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const __amdgpu_buffer_rsrc_t act_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.act), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wgt_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wgt), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t act2_rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.act2 ? p.act2 : p.act), 0, -1, 0x00020000);
 
     // Issue the LDS-DMA loads of the k-step under the cursor into stage BUF, then
     // advance the cursor. Each wave instruction fills WAVE_ROWS rows (1 KiB).
@@ -164,25 +170,25 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const GemmParams p) {
         if (issue_ks >= nk_main) {                                                                            \
             const int kc2 = (issue_ks - nk_main) * BK;                                                        \
             _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i)                                                \
-                glds16(p.act2 + a_off2[i] + kc2, As_w + i * 1024);                                            \
+                glds16(act2_rs, a_off2[i] + kc2, As_w + i * 1024);                                            \
             const int koff2 = nk_main * BK + kc2;                                                             \
             _Pragma("unroll") for (int i = 0; i < B_ROWS; ++i)                                                \
-                glds16(p.wgt + b_off[i] + koff2, Bs_w + i * 1024);                                            \
+                glds16(wgt_rs, b_off[i] + koff2, Bs_w + i * 1024);                                            \
         } else {                                                                                              \
             const int tap = cur_ky * p.kw_taps + cur_kx;                                                      \
             if (GATHER) {                                                                                     \
                 _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i) {                                          \
                     const int row = p.gather[a_off[i] + tap];                                                 \
-                    glds16(p.act + (size_t)row * p.in_px_stride + cur_kc + colq * 4, As_w + i * 1024);        \
+                    glds16(act_rs, row * p.in_px_stride + cur_kc + colq * 4, As_w + i * 1024);        \
                 }                                                                                             \
             } else {                                                                                          \
                 const int tapoff = (cur_ky + p.off_y) * p.in_row_stride + (cur_kx + p.off_x) * p.in_px_stride + cur_kc; \
                 _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i)                                            \
-                    glds16(p.act + a_off[i] + tapoff, As_w + i * 1024);                                       \
+                    glds16(act_rs, a_off[i] + tapoff, As_w + i * 1024);                                       \
             }                                                                                                 \
             const int koff = tap * p.chunk + cur_kc;                                                          \
             _Pragma("unroll") for (int i = 0; i < B_ROWS; ++i)                                                \
-                glds16(p.wgt + b_off[i] + koff, Bs_w + i * 1024);                                             \
+                glds16(wgt_rs, b_off[i] + koff, Bs_w + i * 1024);                                             \
             cur_kc += BK;                                                                                     \
             if (cur_kc == p.chunk) {                                                                          \
                 cur_kc = 0;                                                                                   \

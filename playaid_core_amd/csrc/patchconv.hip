@@ -32,9 +32,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-__device__ __forceinline__ void glds16(const float* gsrc, float* lds_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+// 16-byte global -> LDS DMA in its buffer form (buffer_load_dwordx4 ... offen lds): LDS
+// destination = wave-uniform `lds_base` + lane*16, source = descriptor base + voff + soff bytes.
+// The FLAT form (global_load_lds) makes hipcc treat every later wait as "a FLAT access may be
+// pending" and emit s_waitcnt vmcnt(0) lgkmcnt(0); with the MUBUF form the waits for the weight
+// ring stay counted (vmcnt(10) instead of a full drain twice per chunk).
+__device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, int voff_bytes, int soff_bytes, float* lds_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_base, 16, voff_bytes,
+                                             soff_bytes, 0, 0);
 }
 
 __device__ __forceinline__ void split_m(const GemmParams& p, int m, int& img, int& oy, int& ox) {
@@ -53,13 +58,18 @@ __device__ __forceinline__ void split_m(const GemmParams& p, int m, int& img, in
 
 }  // namespace
 
-extern __shared__ __attribute__((aligned(16))) float pc_lds[];
+// Patch buffer capacity in pixels: 128-row tiles of the 32- and 16-wide maps need 204 / 180,
+// 64-row tiles of the 8- and 4-wide maps 100 / 144 (rounded up to whole 32-pixel DMA passes).
+// A static array, not dynamic LDS: with `extern __shared__` hipcc cannot tell the DMA's target
+// buffer from the one the ds_reads use and drains vmcnt to 0 in front of every operand read.
+template <int BM> struct PatchCap { static constexpr int slots = BM == 128 ? 224 : 160; };
 
 template <int BM>
 __global__ __launch_bounds__(256) void conv3x3_patch_kernel(const GemmParams p) {
     constexpr int BN = 64;
     constexpr int MI = BM / 64;
-    const int PP = p.patch_slots * 32;     // floats per patch buffer
+    constexpr int PP = PatchCap<BM>::slots * 32;  // floats per patch buffer
+    __shared__ __attribute__((aligned(16))) float pc_lds[2 * PP];
     float* const patch0 = pc_lds;
 
     // XCD-aware (bijective) remap: blocks with equal b % 8 share an XCD.
@@ -89,11 +99,13 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(const GemmParams p) 
     ch_end = ch_end < n_ch ? ch_end : n_ch;
 
     // One DMA pass (32 pixels x 128 B, one piece per wave) of chunk CH's patch into buffer PB.
+    const __amdgpu_buffer_rsrc_t act_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.act), 0, -1, 0x00020000);
 #define PC_PATCH_PASS(CH, PB, Q)                                                                   \
     {                                                                                              \
         int px_ = p0 + row0 + 32 * (Q);                                                            \
         px_ = px_ < p.total_px ? px_ : p.total_px - 1;                                             \
-        glds16(p.act + (size_t)px_ * p.in_px_stride + (CH) * 32 + colq * 4,                        \
+        blds16(act_rsrc, (px_ * p.in_px_stride + colq * 4) * 4, (CH) * 128,                        \
                patch0 + (PB) * PP + (Q) * 1024 + wave_id * 256);                                   \
     }
 
@@ -151,7 +163,7 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(const GemmParams p) 
     int pb = 0;
     for (int ch = ch_begin; ch < ch_end; ++ch) {
         const float* patch = patch0 + pb * PP;
-        const bool more = ch + 1 < ch_end;
+        const int chn = ch + 1 < ch_end ? ch + 1 : ch;
         f32x4 af[2][MI];
 #define PC_LOAD_A(SET, TAP, KK)                                                                    \
     {                                                                                              \
@@ -166,12 +178,14 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(const GemmParams p) 
         for (int tap = 0; tap < 9; ++tap) {
             // loads for later steps first: weights of step +2 (ring stage (tap + 2) % 3), and one
             // pass of the next chunk's patch per tap
+            // (behind the last chunk both re-fetch that chunk, unused: the 9-tap body then has no
+            // data-dependent branch, which keeps hipcc's vmcnt bookkeeping exact)
             if (tap + 2 < 9) {
                 PC_LOAD_B((tap + 2) % 3, ch, tap + 2);
-            } else if (more) {
-                PC_LOAD_B((tap + 2) % 3, ch + 1, tap + 2 - 9);
+            } else {
+                PC_LOAD_B((tap + 2) % 3, chn, tap + 2 - 9);
             }
-            if (more && tap < npass) PC_PATCH_PASS(ch + 1, pb ^ 1, tap);
+            if (tap < npass) PC_PATCH_PASS(chn, pb ^ 1, tap);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
@@ -307,7 +321,6 @@ hipError_t launch_conv3x3_patch(const GemmParams& p_in, int bm, hipStream_t s) {
     }
     (void)ho;
     p.patch_slots = (patch_px + 31) & ~31;  // whole 32-pixel DMA passes (no partially masked wave instruction)
-    if (p.patch_slots > 9 * 32) return hipErrorInvalidValue;
     p.total_px = (p.M / p.howo) * p.img_px;
     if (p.M % p.howo != 0) return hipErrorInvalidValue;
     p.tiles_m = (p.M + bm - 1) / bm;
@@ -317,14 +330,8 @@ hipError_t launch_conv3x3_patch(const GemmParams& p_in, int bm, hipStream_t s) {
     if (p.splitk > n_ch) p.splitk = n_ch;
     p.ksteps_per_split = (n_ch + p.splitk - 1) / p.splitk;  // chunks per split
     p.splitk = (n_ch + p.ksteps_per_split - 1) / p.ksteps_per_split;
-    size_t lds_bytes = (size_t)2 * p.patch_slots * 128;
-    if (lds_bytes < (size_t)bm * 72 * 4) lds_bytes = (size_t)bm * 72 * 4;  // the epilogue's transposed tile
-    static bool attr_set = false;
-    if (!attr_set) {  // dynamic LDS beyond the 64 KiB default
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    if (p.patch_slots > (bm == 128 ? PatchCap<128>::slots : PatchCap<64>::slots)) return hipErrorInvalidValue;
+    const size_t lds_bytes = 0;
     const int grid = p.tiles_m * p.tiles_n * p.splitk;
 #ifdef PA_STAMP_BUILD
     // timeline stamps of every workgroup of launch number PA_STAMP_CALL, written to PA_STAMP_FILE
