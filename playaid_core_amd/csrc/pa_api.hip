@@ -359,7 +359,7 @@ int run_conv(pa_engine* e, const ConvLayer& L, int crop0, int ncrops, size_t sla
     static const int use_patch = getenv("PA_PATCH") ? atoi(getenv("PA_PATCH")) : 1;
     if (bf) {
         HIPCHK(e, launch_igemm_bf16(p, tile, s));
-    } else if (use_patch && L.kh == 3 && L.stride == 1 && !L.in2) {
+    } else if (use_patch && L.kh == 3 && L.stride == 1) {
         int bm = tile == TILE_64x64 || tile == TILE_64x64_K64 ? 64 : 128;
         const int howo = L.out_hw * L.out_hw, in_w2 = L.out_hw + 2;
         const int px128 = howo >= 128 ? (128 / L.out_hw + 2) * in_w2 : (128 / howo) * in_w2 * in_w2;

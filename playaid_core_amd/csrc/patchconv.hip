@@ -64,8 +64,8 @@ __device__ __forceinline__ void split_m(const GemmParams& p, int m, int& img, in
 // buffer from the one the ds_reads use and drains vmcnt to 0 in front of every operand read.
 template <int BM> struct PatchCap { static constexpr int slots = BM == 128 ? 224 : 160; };
 
-template <int BM>
-__global__ __launch_bounds__(256) void conv3x3_patch_kernel(const GemmParams p) {
+template <int BM, bool K2>
+__global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const GemmParams p) {
     constexpr int BN = 64;
     constexpr int MI = BM / 64;
     constexpr int PP = PatchCap<BM>::slots * 32;  // floats per patch buffer
@@ -97,6 +97,29 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(const GemmParams p) 
     const int ch_begin = z * p.ksteps_per_split;            // (per split: whole chunks)
     int ch_end = ch_begin + p.ksteps_per_split;
     ch_end = ch_end < n_ch ? ch_end : n_ch;
+    // fused 1x1/2 second source (block 0 of layers 2-4): k2_steps extra 32-channel steps after the
+    // 3x3 chunks; their "patch" is the gathered BM x 32 tile
+    // (shared evenly between the splits)
+    const int j0 = K2 ? (z * p.k2_steps) / p.splitk : 0;
+    const int k2n = K2 ? ((z + 1) * p.k2_steps) / p.splitk - j0 : 0;
+    constexpr int ROWS2 = BM / 32;
+    int a_off2[ROWS2];
+#pragma unroll
+    for (int i = 0; i < ROWS2; ++i) {
+        a_off2[i] = 0;
+        if (K2 && k2n) {
+            int m = tile_m * BM + row0 + 32 * i;
+            m = m < p.M ? m : p.M - 1;
+            int img, oy, ox;
+            split_m(p, m, img, oy, ox);
+            a_off2[i] = (img * p.in2_img_stride + (oy * p.stride2 + p.off2) * p.in2_row_stride +
+                         (ox * p.stride2 + p.off2) * p.in2_px_stride + colq * 4) * 4;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t act2_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.act2 ? p.act2 : p.act), 0, -1, 0x00020000);
+    // pass Q of the gathered tile of second-source step J into buffer PB
+#define PC_TILE2_PASS(J, PB, Q) blds16(act2_rsrc, a_off2[Q], (j0 + (J)) * 128, patch0 + (PB) * PP + (Q) * 1024 + wave_id * 256)
 
     // One DMA pass (32 pixels x 128 B, one piece per wave) of chunk CH's patch into buffer PB.
     const __amdgpu_buffer_rsrc_t act_rsrc =
@@ -126,6 +149,14 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(const GemmParams p) 
 #define PC_LOAD_B(STAGE, CH, TAP)                                                                  \
     {                                                                                              \
         const float* w_ = wrow + (TAP) * p.chunk + (CH) * 32;                                      \
+        _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_)                                        \
+            breg[STAGE][kk_] = *reinterpret_cast<const f32x4*>(w_ + kk_ * 8);                      \
+    }
+
+#define PC_LOAD_B2(STAGE, J)                                                                       \
+    {                                                                                              \
+        const int j_ = j0 + (J) < p.k2_steps ? j0 + (J) : p.k2_steps - 1;                          \
+        const float* w_ = wrow + 9 * p.chunk + j_ * 32;                                            \
         _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_)                                        \
             breg[STAGE][kk_] = *reinterpret_cast<const f32x4*>(w_ + kk_ * 8);                      \
     }
@@ -164,6 +195,7 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(const GemmParams p) 
     for (int ch = ch_begin; ch < ch_end; ++ch) {
         const float* patch = patch0 + pb * PP;
         const int chn = ch + 1 < ch_end ? ch + 1 : ch;
+        const bool to_k2 = K2 && ch + 1 == ch_end && k2n > 0;  // last 3x3 chunk: prefetch the second source instead
         f32x4 af[2][MI];
 #define PC_LOAD_A(SET, TAP, KK)                                                                    \
     {                                                                                              \
@@ -182,10 +214,16 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(const GemmParams p) 
             // data-dependent branch, which keeps hipcc's vmcnt bookkeeping exact)
             if (tap + 2 < 9) {
                 PC_LOAD_B((tap + 2) % 3, ch, tap + 2);
+            } else if (to_k2) {
+                PC_LOAD_B2((tap + 2) % 3, tap + 2 - 9);
             } else {
                 PC_LOAD_B((tap + 2) % 3, chn, tap + 2 - 9);
             }
-            if (tap < npass) PC_PATCH_PASS(chn, pb ^ 1, tap);
+            if (to_k2) {
+                if (tap < ROWS2) PC_TILE2_PASS(0, pb ^ 1, tap);
+            } else if (tap < npass) {
+                PC_PATCH_PASS(chn, pb ^ 1, tap);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
@@ -217,8 +255,60 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(const GemmParams p) 
         __syncthreads();
         pb ^= 1;
     }
+    // ---- second-source steps: one 32-channel step each, tile j+1 and weights j+2 in flight ----
+    if (K2 && k2n > 0) {
+        if (ch_begin >= ch_end) {  // (split without 3x3 chunks: nothing was prefetched)
+#pragma unroll
+            for (int qq = 0; qq < ROWS2; ++qq) PC_TILE2_PASS(0, pb, qq);
+            PC_LOAD_B2(0, 0);
+            if (k2n > 1) PC_LOAD_B2(1, 1);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j < k2n) {
+                const float* tile2 = patch0 + pb * PP;
+                if (j + 2 < k2n) PC_LOAD_B2((j + 2) % 3, j + 2);
+                if (j + 1 < k2n) {
+#pragma unroll
+                    for (int qq = 0; qq < ROWS2; ++qq) PC_TILE2_PASS(j + 1, pb ^ 1, qq);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                f32x4 a2[2][MI];
+#define PC_LOAD_A2(SET, KK)                                                                        \
+    {                                                                                              \
+        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                        \
+            const int r_ = wm * (BM / 2) + mi * 32 + lr;                                           \
+            a2[SET][mi] = *reinterpret_cast<const f32x4*>(tile2 + r_ * 32 + ((((KK) * 2 + lh) ^ ((r_ >> 1) & 7)) << 2)); \
+        }                                                                                          \
+    }
+                PC_LOAD_A2(0, 0);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        const f32x4 a4 = a2[kk & 1][mi], b4 = breg[j % 3][kk];
+                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[mi], 0, 0, 0);
+                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[mi], 0, 0, 0);
+                        if (mi == 0 && kk + 1 < 4) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            PC_LOAD_A2((kk + 1) & 1, kk + 1);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[mi], 0, 0, 0);
+                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[mi], 0, 0, 0);
+                    }
+                }
+#undef PC_LOAD_A2
+                __syncthreads();
+                pb ^= 1;
+            }
+        }
+    }
 #undef PC_PATCH_PASS
 #undef PC_LOAD_B
+#undef PC_LOAD_B2
+#undef PC_TILE2_PASS
 #ifdef PA_STAMP_BUILD
     const unsigned long long st2 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -294,7 +384,8 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(const GemmParams p) 
 hipError_t launch_conv3x3_patch(const GemmParams& p_in, int bm, hipStream_t s) {
     GemmParams p = p_in;
     if (p.gather || p.taps != 9 || p.kw_taps != 3 || p.stride != 1 || p.chunk % 32 != 0 || p.N % 64 != 0 || p.M <= 0 ||
-        p.k2_steps != 0 || p.ktot != 9 * p.chunk || (bm != 128 && bm != 64))
+        p.k2_steps < 0 || p.k2_steps > 8 || p.k2_steps == 1 || p.ktot != 9 * p.chunk + 32 * p.k2_steps ||
+        (p.k2_steps && !p.act2) || (bm != 128 && bm != 64))
         return hipErrorInvalidValue;
     auto ilog2 = [](int v) { int sh = 0; while ((1 << sh) < v) ++sh; return (1 << sh) == v ? sh : -1; };
     p.howo_shift = ilog2(p.howo);
@@ -344,10 +435,13 @@ hipError_t launch_conv3x3_patch(const GemmParams& p_in, int bm, hipStream_t s) {
         p.clk = stamp_dev;
     }
 #endif
-    if (bm == 128)
-        hipLaunchKernelGGL((conv3x3_patch_kernel<128>), dim3(grid), dim3(256), lds_bytes, s, p);
-    else
-        hipLaunchKernelGGL((conv3x3_patch_kernel<64>), dim3(grid), dim3(256), lds_bytes, s, p);
+    if (bm == 128) {
+        if (p.k2_steps) hipLaunchKernelGGL((conv3x3_patch_kernel<128, true>), dim3(grid), dim3(256), lds_bytes, s, p);
+        else hipLaunchKernelGGL((conv3x3_patch_kernel<128, false>), dim3(grid), dim3(256), lds_bytes, s, p);
+    } else {
+        if (p.k2_steps) hipLaunchKernelGGL((conv3x3_patch_kernel<64, true>), dim3(grid), dim3(256), lds_bytes, s, p);
+        else hipLaunchKernelGGL((conv3x3_patch_kernel<64, false>), dim3(grid), dim3(256), lds_bytes, s, p);
+    }
 #ifdef PA_STAMP_BUILD
     if (stamp_now) {
         (void)hipStreamSynchronize(s);
