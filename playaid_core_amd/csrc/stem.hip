@@ -35,15 +35,18 @@ constexpr int PATCH_CH = PATCH_ROWS * IN_W;  // 16-byte chunks per patch (1206)
 constexpr int STAGE_CH = 1280;             // chunks per LDS stage (5 passes of 256 lanes)
 constexpr int KTOT = 224;                  // weight row stride of the igemm layout (7 ky x 32)
 
-__device__ __forceinline__ void glds16(const float* gsrc, float* lds_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+// 16-byte global -> LDS DMA, buffer form (see igemm.hip: behind the FLAT form hipcc turns every
+// later wait into vmcnt(0) lgkmcnt(0)); source = descriptor base + `off` floats.
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, int off, float* lds_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_base, 16, off * 4, 0, 0, 0);
 }
 
 }  // namespace
 
 __global__ __launch_bounds__(256, 2) void stem7x7_kernel(const StemParams p) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE_CH * 4];
+    constexpr int TS = 72;  // padded row (floats) of the transposed output tile, as in igemm.hip's epilogue
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE_CH * 4 + 128 * TS];
+    float* const tbuf = lds + 2 * STAGE_CH * 4;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -60,14 +63,15 @@ __global__ __launch_bounds__(256, 2) void stem7x7_kernel(const StemParams p) {
     const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
     const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
 
+    const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, -1, 0x00020000);
 #define PA_STEM_ISSUE(TILE, BUF)                                                                   \
     {                                                                                              \
         const int img_ = (TILE) >> 5, oy0_ = ((TILE) & 31) * 2;                                    \
-        const float* src_ = p.x + ((size_t)img_ * IN_W * IN_W + (size_t)(2 * oy0_) * IN_W) * 4;   \
+        const int src_ = (img_ * IN_W * IN_W + (2 * oy0_) * IN_W) * 4;                             \
         float* dst_ = lds + (BUF) * (STAGE_CH * 4) + wave_id * 256;                                \
         _Pragma("unroll") for (int i = 0; i < 5; ++i) {                                            \
             const int j = tid + 256 * i;                                                           \
-            if (j < PATCH_CH) glds16(src_ + (j ^ ((j >> 4) & 1)) * 4, dst_ + i * 1024);            \
+            if (j < PATCH_CH) glds16(x_rs, src_ + (j ^ ((j >> 4) & 1)) * 4, dst_ + i * 1024);      \
         }                                                                                          \
     }
 
@@ -131,24 +135,40 @@ __global__ __launch_bounds__(256, 2) void stem7x7_kernel(const StemParams p) {
         }
 #undef PA_STEM_FRAGS
 
-        // epilogue: + folded BN bias, ReLU, into the bordered NHWC map [crop][66][66][64]
-        const int img = t >> 5, oy = (t & 31) * 2 + wm;
-        const size_t obase = ((size_t)img * OUT_W * OUT_W + (size_t)(oy + 1) * OUT_W + 1) * COUT + n;
+        // epilogue: + folded BN bias, ReLU, into the bordered NHWC map [crop][66][66][64]. The tile
+        // (2 rows x 64 pixels x 64 channels) is transposed through LDS so that each thread stores 16
+        // bytes (8 stores per thread instead of 32 four-byte ones per lane -- the stores of a whole
+        // grid reaching its epilogue together otherwise queue up, see igemm.hip).
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int ox = mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 float v = acc[mi][e] + bias;
-                v = v > 0.f ? v : 0.f;
-                if (p.out_bf16) {  // bf16 conv path: round to nearest even
-                    uint32_t u = __float_as_uint(v);
-                    u += 0x7fffu + ((u >> 16) & 1u);
-                    reinterpret_cast<uint16_t*>(p.out)[obase + (size_t)ox * COUT] = (uint16_t)(u >> 16);
+                tbuf[(wm * 64 + ox) * TS + n] = v > 0.f ? v : 0.f;
+            }
+        __syncthreads();
+        {
+            const int img = t >> 5, oy0 = (t & 31) * 2;
+            const int c4 = (tid & 15) * 4;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = (tid >> 4) + 16 * i;  // wm * 64 + ox
+                const f32x4 v = *reinterpret_cast<const f32x4*>(tbuf + row * TS + c4);
+                const size_t o = ((size_t)img * OUT_W * OUT_W + (size_t)(oy0 + (row >> 6) + 1) * OUT_W + (row & 63) + 1) * COUT + c4;
+                if (p.out_bf16) {  // bf16 conv path: round to nearest even, 4 channels = 8 bytes
+                    uint32_t u[4] = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) u[k] = (u[k] + 0x7fffu + ((u[k] >> 16) & 1u)) >> 16;
+                    uint2 pk;
+                    pk.x = u[0] | (u[1] << 16);
+                    pk.y = u[2] | (u[3] << 16);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + o) = pk;
                 } else {
-                    p.out[obase + (size_t)ox * COUT] = v;
+                    *reinterpret_cast<f32x4*>(p.out + o) = v;
                 }
             }
+        }
         __syncthreads();  // next patch landed (vmcnt drained) and every wave is done with this one
         buf ^= 1;
     }
