@@ -24,9 +24,9 @@ typedef uint16_t bf16_t;  // storage
 
 namespace {
 
-__device__ __forceinline__ void glds16(const void* gsrc, float* lds_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+// 16-byte global -> LDS DMA, buffer form (see igemm.hip); source = descriptor base + `off` bf16 elements.
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, int off, float* lds_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_base, 16, off * 2, 0, 0, 0);
 }
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float((uint32_t)h << 16); }
@@ -121,6 +121,10 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const GemmParams p) {
         cur_kx = tap - cur_ky * p.kw_taps;
     }
     const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const __amdgpu_buffer_rsrc_t act_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(act), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wgt_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(wgt), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t act2_rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(act2 ? act2 : act), 0, -1, 0x00020000);
 
 #define PA_ISSUE_STAGE(BUF)                                                                                   \
     {                                                                                                         \
@@ -128,15 +132,15 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const GemmParams p) {
         float* Bs_w = As_w + BM * ROW_F;                                                                      \
         if (issue_ks >= nk_main) {                                                                            \
             const int kc2 = (issue_ks - nk_main) * BK;                                                        \
-            _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i) glds16(act2 + a_off2[i] + kc2, As_w + i * 1024); \
+            _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i) glds16(act2_rs, a_off2[i] + kc2, As_w + i * 1024); \
             const int koff2 = nk_main * BK + kc2;                                                             \
-            _Pragma("unroll") for (int i = 0; i < B_ROWS; ++i) glds16(wgt + b_off[i] + koff2, Bs_w + i * 1024); \
+            _Pragma("unroll") for (int i = 0; i < B_ROWS; ++i) glds16(wgt_rs, b_off[i] + koff2, Bs_w + i * 1024); \
         } else {                                                                                              \
             const int tap = cur_ky * p.kw_taps + cur_kx;                                                      \
             const int tapoff = (cur_ky + p.off_y) * p.in_row_stride + (cur_kx + p.off_x) * p.in_px_stride + cur_kc; \
-            _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i) glds16(act + a_off[i] + tapoff, As_w + i * 1024); \
+            _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i) glds16(act_rs, a_off[i] + tapoff, As_w + i * 1024); \
             const int koff = tap * p.chunk + cur_kc;                                                          \
-            _Pragma("unroll") for (int i = 0; i < B_ROWS; ++i) glds16(wgt + b_off[i] + koff, Bs_w + i * 1024); \
+            _Pragma("unroll") for (int i = 0; i < B_ROWS; ++i) glds16(wgt_rs, b_off[i] + koff, Bs_w + i * 1024); \
             cur_kc += BK;                                                                                     \
             if (cur_kc == p.chunk) {                                                                          \
                 cur_kc = 0;                                                                                   \
@@ -167,33 +171,35 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const GemmParams p) {
     const int b_rd_off = BM * ROW_F + (wn * (BN / 2) + lr) * ROW_F;
     const int swz = CH == 8 ? ((lr >> 1) & 7) : (lr & 15);
 
-    // Epilogue operands are fetched now so their latency hides under the k loop.
+    // Epilogue operands (thread-mapped, see the epilogue) are fetched now so their latency hides
+    // under the k loop: thread t owns channels [c8, c8+8) of rows r_t + ROWS_PP * i.
+    constexpr int TS = BN + 8;             // padded fp32 row of the transposed tile
+    constexpr int CPR = BN / 8;            // 16-byte (8 x bf16) chunks per output row
+    constexpr int ROWS_PP = 256 / CPR;
+    constexpr int EP_IT = BM / ROWS_PP;
+    static_assert(BM * TS <= 3 * STAGE, "transposed tile must fit the LDS ring");
     const bool direct_out = p.splitk <= 1;
-    float bias_r[NI];
-    // each lane fetches the aligned dword that holds its bf16 (a lane pair shares it): 2-byte loads
-    // into packed registers made hipcc wait on every single one of them
-    uint32_t res_r[MI][NI][16];
+    const int c8 = (tid & (CPR - 1)) * 8;
+    const int r_t = tid / CPR;
+    int o_t[EP_IT];
+    uint4 res_t[EP_IT];
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-        bias_r[ni] = (direct_out && p.bias) ? p.bias[tile_n * BN + wn * (BN / 2) + ni * 32 + lr] : 0.f;
+    for (int i = 0; i < EP_IT; ++i) {
+        int m = tile_m * BM + r_t + ROWS_PP * i;
+        m = m < p.M ? m : p.M - 1;
+        int img, oy, ox;
+        split_m(p, m, img, oy, ox);
+        o_t[i] = img * p.out_img_stride + (oy + p.out_pad) * p.out_row_stride + (ox + p.out_pad) * p.out_px_stride +
+                 tile_n * BN + c8;
+        res_t[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    if (direct_out && residual) {
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+        for (int i = 0; i < EP_IT; ++i) res_t[i] = *reinterpret_cast<const uint4*>(residual + o_t[i]);
+    }
+    float bias8[8];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int m = tile_m * BM + wm * (BM / 2) + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            size_t o = 0;
-            const bool ok = direct_out && residual && m < p.M;
-            if (ok) {
-                int img, oy, ox;
-                split_m(p, m, img, oy, ox);
-                o = (size_t)img * p.out_img_stride + (size_t)(oy + p.out_pad) * p.out_row_stride +
-                    (size_t)(ox + p.out_pad) * p.out_px_stride;
-            }
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-                res_r[mi][ni][e] =
-                    ok ? *reinterpret_cast<const uint32_t*>(residual + o + tile_n * BN + wn * (BN / 2) + ni * 32 + (lr & ~1)) : 0u;
-        }
+    for (int k = 0; k < 8; ++k) bias8[k] = (direct_out && p.bias) ? p.bias[tile_n * BN + c8 + k] : 0.f;
 
     f32x4 af[2][MI], bf[2][NI];
 #define PA_LOAD_FRAGS(SET, STAGE_PTR, G)                                                                      \
@@ -242,35 +248,46 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const GemmParams p) {
 #undef PA_LOAD_FRAGS
 #undef PA_ISSUE_STAGE
 
-    // Epilogue. 32x32 C/D map: col = lane & 31, row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5).
+    // Epilogue: the fp32 accumulators are transposed through the idle LDS ring (rows padded to
+    // BN + 8 floats) so that each thread converts and stores 8 channels = 16 bytes per row, EP_IT
+    // wide stores (and residual loads) per thread instead of 16*MI*NI two-byte ones per lane.
+    float* const tbuf = lds;  // every wave left the k loop through its final barrier
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = wm * (BM / 2) + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            const int m = tile_m * BM + row;
-            if (m >= p.M) continue;
-            if (p.splitk > 1) {
-                float* dst = p.slab + ((size_t)z * p.M + m) * p.N;
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) dst[tile_n * BN + wn * (BN / 2) + ni * 32 + lr] = acc[mi][ni][e];
-            } else {
-                int img, oy, ox;
-                split_m(p, m, img, oy, ox);
-                const size_t o = (size_t)img * p.out_img_stride + (size_t)(oy + p.out_pad) * p.out_row_stride +
-                                 (size_t)(ox + p.out_pad) * p.out_px_stride;
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    const int n = tile_n * BN + wn * (BN / 2) + ni * 32 + lr;
-                    const uint32_t rw = res_r[mi][ni][e];
-                    float v = acc[mi][ni][e] + bias_r[ni] + __uint_as_float((lr & 1) ? (rw & 0xffff0000u) : (rw << 16));
-                    if (p.relu) v = v > 0.f ? v : 0.f;
-                    // neighbouring lanes hold neighbouring channels: pair them into one 4-byte store
-                    const uint32_t mine = f2bf(v);
-                    const uint32_t other = (uint32_t)__shfl_xor((int)mine, 1, 64);
-                    if (!(lr & 1)) *reinterpret_cast<uint32_t*>(out + o + n) = mine | (other << 16);
-                }
+            for (int e = 0; e < 16; ++e) {
+                const int row = wm * (BM / 2) + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                tbuf[row * TS + wn * (BN / 2) + ni * 32 + lr] = acc[mi][ni][e];
             }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < EP_IT; ++i) {
+        const int row = r_t + ROWS_PP * i;
+        const int m = tile_m * BM + row;
+        if (m >= p.M) continue;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(tbuf + row * TS + c8);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(tbuf + row * TS + c8 + 4);
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        if (!direct_out) {
+            float* dst = p.slab + ((size_t)z * p.M + m) * p.N + tile_n * BN + c8;
+            *reinterpret_cast<f32x4*>(dst) = v0;
+            *reinterpret_cast<f32x4*>(dst + 4) = v1;
+        } else {
+            const uint32_t rw[4] = {res_t[i].x, res_t[i].y, res_t[i].z, res_t[i].w};
+            uint32_t pk[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float a = v[2 * k] + bias8[2 * k] + __uint_as_float(rw[k] << 16);
+                float b = v[2 * k + 1] + bias8[2 * k + 1] + __uint_as_float(rw[k] & 0xffff0000u);
+                if (p.relu) {
+                    a = a > 0.f ? a : 0.f;
+                    b = b > 0.f ? b : 0.f;
+                }
+                pk[k] = (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+            }
+            *reinterpret_cast<uint4*>(out + o_t[i]) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
         }
     }
 }
