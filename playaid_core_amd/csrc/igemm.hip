@@ -222,7 +222,8 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const GemmParams p) {
     // The epilogue moves the tile through LDS so that every thread stores 16 bytes (see below):
     // thread t owns channels [c4, c4+4) of rows r_t + ROWS_PP * i. Its bias / residual operands
     // are fetched now, so their latency hides under the whole k loop.
-    constexpr int TS = BN + 8;             // padded row of the transposed tile (floats)
+    constexpr int TS = BN;                 // row of the transposed tile (floats): unpadded is the conflict-free choice
+                                           // for ds_read_b128's lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31}
     constexpr int CPR = BN / 4;            // 16-byte chunks per row
     constexpr int ROWS_PP = 256 / CPR;     // rows covered by one pass of the 256 threads
     constexpr int EP_IT = BM / ROWS_PP;
@@ -345,8 +346,7 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const GemmParams p) {
     // row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5)): stored directly that is 16*MI*NI four-byte stores
     // per lane, and since every workgroup of a launch reaches its epilogue at about the same time
     // the stores queue up (timeline stamps: 8 us median, 16 us worst, of a 46 us workgroup). The
-    // tile is therefore transposed through the (now idle) LDS ring -- rows padded to BN + 8 floats:
-    // conflict-free for the ds_write_b32 pairs 4 rows apart and for the ds_read_b128 -- and each
+    // tile is therefore transposed through the (now idle) LDS ring -- rows of BN floats -- and each
     // thread moves 16 bytes per row: EP_IT dwordx4 stores (and residual loads) instead.
     float* const tbuf = lds;  // every wave left the k loop through its final barrier
 #pragma unroll

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const GemmParams p) {
 
     // Epilogue operands (thread-mapped, see the epilogue) are fetched now so their latency hides
     // under the k loop: thread t owns channels [c8, c8+8) of rows r_t + ROWS_PP * i.
-    constexpr int TS = BN + 8;             // padded fp32 row of the transposed tile
+    constexpr int TS = BN;                 // fp32 row of the transposed tile (see igemm.hip)
     constexpr int CPR = BN / 8;            // 16-byte (8 x bf16) chunks per output row
     constexpr int ROWS_PP = 256 / CPR;
     constexpr int EP_IT = BM / ROWS_PP;
@@ -248,8 +248,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const GemmParams p) {
 #undef PA_LOAD_FRAGS
 #undef PA_ISSUE_STAGE
 
-    // Epilogue: the fp32 accumulators are transposed through the idle LDS ring (rows padded to
-    // BN + 8 floats) so that each thread converts and stores 8 channels = 16 bytes per row, EP_IT
+    // Epilogue: the fp32 accumulators are transposed through the idle LDS ring (rows of BN floats) so that each thread converts and stores 8 channels = 16 bytes per row, EP_IT
     // wide stores (and residual loads) per thread instead of 16*MI*NI two-byte ones per lane.
     float* const tbuf = lds;  // every wave left the k loop through its final barrier
 #pragma unroll

@@ -43,6 +43,7 @@ struct GemmParams {
     // patch-resident 3x3 kernel (patchconv.hip), filled by its launcher: pixels per LDS patch buffer,
     // input row pitch and image size in pixels, tile -> first patch pixel, pixels in the whole buffer
     int32_t patch_slots, patch_pitch, img_px, tiles_per_img, p0_img, p0_row, total_px;
+    int32_t swz_a, magic_pitch, magic_img, img_px_patch;  // chunk-swizzle key of a patch pixel (see patchconv.hip)
     unsigned long long* clk;  // ablation builds only: in-kernel clock stamps
 };
 

@@ -93,6 +93,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const GemmParams 
 
     // first pixel of this tile's patch inside the zero-bordered input buffer
     const int p0 = (tile_m / p.tiles_per_img) * p.p0_img + (tile_m % p.tiles_per_img) * p.p0_row;
+    // Chunk swizzle. LDS slot c of patch pixel (row, col) [padded image coordinates] holds logical
+    // chunk c ^ key, key = (R >> 1) & 7 with R = (A*row + col) & 15, A = W & 15: the 32 lanes of an
+    // MFMA row group are 32 consecutive output pixels, i.e. R advances by one per lane whatever the
+    // map width (8-wide maps wrap to the next row after 8 lanes, A = 8 keeps R counting), so every
+    // 16-lane ds_read_b128 phase sees 16 distinct R = 16 distinct bank slots for all nine taps
+    // (brute-forced for W = 32, 16, 8, 4; keying on the linear patch pixel instead cost 5-10 % of
+    // the cycles in bank conflicts on the 16/8/4-wide maps: SQ_LDS_BANK_CONFLICT).
+    const int band_row0 = p.p0_row ? (tile_m % p.tiles_per_img) * (p.p0_row / p.patch_pitch) : 0;
     const int n_ch = p.chunk >> 5;                          // 32-channel chunks
     const int ch_begin = z * p.ksteps_per_split;            // (per split: whole chunks)
     int ch_end = ch_begin + p.ksteps_per_split;
@@ -128,7 +136,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const GemmParams 
     {                                                                                              \
         int px_ = p0 + row0 + 32 * (Q);                                                            \
         px_ = px_ < p.total_px ? px_ : p.total_px - 1;                                             \
-        blds16(act_rsrc, (px_ * p.in_px_stride + colq * 4) * 4, (CH) * 128,                        \
+        const int pp_ = row0 + 32 * (Q);                       /* pixel inside the patch */           \
+        const int im_ = (pp_ * p.magic_img) >> 16;              /* padded image it belongs to */       \
+        const int rem_ = pp_ - im_ * p.img_px_patch;                                                   \
+        const int rw_ = (rem_ * p.magic_pitch) >> 16;           /* its padded row and column */        \
+        const int key_ = ((p.swz_a * (rw_ + band_row0) + rem_ - rw_ * p.patch_pitch) >> 1) & 7;        \
+        blds16(act_rsrc, (px_ * p.in_px_stride + ((tid & 7) ^ key_) * 4) * 4, (CH) * 128,              \
                patch0 + (PB) * PP + (Q) * 1024 + wave_id * 256);                                   \
     }
 
@@ -162,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const GemmParams 
     }
 
     // patch pixel of this lane's MFMA row (tap 0,0) for each 32-row group
-    int pbase[MI];
+    int pbase[MI], rbase[MI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         int m = tile_m * BM + wm * (BM / 2) + mi * 32 + lr;
@@ -170,6 +183,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const GemmParams 
         int img, oy, ox;
         split_m(p, m, img, oy, ox);
         pbase[mi] = img * p.img_px + oy * p.patch_pitch + ox - p0;
+        rbase[mi] = p.swz_a * oy + ox;
     }
 
     f32x16 acc[MI];
@@ -200,9 +214,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const GemmParams 
 #define PC_LOAD_A(SET, TAP, KK)                                                                    \
     {                                                                                              \
         const int toff_ = ((TAP) / 3) * p.patch_pitch + ((TAP) % 3);                               \
+        const int roff_ = ((TAP) / 3) * p.swz_a + ((TAP) % 3);                                     \
         _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                        \
             const int px_ = pbase[mi] + toff_;                                                     \
-            af[SET][mi] = *reinterpret_cast<const f32x4*>(patch + px_ * 32 + ((((KK) * 2 + lh) ^ ((px_ >> 1) & 7)) << 2)); \
+            const int key_ = ((rbase[mi] + roff_) >> 1) & 7;                                       \
+            af[SET][mi] = *reinterpret_cast<const f32x4*>(patch + px_ * 32 + ((((KK) * 2 + lh) ^ key_) << 2)); \
         }                                                                                          \
     }
         PC_LOAD_A(0, 0, 0);
@@ -317,10 +333,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const GemmParams 
     // row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5)), which would mean 32 four-byte stores per lane,
     // and with every workgroup of the launch reaching its epilogue together the stores queue up
     // (timeline stamps: 8 us median, 16 us worst, of a 46 us workgroup lifetime). So the tile is
-    // transposed through the (now idle) patch buffers: rows of 64 channels padded to 72 floats
-    // (conflict-free for the ds_write_b32 pairs 4 rows apart and for the ds_read_b128), then each
+    // transposed through the (now idle) patch buffers: rows of 64 channels, then each
     // thread moves 16 bytes: BM/16 residual loads + stores of dwordx4 instead of 32 of a dword.
-    constexpr int TS = 72;
+    constexpr int TS = 64;  // unpadded: conflict-free for ds_read_b128's lane groups (see igemm.hip)
     const bool direct_out = p.splitk <= 1;
     const int c4 = (tid & 15) * 4;  // first of this thread's 4 channels inside the tile
     const int r_t = tid >> 4;       // its row in each 16-row slice
@@ -412,6 +427,15 @@ hipError_t launch_conv3x3_patch(const GemmParams& p_in, int bm, hipStream_t s) {
     }
     (void)ho;
     p.patch_slots = (patch_px + 31) & ~31;  // whole 32-pixel DMA passes (no partially masked wave instruction)
+    p.swz_a = p.wo & 15;
+    p.magic_pitch = (65536 + p.patch_pitch - 1) / p.patch_pitch;  // x / pitch == (x * magic) >> 16 for x < 1024
+    if (p.howo >= bm) {
+        p.img_px_patch = 1 << 20;  // one band of one image: no image split inside the patch
+        p.magic_img = 0;
+    } else {
+        p.img_px_patch = p.img_px;
+        p.magic_img = (65536 + p.img_px - 1) / p.img_px;
+    }
     p.total_px = (p.M / p.howo) * p.img_px;
     if (p.M % p.howo != 0) return hipErrorInvalidValue;
     p.tiles_m = (p.M + bm - 1) / bm;

@@ -44,7 +44,7 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, int off, flo
 }  // namespace
 
 __global__ __launch_bounds__(256, 2) void stem7x7_kernel(const StemParams p) {
-    constexpr int TS = 72;  // padded row (floats) of the transposed output tile, as in igemm.hip's epilogue
+    constexpr int TS = 64;  // row (floats) of the transposed output tile, as in igemm.hip's epilogue
     __shared__ __attribute__((aligned(16))) float lds[2 * STAGE_CH * 4 + 128 * TS];
     float* const tbuf = lds + 2 * STAGE_CH * 4;
 

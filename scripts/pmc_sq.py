@@ -21,8 +21,8 @@ if dtype == "bf16":
     conv = [d for d in ds if "igemm_bf16_kernel" in d["name"]]
 else:
     ig = [d for d in ds if "igemm_f32_kernel" in d["name"] and ", true," not in d["name"]]
-    assert len(ig) % 17 == 0, len(ig)
-    conv = [d for s in range(len(ig) // 17) for d in ig[s * 17:s * 17 + 16]]
+    assert len(ig) % 4 == 0, len(ig)
+    conv = [d for d in ds if "conv3x3_patch_kernel" in d["name"]] + [d for s in range(len(ig) // 4) for d in ig[s * 4:s * 4 + 3]]
 n = len(conv)
 mean = lambda k: sum(d.get(k, 0.0) for d in conv) / n
 gui = mean("GRBM_GUI_ACTIVE") / 8.0  # the counter comes back summed over the 8 XCDs

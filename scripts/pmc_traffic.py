@@ -6,9 +6,9 @@
 
 Units: both counters are in KiB. On gfx950 FETCH_SIZE reports half the bytes of a wide
 coalesced read stream (guide, section HBM), so it is doubled; WRITE_SIZE is taken as is.
-fp32: the igemm_f32_kernel launches of one bench step come in a fixed order (the sixteen 3x3
-convs, then the fc; the gather-mode head is a different instantiation), which is how the 3x3
-launches are told apart. bf16: every igemm_bf16_kernel launch is a 3x3 conv."""
+fp32: the family = every conv3x3_patch_kernel launch (thirteen stride-1 convs per step) plus
+the first three of each four non-gather igemm_f32_kernel launches (the stride-2 convs; the fourth
+is the fc). bf16: every igemm_bf16_kernel launch is a 3x3 conv."""
 import collections, csv, glob, json, sys
 
 
@@ -24,12 +24,12 @@ def dispatches(path, counter):
 def conv3x3_values(disp, dtype):
     if dtype == "bf16":
         return [v for (name, v) in disp if "igemm_bf16_kernel" in name]
+    vals = [v for (name, v) in disp if "conv3x3_patch_kernel" in name]
     ig = [v for (name, v) in disp if "igemm_f32_kernel" in name and ", true," not in name]
-    per_step = 16 + 1
+    per_step = 3 + 1  # the three stride-2 convs, then the fc
     assert len(ig) % per_step == 0, (len(ig), per_step)
-    vals = []
     for s in range(len(ig) // per_step):
-        vals += ig[s * per_step:s * per_step + 16]
+        vals += ig[s * per_step:s * per_step + 3]
     return vals
 
 

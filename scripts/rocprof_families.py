@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
 """Average duration per kernel FAMILY from a rocprofv3 --kernel-trace CSV of bench.py.
 
-rocprofv3 --stats groups by kernel symbol, and one symbol (igemm_f32_kernel<...>) serves the
-sixteen 3x3 convolutions and the fc (the stem has its own kernel, stem7x7_kernel). The launches
-of a bench step come in a fixed order (16 x conv3x3, fc, then the gather-mode Conv1d), which this script uses to split
-them, so that bench.py's roofline.avg_launch_ms can be checked against the profiler.
+rocprofv3 --stats groups by kernel symbol. The conv3x3 family of bench.py's `roofline` is served
+by two symbols: conv3x3_patch_kernel<...> (the thirteen stride-1 3x3 convs) and
+igemm_f32_kernel<...> (the three stride-2 ones), and igemm_f32_kernel also runs the fc. The
+non-gather igemm launches of a bench step come in a fixed order (layer2.0.conv1, layer3.0.conv1,
+layer4.0.conv1, fc; the gather-mode Conv1d is a different instantiation), which this script uses
+to split them, so that bench.py's roofline.avg_launch_ms can be checked against the profiler.
 
-  python scripts/rocprof_families.py <dir>/runc/<pid>_kernel_trace.csv out.json"""
+  python scripts/rocprof_families.py <dir>/<host>/<pid>_kernel_trace.csv out.json"""
 import collections, csv, json, sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
@@ -23,12 +25,14 @@ for r in rows:
             ig.append(dur)
     elif name.startswith("pa::") or " pa::" in name:
         fam[name.split("(")[0].replace("void ", "").replace("pa::", "")].append(dur)
-per = 17
+per = 4
 assert len(ig) % per == 0, len(ig)
 for s in range(len(ig) // per):
     step = ig[s * per:(s + 1) * per]
-    fam["igemm_conv3x3"] += step[0:16]
-    fam["igemm_fc"].append(step[16])
+    fam["igemm_conv3x3"] += step[0:3]
+    fam["igemm_fc"].append(step[3])
+for k in [k for k in fam if k.startswith("conv3x3_patch_kernel")]:
+    fam["igemm_conv3x3"] += fam.pop(k)
 out = {k: {"launches": len(v), "avg_us": round(sum(v) / len(v) / 1e3, 2), "total_ms": round(sum(v) / 1e6, 3)} for k, v in sorted(fam.items())}
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 for k, v in out.items():
