@@ -376,28 +376,46 @@ int run_backbone_part(pa_engine* e, int crop0, int ncrops, const float* x_in, fl
     ConvLayer stem = e->convs[0];
     stem.in = const_cast<float*>(x_in);  // x_in / feats_out are the caller's bases: crop0 is applied by run_conv
     static const bool stem_igemm = getenv("PA_STEM_IGEMM") && atoi(getenv("PA_STEM_IGEMM"));  // A/B knob: generic engine
-    if (stem_igemm && !e->bf16) {
-        rc = run_conv(e, stem, crop0, ncrops, slab_off, s, "igemm_conv7x7_stem");
-        if (rc) return rc;
-    } else {
+    auto stem_part = [&](int c0, int n, hipStream_t st) -> int {
+        if (stem_igemm && !e->bf16) return run_conv(e, stem, c0, n, slab_off, st, "igemm_conv7x7_stem");
         StemParams sp;
-        sp.x = x_in + (size_t)crop0 * 134 * 134 * 4;
+        sp.x = x_in + (size_t)c0 * 134 * 134 * 4;
         sp.wgt = stem.wgt;
         sp.bias = stem.bias;
-        sp.out = reinterpret_cast<float*>(reinterpret_cast<char*>(e->c1) + (size_t)crop0 * 66 * 66 * 64 * (e->bf16 ? 2 : 4));
-        sp.tiles = ncrops * 32;
+        sp.out = reinterpret_cast<float*>(reinterpret_cast<char*>(e->c1) + (size_t)c0 * 66 * 66 * 64 * (e->bf16 ? 2 : 4));
+        sp.tiles = n * 32;
         sp.out_bf16 = e->bf16 ? 1 : 0;
-        const double px = (double)ncrops * 64 * 64;
-        ProfScope ps(e, s, "stem_conv7x7", 2.0 * px * 64 * 147, 4.0 * ((double)ncrops * 128 * 128 * 3 + px * 64 + 64.0 * 147));
-        HIPCHK(e, launch_stem7x7(sp, s));
-    }
-    {
-        ProfScope ps(e, s, "maxpool3x3", 0.0, (e->bf16 ? 2.0 : 4.0) * ncrops * (64.0 * 64 * 64 + 32.0 * 32 * 64));
+        const double px = (double)n * 64 * 64;
+        ProfScope ps(e, st, "stem_conv7x7", 2.0 * px * 64 * 147, 4.0 * ((double)n * 128 * 128 * 3 + px * 64 + 64.0 * 147));
+        HIPCHK(e, launch_stem7x7(sp, st));
+        return PA_OK;
+    };
+    auto pool_part = [&](int c0, int n, hipStream_t st) -> int {
+        ProfScope ps(e, st, "maxpool3x3", 0.0, (e->bf16 ? 2.0 : 4.0) * n * (64.0 * 64 * 64 + 32.0 * 32 * 64));
         if (e->bf16)
-            HIPCHK(e, launch_maxpool_bf16(reinterpret_cast<uint16_t*>(e->c1) + (size_t)crop0 * 66 * 66 * 64,
-                                          reinterpret_cast<uint16_t*>(e->p1) + (size_t)crop0 * 34 * 34 * 64, ncrops, s));
+            HIPCHK(e, launch_maxpool_bf16(reinterpret_cast<uint16_t*>(e->c1) + (size_t)c0 * 66 * 66 * 64,
+                                          reinterpret_cast<uint16_t*>(e->p1) + (size_t)c0 * 34 * 34 * 64, n, st));
         else
-            HIPCHK(e, launch_maxpool(e->c1 + (size_t)crop0 * 66 * 66 * 64, e->p1 + (size_t)crop0 * 34 * 34 * 64, ncrops, s));
+            HIPCHK(e, launch_maxpool(e->c1 + (size_t)c0 * 66 * 66 * 64, e->p1 + (size_t)c0 * 34 * 34 * 64, n, st));
+        return PA_OK;
+    };
+    // The max-pool is pure HBM/L2 streaming and the stem pure matrix work: with the batch cut in two,
+    // the pool of the first half runs on the side stream underneath the stem of the second half.
+    // (Not while kernels are being timed one by one, and not inside the two-stream interleave.)
+    static const int overlap_pool = getenv("PA_POOL_OVERLAP") ? atoi(getenv("PA_POOL_OVERLAP")) : 1;
+    if (overlap_pool && !e->profiling && !e->interleave && e->side && s != e->side && ncrops >= 64) {
+        const int half = (ncrops / 2 + 7) & ~7;
+        if ((rc = stem_part(crop0, half, s))) return rc;
+        HIPCHK(e, hipEventRecord(e->ev_fork, s));
+        HIPCHK(e, hipStreamWaitEvent(e->side, e->ev_fork, 0));
+        if ((rc = pool_part(crop0, half, e->side))) return rc;
+        HIPCHK(e, hipEventRecord(e->ev_join, e->side));
+        if ((rc = stem_part(crop0 + half, ncrops - half, s))) return rc;
+        if ((rc = pool_part(crop0 + half, ncrops - half, s))) return rc;
+        HIPCHK(e, hipStreamWaitEvent(s, e->ev_join, 0));
+    } else {
+        if ((rc = stem_part(crop0, ncrops, s))) return rc;
+        if ((rc = pool_part(crop0, ncrops, s))) return rc;
     }
     for (size_t i = 1; i < e->convs.size(); ++i) {
         const ConvLayer& L = e->convs[i];
