@@ -102,6 +102,7 @@ class FrameParallelClip:
         self._slot_used = [False, False]
         self._slot = 0
         self._out = None
+        self._pack = None
 
     def backbone_shard(self, frames_local, boxes_local, lo: int, pipeline: bool = False):
         """Crop + backbone for this rank's frames, in chunks of the engine's batch size.
@@ -180,23 +181,28 @@ class FrameParallelClip:
             eng.head_frames(f_lo, f_hi, records, logp)
         if not gather or self.world == 1:
             return records[:count], logp[:count]
-        # equal-size all_gather of padded shards, trimmed on the way out
-        cap = max(owned_frame_nums(n_total, self.world, r)[1] - owned_frame_nums(n_total, self.world, r)[0] for r in range(self.world))
-        cap = max(cap, 1)
-        rec_pad = eng.alloc_records(cap)
-        lp_pad = eng.alloc_logp(cap)
-        rec_pad[:count] = records[:count]
-        lp_pad[:count] = logp[:count]
-        if _host_staged(self.group):
-            rec_pad, lp_pad = rec_pad.cpu(), lp_pad.cpu()
-        rec_all = [torch.empty_like(rec_pad) for _ in range(self.world)]
-        lp_all = [torch.empty_like(lp_pad) for _ in range(self.world)]
-        dist.all_gather(rec_all, rec_pad, group=self.group)
-        dist.all_gather(lp_all, lp_pad, group=self.group)
+        # ONE equal-size all_gather of padded shards: records (as int32 bit patterns) and
+        # log-probs travel in the same float32 buffer [cap, F, 4 + A]; trimmed on the way out
         counts = [
             max(owned_frame_nums(n_total, self.world, r)[1] - owned_frame_nums(n_total, self.world, r)[0], 0)
             for r in range(self.world)
         ]
-        rec = torch.cat([rec_all[r][: counts[r]] for r in range(self.world)])
-        lp = torch.cat([lp_all[r][: counts[r]] for r in range(self.world)])
+        cap = max(max(counts), 1)
+        A = logp.shape[-1]
+        staged = _host_staged(self.group)
+        if self._pack is None or self._pack[0].shape[0] != cap or self._pack[1].shape[0] != self.world:
+            mine = torch.zeros((cap, eng.F, 4 + A), dtype=torch.float32, device=records.device)
+            everyone = torch.zeros((self.world, cap, eng.F, 4 + A), dtype=torch.float32, device="cpu" if staged else records.device)
+            self._pack = (mine, everyone)
+        mine, everyone = self._pack
+        mine[:count, :, :4].view(torch.int32).copy_(records[:count])
+        mine[:count, :, 4:].copy_(logp[:count])
+        if staged:
+            parts = [torch.empty((cap, eng.F, 4 + A), dtype=torch.float32) for _ in range(self.world)]
+            dist.all_gather(parts, mine.cpu(), group=self.group)
+            everyone = torch.stack(parts)
+        else:
+            dist.all_gather_into_tensor(everyone, mine, group=self.group)
+        rec = torch.cat([everyone[r, : counts[r], :, :4] for r in range(self.world)]).view(torch.int32)
+        lp = torch.cat([everyone[r, : counts[r], :, 4:] for r in range(self.world)])
         return rec, lp
