@@ -24,6 +24,10 @@
 // size general (any box, any frame): a fused LDS kernel for crops whose bands fit 48 KB,
 // a multi-pass fallback over global scratch for the rest.
 #include "pa_kernels.h"
+#ifdef PA_STAMP_BUILD
+#include <cstdio>
+#include <vector>
+#endif
 #include "../../include/playaid_hip.h"
 #include <cstdlib>
 
@@ -692,6 +696,9 @@ struct LdsCanvas {
 };
 
 __global__ __launch_bounds__(256) void crop_fused_kernel(const PreprocParams p) {
+#ifdef PA_STAMP_BUILD
+    const unsigned long long st0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int crop = blockIdx.y;
     const int band0 = blockIdx.x * 8;  // first of this workgroup's 8 output rows
     const int tid = threadIdx.x;
@@ -1019,6 +1026,12 @@ __global__ __launch_bounds__(256) void crop_fused_kernel(const PreprocParams p) 
             }
         }
         __syncthreads();  // the next sub-band reuses the LDS stages
+#ifdef PA_STAMP_BUILD
+        if (p.dbg && threadIdx.x == 0 && r0 + rb >= band0 + 8) {
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(p.dbg) + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4;
+            o[0] = st0; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = (unsigned long long)pl.d; o[3] = rb;
+        }
+#endif
     }
 }
 
@@ -1086,8 +1099,29 @@ hipError_t launch_preprocess(const PreprocParams& p_in, hipStream_t s) {
     if (ncrops <= 0) return hipSuccess;
     hipLaunchKernelGGL(crop_plan_kernel, dim3(ncrops), dim3(64), 0, s, p);
     hipLaunchKernelGGL(crop_coef_kernel, dim3((p.coef_dim + 127) / 128, ncrops * 2), dim3(128), 0, s, p);
+#ifdef PA_STAMP_BUILD
+    static int calls = 0;
+    static unsigned long long* sd = nullptr;
+    const char* sf = getenv("PA_CROP_STAMP_FILE");
+    const bool now = sf && calls++ == 5;
+    if (now) {
+        if (!sd) (void)hipMalloc(&sd, (size_t)16 * ncrops * 32);
+        (void)hipMemsetAsync(sd, 0, (size_t)16 * ncrops * 32, s);
+        p.dbg = reinterpret_cast<uint8_t*>(sd);
+    }
+#endif
     hipLaunchKernelGGL(crop_fused_kernel, dim3(PA_CROP / 8, ncrops), dim3(256), p.fused_lds + (PA_CROP + 8) * sizeof(AreaTabPacked), s, p);
     { hipError_t e1 = hipGetLastError(); if (e1 != hipSuccess) return e1; }
+#ifdef PA_STAMP_BUILD
+    if (now) {
+        (void)hipStreamSynchronize(s);
+        std::vector<unsigned long long> h((size_t)16 * ncrops * 4);
+        (void)hipMemcpy(h.data(), sd, h.size() * 8, hipMemcpyDeviceToHost);
+        FILE* f = fopen(sf, "wb");
+        if (f) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+        p.dbg = nullptr;
+    }
+#endif
     hipLaunchKernelGGL(crop_fallback_kernel, dim3(16), dim3(1024), 0, s, p);
     return hipGetLastError();
 }
