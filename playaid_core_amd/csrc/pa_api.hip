@@ -365,7 +365,9 @@ int run_conv(pa_engine* e, const ConvLayer& L, int crop0, int ncrops, size_t sla
         const int howo = L.out_hw * L.out_hw, in_w2 = L.out_hw + 2;
         const int px128 = howo >= 128 ? (128 / L.out_hw + 2) * in_w2 : (128 / howo) * in_w2 * in_w2;
         if (bm == 128 && px128 > 224) bm = 64;  // keep two workgroups per CU (2 patch buffers + weight ring <= 80 KB)
-        HIPCHK(e, launch_conv3x3_patch(p, bm, s));
+        hipError_t pe = launch_conv3x3_patch(p, bm, s);
+        if (pe == hipErrorInvalidValue) pe = launch_igemm(p, tile, s);  // geometry the patch kernel does not cover
+        HIPCHK(e, pe);
     } else {
         HIPCHK(e, launch_igemm(p, tile, s));
     }
