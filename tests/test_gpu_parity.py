@@ -97,10 +97,13 @@ def test_square_crops_small_boxes_enlarge(engine):
     assert status[0, 0] == 4  # PA_CROP_FILTER_TOO_WIDE
 
 
-def test_infer_windows_matches_oracle(engine, state_dict):
+@pytest.mark.parametrize("nwin", [1, 3, 5, 10])
+def test_infer_windows_matches_oracle(engine, state_dict, nwin):
+    """b1 surface. 7 / 21 / 35 / 70 crops: the conv kernels' partial last tiles (a tile of the 4x4
+    maps holds 4 or 8 images, of the 8x8 maps 1 or 2) and every per-launch tile / split-K choice."""
     cnn, _, _ = _oracle()
-    rng = np.random.default_rng(3)
-    x = torch.from_numpy(rng.integers(0, 256, (3, 7, 3, 128, 128)).astype(np.float32) / np.float32(255.0))
+    rng = np.random.default_rng(3 + nwin)
+    x = torch.from_numpy(rng.integers(0, 256, (nwin, 7, 3, 128, 128)).astype(np.float32) / np.float32(255.0))
     ref = cnn.forward(x, state_dict).numpy()
     got = engine.infer_windows(x).cpu().numpy()
     assert got.shape == ref.shape
