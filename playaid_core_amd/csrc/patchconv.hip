@@ -64,13 +64,19 @@ __device__ __forceinline__ void split_m(const GemmParams& p, int m, int& img, in
 // buffer from the one the ds_reads use and drains vmcnt to 0 in front of every operand read.
 template <int BM> struct PatchCap { static constexpr int slots = BM == 128 ? 224 : 160; };
 
-template <int BM, bool K2>
-__global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const GemmParams p) {
+// KS2: split-K by two INSIDE the workgroup. 512 threads; waves 0-3 ("half" 0) take the first half
+// of the channel chunks (and of the second-source steps), waves 4-7 the second half, each with its
+// own pair of patch buffers; the two partial tiles meet in LDS in the epilogue. Same occupancy as
+// two 256-thread split-K workgroups per CU, but no slab round trip through HBM and no reduce
+// kernel behind the launch (the layer-4 convs: M = 2048 gives only 256 tiles of 64 x 64).
+template <int BM, bool K2, bool KS2>
+__global__ __launch_bounds__(KS2 ? 512 : 256, 2) void conv3x3_patch_kernel(const GemmParams p) {
     constexpr int BN = 64;
     constexpr int MI = BM / 64;
     constexpr int PP = PatchCap<BM>::slots * 32;  // floats per patch buffer
-    __shared__ __attribute__((aligned(16))) float pc_lds[2 * PP];
-    float* const patch0 = pc_lds;
+    __shared__ __attribute__((aligned(16))) float pc_lds[(KS2 ? 2 : 1) * 2 * PP];
+    const int half = KS2 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;
+    float* const patch0 = pc_lds + half * 2 * PP;
 
     // XCD-aware (bijective) remap: blocks with equal b % 8 share an XCD.
     const int nwg = gridDim.x;
@@ -78,12 +84,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const GemmParams 
     const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
     const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     const int tiles_mn = p.tiles_m * p.tiles_n;
-    const int z = wg / tiles_mn;
-    const int t_id = wg - z * tiles_mn;
+    const int z = KS2 ? half : wg / tiles_mn;   // which share of K this group of four waves sums
+    const int t_id = KS2 ? wg : wg - (wg / tiles_mn) * tiles_mn;
     const int tile_m = t_id / p.tiles_n;
     const int tile_n = t_id - tile_m * p.tiles_n;
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x & 255;
 #ifdef PA_STAMP_BUILD
     const unsigned long long st0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -108,8 +114,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const GemmParams 
     // fused 1x1/2 second source (block 0 of layers 2-4): k2_steps extra 32-channel steps after the
     // 3x3 chunks; their "patch" is the gathered BM x 32 tile
     // (shared evenly between the splits)
-    const int j0 = K2 ? (z * p.k2_steps) / p.splitk : 0;
-    const int k2n = K2 ? ((z + 1) * p.k2_steps) / p.splitk - j0 : 0;
+    const int nsplit = KS2 ? 2 : p.splitk;
+    const int j0 = K2 ? (z * p.k2_steps) / nsplit : 0;
+    const int k2n = K2 ? ((z + 1) * p.k2_steps) / nsplit - j0 : 0;
     constexpr int ROWS2 = BM / 32;
     int a_off2[ROWS2];
 #pragma unroll
@@ -336,14 +343,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const GemmParams 
     // transposed through the (now idle) patch buffers: rows of 64 channels, then each
     // thread moves 16 bytes: BM/16 residual loads + stores of dwordx4 instead of 32 of a dword.
     constexpr int TS = 64;  // unpadded: conflict-free for ds_read_b128's lane groups (see igemm.hip)
-    const bool direct_out = p.splitk <= 1;
-    const int c4 = (tid & 15) * 4;  // first of this thread's 4 channels inside the tile
-    const int r_t = tid >> 4;       // its row in each 16-row slice
-    int o_t[BM / 16];
-    f32x4 res_t[BM / 16];
+    constexpr int ET = KS2 ? 512 : 256;      // threads sharing the stores (both halves under KS2)
+    constexpr int EP_IT = BM * 16 / ET;      // 16-byte stores per thread
+    const bool direct_out = KS2 || p.splitk <= 1;
+    const int et = KS2 ? (int)threadIdx.x : tid;
+    const int c4 = (et & 15) * 4;   // first of this thread's 4 channels inside the tile
+    const int r_t = et >> 4;        // its row in each (ET / 16)-row slice
+    int o_t[EP_IT];
+    f32x4 res_t[EP_IT];
 #pragma unroll
-    for (int i = 0; i < BM / 16; ++i) {
-        int m = tile_m * BM + r_t + 16 * i;
+    for (int i = 0; i < EP_IT; ++i) {
+        int m = tile_m * BM + r_t + (ET / 16) * i;
         m = m < p.M ? m : p.M - 1;
         int img, oy, ox;
         split_m(p, m, img, oy, ox);
@@ -353,11 +363,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const GemmParams 
     }
     if (direct_out && p.residual) {
 #pragma unroll
-        for (int i = 0; i < BM / 16; ++i) res_t[i] = *reinterpret_cast<const f32x4*>(p.residual + o_t[i]);
+        for (int i = 0; i < EP_IT; ++i) res_t[i] = *reinterpret_cast<const f32x4*>(p.residual + o_t[i]);
     }
     f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
     if (direct_out && p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + tile_n * BN + c4);
-    float* const tbuf = pc_lds;  // every wave left the k loop through the final barrier
+    float* const tbuf = patch0;  // (this half's buffers) every wave left the k loop through the final barrier
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -367,11 +377,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const GemmParams 
         }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < BM / 16; ++i) {
-        const int row = r_t + 16 * i;
+    for (int i = 0; i < EP_IT; ++i) {
+        const int row = r_t + (ET / 16) * i;
         const int m = tile_m * BM + row;
         if (m >= p.M) continue;
-        f32x4 v = *reinterpret_cast<const f32x4*>(tbuf + row * TS + c4);
+        f32x4 v = *reinterpret_cast<const f32x4*>(pc_lds + row * TS + c4);
+        if (KS2) v += *reinterpret_cast<const f32x4*>(pc_lds + 2 * PP + row * TS + c4);  // + the other half of K
         if (!direct_out) {
             *reinterpret_cast<f32x4*>(p.slab + ((size_t)z * p.M + m) * p.N + tile_n * BN + c4) = v;
         } else {
@@ -384,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(const GemmParams 
         }
     }
 #ifdef PA_STAMP_BUILD
-    if (p.clk && tid == 0) {
+    if (p.clk && threadIdx.x == 0) {
         unsigned long long* o = p.clk + (size_t)blockIdx.x * 6;
         o[0] = st0; o[1] = st1; o[2] = st2; o[3] = __builtin_amdgcn_s_memrealtime();
         o[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
@@ -447,6 +458,14 @@ hipError_t launch_conv3x3_patch(const GemmParams& p_in, int bm, hipStream_t s) {
     p.splitk = (n_ch + p.ksteps_per_split - 1) / p.ksteps_per_split;
     if (p.patch_slots > (bm == 128 ? PatchCap<128>::slots : PatchCap<64>::slots)) return hipErrorInvalidValue;
     const size_t lds_bytes = 0;
+    // a two-way split of 64-row tiles is done inside 512-thread workgroups (no slabs, no reduce
+    // kernel) when the chunks and second-source steps divide evenly; PA_PATCH_KS2=0 disables (A/B)
+    static const int want_ks2 = getenv("PA_PATCH_KS2") ? atoi(getenv("PA_PATCH_KS2")) : 1;
+    const bool ks2 = want_ks2 && bm == 64 && p.splitk == 2 && n_ch % 2 == 0 && p.k2_steps % 2 == 0;
+    if (ks2) {
+        p.splitk = 1;
+        p.ksteps_per_split = n_ch / 2;
+    }
     const int grid = p.tiles_m * p.tiles_n * p.splitk;
 #ifdef PA_STAMP_BUILD
     // timeline stamps of every workgroup of launch number PA_STAMP_CALL, written to PA_STAMP_FILE
@@ -459,13 +478,16 @@ hipError_t launch_conv3x3_patch(const GemmParams& p_in, int bm, hipStream_t s) {
         p.clk = stamp_dev;
     }
 #endif
-    if (bm == 128) {
-        if (p.k2_steps) hipLaunchKernelGGL((conv3x3_patch_kernel<128, true>), dim3(grid), dim3(256), lds_bytes, s, p);
-        else hipLaunchKernelGGL((conv3x3_patch_kernel<128, false>), dim3(grid), dim3(256), lds_bytes, s, p);
+#define PC_LAUNCH(BM_, K2_, KS2_, GRID_, THREADS_) \
+    hipLaunchKernelGGL((conv3x3_patch_kernel<BM_, K2_, KS2_>), dim3(GRID_), dim3(THREADS_), lds_bytes, s, p)
+    if (ks2) {
+        if (p.k2_steps) PC_LAUNCH(64, true, true, grid, 512); else PC_LAUNCH(64, false, true, grid, 512);
+    } else if (bm == 128) {
+        if (p.k2_steps) PC_LAUNCH(128, true, false, grid, 256); else PC_LAUNCH(128, false, false, grid, 256);
     } else {
-        if (p.k2_steps) hipLaunchKernelGGL((conv3x3_patch_kernel<64, true>), dim3(grid), dim3(256), lds_bytes, s, p);
-        else hipLaunchKernelGGL((conv3x3_patch_kernel<64, false>), dim3(grid), dim3(256), lds_bytes, s, p);
+        if (p.k2_steps) PC_LAUNCH(64, true, false, grid, 256); else PC_LAUNCH(64, false, false, grid, 256);
     }
+#undef PC_LAUNCH
 #ifdef PA_STAMP_BUILD
     if (stamp_now) {
         (void)hipStreamSynchronize(s);
