@@ -753,7 +753,11 @@ int pa_create(const pa_config* cfg, const void* blob, size_t blob_bytes, pa_engi
         if (rc) return rc;
         rc = upload(e, &L.bias, bp);
         if (rc) return rc;
-        choose_tile(NC, PA_FEATURE_STRIDE, 16, &L.tile, &L.splitk);
+        // 32 tiles of 64x64 only: split the 16 k-steps four ways (measured 16.9 / 14.5 / 12.3 us for 1 / 2 / 4)
+        L.tile = TILE_64x64;
+        L.splitk = 4;
+        L.forced = true;
+        if (const char* fs = getenv("PA_FC_SPLITK")) L.splitk = std::max(1, atoi(fs));
     }
     {  // Conv1d(1000 -> 512, k=S): [512][1000][S] -> [512][S][1024]
         const float* w = br.take((size_t)512 * 1000 * S);
@@ -769,6 +773,9 @@ int pa_create(const pa_config* cfg, const void* blob, size_t blob_bytes, pa_engi
         rc = upload(e, &e->b1d, std::vector<float>(b, b + 512));
         if (rc) return rc;
         choose_tile(NC, 512, S * 32, &e->head_tile, &e->head_splitk);
+        // 16 tiles x 224 k-steps: 16 splits of 14 steps beat 32 of 7 (26.2 vs 28.6 us incl. the reduce)
+        if (e->head_splitk > 16) e->head_splitk = 16;
+        if (const char* hs = getenv("PA_HEAD_SPLITK")) e->head_splitk = std::max(1, atoi(hs));
     }
     {
         const float* w2 = br.take(128 * 512);
