@@ -382,6 +382,7 @@ int run_backbone_part(pa_engine* e, int crop0, int ncrops, const float* x_in, fl
     auto stem_part = [&](int c0, int n, hipStream_t st) -> int {
         if (stem_igemm && !e->bf16) return run_conv(e, stem, c0, n, slab_off, st, "igemm_conv7x7_stem");
         StemParams sp;
+        memset(&sp, 0, sizeof(sp));
         sp.x = x_in + (size_t)c0 * 134 * 134 * 4;
         sp.wgt = stem.wgt;
         sp.bias = stem.bias;

@@ -64,6 +64,7 @@ struct StemParams {
     float* out;     // fp32, or bf16 (uint16_t storage) when out_bf16 != 0
     int32_t tiles;  // crops * 32 (one tile = two output rows of one crop)
     int32_t out_bf16;
+    unsigned long long* clk;  // stamp builds only
 };
 hipError_t launch_stem7x7(const StemParams& p, hipStream_t s);
 hipError_t launch_splitk_reduce(const GemmParams& p, hipStream_t s);

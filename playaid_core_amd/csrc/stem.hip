@@ -18,6 +18,11 @@
 // The summation order (ky, pixel pair, channel) is the one igemm.hip uses for the stem, so the
 // two kernels produce bit-identical outputs.
 #include "pa_kernels.h"
+#ifdef PA_STAMP_BUILD
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#endif
 
 namespace pa {
 
@@ -49,6 +54,11 @@ __global__ __launch_bounds__(256, 2) void stem7x7_kernel(const StemParams p) {
     float* const tbuf = lds + 2 * STAGE_CH * 4;
 
     const int tid = threadIdx.x;
+#ifdef PA_STAMP_BUILD
+    const unsigned long long st0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long st1 = 0, st_ep = 0;
+    int ntile = 0;
+#endif
     const int lane = tid & 63;
     const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave_id >> 1;  // output row of the pair
@@ -94,6 +104,9 @@ __global__ __launch_bounds__(256, 2) void stem7x7_kernel(const StemParams p) {
     const int c_lane = (2 * wm) * IN_W + 2 * lr + lh;  // chunk of (ky 0, mi 0, kk 0) for this lane
 
     __syncthreads();
+#ifdef PA_STAMP_BUILD
+    st1 = __builtin_amdgcn_s_memrealtime();
+#endif
     int buf = 0;
     for (; t < p.tiles; t += nwg) {
         const int tn = t + nwg;
@@ -135,6 +148,9 @@ __global__ __launch_bounds__(256, 2) void stem7x7_kernel(const StemParams p) {
         }
 #undef PA_STEM_FRAGS
 
+#ifdef PA_STAMP_BUILD
+        const unsigned long long e0 = __builtin_amdgcn_s_memrealtime();
+#endif
         // epilogue: + folded BN bias, ReLU, into the bordered NHWC map [crop][66][66][64]. The tile
         // (2 rows x 64 pixels x 64 channels) is transposed through LDS so that each thread stores 16
         // bytes (8 stores per thread instead of 32 four-byte ones per lane -- the stores of a whole
@@ -170,16 +186,48 @@ __global__ __launch_bounds__(256, 2) void stem7x7_kernel(const StemParams p) {
             }
         }
         __syncthreads();  // next patch landed (vmcnt drained) and every wave is done with this one
+#ifdef PA_STAMP_BUILD
+        st_ep += __builtin_amdgcn_s_memrealtime() - e0;
+        ++ntile;
+#endif
         buf ^= 1;
     }
 #undef PA_STEM_ISSUE
+#ifdef PA_STAMP_BUILD
+    if (p.clk && tid == 0) {
+        unsigned long long* o = p.clk + (size_t)blockIdx.x * 6;
+        o[0] = st0; o[1] = st1; o[2] = __builtin_amdgcn_s_memrealtime(); o[3] = st_ep; o[4] = ntile;
+        o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    }
+#endif
 }
 
 hipError_t launch_stem7x7(const StemParams& p, hipStream_t s) {
     if (p.tiles <= 0) return hipErrorInvalidValue;
     int grid = p.tiles < 512 ? p.tiles : 512;  // 2 resident workgroups per CU
+#ifdef PA_STAMP_BUILD
+    static int calls = 0;
+    static unsigned long long* sd = nullptr;
+    const char* sf = getenv("PA_STEM_STAMP_FILE");
+    const bool now = sf && calls++ == 8;
+    StemParams q = p;
+    if (now) {
+        if (!sd) (void)hipMalloc(&sd, 512 * 6 * 8);
+        q.clk = sd;
+    }
+    hipLaunchKernelGGL(stem7x7_kernel, dim3(grid), dim3(256), 0, s, q);
+    if (now) {
+        (void)hipStreamSynchronize(s);
+        std::vector<unsigned long long> h((size_t)grid * 6);
+        (void)hipMemcpy(h.data(), sd, h.size() * 8, hipMemcpyDeviceToHost);
+        FILE* f = fopen(sf, "wb");
+        if (f) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+    }
+    return hipGetLastError();
+#else
     hipLaunchKernelGGL(stem7x7_kernel, dim3(grid), dim3(256), 0, s, p);
     return hipGetLastError();
+#endif
 }
 
 }  // namespace pa
