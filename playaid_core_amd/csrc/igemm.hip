@@ -483,7 +483,8 @@ hipError_t launch_igemm(const GemmParams& p_in, GemmTile tile, hipStream_t s) {
         default: err = launch_tile<64, 64, 64>(p, s); break;
     }
     if (err != hipSuccess) return err;
-    if (p.splitk > 1) return launch_splitk_reduce(p, s);
+    if (p.splitk_used) *p.splitk_used = p.splitk;
+    if (p.splitk > 1 && !p.defer_reduce) return launch_splitk_reduce(p, s);
     return hipSuccess;
 }
 

@@ -243,7 +243,18 @@ __global__ __launch_bounds__(1024) void head_mlp_kernel(const HeadParams p) {
     const int w = blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    if (tid < 512) h1[tid] = p.h1[(size_t)w * 512 + tid];
+    if (tid < 512) {
+        if (p.h1) {
+            h1[tid] = p.h1[(size_t)w * 512 + tid];
+        } else {
+            // the Conv1d's split-K slabs, summed in slab order, + bias, ReLU: exactly what
+            // splitk_reduce_kernel would have written (that launch is saved)
+            float s = p.slab[(size_t)w * 512 + tid];
+            for (int z = 1; z < p.splitk; ++z) s += p.slab[((size_t)z * p.nwin + w) * 512 + tid];
+            s += p.b1[tid];
+            h1[tid] = s > 0.f ? s : 0.f;
+        }
+    }
     __syncthreads();
     {
         // 1024 threads = 128 outputs x 8 k-slices of 64: every load is independent and coalesced

@@ -485,6 +485,9 @@ int run_head(pa_engine* e, int nwin, const float* feats, const int32_t* gather, 
     p.relu = 1;
     p.splitk = e->head_splitk;
     if ((size_t)p.splitk * p.M * p.N > e->slab_floats) p.splitk = 1;
+    int32_t splitk_used = 1;
+    p.defer_reduce = 1;  // the MLP kernel sums the slabs itself
+    p.splitk_used = &splitk_used;
     {
         ProfScope ps(e, s, "igemm_conv1d_head", 2.0 * nwin * 512.0 * 1000.0 * S,
                      4.0 * (512.0 * 1000 * S + (double)nwin * S * 1000 + nwin * 512.0));
@@ -492,7 +495,10 @@ int run_head(pa_engine* e, int nwin, const float* feats, const int32_t* gather, 
     }
     HeadParams h;
     memset(&h, 0, sizeof(h));
-    h.h1 = e->h1;
+    h.h1 = splitk_used > 1 ? nullptr : e->h1;
+    h.slab = e->slab;
+    h.b1 = e->b1d;
+    h.splitk = splitk_used;
     h.w2 = e->w2;
     h.b2 = e->b2;
     h.w3 = e->w3;

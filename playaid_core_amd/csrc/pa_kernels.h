@@ -38,6 +38,9 @@ struct GemmParams {
     const float* act2;
     int32_t k2_steps, in2_img_stride, in2_row_stride, in2_px_stride, stride2, off2;
     int32_t splitk, ksteps_per_split;
+    int32_t defer_reduce;   // 1: leave the split-K slabs to the consumer (the head MLP sums them itself); the
+                            //    launcher writes the split count it actually used to *splitk_used
+    int32_t* splitk_used;
     int32_t skip_w;         // 1: k % 4 == 3 always meets a zero weight (stem channel pad): those MFMAs are skipped
     int32_t tiles_m, tiles_n;
     // patch-resident 3x3 kernel (patchconv.hip), filled by its launcher: pixels per LDS patch buffer,
@@ -139,7 +142,10 @@ hipError_t launch_scatter_rows(const float* feats, const int32_t* st, const int3
                                int32_t n, int32_t fighters, hipStream_t s);
 
 struct HeadParams {
-    const float* h1;      // [nwin][512] post-ReLU Conv1d output
+    const float* h1;      // [nwin][512] post-ReLU Conv1d output, or nullptr when the slabs below are given
+    const float* slab;    // split-K partial sums of the Conv1d [splitk][nwin][512] (ordered sum + bias + ReLU done here)
+    const float* b1;      // Conv1d bias [512]
+    int32_t splitk;
     const float* w2;      // [128][512]
     const float* b2;      // [128]
     const float* w3;      // [A][128]
