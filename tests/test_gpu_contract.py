@@ -12,6 +12,7 @@ from playaid_core_amd.anim_ontology import ACTIONS, MOVE_TO_CLASS_ID
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_golden_crops_on_gpu(engine):
@@ -126,6 +127,32 @@ def test_runner_repairs_label_gaps(tmp_path, state_dict):
     assert np.array_equal(res["action_id"], want["action_id"])
     for f in range(1, n):
         assert runner.ai_output_data["Joker"][f - 1].action == ACTIONS[int(want["action_id"][f - 1, 1])]
+
+
+def test_im2col_engine_still_agrees(engine, tmp_path):
+    """The thirteen stride-1 3x3 convs run on conv3x3_patch_kernel; PA_PATCH=0 (read once per process)
+    sends them back through the im2col engine, which stays the fallback for geometries the patch
+    kernel rejects. Both kernels must agree to fp32 rounding (different summation order)."""
+    import subprocess
+    import sys
+
+    n, h, w = 24, 720, 1280
+    frames, boxes = synth.make_frames(n, h, w, seed=31), synth.make_boxes(n, h, w)
+    ours = engine.infer_clip(frames, boxes)
+    out = tmp_path / "igemm_logp.npy"
+    code = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from playaid_core_amd import synth\n"
+        "from playaid_core_amd.engine import Engine\n"
+        "e = Engine(synth.make_state_dict(seed=1234), max_batch_frames=64, max_clip_frames=512)\n"
+        "r = e.infer_clip(synth.make_frames(%d, %d, %d, seed=31), synth.make_boxes(%d, %d, %d))\n"
+        "np.save(%r, r['logp'])\n" % (str(ROOT), n, h, w, n, h, w, str(out))
+    )
+    env = dict(os.environ, PA_PATCH="0", PA_STEM_IGEMM="1")
+    subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=300)
+    other = np.load(out)
+    assert np.abs(other - ours["logp"]).max() <= 1e-5
 
 
 BF16_LOGP_TOL = 5e-2  # bf16 conv path (configs[2]); measured 1.8e-2 on this clip. The fp32 path's bar is 1e-4.
