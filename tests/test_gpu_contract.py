@@ -129,6 +129,35 @@ def test_runner_repairs_label_gaps(tmp_path, state_dict):
         assert runner.ai_output_data["Joker"][f - 1].action == ACTIONS[int(want["action_id"][f - 1, 1])]
 
 
+def test_capacity_and_argument_errors(state_dict):
+    """The reference's asserts / exit()s become status codes: nothing is silently truncated."""
+    from playaid_core_amd import _lib
+    from playaid_core_amd.engine import Engine, EngineError
+
+    eng = Engine(state_dict, max_batch_frames=4, max_clip_frames=16, max_frame_height=360, max_frame_width=640)
+    try:
+        h, w = 360, 640
+        frames, boxes = synth.make_frames(20, h, w), synth.make_boxes(20, h, w)
+        with pytest.raises(EngineError) as ei:  # clip longer than the feature cache
+            eng.infer_clip(frames, boxes)
+        assert ei.value.code == _lib.PA_ERR_CAPACITY
+        with pytest.raises(EngineError) as ei:  # frame larger than the resampler scratch
+            eng.infer_clip(synth.make_frames(4, 720, 1280), synth.make_boxes(4, 720, 1280))
+        assert ei.value.code == _lib.PA_ERR_CAPACITY
+        with pytest.raises(EngineError) as ei:  # a window needs at least two frames (max_frames - 1 >= 1)
+            eng.infer_clip(frames[:1], boxes[:1])
+        assert ei.value.code == _lib.PA_ERR_INVALID_ARG
+        with pytest.raises(EngineError) as ei:  # more frames in one backbone call than max_batch_frames
+            eng.clip_begin(16)
+            eng.backbone_frames(torch.from_numpy(frames[:8]).cuda(), torch.from_numpy(boxes[:8]).cuda(), 0)
+        assert ei.value.code == _lib.PA_ERR_CAPACITY
+        # the longest clip that fits, fed in the largest chunks that fit, still works
+        out = eng.infer_clip(frames[:16], boxes[:16])
+        assert out["logp"].shape == (15, 2, 63) and np.isfinite(out["logp"]).all()
+    finally:
+        eng.close()
+
+
 def test_im2col_engine_still_agrees(engine, tmp_path):
     """The thirteen stride-1 3x3 convs run on conv3x3_patch_kernel; PA_PATCH=0 (read once per process)
     sends them back through the im2col engine, which stays the fallback for geometries the patch
