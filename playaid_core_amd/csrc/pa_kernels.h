@@ -78,7 +78,13 @@ hipError_t launch_conv3x3_patch(const GemmParams& p, int bm, hipStream_t s);
 // crop preprocessing (preprocess.hip)
 // ---------------------------------------------------------------------------
 #define PA_KSIZE_MAX 15
-#define PA_FUSED_LDS_BYTES 50944  // stage buffers of crop_fused_kernel; + 2176 B of INTER_AREA tables = 53120 B -> 3 workgroups per CU
+// Stage buffers of crop_fused_kernel; + 2176 B of INTER_AREA tables = 48768 B. Three workgroups per CU
+// when the kernel runs alone, and -- what the number is tuned for -- one of them fits beside TWO
+// 57344-byte workgroups of the 128-row conv kernel (160 KiB - 2 * 57344 = 49152): the crop stage of
+// step k+1 runs on a second stream under the backbone of step k, and its VALU/LDS-bound waves then
+// share CUs with the MFMA-bound conv waves instead of displacing one of them (+0.8 % end to end
+// over the 50944 that maximised the kernel alone).
+#define PA_FUSED_LDS_BYTES 46592
 
 struct CropPlan {
     int32_t status;
