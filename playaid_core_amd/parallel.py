@@ -202,7 +202,13 @@ class FrameParallelClip:
             dist.all_gather(parts, mine.cpu(), group=self.group)
             everyone = torch.stack(parts)
         else:
-            dist.all_gather_into_tensor(everyone, mine, group=self.group)
+            try:
+                dist.all_gather_into_tensor(everyone, mine, group=self.group)
+            except (RuntimeError, NotImplementedError, AttributeError):
+                # a backend without the single-tensor form: the list form moves the same bytes
+                parts = [torch.empty_like(mine) for _ in range(self.world)]
+                dist.all_gather(parts, mine, group=self.group)
+                everyone = torch.stack(parts)
         rec = torch.cat([everyone[r, : counts[r], :, :4] for r in range(self.world)]).view(torch.int32)
         lp = torch.cat([everyone[r, : counts[r], :, 4:] for r in range(self.world)])
         return rec, lp
