@@ -131,3 +131,25 @@ def test_infer_clip_matches_oracle(engine, state_dict):
     )
     idx = [0, 16, 38]
     assert np.abs(got["logp"][idx].astype(np.float64) - lit["logp"]).max() <= LOGP_TOL
+
+
+def test_other_geometry_matches_oracle():
+    """The reference's ``sequence_length`` / ``frame_delta`` hyper-parameters and label table size
+    are not hard-wired: S = 5, delta = 2, A = 10 (windows m + {-8, -2, 0, 2, 8})."""
+    _, pipeline, _ = _oracle()
+    from playaid_core_amd.engine import Engine
+
+    sd = synth.make_state_dict(seed=77, num_actions=10, sequence_length=5)
+    n, h, w = 30, 360, 640
+    frames, boxes = synth.make_frames(n, h, w, seed=4), synth.make_boxes(n, h, w)
+    ref = pipeline.run_action_recognition(frames, boxes, sd, num_frames_per_sample=5, frame_delta=2, mode="cached")
+    eng = Engine(sd, frame_delta=2, max_batch_frames=16, max_clip_frames=32, max_frame_height=h, max_frame_width=w)
+    try:
+        assert (eng.S, eng.A) == (5, 10)
+        got = eng.infer_clip(frames, boxes, want_crops=True)
+    finally:
+        eng.close()
+    assert np.array_equal(got["crops_rgb"], ref["crops_rgb"])
+    assert got["logp"].shape == (n - 1, 2, 10)
+    assert np.abs(got["logp"].astype(np.float64) - ref["logp"]).max() <= LOGP_TOL
+    assert np.array_equal(got["action_id"], ref["action_id"])
