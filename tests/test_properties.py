@@ -88,3 +88,30 @@ def test_label_repair_invariants(presence):
     again = clean_yolo_labels(c.labels, FIGHTERS, len(labels))
     assert again.labels == c.labels
     assert np.array_equal(again.pixel_box, c.pixel_box)
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.integers(1, 90), st.integers(1, 90), st.integers(1, 90), st.integers(1, 90), st.integers(0, 2**31 - 1))
+def test_bicubic_restatement_equals_live_pillow_on_random_shapes(h, w, oh, ow, seed):
+    """The Pillow half of the oracle is pinned against the live library (the reference's own
+    dependency): enlarging, shrinking and mixed, down to 1-pixel images."""
+    from PIL import Image
+
+    from oracle import resample as R
+
+    a = np.random.default_rng(seed).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    ref = np.array(Image.fromarray(a).resize((ow, oh), Image.BICUBIC))
+    assert np.array_equal(R.pil_resize_bicubic(a, ow, oh), ref)
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.integers(2, 120), st.integers(2, 120), st.integers(0, 2**31 - 1))
+def test_pad_restatement_equals_live_imageops_pad(h, w, seed):
+    from PIL import Image, ImageOps
+
+    from oracle import resample as R
+
+    a = np.random.default_rng(seed).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    d = max(h, w)
+    ref = np.array(ImageOps.pad(Image.fromarray(a), (d, d), color="black"))
+    assert np.array_equal(R.pil_pad_black(a, (d, d)), ref)
