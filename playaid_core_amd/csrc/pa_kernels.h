@@ -78,13 +78,13 @@ hipError_t launch_conv3x3_patch(const GemmParams& p, int bm, hipStream_t s);
 // crop preprocessing (preprocess.hip)
 // ---------------------------------------------------------------------------
 #define PA_KSIZE_MAX 15
-// Stage buffers of crop_fused_kernel; + 2176 B of INTER_AREA tables = 48768 B. Three workgroups per CU
-// when the kernel runs alone, and -- what the number is tuned for -- one of them fits beside TWO
-// 57344-byte workgroups of the 128-row conv kernel (160 KiB - 2 * 57344 = 49152): the crop stage of
-// step k+1 runs on a second stream under the backbone of step k, and its VALU/LDS-bound waves then
-// share CUs with the MFMA-bound conv waves instead of displacing one of them (+0.8 % end to end
-// over the 50944 that maximised the kernel alone).
-#define PA_FUSED_LDS_BYTES 46592
+// Stage buffers of crop_fused_kernel; + 2176 B of INTER_AREA tables = 80000 B: two 512-thread
+// workgroups per CU (16 waves). Measured ladder of this choice (64 x 1080p step, kernel alone):
+// 256 threads / 50944 B (3 per CU) 0.189 ms -> 512 threads / 46592 B 0.169 -> 512 threads / 77824 B
+// 0.144: eight waves per band halve a workgroup's lifetime, and the larger budget lets most crops use
+// 8-row sub-bands (the 7-tap vertical support makes 4-row sub-bands recompute 1.7x of the horizontal
+// pass, 8-row ones 1.35x).
+#define PA_FUSED_LDS_BYTES 77824
 
 struct CropPlan {
     int32_t status;

@@ -695,7 +695,9 @@ struct LdsCanvas {
     }
 };
 
-__global__ __launch_bounds__(256) void crop_fused_kernel(const PreprocParams p) {
+constexpr int CF_NT = 512;         // threads of a crop_fused_kernel workgroup
+constexpr int CF_NW = CF_NT / 64;   // its waves
+__global__ __launch_bounds__(CF_NT) void crop_fused_kernel(const PreprocParams p) {
 #ifdef PA_STAMP_BUILD
     const unsigned long long st0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -705,7 +707,7 @@ __global__ __launch_bounds__(256) void crop_fused_kernel(const PreprocParams p) 
     const CropPlan pl = p.plans[crop];
     if (pl.status != PA_CROP_OK) {
         // failed crop: all-zero rows (the fallback kernels skip it as well)
-        for (int i = tid; i < 8 * PA_CROP; i += 256) write_crop_pixel(p, crop, band0 * PA_CROP + i, 0, 0, 0);
+        for (int i = tid; i < 8 * PA_CROP; i += CF_NT) write_crop_pixel(p, crop, band0 * PA_CROP + i, 0, 0, 0);
         return;
     }
     if (!pl.fused_rb) return;
@@ -735,7 +737,7 @@ __global__ __launch_bounds__(256) void crop_fused_kernel(const PreprocParams p) 
         if (!(p.ablate & 1)) {
             const int row_dwords = (pl.sw * 3 + 3) >> 2;
             const int row_bytes = pl.sw * 3;
-            for (int y = wave; y < n0; y += 4) {
+            for (int y = wave; y < n0; y += CF_NW) {
                 const uintptr_t ga = (uintptr_t)(slice + (size_t)(b.ty0 + y) * frame_pitch);
                 const uint32_t* g4 = reinterpret_cast<const uint32_t*>(ga & ~(uintptr_t)3);
                 const uint32_t sh = (uint32_t)(ga & 3);  // wave-uniform misalignment of this row
@@ -766,7 +768,7 @@ __global__ __launch_bounds__(256) void crop_fused_kernel(const PreprocParams p) 
             // threads busy (one item per column would leave the second pass 3/4 empty).
             const int chunks = (n0 + 3) >> 2;
             const int items = chunks * pl.rw;
-            for (int it = tid; it < items; it += 256) {
+            for (int it = tid; it < items; it += CF_NT) {
                 const int ck = it / pl.rw, xx = it - ck * pl.rw;
                 const int32_t* row = coef_h + (size_t)xx * COEF_ROW;
                 const int xmin = row[0], cnt = row[1];
@@ -851,7 +853,7 @@ __global__ __launch_bounds__(256) void crop_fused_kernel(const PreprocParams p) 
             const int row_dwords = (pl.rw * 3 + 3) >> 2;
             const uint32_t* lds32 = reinterpret_cast<const uint32_t*>(pa_smem);
             const int pitch_dw = in_pitch >> 2;
-            for (int yy = wave; yy < n2; yy += 4) {
+            for (int yy = wave; yy < n2; yy += CF_NW) {
                 const int32_t* row = coef_v + (size_t)(b.ry0 + yy) * COEF_ROW;
                 const int ymin = row[0], cnt = row[1];
                 const int s0 = (in_base >> 2) + (ymin - b.ty0) * pitch_dw;
@@ -929,7 +931,7 @@ __global__ __launch_bounds__(256) void crop_fused_kernel(const PreprocParams p) 
                 meta[12] = pl.sw; meta[13] = pl.sh; meta[14] = pl.rw; meta[15] = pl.rh; meta[16] = pl.px; meta[17] = pl.py;
                 meta[18] = pl.need_h; meta[19] = pl.need_v; meta[20] = pl.d; meta[21] = pl.area_mode; meta[22] = pl.sx0; meta[23] = pl.sy0;
             }
-            for (int i = tid; i < L.total; i += 256) p.dbg[256 + i] = pa_smem[i];
+            for (int i = tid; i < L.total; i += CF_NT) p.dbg[256 + i] = pa_smem[i];
         }
 #endif
         // ---- stage A: INTER_AREA + pad + outputs --------------------------------
@@ -939,7 +941,7 @@ __global__ __launch_bounds__(256) void crop_fused_kernel(const PreprocParams p) 
             cv.pitch = in_pitch;
             cv.px = pl.px; cv.py = pl.py; cv.rw = pl.rw;
             cv.ry0 = b.ry0; cv.ry1 = b.ry1;
-            for (int i = tid; i < rb * PA_CROP; i += 256) {
+            for (int i = tid; i < rb * PA_CROP; i += CF_NT) {
                 const int dy = r0 + (i >> 7), dx = i & 127;
                 int o0 = 0, o1 = 0, o2 = 0;
                 if (dy < pl.out_h) {
@@ -1110,7 +1112,12 @@ hipError_t launch_preprocess(const PreprocParams& p_in, hipStream_t s) {
         p.dbg = reinterpret_cast<uint8_t*>(sd);
     }
 #endif
-    hipLaunchKernelGGL(crop_fused_kernel, dim3(PA_CROP / 8, ncrops), dim3(256), p.fused_lds + (PA_CROP + 8) * sizeof(AreaTabPacked), s, p);
+    static bool lds_attr = false;
+    if (!lds_attr) {  // dynamic LDS beyond the 64 KiB default
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&crop_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        lds_attr = true;
+    }
+    hipLaunchKernelGGL(crop_fused_kernel, dim3(PA_CROP / 8, ncrops), dim3(CF_NT), p.fused_lds + (PA_CROP + 8) * sizeof(AreaTabPacked), s, p);
     { hipError_t e1 = hipGetLastError(); if (e1 != hipSuccess) return e1; }
 #ifdef PA_STAMP_BUILD
     if (now) {
