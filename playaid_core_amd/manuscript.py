@@ -24,51 +24,22 @@ from typing import Dict, List, Optional
 
 import click
 
-from .fighter import YoloCrop
+from . import anim_ontology
+from .fighter import Fighter
 from .timeline import load_ground_truth_from_path, load_timeline_from_ai_output
 
 
-class FighterRecord:
-    """The fields of ``playaid.fighter.Fighter`` that the AI overlay feeds
-    (``fighter.py:458-555``): scalar copy-through, ``crop`` from the YOLO string
-    (``:503-504``) and the ``action`` override (``:551-552``). The log-projection
-    geometry (``:494-539``) is listed under "next" in DESIGN.md."""
-
-    def __init__(self, frame_num: int, data: Dict):
-        self.move_counter = 0
-        self.animation_frame_num = 1
-        self.action = ""
-        self.damage = 0.0
-        self.set_from_json(frame_num, data)
-
-    def set_from_json(self, frame_num: int, data: Dict):
-        self.frame_num = frame_num
-        self.fighter_id = data["fighter_id"]
-        self.fighter_name = data["fighter_name"]
-        self.previous_damage = self.damage
-        self.damage = data["damage"]
-        self.num_frames_left = data["num_frames_left"]
-        self.stock_count = data["stock_count"]
-        self.motion_kind = data["motion_kind"]
-        self.motion_hex = f"{self.motion_kind:#0{12}x}"
-        self.crop: Optional[YoloCrop] = YoloCrop.from_string(data["crop"]) if "crop" in data else None
-        previous_action = self.action
-        self.action = data.get("action", "")
-        self.action_confidence = data.get("predicted_action_confidence", 0.0)
-        self.new_action = previous_action != self.action
-        if self.new_action:
-            self.move_counter += 1
-        self.animation_frame_num = 1 if self.new_action else self.animation_frame_num + 1
-        self.damage_delta = max(self.damage - self.previous_damage, 0)
+FighterRecord = Fighter  # round-1 name of the per-fighter record
 
 
-def update_fighters_from_timeline(frame_number: int, ground_truth: List[Dict], fighters: List[FighterRecord]):
-    """``timeline.py:186-201``."""
-    ground_truth = sorted(ground_truth, key=lambda x: x["fighter_id"])
-    if not fighters or frame_number == 0:
-        return [FighterRecord(frame_number, d) for d in ground_truth]
-    for i, d in enumerate(ground_truth):
-        fighters[i].set_from_json(frame_number, d)
+def update_fighters_from_timeline(frame_number: int, ground_truth: List[Dict], fighters: List[Fighter]):
+    """``timeline.py:186-201``: construct on the first call / frame 0, ``Fighter.update`` afterwards."""
+    by_id = sorted(ground_truth, key=lambda d: d["fighter_id"])
+    if fighters and frame_number != 0:
+        for fighter, row in zip(fighters, by_id):
+            fighter.update(frame_number, row)
+    else:
+        fighters.extend(Fighter(frame_num=frame_number, data=row) for row in by_id)
     return fighters
 
 
@@ -85,7 +56,7 @@ class Manuscript:
         self.max_frames = len(self.timeline) if max_frames < 0 else min(max_frames, len(self.timeline))
 
     def render(self) -> Dict:
-        fighters: List[FighterRecord] = []
+        fighters: List[Fighter] = []
         actions = [Counter(), Counter()]
         moves = [0, 0]
         for i in range(self.start_frame, self.max_frames):
@@ -114,9 +85,14 @@ class Manuscript:
 @click.option("--run-ai", is_flag=True, help="Run AIRunner on the MI355X first and use its ai_output.yaml")
 @click.option("--checkpoint", default=None, help="CNNActionDetector .ckpt for --run-ai")
 @click.option("--summary-json", default=None, help="Where to write the summary (default: stdout only)")
+@click.option("--params-labels", default=None,
+              help="params_labels.csv (motion_kind hex -> param string); default $PLAYAID_PARAMS_LABELS. "
+                   "Without it log-derived actions are 'Undefined', as for any hex the table lacks")
 def run_manuscript(frames, skip_graphs, skip_summaries, show_timer, video_path, log_path, ai_output_path, run_ai,
-                   checkpoint, summary_json):
+                   checkpoint, summary_json, params_labels):
     """Entrypoint to Manuscript"""
+    if params_labels or os.environ.get("PLAYAID_PARAMS_LABELS"):
+        anim_ontology.load_hex_to_action(params_labels)
     if not video_path:
         print("Must specify --video-path")
         return

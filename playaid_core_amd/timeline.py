@@ -68,38 +68,67 @@ def load_timeline_from_ai_output(file_path: str, max_frames: int = None, fighter
     return timeline
 
 
+class _LogAssembler:
+    """Folds the half-frame rows of a game log (one JSON line per fighter per frame) into a timeline.
+
+    ``slots`` counts half-frames consumed. A row whose ``num_frames_left`` has dropped by d > 1 since
+    the previous row means the logger skipped d - 1 frames: the reference fills them by repeating
+    the LAST frame list (``timeline.py:249-255``) -- which at that moment is the list of the frame
+    being read, so the d - 1 fillers and the post-gap frame are ONE shared list holding the post-gap
+    rows, not copies of the pre-gap frame. Callers rely on nothing else, but the timeline's length
+    (and therefore every later frame's index) depends on it, so the behaviour is kept."""
+
+    def __init__(self):
+        self.frames: List[List[Dict]] = []
+        self.slots = 0
+        self.last_left = -1
+
+    def prefill(self, rows: List[Dict], copies: int):
+        self.frames = [rows] * copies  # negative log_offset: the reference marks this branch "DOES NOT WORK"
+        self.slots = 2 * copies
+
+    def push(self, row: Dict):
+        at = self.slots // 2
+        if at >= len(self.frames):
+            self.frames.append([])
+        skipped = self.last_left - row["num_frames_left"] - 1 if self.last_left > 0 else 0
+        if skipped > 0:
+            self.frames.extend([self.frames[-1]] * skipped)
+            self.slots += 2 * skipped
+        self.frames[at].append(row)
+        self.slots += 1
+        self.last_left = row["num_frames_left"]
+
+    def finish(self, validate: bool) -> List[List[Dict]]:
+        # fighter ids can be anything in the log (p1 = 0, p2 = 4 ...): order by id, then renumber 0, 1
+        timeline = []
+        for rows in self.frames:
+            ordered = sorted(rows, key=lambda r: r["fighter_id"])
+            for slot, r in enumerate(ordered):
+                r["fighter_id"] = slot
+            timeline.append(ordered)
+        if validate:
+            for i, rows in enumerate(timeline):
+                assert len(rows) == 2, (
+                    "there should be the ground truth for 2 players for every frame, found " + f"{len(rows)} for frame #{i}"
+                )
+        return timeline
+
+
 def load_ground_truth_from_path(label_path: str, validate: bool = True, log_offset: int = 0, max_lines=0):
-    """JSON-lines game log -> timeline (``timeline.py:204-280``)."""
-    ground_truth: List[List[Dict]] = []
-    prev_num_frames_left = -1
-    index = 0
-    offset_count = 0
+    """JSON-lines game log -> timeline (``timeline.py:204-280``). ``log_offset`` > 0 drops that many
+    leading frames (2 lines each); ``max_lines`` stops once more than that many half-frame slots are
+    filled."""
+    asm = _LogAssembler()
     with open(label_path, "r") as f:
-        for line in f:
-            if max_lines and index > max_lines:
+        if log_offset < 0:
+            first_two = [json.loads(f.readline()), json.loads(f.readline())]
+            asm.prefill(first_two, -log_offset)
+            f.seek(0)
+        for lineno, line in enumerate(f):
+            if max_lines and asm.slots > max_lines:
                 break
-            if offset_count < (2 * log_offset):
-                offset_count += 1
+            if lineno < 2 * log_offset:
                 continue
-            json_data = json.loads(line)
-            frame_number = index // 2
-            if frame_number >= len(ground_truth):
-                ground_truth.append([])
-            diff = prev_num_frames_left - json_data["num_frames_left"]
-            if prev_num_frames_left > 0 and diff > 1:
-                ground_truth += [ground_truth[-1]] * (diff - 1)
-                index += (diff - 1) * 2
-            ground_truth[frame_number].append(json_data)
-            index += 1
-            prev_num_frames_left = json_data["num_frames_left"]
-    for i, frame_data in enumerate(ground_truth):
-        frame_data = sorted(frame_data, key=lambda x: x["fighter_id"])
-        for j, fighter_data in enumerate(frame_data):
-            fighter_data["fighter_id"] = j
-        ground_truth[i] = frame_data
-    if validate:
-        for i, gt in enumerate(ground_truth):
-            assert len(gt) == 2, (
-                "there should be the ground truth for 2 players for every frame, found " + f"{len(gt)} for frame #{i}"
-            )
-    return ground_truth
+            asm.push(json.loads(line))
+    return asm.finish(validate)

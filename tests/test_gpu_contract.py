@@ -375,3 +375,22 @@ def test_log_projection_boxes(engine, tmp_path):
     d0 = tl[3][1]
     assert tuple(boxes[3, 1]) == oproj.project_box(d0["pos_x"], d0["pos_y"], list(d0["camera_position"].values()),
                                                     list(d0["camera_target_position"].values()), 50)
+
+
+def test_fighter_kat_box_on_gpu(engine):
+    """The camera / position of the reference-held fixture (fighter_test.py:9-28) through
+    pa_project_boxes == the literal numpy oracle == the host Fighter mirror."""
+    import json
+
+    from oracle import projection as oproj
+    from playaid_core_amd import projection
+    from playaid_core_amd.fighter import Fighter
+
+    k = json.load(open(os.path.join(GOLD, "fighter_kat.json")))
+    data = dict(k["data"], **k["added_keys"])
+    rows = projection.log_rows_from_timeline([[data]])
+    got = tuple(engine.project_boxes(rows).cpu().numpy()[0, 0])
+    want = oproj.project_box(data["pos_x"], data["pos_y"], list(data["camera_position"].values()),
+                             list(data["camera_target_position"].values()), 50)
+    assert got == want
+    assert Fighter(frame_num=0, data=data).crop.yolo_crop() == want

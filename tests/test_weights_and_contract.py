@@ -129,6 +129,17 @@ def test_manuscript_cli_plumbing_config0(tmp_path):
     assert r.exit_code == 0, r.output
     s = json.load(open(out))
     assert s["frames"] == 128 - 5  # log_offset 5 (manuscript.py:377)
+    # a log-only run derives the action from motion_kind (fighter.py:540-547): nothing in the table -> Undefined
+    assert [f["actions"] for f in s["fighters"]] == [{"Undefined": 123}] * 2
+    labels = tmp_path / "params_labels.csv"
+    labels.write_text("0x0000000000,\n0x047dee83e5,wait\n")
+    r = CliRunner().invoke(run_manuscript, ["--video-path", "synthetic_128.npz", "--log-path", log, "--params-labels", str(labels), "--summary-json", out])
+    assert r.exit_code == 0, r.output
+    s = json.load(open(out))
+    assert [f["actions"] for f in s["fighters"]] == [{"Wait": 123}] * 2 and [f["moves"] for f in s["fighters"]] == [0, 0]
+    assert [f["fighter_name"] for f in s["fighters"]] == ["Pikachu", "Joker"]
+    anim_ontology.HEX_TO_ACTION.clear()
+    anim_ontology._hex_table_path = None
     r = CliRunner().invoke(
         run_manuscript,
         ["--video-path", "synthetic_128.npz", "--log-path", log, "--ai-output-path", os.path.join(GOLD, "ai_output_128.yaml"), "--summary-json", out],
@@ -138,6 +149,6 @@ def test_manuscript_cli_plumbing_config0(tmp_path):
     assert s["frames"] == 127 and len(s["fighters"]) == 2
     gold = yaml.safe_load(open(os.path.join(GOLD, "ai_output_128.yaml")))
     for f in s["fighters"]:
-        name = anim_ontology.FIGHTER_ENUM_TO_NAME[f["fighter_name"]]
+        name = f["fighter_name"]  # the enum of the timeline dict resolved to a name, as Fighter.set_from_json does
         assert sum(f["actions"].values()) == 127
         assert f["last_crop"] == gold[name][126]["crop"]
