@@ -1,18 +1,29 @@
 #!/usr/bin/env python3
 """Headline benchmark: 1080p frames/s, raw BGR frame -> per-frame labels, on N
-MI355X (BASELINE.json `metric`, config[1]: batch = 64 x 1080p frames, fp32).
+MI355X (BASELINE.json `metric`).
 
-A "step" is one pass of the hot path over one 64-frame clip per GPU, inputs
-already resident in HBM: square-crop + resample + /255 (HIP), ResNet-18 on the
-128 crops (fp32 MFMA implicit GEMM), temporal Conv1d/MLP head + log-softmax +
-argmax (HIP) -> pa_record per (frame, fighter). At N > 1 the N*64-frame clip is
-sharded frame-parallel: one process per GPU, the only data-path exchange is the
-27-frame feature halo (RCCL send/recv) plus the record gather.
+Two workloads, both with the frames already resident in HBM when the timed
+region starts (no decode, no host->device copy inside it; the PCIe-inclusive
+rate is measured separately and reported next to `value`, never as it):
+
+* N = 1 (default): configs[1], batch = 64 x 1080p frames, fp32. One "clip" is
+  one pass of the hot path over those 64 frames: square-crop + resample + /255
+  (HIP), ResNet-18 on the 128 crops (fp32 MFMA implicit GEMM), temporal
+  Conv1d/MLP head + log-softmax + argmax (HIP) -> pa_record per (frame,
+  fighter). A timed step runs `--inner-repeat` such clips back to back so that
+  the driver's 20 steps time ~0.6 s instead of 0.03 s; `ms_per_step` stays the
+  time of ONE 64-frame clip (timed region / (steps x inner_repeat)).
+* N > 1 (or `--clip-frames F`): configs[3], ONE F = 8192-frame clip sharded
+  frame-parallel over the ranks (strong scaling): each rank holds, crops and
+  runs the backbone on its 8192/N frames in chunks of 64, the 27-frame feature
+  halo goes to the neighbouring rank(s) by RCCL send/recv underneath the head of
+  the interior frames, one all-gather collects the records. A step is one pass
+  over the whole clip.
 
 Prints ONE JSON line on rank 0 (contract in the task prompt) with `roofline`
 (dominant kernel family, timed with HIP events on the launch stream in a second
-pass of the same K steps right after the timed region) and `cpu_baseline` (the CPU oracle, reference-literal shape, on a
-bounded sample, N=1 only).
+pass right after the timed region) and `cpu_baseline` (the CPU oracle,
+reference-literal shape, on a bounded sample, N=1 only).
 """
 import argparse
 import json
@@ -30,26 +41,29 @@ import torch.distributed as dist
 
 from playaid_core_amd import synth
 from playaid_core_amd.engine import Engine
-from playaid_core_amd.parallel import FrameParallelClip, broadcast_blob, shard_range
-from playaid_core_amd.weights import pack_state_dict
+from playaid_core_amd.parallel import FrameParallelClip, broadcast_engine, halo_plan, shard_range
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, = fp32 vector peak
 PEAK_HBM_GBS = 8000.0
+TRAFFIC_FILES = {"f32": "r02_traffic.json", "bf16": "r02_cfg2_bf16_traffic.json"}
+TRAFFIC_FALLBACK = {"f32": "r01_traffic.json", "bf16": "r01_cfg2_bf16_traffic.json"}
 
 
 def _pmc_traffic(kernel_name, dtype, frames, height, width):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_traffic.json for the fp32 headline, profiles/r01_cfg2_bf16_traffic.json for
-    configs[2]; produced by scripts/pmc_traffic.py -- counters cannot be read from inside this
-    process). None when no measurement of that kernel on that workload shape is on file."""
-    name = "r01_traffic.json" if dtype == "f32" else "r01_cfg2_bf16_traffic.json"
-    try:
-        with open(os.path.join(ROOT, "profiles", name)) as f:
-            t = json.load(f)
-        same = t.get("kernel") == kernel_name and t.get("workload") == {"frames": frames, "height": height, "width": width}
-        return t["traffic_bytes_per_launch"] if same else None
-    except Exception:
-        return None
+    (produced by scripts/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs of this same
+    command -- counters cannot be read from inside this process, so the figure is REPLAYED from the
+    file named in `traffic_source`, not measured in this run). (None, None) when no measurement of
+    that kernel on that workload shape is on file."""
+    for name in (TRAFFIC_FILES[dtype], TRAFFIC_FALLBACK[dtype]):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                t = json.load(f)
+        except Exception:
+            continue
+        if t.get("kernel") == kernel_name and t.get("workload") == {"frames": frames, "height": height, "width": width}:
+            return t["traffic_bytes_per_launch"], f"profiles/{name} (committed rocprofv3 PMC pass, replayed)"
+    return None, None
 
 
 def cpu_baseline(sd, height, width, sample_frames):
@@ -81,16 +95,66 @@ def cpu_baseline(sd, height, width, sample_frames):
     }
 
 
+def pcie_inclusive(eng, frames_dev, boxes_dev, steps=8):
+    """The same 64-frame clip with the frames starting in pinned HOST memory: every clip's 398 MB
+    cross PCIe on a side stream into one of two device buffers while the previous clip computes
+    (DESIGN.md section 6). Reported beside `value`, never as it."""
+    dev = eng.device
+    n = frames_dev.shape[0]
+    host = frames_dev.cpu().pin_memory()
+    bufs = [torch.empty_like(frames_dev), torch.empty_like(frames_dev)]
+    rec = eng.alloc_records(n - 1)
+    side, main = torch.cuda.Stream(dev), torch.cuda.current_stream(dev)
+    ready = [torch.cuda.Event(), torch.cuda.Event()]
+    free = [torch.cuda.Event(), torch.cuda.Event()]
+
+    def run(k_steps):
+        for e in free:
+            e.record(main)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for k in range(k_steps + 1):
+            if k < k_steps:
+                with torch.cuda.stream(side):
+                    side.wait_event(free[k & 1])
+                    bufs[k & 1].copy_(host, non_blocking=True)
+                    ready[k & 1].record(side)
+            if k > 0:
+                j = (k - 1) & 1
+                main.wait_event(ready[j])
+                eng.infer_clip_device(bufs[j], boxes_dev, rec)
+                free[j].record(main)
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / k_steps
+
+    run(2)
+    dt = run(steps)
+    return {
+        "value": round(n / dt, 1),
+        "unit": "frames/s",
+        "ms_per_clip": round(dt * 1e3, 3),
+        "h2d_MB_per_clip": round(host.numel() / 1e6, 1),
+        "method": f"{steps} clips, frames in pinned host memory, whole-frame H2D copy of clip k+1 on a side stream under the "
+        "compute of clip k (two device buffers); no decode",
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)   # 0.16 s of timed work; 20 steps still carry ~2 % of pipeline fill
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--frames", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=64, help="frames per backbone batch (and per clip in the configs[1]/[2] workloads)")
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--clip-frames", type=int, default=None,
+                    help="configs[3]: ONE clip of this many frames sharded over the ranks (strong scaling); default 8192 when "
+                    "--gpus > 1, off (configs[1]: a 64-frame clip per step) when --gpus 1; 0 = a --frames clip per rank (weak scaling)")
+    ap.add_argument("--inner-repeat", type=int, default=20,
+                    help="configs[1]/[2] only: clips per timed step (ms_per_step stays per clip)")
     ap.add_argument("--cpu-sample-frames", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive side measurement")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse ranks > GPUs)")
     ap.add_argument("--no-pipeline", action="store_true", help="crop stage and backbone on one stream (no overlap across steps)")
@@ -115,38 +179,30 @@ def main():
             dist.init_process_group(args.backend)
 
     F, S, A, DELTA = 2, 7, 63, 3
-    n_local = args.frames
-    n_total = n_local * world
+    clip_frames = args.clip_frames if args.clip_frames is not None else (8192 if world > 1 else 0)
+    long_clip = clip_frames > 0
+    n_batch = args.frames
+    n_total = clip_frames if long_clip else n_batch * world
     lo, hi = shard_range(n_total, world, rank)
+    repeat = 1 if (long_clip or world > 1) else max(args.inner_repeat, 1)
 
-    # weights: rank 0 packs, one RCCL broadcast
-    nbytes = None
-    if rank == 0:
-        sd = synth.make_state_dict(seed=1234)
-        blob = pack_state_dict(sd, S, A)
-        nbytes = blob.nbytes
-    if world > 1:
-        comm_dev = device if args.backend == "nccl" else "cpu"
-        nb = torch.tensor([nbytes if rank == 0 else 0], dtype=torch.int64, device=comm_dev)
-        dist.broadcast(nb, src=0)
-        blob = broadcast_blob(blob if rank == 0 else None, int(nb.item()), device)
-    eng = Engine(
-        blob,
-        device=str(device),
-        max_batch_frames=n_local,
-        max_clip_frames=max(n_total, 64),
-        max_frame_height=args.height,
-        max_frame_width=args.width,
-        compute_dtype=args.dtype,
-    )
-    # this rank's shard of the synthetic clip, resident in HBM before timing
-    frames = torch.from_numpy(synth.make_frames(hi - lo, args.height, args.width, first_frame=lo)).to(device)
+    # weights: rank 0 folds them once; the prepared device arena crosses xGMI in one RCCL broadcast
+    sd = synth.make_state_dict(seed=1234) if rank == 0 else None
+
+    def make_engine(w):
+        return Engine(w, device=str(device), max_batch_frames=n_batch, max_clip_frames=max(n_total, 64),
+                      max_frame_height=args.height, max_frame_width=args.width, compute_dtype=args.dtype)
+
+    eng = broadcast_engine(make_engine, sd, device) if world > 1 else make_engine(sd)
+    # this rank's shard of the synthetic clip, generated on the device it will be read from (bit-identical to
+    # synth.make_frames) and resident in HBM before timing
+    frames = synth.make_frames_torch(hi - lo, args.height, args.width, first_frame=lo, device=device)
     boxes = torch.from_numpy(synth.make_boxes(hi - lo, args.height, args.width, first_frame=lo)).to(device)
     runner = FrameParallelClip(eng, S, DELTA)
 
     def step(pipeline=None):
         pipeline = (not args.no_pipeline) if pipeline is None else pipeline
-        return runner.run(frames, boxes, n_total, gather=True, pipeline=pipeline)
+        return runner.run(frames, boxes, n_total, gather=True, pipeline=pipeline, reuse_buffers=True)
 
     def fence():
         torch.cuda.synchronize(device)
@@ -154,28 +210,33 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    for _ in range(args.warmup):
+    for _ in range(args.warmup * repeat):
         step()
     fence()
     # ---- timed region: exactly K steps, barrier + synchronize on both sides ----
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        rec, lp = step()
+        for _ in range(repeat):
+            rec, lp = step()
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    # ---- kernel pass: the same K steps again with every launch bracketed by HIP events on
-    # the launch stream (pa_profile_enable). Kept out of the timed region because the event
-    # pairs serialise neighbouring kernels and cost ~10 % throughput; its own wall time is
-    # reported as profiled_ms_per_step.
-    stats, dt_prof = [], None
+    n_clips = args.steps * repeat
+    # ---- kernel pass: clips again with every launch bracketed by HIP events on the launch stream
+    # (pa_profile_enable). Kept out of the timed region because the event pairs serialise
+    # neighbouring kernels and cost ~10 % throughput; its own wall time is reported as
+    # profiled_ms_per_step.
+    stats, dt_prof, prof_clips = [], None, 0
     if not args.no_profile:
+        prof_clips = args.steps if long_clip else min(n_clips, 40)
+        if long_clip:
+            prof_clips = min(prof_clips, 2)
         eng.profile_enable(True)
         t1 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(prof_clips):
             step(pipeline=False)  # one stream: kernel durations free of cross-stream overlap
         fence()
         dt_prof = time.perf_counter() - t1
@@ -185,37 +246,57 @@ def main():
     if rank == 0:
         # sanity: results are finite and complete
         assert rec.shape[0] == n_total - 1 and torch.isfinite(lp).all()
-        fps = n_total * args.steps / dt
-        shape = (n_local, args.height, args.width, args.dtype)
-        cfg_name = {(64, 1080, 1920, "f32"): "configs[1]", (256, 720, 1280, "bf16"): "configs[2]"}.get(shape, "custom shape")
+        fps = n_total * n_clips / dt
+        shape = (n_batch, args.height, args.width, args.dtype)
+        if long_clip:
+            cfg_name = "configs[3]" if (clip_frames, args.height, args.width, args.dtype) == (8192, 1080, 1920, "f32") else "custom long clip"
+            what = (f"ONE {clip_frames}-frame {args.height}x{args.width} BGR clip sharded frame-parallel over {world} rank(s) "
+                    f"({hi - lo} frames on rank 0, backbone batches of {n_batch})")
+        else:
+            cfg_name = {(64, 1080, 1920, "f32"): "configs[1]", (256, 720, 1280, "bf16"): "configs[2]"}.get(shape, "custom shape")
+            what = f"{n_batch} x {args.height}x{args.width} BGR frames per GPU per clip"
+        reach = DELTA * (S // 2) ** 2
         result = {
-            "metric": f"{args.height}p frames/sec end-to-end (decode->labels)",
+            "metric": f"{args.height}p frames/sec end-to-end (decode->labels; 'decode' here = ingest of raw BGR frames already resident in HBM)",
             "value": round(fps, 2),
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(1000.0 * dt / args.steps, 4),
-            "profiled_ms_per_step": round(1000.0 * dt_prof / args.steps, 4) if dt_prof else None,
+            "ms_per_step": round(1000.0 * dt / n_clips, 4),
+            "ms_per_timed_step": round(1000.0 * dt / args.steps, 4),
+            "profiled_ms_per_step": round(1000.0 * dt_prof / prof_clips, 4) if dt_prof else None,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if long_clip else "weak",
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {
-                "workload": f"{cfg_name}: {n_local} x {args.height}x{args.width} BGR frames per GPU per step, 2 fighters/frame, "
-                f"S=7 delta=3 window, {'fp32' if args.dtype == 'f32' else 'bf16-conv (3x3 stack in bf16, fp32 accumulate; stem, fc, head fp32)'} "
+                "workload": f"{cfg_name}: {what}, 2 fighters/frame, S=7 delta=3 window, "
+                f"{'fp32' if args.dtype == 'f32' else 'bf16-conv (3x3 stack in bf16, fp32 accumulate; stem, fc, head fp32)'} "
                 f"CNNActionDetector (ResNet-18 + Conv1d/MLP head, 63 actions), seeded weights",
-                "frames_per_gpu_per_step": n_local,
-                "crops_per_gpu_per_step": n_local * F,
+                "ingest": "frames resident in HBM before the timed region; no decode (BASELINE metric's 'decode' = ingest of raw BGR frames, SURVEY.md 8a1)",
+                "clip_frames": n_total,
+                "frames_per_backbone_batch": n_batch,
+                "crops_per_backbone_batch": n_batch * F,
+                "inner_repeat": repeat,
+                "inner_repeat_note": "clips per timed step; ms_per_step = timed region / (steps x inner_repeat) = one clip",
                 "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU",
-                "pipeline": "crop stage of step k+1 overlaps the backbone of step k (2 streams, 2 input slots)" if not args.no_pipeline else "none",
+                "pipeline": "crop stage of batch k+1 overlaps the backbone of batch k (2 streams, 2 input slots)" if not args.no_pipeline else "none",
             },
         }
+        if world > 1:
+            recvs, sends = halo_plan(n_total, world, 0, reach)
+            result["config"]["exchange"] = {
+                "halo_rows_sent_rank0": sum(c for _, _, c in sends) * F,
+                "halo_bytes_per_edge": reach * F * 4096,
+                "gather_bytes_per_rank": max(hi - lo, 1) * F * (4 + A) * 4,
+                "weights_broadcast_bytes_once": int(eng._lib.pa_weights_arena_bytes(eng._h)),
+            }
         # whole-path fractions per SURVEY 8d: algorithmic bytes / FLOPs per frame (feature-cached
         # formulation, F frames per batch) x measured frames/s against the two chip roofs
         if (args.height, args.width) == (1080, 1920) and args.dtype == "f32":
-            bytes_frame = 6220800 + 2 * (49152 * 2) + 2 * 8388608 + 61391260 / n_local
+            bytes_frame = 6220800 + 2 * (49152 * 2) + 2 * 8388608 + 61391260 / n_batch
             flops_frame = 2 * (1185390592 + 2 * 3584000 + 2 * 73600)
             per_gpu_fps = fps / world
             result["roofline_path"] = {
@@ -229,6 +310,7 @@ def main():
             by = {s["name"]: s for s in stats}
             dom = max(stats, key=lambda s: s["total_ms"])
             tf = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12 if dom["total_ms"] > 0 else 0.0
+            traffic, traffic_src = _pmc_traffic(dom["name"], args.dtype, n_batch, args.height, args.width)
             if args.dtype == "f32":
                 result["roofline"] = {
                     "kernel": dom["name"],
@@ -237,7 +319,9 @@ def main():
                     "peak": PEAK_FP32_MATRIX_TFLOPS,
                     "unit": "TFLOP/s",
                     "frac": round(tf / PEAK_FP32_MATRIX_TFLOPS, 4),
-                    "traffic": _pmc_traffic(dom["name"], "f32", n_local, args.height, args.width),
+                    "traffic": traffic,
+                    "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": round(dom["bytes"] / max(dom["launches"], 1)),
                     "launches": dom["launches"],
                     "avg_launch_ms": round(dom["total_ms"] / max(dom["launches"], 1), 5),
                 }
@@ -252,16 +336,19 @@ def main():
                     "peak": PEAK_HBM_GBS,
                     "unit": "GB/s",
                     "frac": round(gbs / PEAK_HBM_GBS, 4),
-                    "traffic": _pmc_traffic(dom["name"], "bf16", n_local, args.height, args.width),
+                    "traffic": traffic,
+                    "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": round(dom["bytes"] / max(dom["launches"], 1)),
                     "launches": dom["launches"],
                     "avg_launch_ms": round(dom["total_ms"] / max(dom["launches"], 1), 5),
                     "tflops": round(tf, 2),
                 }
             total_ms = sum(s["total_ms"] for s in stats)
+            batches = prof_clips * max((hi - lo + n_batch - 1) // n_batch, 1)
             result["kernels"] = {
                 s["name"]: {
-                    "launches_per_step": s["launches"] / args.steps,
-                    "ms_per_step": round(s["total_ms"] / args.steps, 4),
+                    "launches_per_batch": round(s["launches"] / batches, 3),
+                    "ms_per_batch": round(s["total_ms"] / batches, 4),
                     "share": round(s["total_ms"] / total_ms, 4),
                     "tflops": round(s["flops"] / (s["total_ms"] * 1e-3) / 1e12, 2) if s["flops"] and s["total_ms"] else None,
                     "algo_GBs": round(s["bytes"] / (s["total_ms"] * 1e-3) / 1e9, 1) if s["total_ms"] else None,
@@ -275,6 +362,8 @@ def main():
                     "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(gbs / PEAK_HBM_GBS, 4),
                 }
+        if world == 1 and not long_clip and not args.no_pcie:
+            result["pcie_inclusive"] = pcie_inclusive(eng, frames, boxes)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(sd, args.height, args.width, args.cpu_sample_frames)
         print(json.dumps(result), flush=True)

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PA_ABI_VERSION 2
+#define PA_ABI_VERSION 3
 #define PA_WEIGHT_MAGIC 0x31574150 /* "PAW1" */
 #define PA_FEATURE_STRIDE 1024     /* floats per cached feature row (1000 used) */
 #define PA_CROP 128
@@ -55,6 +55,7 @@ typedef enum pa_status {
 #define PA_CROP_BAD_BOX 2      /* non-finite box or square side <= 0 (reference raises) */
 #define PA_CROP_UPSCALE 3      /* reserved (was: square side < 128 px rejected; the enlarging branch is implemented now) */
 #define PA_CROP_FILTER_TOO_WIDE 4 /* bicubic support beyond the kernel's table size (scale > 3.5) */
+#define PA_CROP_BAD_FRAME 5    /* pa_backbone_frames_src: source index outside the frame buffer */
 
 typedef struct pa_engine pa_engine;
 
@@ -119,6 +120,16 @@ typedef struct pa_kernel_stat {
  * BatchNorm (eval, eps 1e-5) is folded into the preceding convolution in fp64
  * on the host and the tensors are re-laid-out for the kernels here. */
 int pa_create(const pa_config* cfg, const void* weight_blob_host, size_t blob_bytes, pa_engine** out);
+/* Weights for the other GPUs of a node (one broadcast of the weights). The
+ * folded, re-laid-out tensors of an engine live in one device arena whose layout depends only on
+ * (sequence_length, num_actions, compute_dtype): pa_weights_export copies it into a caller buffer of
+ * pa_weights_arena_bytes() bytes (device to device, on `stream`); after that buffer has been broadcast
+ * (RCCL), every other rank builds its engine from it with pa_create_from_arena -- no host copy of the
+ * weights, no second BatchNorm fold. The reference has no counterpart (single process,
+ * ai_runner.py:164-168). */
+int pa_create_from_arena(const pa_config* cfg, const void* arena_dev, size_t arena_bytes, pa_engine** out);
+size_t pa_weights_arena_bytes(const pa_engine* e);
+int pa_weights_export(pa_engine* e, void* arena_dst_dev, size_t arena_bytes, void* stream);
 void pa_destroy(pa_engine* e);
 const char* pa_last_error(const pa_engine* e);
 const char* pa_status_string(int status);
@@ -198,6 +209,19 @@ int pa_backbone_frames_indexed(pa_engine* e, const uint8_t* frames, int32_t n, i
                                const double* boxes, const int32_t* frame_ids, uint8_t* crops_rgb,
                                int32_t* status, void* stream);
 int pa_clip_mark_ready(pa_engine* e, const int32_t* frame_ids_host, int32_t n);
+/* pa_backbone_frames_indexed cannot validate device-resident ids on the host: a frame id outside
+ * [0, clip_frames) writes nothing and is counted on the device. This call synchronises `stream`, returns
+ * the count since the last call in *bad_frame_ids_host (and clears it); PA_ERR_CAPACITY when non-zero. */
+int pa_device_errors(pa_engine* e, int32_t* bad_frame_ids_host, void* stream);
+
+/* pa_backbone_frames for a clip whose crops are NOT cut from their own frame: crop (i, p) of clip frame
+ * frame0 + i comes from frames[src_frame[i*num_fighters + p]] (device int32, values in [0, n_src)).
+ * This is what clean_yolo_crops_for_fighter does for repaired gaps -- it re-cuts a missing crop from
+ * VideoCapture position j, one decoded frame late, per fighter (ai_runner.py:404-418) -- in one pass.
+ * A source index outside the buffer gives that crop status PA_CROP_BAD_FRAME (all-zero pixels). */
+int pa_backbone_frames_src(pa_engine* e, const uint8_t* frames, int32_t n_src, int32_t height, int32_t width,
+                           const double* boxes, const int32_t* src_frame, int32_t n, int32_t frame0,
+                           uint8_t* crops_rgb, int32_t* status, void* stream);
 
 /* Window gather + Conv1d/MLP head + log_softmax + argmax for frame numbers
  * frame_num_lo .. frame_num_hi-1 (1-based, as run_action_recognition iterates

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # PA_LIB_PATH: load a differently built library (e.g. the ablation build used by scripts/)
 LIB_PATH = os.environ.get("PA_LIB_PATH") or os.path.join(HERE, "libplayaid_hip.so")
 
-PA_ABI_VERSION = 2
+PA_ABI_VERSION = 3
 PA_DTYPE_F32 = 0
 PA_DTYPE_BF16 = 1
 PA_WEIGHT_MAGIC = 0x31574150
@@ -31,6 +31,7 @@ PA_CROP_EMPTY = 1
 PA_CROP_BAD_BOX = 2
 PA_CROP_UPSCALE = 3
 PA_CROP_FILTER_TOO_WIDE = 4
+PA_CROP_BAD_FRAME = 5
 
 
 class HipLibraryError(RuntimeError):
@@ -78,6 +79,9 @@ class pa_kernel_stat(C.Structure):
 _P = C.c_void_p
 SYMBOLS = [
     ("pa_create", C.c_int, [C.POINTER(pa_config), _P, C.c_size_t, C.POINTER(_P)]),
+    ("pa_create_from_arena", C.c_int, [C.POINTER(pa_config), _P, C.c_size_t, C.POINTER(_P)]),
+    ("pa_weights_arena_bytes", C.c_size_t, [_P]),
+    ("pa_weights_export", C.c_int, [_P, _P, C.c_size_t, _P]),
     ("pa_destroy", None, [_P]),
     ("pa_last_error", C.c_char_p, [_P]),
     ("pa_status_string", C.c_char_p, [C.c_int]),
@@ -92,6 +96,8 @@ SYMBOLS = [
     ("pa_backbone_slot", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P]),
     ("pa_backbone_frames_indexed", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
     ("pa_clip_mark_ready", C.c_int, [_P, _P, C.c_int32]),
+    ("pa_device_errors", C.c_int, [_P, C.POINTER(C.c_int32), _P]),
+    ("pa_backbone_frames_src", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     ("pa_head_frames", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P]),
     ("pa_infer_clip", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P]),
     ("pa_features_export", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),

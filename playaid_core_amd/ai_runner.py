@@ -199,17 +199,10 @@ class AIRunner:
         if all(np.array_equal(src[:, p], own) for p in range(src.shape[1])):
             out = eng.infer_clip(self.clip.frames[:n], boxes, want_crops=True)
         else:
-            # repaired gaps are cut from VideoCapture position j, not j-1 (ai_runner.py:405-406), so the
-            # two fighters may read different decoded frames: one pass per fighter, columns merged
-            # (crops are independent of each other in eval mode, so this is exact)
-            out = None
-            for p in range(src.shape[1]):
-                r = eng.infer_clip(self.clip.frames[src[:, p]], boxes, want_crops=True)
-                if out is None:
-                    out = r
-                else:
-                    for k, v in r.items():
-                        out[k][:, p] = v[:, p]
+            # repaired gaps are cut from VideoCapture position j, not j-1 (ai_runner.py:405-406), so a crop
+            # may come from another decoded frame than its own, differently per fighter: the crop stage
+            # takes a per-crop source index and the clip still runs once
+            out = eng.infer_clip(self.clip.frames, boxes, want_crops=True, src=src)
         st = out["crop_status"].copy()
         st[missing] = 0
         bad = np.argwhere(st != 0)

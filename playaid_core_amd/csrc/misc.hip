@@ -200,12 +200,19 @@ hipError_t launch_window_gather(int32_t* gather, int32_t frame_num_lo, int32_t c
 }
 
 // feats[i][fighter][:] -> cache[(ids[i]*fighters + fighter)][:], status likewise: places the
-// features of a resolution bucket (non-contiguous frame numbers) into the clip's cache.
+// features of a resolution bucket (non-contiguous frame numbers) into the clip's cache. An id
+// outside [0, clip_frames) writes nothing and bumps the engine's device error counter.
 __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ feats, const int32_t* __restrict__ st,
                                                            const int32_t* __restrict__ ids, float* __restrict__ cache,
-                                                           int32_t* __restrict__ cache_st, int n, int fighters) {
+                                                           int32_t* __restrict__ cache_st, int n, int fighters,
+                                                           int clip_frames, int32_t* __restrict__ bad_ids) {
     const int row = blockIdx.x;  // 0 .. n*fighters-1
-    const int dst = ids[row / fighters] * fighters + row % fighters;
+    const int id = ids[row / fighters];
+    if ((unsigned)id >= (unsigned)clip_frames) {
+        if (threadIdx.x == 0 && row % fighters == 0) atomicAdd(bad_ids, 1);
+        return;
+    }
+    const int dst = id * fighters + row % fighters;
     const float4* s4 = reinterpret_cast<const float4*>(feats + (size_t)row * PA_FEATURE_STRIDE);
     float4* d4 = reinterpret_cast<float4*>(cache + (size_t)dst * PA_FEATURE_STRIDE);
     d4[threadIdx.x] = s4[threadIdx.x];
@@ -213,9 +220,9 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restri
 }
 
 hipError_t launch_scatter_rows(const float* feats, const int32_t* st, const int32_t* ids, float* cache, int32_t* cache_st,
-                               int32_t n, int32_t fighters, hipStream_t s) {
+                               int32_t n, int32_t fighters, int32_t clip_frames, int32_t* bad_ids, hipStream_t s) {
     hipLaunchKernelGGL(scatter_rows_kernel, dim3(n * fighters), dim3(PA_FEATURE_STRIDE / 4), 0, s, feats, st, ids, cache,
-                       cache_st, n, fighters);
+                       cache_st, n, fighters, clip_frames, bad_ids);
     return hipGetLastError();
 }
 

@@ -59,6 +59,14 @@ struct pa_engine {
     std::vector<char> ready;
     // device memory (all freed in pa_destroy)
     std::vector<void*> allocs;
+    // every folded / re-laid-out weight tensor lives in ONE device arena at offsets that depend only on
+    // (S, A, compute_dtype): a rank that received the arena over RCCL adopts it with one device copy
+    // (pa_create_from_arena) instead of folding the blob again
+    uint8_t* arena = nullptr;
+    size_t arena_cap = 0, arena_used = 0;
+    std::vector<uint8_t> arena_stage;  // host mirror while pa_create folds (empty in adopt mode and afterwards)
+    bool adopt = false;
+    int32_t* dev_errors = nullptr;  // [4] device-side error counters ([0] = scatter ids outside the clip)
     float* x0 = nullptr;      // slot 0 of the model-input double buffer [max_crops][134][134][4]
     float* x0_slot[2] = {nullptr, nullptr};
     int32_t* pre_status[2] = {nullptr, nullptr};  // per-slot crop status written by the preprocess stage
@@ -128,39 +136,44 @@ int dev_alloc(pa_engine* e, T** ptr, size_t count, bool zero) {
     return PA_OK;
 }
 
-int upload(pa_engine* e, float** dst, const std::vector<float>& host) {
-    int rc = dev_alloc(e, dst, host.size(), false);
-    if (rc != PA_OK) return rc;
-    HIPCHK(e, hipMemcpy(*dst, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+// Bump-allocate `bytes` in the weight arena (256-byte aligned) and, unless the arena is being adopted,
+// stage the host data for the single upload at the end of pa_create.
+int arena_put(pa_engine* e, void** dst, const void* host, size_t bytes) {
+    const size_t off = (e->arena_used + 255) & ~(size_t)255;
+    if (off + bytes > e->arena_cap) return fail(e, PA_ERR_BAD_WEIGHTS, "weight arena overflow");
+    e->arena_used = off + bytes;
+    *dst = e->arena + off;
+    if (!e->adopt) memcpy(e->arena_stage.data() + off, host, bytes);
     return PA_OK;
+}
+
+int upload(pa_engine* e, float** dst, const std::vector<float>& host) {
+    return arena_put(e, reinterpret_cast<void**>(dst), host.data(), host.size() * sizeof(float));
 }
 
 // fp32 -> bf16 (round to nearest even) weights of the bf16 conv path; the device pointer keeps
 // the float* type of ConvLayer::wgt, the kernels reinterpret it.
 int upload_bf16(pa_engine* e, float** dst, const std::vector<float>& host) {
     std::vector<uint16_t> h(host.size());
-    for (size_t i = 0; i < host.size(); ++i) {
-        uint32_t u;
-        memcpy(&u, &host[i], 4);
-        u += 0x7fffu + ((u >> 16) & 1u);
-        h[i] = (uint16_t)(u >> 16);
-    }
-    uint16_t* d = nullptr;
-    int rc = dev_alloc(e, &d, h.size(), false);
-    if (rc != PA_OK) return rc;
-    HIPCHK(e, hipMemcpy(d, h.data(), h.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    *dst = reinterpret_cast<float*>(d);
-    return PA_OK;
+    if (!e->adopt)
+        for (size_t i = 0; i < host.size(); ++i) {
+            uint32_t u;
+            memcpy(&u, &host[i], 4);
+            u += 0x7fffu + ((u >> 16) & 1u);
+            h[i] = (uint16_t)(u >> 16);
+        }
+    return arena_put(e, reinterpret_cast<void**>(dst), h.data(), h.size() * sizeof(uint16_t));
 }
 
 // --- weight blob walking -----------------------------------------------------
 struct BlobReader {
-    const float* p;
-    const float* end;
+    const float* base;
+    size_t pos, limit;  // in floats
+    bool dry;  // adopting a prepared arena: only the sizes matter, nothing returned by take() is read
     const float* take(size_t n) {
-        if (p + n > end) return nullptr;
-        const float* r = p;
-        p += n;
+        if (pos + n > limit) return nullptr;
+        const float* r = dry ? base : base + pos;
+        pos += n;
         return r;
     }
 };
@@ -209,6 +222,7 @@ bool fold_conv(BlobReader& br, const ConvLayer& L, std::vector<float>& w_out, st
     const int ktot = L.taps * L.chunk;
     w_out.assign((size_t)L.cout * ktot, 0.f);
     b_out.assign(L.cout, 0.f);
+    if (br.dry) return true;
     const bool stem = (L.kh == 7);
     for (int co = 0; co < L.cout; ++co) {
         const double scale = (double)gamma[co] / std::sqrt((double)var[co] + 1e-5);
@@ -521,11 +535,14 @@ int run_head(pa_engine* e, int nwin, const float* feats, const int32_t* gather, 
 }
 
 int run_preprocess(pa_engine* e, const uint8_t* frames, int n, int height, int width, const double* boxes, int padding,
-                   int swap_rb, uint8_t* crops_u8, float* crops_f32, int32_t* status, hipStream_t s) {
+                   int swap_rb, uint8_t* crops_u8, float* crops_f32, int32_t* status, hipStream_t s,
+                   const int32_t* src_frame = nullptr, int n_src = 0) {
     PreprocParams p;
     memset(&p, 0, sizeof(p));
     p.frames = frames;
     p.boxes = boxes;
+    p.src_frame = src_frame;
+    p.n_src = src_frame ? n_src : n;
     p.n_frames = n;
     p.height = height;
     p.width = width;
@@ -576,8 +593,14 @@ const char* pa_last_error(const pa_engine* e) { return e ? e->last_error.c_str()
 
 size_t pa_weight_blob_bytes(int S, int A) { return 8 * sizeof(int32_t) + blob_float_count(S, A) * sizeof(float); }
 
-int pa_create(const pa_config* cfg, const void* blob, size_t blob_bytes, pa_engine** out) {
-    if (!cfg || !blob || !out) return PA_ERR_INVALID_ARG;
+}  // extern "C"
+
+namespace {
+
+// pa_create (blob != nullptr: fold the Lightning tensors) and pa_create_from_arena (arena_dev != nullptr:
+// adopt a prepared weight arena of `src_bytes` bytes) share everything but the source of the weights.
+int create_impl(const pa_config* cfg, const void* blob, size_t src_bytes, const void* arena_dev, pa_engine** out) {
+    if (!cfg || (!blob && !arena_dev) || !out) return PA_ERR_INVALID_ARG;
     *out = nullptr;
     if (cfg->abi_version != PA_ABI_VERSION) return PA_ERR_INVALID_ARG;
     const int S = cfg->sequence_length, A = cfg->num_actions, F = cfg->num_fighters;
@@ -586,11 +609,12 @@ int pa_create(const pa_config* cfg, const void* blob, size_t blob_bytes, pa_engi
         (cfg->compute_dtype != PA_DTYPE_F32 && cfg->compute_dtype != PA_DTYPE_BF16))
         return PA_ERR_INVALID_ARG;
     const int32_t* hdr = reinterpret_cast<const int32_t*>(blob);
-    if (blob_bytes != pa_weight_blob_bytes(S, A) || hdr[0] != PA_WEIGHT_MAGIC || hdr[1] != 1 || hdr[2] != S || hdr[3] != A)
+    if (blob && (src_bytes != pa_weight_blob_bytes(S, A) || hdr[0] != PA_WEIGHT_MAGIC || hdr[1] != 1 || hdr[2] != S || hdr[3] != A))
         return PA_ERR_BAD_WEIGHTS;
     pa_engine* e = new pa_engine();
     e->cfg = *cfg;
     e->bf16 = cfg->compute_dtype == PA_DTYPE_BF16;
+    e->adopt = blob == nullptr;
     {
         const char* pl = getenv("PA_PROFILE_LAYERS");
         e->profile_layers = pl && pl[0] == '1';
@@ -605,6 +629,7 @@ int pa_create(const pa_config* cfg, const void* blob, size_t blob_bytes, pa_engi
                             ", requested device " + std::to_string(cfg->device_id));
     }
     HIPCHK(e, hipSetDevice(cfg->device_id));
+    HIPCHK(e, preprocess_init_device());
     const int NC = cfg->max_batch_frames * F;
     e->max_crops = NC;
     e->cache_rows = cfg->max_clip_frames * F;
@@ -629,9 +654,22 @@ int pa_create(const pa_config* cfg, const void* blob, size_t blob_bytes, pa_engi
     ALLOC(e->h1, (size_t)NC * 512, true);
     ALLOC(e->gather, (size_t)NC * S, true);
     ALLOC(e->status_tmp, (size_t)NC, true);
+    ALLOC(e->dev_errors, 4, true);
 
     // ---- layer table + weights --------------------------------------------
-    BlobReader br{reinterpret_cast<const float*>(hdr + 8), reinterpret_cast<const float*>(hdr + 8) + blob_float_count(S, A)};
+    // arena capacity: the folded tensors are the blob's plus zero padding (stem K 147 -> 224, fc and
+    // Conv1d 1000 -> 1024) and 256-byte alignment per tensor; 1.25x + 1 MiB covers every (S, A)
+    e->arena_cap = pa_weight_blob_bytes(S, A) / 4 * 5 + (1u << 20);
+    {
+        void* ar = nullptr;
+        HIPCHK(e, hipMalloc(&ar, e->arena_cap));
+        e->allocs.push_back(ar);
+        e->arena = reinterpret_cast<uint8_t*>(ar);
+    }
+    if (!e->adopt) e->arena_stage.assign(e->arena_cap, 0);
+    static const float dry_source[1] = {0.f};  // adopt mode: take() only has to return non-null
+    const float* blob_f = e->adopt ? dry_source : reinterpret_cast<const float*>(hdr + 8);
+    BlobReader br{blob_f, 0, blob_float_count(S, A), e->adopt};
     std::vector<float> keep_w, keep_b;  // host copy of the last conv added with keep=true (not uploaded yet)
     auto add_conv = [&](const std::string& name, int cin, int cout, int k, int stride, int in_hw, float* in, float* outb,
                         float* residual, int relu, bool keep = false) -> int {
@@ -747,8 +785,10 @@ int pa_create(const pa_config* cfg, const void* blob, size_t blob_bytes, pa_engi
         const float* b = br.take(1000);
         if (!w || !b) return fail(e, PA_ERR_BAD_WEIGHTS, "weight blob too short at fc");
         std::vector<float> wp((size_t)PA_FEATURE_STRIDE * 512, 0.f), bp(PA_FEATURE_STRIDE, 0.f);
-        memcpy(wp.data(), w, sizeof(float) * 1000 * 512);
-        memcpy(bp.data(), b, sizeof(float) * 1000);
+        if (!br.dry) {
+            memcpy(wp.data(), w, sizeof(float) * 1000 * 512);
+            memcpy(bp.data(), b, sizeof(float) * 1000);
+        }
         ConvLayer& L = e->fc;
         L.name = "fc";
         L.cin = 512; L.cout = PA_FEATURE_STRIDE; L.kh = L.kw = 1; L.stride = 1;
@@ -771,13 +811,13 @@ int pa_create(const pa_config* cfg, const void* blob, size_t blob_bytes, pa_engi
         const float* b = br.take(512);
         if (!w || !b) return fail(e, PA_ERR_BAD_WEIGHTS, "weight blob too short at cnn1d");
         std::vector<float> wp((size_t)512 * S * PA_FEATURE_STRIDE, 0.f);
-        for (int o = 0; o < 512; ++o)
+        for (int o = 0; o < 512 && !br.dry; ++o)
             for (int c = 0; c < 1000; ++c)
                 for (int t = 0; t < S; ++t)
                     wp[((size_t)o * S + t) * PA_FEATURE_STRIDE + c] = w[((size_t)o * 1000 + c) * S + t];
         rc = upload(e, &e->w1d, wp);
         if (rc) return rc;
-        rc = upload(e, &e->b1d, std::vector<float>(b, b + 512));
+        rc = upload(e, &e->b1d, br.dry ? std::vector<float>(512) : std::vector<float>(b, b + 512));
         if (rc) return rc;
         choose_tile(NC, 512, S * 32, &e->head_tile, &e->head_splitk);
         // 16 tiles x 224 k-steps: 16 splits of 14 steps beat 32 of 7 (26.2 vs 28.6 us incl. the reduce)
@@ -789,17 +829,25 @@ int pa_create(const pa_config* cfg, const void* blob, size_t blob_bytes, pa_engi
         const float* b2 = br.take(128);
         const float* w3 = br.take((size_t)A * 128);
         const float* b3 = br.take(A);
-        if (!w2 || !b2 || !w3 || !b3 || br.p != br.end) return fail(e, PA_ERR_BAD_WEIGHTS, "weight blob size mismatch at classifier");
+        if (!w2 || !b2 || !w3 || !b3 || br.pos != br.limit) return fail(e, PA_ERR_BAD_WEIGHTS, "weight blob size mismatch at classifier");
         // head_mlp_kernel reads both matrices k-major (lanes = outputs): w2 -> [512][128], w3 -> [128][64]
         std::vector<float> w2t((size_t)512 * 128), w3t((size_t)128 * 64, 0.f);
-        for (int o = 0; o < 128; ++o)
+        for (int o = 0; o < 128 && !br.dry; ++o)
             for (int k = 0; k < 512; ++k) w2t[(size_t)k * 128 + o] = w2[(size_t)o * 512 + k];
-        for (int a = 0; a < A; ++a)
+        for (int a = 0; a < A && !br.dry; ++a)
             for (int k = 0; k < 128; ++k) w3t[(size_t)k * 64 + a] = w3[(size_t)a * 128 + k];
         if ((rc = upload(e, &e->w2, w2t))) return rc;
-        if ((rc = upload(e, &e->b2, std::vector<float>(b2, b2 + 128)))) return rc;
+        if ((rc = upload(e, &e->b2, br.dry ? std::vector<float>(128) : std::vector<float>(b2, b2 + 128)))) return rc;
         if ((rc = upload(e, &e->w3, w3t))) return rc;
-        if ((rc = upload(e, &e->b3, std::vector<float>(b3, b3 + A)))) return rc;
+        if ((rc = upload(e, &e->b3, br.dry ? std::vector<float>(A) : std::vector<float>(b3, b3 + A)))) return rc;
+    }
+    // the arena is complete: one host-to-device copy (fold mode) or one device copy (adopt mode)
+    if (e->adopt) {
+        if (src_bytes != e->arena_used) return fail(e, PA_ERR_BAD_WEIGHTS, "weight arena size does not match this configuration");
+        HIPCHK(e, hipMemcpy(e->arena, arena_dev, e->arena_used, hipMemcpyDeviceToDevice));
+    } else {
+        HIPCHK(e, hipMemcpy(e->arena, e->arena_stage.data(), e->arena_used, hipMemcpyHostToDevice));
+        std::vector<uint8_t>().swap(e->arena_stage);
     }
     // split-K slabs: the largest splitk*M*N over all layers
     {
@@ -826,6 +874,28 @@ int pa_create(const pa_config* cfg, const void* blob, size_t blob_bytes, pa_engi
     HIPCHK(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
     HIPCHK(e, hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
     HIPCHK(e, hipDeviceSynchronize());
+    return PA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pa_create(const pa_config* cfg, const void* blob, size_t blob_bytes, pa_engine** out) {
+    if (!blob) return PA_ERR_INVALID_ARG;
+    return create_impl(cfg, blob, blob_bytes, nullptr, out);
+}
+
+int pa_create_from_arena(const pa_config* cfg, const void* arena_dev, size_t arena_bytes, pa_engine** out) {
+    if (!arena_dev) return PA_ERR_INVALID_ARG;
+    return create_impl(cfg, nullptr, arena_bytes, arena_dev, out);
+}
+
+size_t pa_weights_arena_bytes(const pa_engine* e) { return e ? e->arena_used : 0; }
+
+int pa_weights_export(pa_engine* e, void* dst_dev, size_t bytes, void* stream) {
+    if (!e || !dst_dev || bytes != e->arena_used) return fail(e, PA_ERR_INVALID_ARG, "pa_weights_export: size must be pa_weights_arena_bytes()");
+    HIPCHK(e, hipMemcpyAsync(dst_dev, e->arena, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return PA_OK;
 }
 
@@ -943,8 +1013,41 @@ int pa_backbone_frames_indexed(pa_engine* e, const uint8_t* frames, int32_t n, i
     rc = run_backbone(e, n * F, e->x0_slot[0], e->feats_tmp, s);
     if (rc) return rc;
     ProfScope ps(e, s, "scatter_features", 0.0, 2.0 * n * F * PA_FEATURE_STRIDE * 4.0);
-    HIPCHK(e, launch_scatter_rows(e->feats_tmp, e->pre_status[0], frame_ids, e->cache, e->cache_status, n, F, s));
+    HIPCHK(e, launch_scatter_rows(e->feats_tmp, e->pre_status[0], frame_ids, e->cache, e->cache_status, n, F, e->clip_frames,
+                                  e->dev_errors, s));
     return PA_OK;
+}
+
+int pa_device_errors(pa_engine* e, int32_t* bad_frame_ids_host, void* stream) {
+    if (!e || !bad_frame_ids_host) return fail(e, PA_ERR_INVALID_ARG, "pa_device_errors: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    int32_t h[4] = {0, 0, 0, 0};
+    HIPCHK(e, hipMemcpyAsync(h, e->dev_errors, sizeof(h), hipMemcpyDeviceToHost, s));
+    HIPCHK(e, hipMemsetAsync(e->dev_errors, 0, sizeof(h), s));
+    HIPCHK(e, hipStreamSynchronize(s));
+    *bad_frame_ids_host = h[0];
+    if (h[0] != 0)
+        return fail(e, PA_ERR_CAPACITY, "pa_backbone_frames_indexed: " + std::to_string(h[0]) +
+                                            " frame id(s) outside the clip were skipped on the device");
+    return PA_OK;
+}
+
+int pa_backbone_frames_src(pa_engine* e, const uint8_t* frames, int32_t n_src, int32_t height, int32_t width,
+                           const double* boxes, const int32_t* src_frame, int32_t n, int32_t frame0, uint8_t* crops_rgb,
+                           int32_t* status, void* stream) {
+    if (!e || !frames || !boxes || !src_frame || n < 1 || n_src < 1 || frame0 < 0 || height < 1 || width < 1)
+        return fail(e, PA_ERR_INVALID_ARG, "pa_backbone_frames_src: bad argument");
+    if (e->clip_frames < 1) return fail(e, PA_ERR_INVALID_ARG, "pa_backbone_frames_src: call pa_clip_begin first");
+    if (n > e->cfg.max_batch_frames || frame0 + n > e->clip_frames || height > e->cfg.max_frame_height ||
+        width > e->cfg.max_frame_width)
+        return fail(e, PA_ERR_CAPACITY, "pa_backbone_frames_src: frames exceed engine / clip capacity");
+    hipStream_t s = (hipStream_t)stream;
+    const int F = e->cfg.num_fighters;
+    int rc = run_preprocess(e, frames, n, height, width, boxes, e->cfg.crop_padding, 1, crops_rgb, e->x0_slot[0],
+                            e->pre_status[0], s, src_frame, n_src);
+    if (rc) return rc;
+    if (status) HIPCHK(e, hipMemcpyAsync(status, e->pre_status[0], sizeof(int32_t) * n * F, hipMemcpyDeviceToDevice, s));
+    return pa_backbone_slot(e, 0, n, frame0, stream);
 }
 
 int pa_clip_mark_ready(pa_engine* e, const int32_t* frame_ids_host, int32_t n) {
@@ -1005,8 +1108,12 @@ int pa_infer_clip(pa_engine* e, const uint8_t* frames, int32_t n, int32_t height
 }
 
 int pa_features_export(pa_engine* e, int32_t frame0, int32_t n, float* feats, void* stream) {
-    if (!e || !feats || frame0 < 0 || n < 1 || frame0 + n > e->cfg.max_clip_frames)
-        return fail(e, PA_ERR_INVALID_ARG, "pa_features_export: bad range");
+    if (!e || !feats || frame0 < 0 || n < 1 || frame0 + n > e->clip_frames)
+        return fail(e, PA_ERR_INVALID_ARG, "pa_features_export: bad range (call pa_clip_begin first)");
+    for (int i = 0; i < n; ++i)
+        if (!e->ready[frame0 + i])
+            return fail(e, PA_ERR_NOT_READY, "pa_features_export: features of frame " + std::to_string(frame0 + i + 1) +
+                                                 " are not cached in this clip");
     const size_t row = (size_t)e->cfg.num_fighters * PA_FEATURE_STRIDE;
     HIPCHK(e, hipMemcpyAsync(feats, e->cache + (size_t)frame0 * row, sizeof(float) * n * row, hipMemcpyDeviceToDevice,
                              (hipStream_t)stream));

@@ -104,8 +104,10 @@ struct CropPlan {
 };
 
 struct PreprocParams {
-    const uint8_t* frames;  // [n][H][W][3]
+    const uint8_t* frames;  // [n_src][H][W][3]
     const double* boxes;    // [ncrops][4]
+    const int32_t* src_frame;  // [ncrops] frame each crop is cut from, or nullptr = crop / fighters
+    int32_t n_src;             // frames in the buffer (bound of src_frame)
     int32_t n_frames, height, width, fighters, padding, swap_rb;
     CropPlan* plans;        // [ncrops]
     int32_t* coef;          // [ncrops][2][maxdim][1 + 1 + PA_KSIZE_MAX]: xmin, count, kk[]
@@ -125,6 +127,8 @@ struct PreprocParams {
 };
 
 hipError_t launch_preprocess(const PreprocParams& p, hipStream_t s);
+// per-device one-time setup of the crop stage (dynamic-LDS attribute); call with the device current
+hipError_t preprocess_init_device();
 // log rows [n][9] (pos_x,pos_y,cam xyz,target xyz,fov deg) -> normalised boxes [n][4]
 hipError_t launch_project_boxes(const double* log, double* boxes, int32_t n, hipStream_t s);
 
@@ -145,7 +149,7 @@ hipError_t launch_window_gather(int32_t* gather, int32_t frame_num_lo, int32_t c
                                 hipStream_t s);
 hipError_t launch_identity_gather(int32_t* gather, int32_t n, hipStream_t s);
 hipError_t launch_scatter_rows(const float* feats, const int32_t* st, const int32_t* ids, float* cache, int32_t* cache_st,
-                               int32_t n, int32_t fighters, hipStream_t s);
+                               int32_t n, int32_t fighters, int32_t clip_frames, int32_t* bad_ids, hipStream_t s);
 
 struct HeadParams {
     const float* h1;      // [nwin][512] post-ReLU Conv1d output, or nullptr when the slabs below are given

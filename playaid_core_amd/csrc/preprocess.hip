@@ -226,7 +226,7 @@ __global__ __launch_bounds__(64) void crop_plan_kernel(const PreprocParams p) {
     const int lane = threadIdx.x;
     CropPlan pl;
     pl.status = PA_CROP_OK;
-    pl.frame = crop / p.fighters;
+    pl.frame = p.src_frame ? p.src_frame[crop] : crop / p.fighters;
     pl.sx0 = pl.sy0 = pl.sw = pl.sh = 0;
     pl.d = pl.rw = pl.rh = pl.px = pl.py = 0;
     pl.need_h = pl.need_v = pl.ksize_h = pl.ksize_v = 0;
@@ -238,10 +238,14 @@ __global__ __launch_bounds__(64) void crop_plan_kernel(const PreprocParams p) {
     pl.scale_x = pl.scale_y = 1.0;
     const double* b = p.boxes + (size_t)crop * 4;
     const int W = p.width, H = p.height, pad = p.padding;
+    if ((unsigned)pl.frame >= (unsigned)p.n_src) {  // a source index outside the frame buffer: never dereferenced
+        pl.frame = 0;
+        pl.status = PA_CROP_BAD_FRAME;
+    }
     int cx, cy, cw, ch;
     // YoloCrop.yolo_pixels (fighter.py:305-314)
-    if (!to_int_checked(b[0] * W, &cx) || !to_int_checked(b[1] * H, &cy) || !to_int_checked(b[2] * W, &cw) ||
-        !to_int_checked(b[3] * H, &ch)) {
+    if (pl.status == PA_CROP_OK && (!to_int_checked(b[0] * W, &cx) || !to_int_checked(b[1] * H, &cy) ||
+                                    !to_int_checked(b[2] * W, &cw) || !to_int_checked(b[3] * H, &ch))) {
         pl.status = PA_CROP_BAD_BOX;
     }
     if (pl.status == PA_CROP_OK) {
@@ -1091,6 +1095,11 @@ hipError_t launch_project_boxes(const double* log, double* boxes, int32_t n, hip
     return hipGetLastError();
 }
 
+hipError_t preprocess_init_device() {
+    // dynamic LDS beyond the 64 KiB default; the attribute is per device, so pa_create sets it for its own
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&crop_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
 hipError_t launch_preprocess(const PreprocParams& p_in, hipStream_t s) {
     PreprocParams p = p_in;
     static const int budget = getenv("PA_FUSED_LDS") ? atoi(getenv("PA_FUSED_LDS")) : PA_FUSED_LDS_BYTES;
@@ -1112,11 +1121,6 @@ hipError_t launch_preprocess(const PreprocParams& p_in, hipStream_t s) {
         p.dbg = reinterpret_cast<uint8_t*>(sd);
     }
 #endif
-    static bool lds_attr = false;
-    if (!lds_attr) {  // dynamic LDS beyond the 64 KiB default
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&crop_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        lds_attr = true;
-    }
     hipLaunchKernelGGL(crop_fused_kernel, dim3(PA_CROP / 8, ncrops), dim3(CF_NT), p.fused_lds + (PA_CROP + 8) * sizeof(AreaTabPacked), s, p);
     { hipError_t e1 = hipGetLastError(); if (e1 != hipSuccess) return e1; }
 #ifdef PA_STAMP_BUILD

@@ -24,6 +24,18 @@ def _ptr(t: Optional[torch.Tensor]):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+class WeightsArena:
+    """The folded, re-laid-out weights of an engine as one device byte tensor
+    (``pa_weights_export``): what rank 0 broadcasts over RCCL so that the other ranks build
+    their engines with ``pa_create_from_arena`` -- no host copy, no second BatchNorm fold."""
+
+    def __init__(self, data: torch.Tensor, sequence_length: int, num_actions: int, compute_dtype: str):
+        self.data = data
+        self.sequence_length = sequence_length
+        self.num_actions = num_actions
+        self.compute_dtype = compute_dtype
+
+
 class Engine:
     """One engine per device (``pa_create`` / ``pa_destroy``)."""
 
@@ -58,7 +70,12 @@ class Engine:
         if not torch.cuda.is_available():
             raise _lib.HipLibraryError("no HIP device visible to PyTorch-ROCm; this path has no CPU fallback")
         self.device = torch.device(device)
-        if isinstance(state_dict, np.ndarray):  # already-packed blob (e.g. received by RCCL broadcast)
+        arena = state_dict if isinstance(state_dict, WeightsArena) else None
+        if arena is not None:  # prepared weights received from another rank (pa_create_from_arena)
+            self.S, self.A = arena.sequence_length, arena.num_actions
+            if arena.compute_dtype != compute_dtype:
+                raise ValueError(f"weight arena was prepared for {arena.compute_dtype}, engine asked for {compute_dtype}")
+        elif isinstance(state_dict, np.ndarray):  # already-packed blob
             hdr = state_dict[:32].view(np.int32)
             self.S, self.A = int(hdr[2]), int(hdr[3])
         else:
@@ -83,13 +100,18 @@ class Engine:
             cfg.fighter_class_ids[i] = ids[i]
         cfg.compute_dtype = _lib.PA_DTYPE_BF16 if compute_dtype == "bf16" else _lib.PA_DTYPE_F32
         self.cfg = cfg
-        if isinstance(state_dict, np.ndarray):
-            blob = np.ascontiguousarray(state_dict, dtype=np.uint8)
-        else:
-            blob = pack_state_dict(state_dict, self.S, self.A)
         self._h = C.c_void_p(0)
         torch.cuda.set_device(self.device)
-        rc = self._lib.pa_create(C.byref(cfg), blob.ctypes.data_as(C.c_void_p), blob.nbytes, C.byref(self._h))
+        if arena is not None:
+            data = arena.data.to(self.device).contiguous()
+            torch.cuda.synchronize(self.device)  # the arena is complete before the library copies it
+            rc = self._lib.pa_create_from_arena(C.byref(cfg), _ptr(data), data.numel(), C.byref(self._h))
+        else:
+            if isinstance(state_dict, np.ndarray):
+                blob = np.ascontiguousarray(state_dict, dtype=np.uint8)
+            else:
+                blob = pack_state_dict(state_dict, self.S, self.A)
+            rc = self._lib.pa_create(C.byref(cfg), blob.ctypes.data_as(C.c_void_p), blob.nbytes, C.byref(self._h))
         if rc != _lib.PA_OK:
             msg = self._lib.pa_last_error(self._h).decode() if self._h else self._lib.pa_status_string(rc).decode()
             if self._h:
@@ -126,6 +148,18 @@ class Engine:
         if isinstance(a, torch.Tensor):
             return a.to(device=self.device, dtype=dtype).contiguous()
         return torch.from_numpy(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype)
+
+    def weights_arena(self) -> WeightsArena:
+        n = int(self._lib.pa_weights_arena_bytes(self._h))
+        out = torch.empty(n, dtype=torch.uint8, device=self.device)
+        self._check(self._lib.pa_weights_export(self._h, _ptr(out), n, self._stream()))
+        return WeightsArena(out, self.S, self.A, self.compute_dtype)
+
+    def check_device_errors(self):
+        """Synchronises the current stream; raises EngineError when ``backbone_frames_indexed`` was
+        handed a frame id outside the clip since the last check (the kernel skipped it)."""
+        bad = C.c_int32(0)
+        self._check(self._lib.pa_device_errors(self._h, C.byref(bad), self._stream()))
 
     # -- b1: operator ------------------------------------------------------
     def infer_windows(self, x: torch.Tensor) -> torch.Tensor:
@@ -178,6 +212,18 @@ class Engine:
         self._check(
             self._lib.pa_backbone_frames(
                 self._h, _ptr(frames_dev), n, h, w, _ptr(boxes_dev), frame0, _ptr(crops_rgb), _ptr(status), self._stream()
+            )
+        )
+
+    def backbone_frames_src(self, frames_dev: torch.Tensor, boxes_dev: torch.Tensor, src_dev: torch.Tensor, frame0: int,
+                            crops_rgb=None, status=None):
+        """Crop (i, p) of clip frame frame0 + i is cut from frames_dev[src_dev[i, p]] (repaired label gaps)."""
+        n_src, h, w, _ = frames_dev.shape
+        n = boxes_dev.shape[0]
+        self._check(
+            self._lib.pa_backbone_frames_src(
+                self._h, _ptr(frames_dev), n_src, h, w, _ptr(boxes_dev), _ptr(src_dev), n, frame0, _ptr(crops_rgb),
+                _ptr(status), self._stream()
             )
         )
 
@@ -241,17 +287,29 @@ class Engine:
             "status": r[..., 3].copy(),
         }
 
-    def infer_clip(self, frames, boxes, want_crops: bool = False):
+    def infer_clip(self, frames, boxes, want_crops: bool = False, src=None):
         """Host convenience: upload, run, download. -> dict with logp[n-1,F,A],
-        action_id, prob, char_id, status[n,F] (and crops_rgb[n,F,128,128,3])."""
+        action_id, prob, char_id, status[n,F] (and crops_rgb[n,F,128,128,3]).
+        ``src`` (int[n,F], optional): the frame each crop is cut from when that is not its own
+        (``pa_backbone_frames_src``); the clip then has ``boxes.shape[0]`` frames."""
         fd = self._dev(frames, torch.uint8)
         bd = self._dev(boxes, torch.float64)
-        n = fd.shape[0]
+        n = bd.shape[0] if src is not None else fd.shape[0]
         records = self.alloc_records(n - 1)
         logp = torch.empty((n - 1, self.F, self.A), dtype=torch.float32, device=self.device)
         status = torch.empty((n, self.F), dtype=torch.int32, device=self.device)
         crops = torch.empty((n, self.F, 128, 128, 3), dtype=torch.uint8, device=self.device) if want_crops else None
-        self.infer_clip_device(fd, bd, records, logp, crops, status)
+        if src is None:
+            self.infer_clip_device(fd, bd, records, logp, crops, status)
+        else:
+            sd = self._dev(src, torch.int32)
+            self.clip_begin(n)
+            step = self.max_batch_frames
+            for f0 in range(0, n, step):
+                cnt = min(step, n - f0)
+                self.backbone_frames_src(fd, bd[f0 : f0 + cnt], sd[f0 : f0 + cnt], f0,
+                                         crops[f0 : f0 + cnt] if want_crops else None, status[f0 : f0 + cnt])
+            self.head_frames(1, n, records, logp)
         torch.cuda.synchronize(self.device)
         out = self.decode_records(records)
         out["logp"] = logp.cpu().numpy()

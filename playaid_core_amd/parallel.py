@@ -10,10 +10,15 @@ MI355X-side design:
   ``delta * (S//2)**2`` = 27 frames past a shard edge
   (``playaid/dataset_utils.py:122-136``), so each rank receives the cached
   1000-d feature rows (4 KB each) of those frames from the neighbouring
-  rank(s) -- point-to-point send/recv, 216 KB per edge;
-* result records are gathered on rank 0.
+  rank(s) -- point-to-point send/recv, 216 KB per edge. The exchange is posted
+  as soon as the backbone of the shard is enqueued and the head of the
+  *interior* frames (whose windows stay inside the shard) runs underneath it;
+  only the <= 2 x 27 edge frames wait for the halo;
+* result records are gathered with one equal-size all-gather.
 
-The weight blob is broadcast once at start-up (``broadcast_blob``).
+The weights cross xGMI once at start-up, already folded and laid out
+(``broadcast_engine``: rank 0 builds its engine, exports the device weight
+arena, one RCCL broadcast, the other ranks adopt it with a device copy).
 The class only needs the engine's clip interface, so the CPU tests drive it
 with an oracle-backed stand-in over gloo.
 """
@@ -21,7 +26,6 @@ from __future__ import annotations
 
 from typing import List, Optional, Tuple
 
-import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -51,6 +55,18 @@ def needed_range(n_total: int, world: int, rank: int, reach: int) -> Tuple[int, 
     return first - 1, last
 
 
+def interior_frame_nums(n_total: int, world: int, rank: int, reach: int) -> Tuple[int, int]:
+    """Sub-range [lo, hi) of ``owned_frame_nums`` whose windows only touch frames this rank owns
+    (sampler clamps included: ``max(1, f - reach)`` .. ``min(max_frames - 1, f + reach)``)."""
+    f_lo, f_hi = owned_frame_nums(n_total, world, rank)
+    own_lo, own_hi = shard_range(n_total, world, rank)  # cached frame numbers own_lo + 1 .. own_hi
+    # a window of frame f reads frame numbers max(1, f - reach) .. min(n_total - 1, f + reach); both
+    # bounds are monotone in f, so the interior is one run
+    lo = f_lo if own_lo == 0 else max(f_lo, own_lo + 1 + reach)
+    hi = f_hi if own_hi >= n_total - 1 else min(f_hi, own_hi - reach + 1)
+    return (lo, hi) if hi > lo else (f_lo, f_lo)
+
+
 def halo_plan(n_total: int, world: int, rank: int, reach: int):
     """-> (recvs, sends): lists of (peer, frame0, count). Deterministic on
     every rank, so sends and receives pair up without negotiation."""
@@ -78,13 +94,34 @@ def _host_staged(group=None) -> bool:
     return dist.get_backend(group) != "nccl"
 
 
-def broadcast_blob(blob: Optional[np.ndarray], nbytes: int, device: torch.device, group=None) -> np.ndarray:
-    """One broadcast of the weight blob (61.4 MB fp32) from rank 0."""
-    t = torch.empty(nbytes, dtype=torch.uint8, device="cpu" if _host_staged(group) else device)
-    if dist.get_rank(group) == 0:
-        t.copy_(torch.from_numpy(blob))
-    dist.broadcast(t, src=0, group=group)
-    return t.cpu().numpy()
+def broadcast_engine(make_engine, weights, device: torch.device, group=None):
+    """Engines for every rank from weights only rank 0 holds.
+
+    ``make_engine(w)`` builds an ``Engine`` on this rank's device from ``w``; rank 0 calls it with
+    ``weights`` (state dict or packed blob), exports the prepared device arena and broadcasts it
+    (61-64 MB fp32, once); the other ranks call it with the received ``WeightsArena``. With RCCL
+    the arena never leaves HBM; a gloo rehearsal stages it through the host."""
+    from .engine import WeightsArena
+
+    rank = dist.get_rank(group)
+    staged = _host_staged(group)
+    meta = torch.zeros(4, dtype=torch.int64, device="cpu" if staged else device)
+    eng = None
+    if rank == 0:
+        eng = make_engine(weights)
+        arena = eng.weights_arena()
+        meta = torch.tensor([arena.data.numel(), arena.sequence_length, arena.num_actions, int(arena.compute_dtype == "bf16")],
+                            dtype=torch.int64, device=meta.device)
+    dist.broadcast(meta, src=0, group=group)
+    nbytes, S, A, is_bf16 = (int(v) for v in meta.tolist())
+    if rank == 0:
+        buf = arena.data.cpu() if staged else arena.data
+    else:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device="cpu" if staged else device)
+    dist.broadcast(buf, src=0, group=group)
+    if rank != 0:
+        eng = make_engine(WeightsArena(buf, S, A, "bf16" if is_bf16 else "f32"))
+    return eng
 
 
 class FrameParallelClip:
@@ -95,6 +132,10 @@ class FrameParallelClip:
         self.world = dist.get_world_size(group) if self.distributed else 1
         self.rank = dist.get_rank(group) if self.distributed else 0
         self.reach = abs(frame_delta) * (sequence_length // 2) ** 2
+        # how results travel is fixed here, once, from what the backend can do -- never by catching a
+        # failed collective (a rank that falls back alone would desynchronise the others)
+        self._staged = self.distributed and _host_staged(group)
+        self._gather_into_tensor = self.distributed and not self._staged and hasattr(dist, "all_gather_into_tensor")
         # two-stream software pipeline (see backbone_shard)
         self._pre_stream = None
         self._pre_done = None
@@ -139,48 +180,73 @@ class FrameParallelClip:
             self._slot_free[slot].record(main)
             self._slot_used[slot] = True
 
-    def exchange_halo(self, n_total: int):
+    def post_halo(self, n_total: int):
+        """Start the halo exchange; returns ``(requests, recv_buffers)`` for ``finish_halo``.
+        With RCCL the transfers run on the communicator's own stream behind the backbone that
+        produced the exported rows, so whatever the caller enqueues next overlaps them."""
         if self.world == 1:
-            return
+            return [], []
         recvs, sends = halo_plan(n_total, self.world, self.rank, self.reach)
-        staged = _host_staged(self.group)
         ops, bufs = [], []
         for peer, f0, cnt in sends:
             t = self.engine.features_export(f0, cnt)
-            ops.append(dist.P2POp(dist.isend, t.cpu() if staged else t, peer, self.group))
+            ops.append(dist.P2POp(dist.isend, t.cpu() if self._staged else t, peer, self.group))
         for peer, f0, cnt in recvs:
             t = self.engine.features_buffer(cnt)
-            if staged:
+            if self._staged:
                 t = torch.empty(t.shape, dtype=t.dtype)
             bufs.append((f0, t))
             ops.append(dist.P2POp(dist.irecv, t, peer, self.group))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+        return (dist.batch_isend_irecv(ops) if ops else []), bufs
+
+    def finish_halo(self, pending):
+        reqs, bufs = pending
+        for req in reqs:
+            req.wait()
         for f0, t in bufs:
             self.engine.features_import(f0, t)
 
-    def run(self, frames_local, boxes_local, n_total: int, gather: bool = True, pipeline: bool = False):
-        """frames_local / boxes_local: this rank's shard (device tensors for the
-        HIP engine). Returns on rank 0 (or every rank when ``gather`` is False:
-        the local part) ``(records int32[count,F,4], logp float32[count,F,A])``
-        for frame numbers 1..n_total-1 in order."""
+    def exchange_halo(self, n_total: int):
+        self.finish_halo(self.post_halo(n_total))
+
+    def run(self, frames_local, boxes_local, n_total: int, gather: bool = True, pipeline: bool = False,
+            reuse_buffers: bool = False):
+        """frames_local / boxes_local: this rank's shard (device tensors for the HIP engine).
+        Returns on every rank ``(records int32[count,F,4], logp float32[count,F,A])`` for frame
+        numbers 1..n_total-1 in order (``gather=False`` or one rank: the local part only).
+
+        Result tensors: the local part lives in buffers this object keeps between calls. With
+        ``reuse_buffers=False`` (default) the caller gets its own copies; ``reuse_buffers=True``
+        (bench loops) returns views that the next ``run`` overwrites in place."""
         eng = self.engine
         lo, hi = shard_range(n_total, self.world, self.rank)
         assert frames_local.shape[0] == hi - lo, "shard size mismatch"
         eng.clip_begin(n_total)
         self.backbone_shard(frames_local, boxes_local, lo, pipeline=pipeline)
-        self.exchange_halo(n_total)
+        pending = self.post_halo(n_total)
         f_lo, f_hi = owned_frame_nums(n_total, self.world, self.rank)
         count = max(f_hi - f_lo, 0)
         # result buffers are kept between calls (a fresh torch.zeros costs a fill kernel each)
         if self._out is None or self._out[0].shape[0] < max(count, 1):
             self._out = (eng.alloc_records(max(count, 1)), eng.alloc_logp(max(count, 1)))
         records, logp = self._out
-        if count > 0:
-            eng.head_frames(f_lo, f_hi, records, logp)
+
+        def head(a, b):
+            if b > a:
+                eng.head_frames(a, b, records[a - f_lo :], logp[a - f_lo :])
+
+        if self.world == 1:
+            head(f_lo, f_hi)
+        else:
+            i_lo, i_hi = interior_frame_nums(n_total, self.world, self.rank, self.reach)
+            head(i_lo, i_hi)             # under the exchange
+            self.finish_halo(pending)
+            head(f_lo, i_lo)             # the edge frames need the neighbours' rows
+            head(i_hi, f_hi)
         if not gather or self.world == 1:
-            return records[:count], logp[:count]
+            if reuse_buffers:
+                return records[:count], logp[:count]
+            return records[:count].clone(), logp[:count].clone()
         # ONE equal-size all_gather of padded shards: records (as int32 bit patterns) and
         # log-probs travel in the same float32 buffer [cap, F, 4 + A]; trimmed on the way out
         counts = [
@@ -189,26 +255,21 @@ class FrameParallelClip:
         ]
         cap = max(max(counts), 1)
         A = logp.shape[-1]
-        staged = _host_staged(self.group)
         if self._pack is None or self._pack[0].shape[0] != cap or self._pack[1].shape[0] != self.world:
             mine = torch.zeros((cap, eng.F, 4 + A), dtype=torch.float32, device=records.device)
-            everyone = torch.zeros((self.world, cap, eng.F, 4 + A), dtype=torch.float32, device="cpu" if staged else records.device)
+            everyone = torch.zeros((self.world, cap, eng.F, 4 + A), dtype=torch.float32,
+                                   device="cpu" if self._staged else records.device)
             self._pack = (mine, everyone)
         mine, everyone = self._pack
         mine[:count, :, :4].view(torch.int32).copy_(records[:count])
         mine[:count, :, 4:].copy_(logp[:count])
-        if staged:
-            parts = [torch.empty((cap, eng.F, 4 + A), dtype=torch.float32) for _ in range(self.world)]
-            dist.all_gather(parts, mine.cpu(), group=self.group)
-            everyone = torch.stack(parts)
+        if self._gather_into_tensor:
+            dist.all_gather_into_tensor(everyone, mine, group=self.group)
         else:
-            try:
-                dist.all_gather_into_tensor(everyone, mine, group=self.group)
-            except (RuntimeError, NotImplementedError, AttributeError):
-                # a backend without the single-tensor form: the list form moves the same bytes
-                parts = [torch.empty_like(mine) for _ in range(self.world)]
-                dist.all_gather(parts, mine, group=self.group)
-                everyone = torch.stack(parts)
+            src = mine.cpu() if self._staged else mine
+            parts = [torch.empty_like(src) for _ in range(self.world)]
+            dist.all_gather(parts, src, group=self.group)
+            everyone = torch.stack(parts)
         rec = torch.cat([everyone[r, : counts[r], :, :4] for r in range(self.world)]).view(torch.int32)
         lp = torch.cat([everyone[r, : counts[r], :, 4:] for r in range(self.world)])
         return rec, lp

@@ -5,10 +5,14 @@ Every frame becomes two 128x128 crops whatever its resolution, so the feature
 cache and the temporal head are resolution-agnostic; only the crop stage cares.
 Frames are bucketed by (H, W); each bucket is fed through fixed-size batches
 whose "crop + backbone + scatter-into-cache" launch sequence is captured ONCE
-per bucket shape into a hipGraph (torch.cuda.CUDAGraph around the C-ABI call
-``pa_backbone_frames_indexed``) and replayed with new buffer contents. A short
-last batch is padded by repeating its last frame (the scatter is idempotent).
-The head runs once the whole clip is cached.
+per (bucket shape, staging slot) into a hipGraph (torch.cuda.CUDAGraph around the
+C-ABI call ``pa_backbone_frames_indexed``) and replayed with new buffer
+contents. Each bucket has two staging slots: while the graph of one slot runs,
+the next batch is copied into the other (pinned host staging, asynchronous
+copies), so the host never waits for the device inside the clip; per-crop status
+words and crops are read back once at the end. A short last batch is padded by
+repeating its last frame (the scatter is idempotent). The head runs once the
+whole clip is cached.
 
 The reference has no counterpart (it reads one video file of one resolution,
 ``playaid/ai_runner.py:153``); the results equal running its per-frame crop at
@@ -22,7 +26,7 @@ import numpy as np
 import torch
 
 
-class _Bucket:
+class _Slot:
     def __init__(self, engine, shape: Tuple[int, int], batch: int):
         h, w = shape
         dev = engine.device
@@ -31,7 +35,19 @@ class _Bucket:
         self.ids = torch.zeros((batch,), dtype=torch.int32, device=dev)
         self.crops = torch.zeros((batch, engine.F, 128, 128, 3), dtype=torch.uint8, device=dev)
         self.status = torch.zeros((batch, engine.F), dtype=torch.int32, device=dev)
+        # pinned host staging so that the uploads are asynchronous
+        self.h_frames = torch.zeros((batch, h, w, 3), dtype=torch.uint8).pin_memory()
+        self.h_boxes = torch.zeros((batch, engine.F, 4), dtype=torch.float64).pin_memory()
+        self.h_ids = torch.zeros((batch,), dtype=torch.int32).pin_memory()
         self.graph = None
+        self.done = torch.cuda.Event()  # recorded after the slot's last replay + read-back copies
+        self.busy = False
+
+
+class _Bucket:
+    def __init__(self, engine, shape, batch):
+        self.slots = [_Slot(engine, shape, batch), _Slot(engine, shape, batch)]
+        self.next = 0
 
 
 class MixedResolutionRunner:
@@ -45,10 +61,10 @@ class MixedResolutionRunner:
         self.replays = 0
         self.captures = 0
 
-    def _step(self, b: _Bucket):
+    def _step(self, b: _Slot):
         self.engine.backbone_frames_indexed(b.frames, b.boxes, b.ids, b.crops, b.status)
 
-    def _run_bucket_batch(self, b: _Bucket):
+    def _launch(self, b: _Slot):
         if not self.use_graphs:
             self._step(b)
             return
@@ -76,31 +92,69 @@ class MixedResolutionRunner:
         order: Dict[Tuple[int, int], List[int]] = {}
         for i, f in enumerate(frames):
             order.setdefault((f.shape[0], f.shape[1]), []).append(i)
-        crops_out = np.zeros((n, eng.F, 128, 128, 3), np.uint8) if want_crops else None
-        status_out = np.zeros((n, eng.F), np.int32)
+        status_dev = torch.zeros((n, eng.F), dtype=torch.int32, device=eng.device)
+        crops_dev = torch.zeros((n, eng.F, 128, 128, 3), dtype=torch.uint8, device=eng.device) if want_crops else None
         for shape, idx in order.items():
-            b = self.buckets.get(shape)
-            if b is None:
-                b = self.buckets[shape] = _Bucket(eng, shape, self.batch)
+            bk = self.buckets.get(shape)
+            if bk is None:
+                bk = self.buckets[shape] = _Bucket(eng, shape, self.batch)
             for k in range(0, len(idx), self.batch):
                 chunk = idx[k : k + self.batch]
                 padded = chunk + [chunk[-1]] * (self.batch - len(chunk))
-                b.frames.copy_(torch.from_numpy(np.stack([frames[i] for i in padded])))
-                b.boxes.copy_(torch.from_numpy(boxes[padded]))
-                b.ids.copy_(torch.tensor(padded, dtype=torch.int32))
-                self._run_bucket_batch(b)
+                # ids are validated on the host BEFORE anything reaches the device (PA_ERR_CAPACITY
+                # for an id outside the clip); the kernel's own range check is the second line
                 eng.clip_mark_ready(chunk)
-                st = b.status.cpu().numpy()  # synchronises; also fences the buffers before their reuse
-                status_out[chunk] = st[: len(chunk)]
+                b = bk.slots[bk.next]
+                bk.next ^= 1
+                if b.busy:
+                    b.done.synchronize()  # only when this slot's previous batch is still in flight
+                for j, i in enumerate(padded):
+                    b.h_frames[j].copy_(torch.from_numpy(frames[i]))
+                b.h_boxes.copy_(torch.from_numpy(boxes[padded]))
+                b.h_ids.copy_(torch.tensor(padded, dtype=torch.int32))
+                b.frames.copy_(b.h_frames, non_blocking=True)
+                b.boxes.copy_(b.h_boxes, non_blocking=True)
+                b.ids.copy_(b.h_ids, non_blocking=True)
+                self._launch(b)
+                sel = torch.tensor(chunk, dtype=torch.int64, device=eng.device)
+                status_dev.index_copy_(0, sel, b.status[: len(chunk)])
                 if want_crops:
-                    crops_out[chunk] = b.crops.cpu().numpy()[: len(chunk)]
+                    crops_dev.index_copy_(0, sel, b.crops[: len(chunk)])
+                b.done.record(torch.cuda.current_stream(eng.device))
+                b.busy = True
         records = eng.alloc_records(n - 1)
         logp = eng.alloc_logp(n - 1)
         eng.head_frames(1, n, records, logp)
-        torch.cuda.synchronize(eng.device)
+        eng.check_device_errors()  # synchronises; raises if the device skipped a frame id
+        for bk in self.buckets.values():
+            for b in bk.slots:
+                b.busy = False
         out = eng.decode_records(records)
         out["logp"] = logp.cpu().numpy()
-        out["crop_status"] = status_out
+        out["crop_status"] = status_dev.cpu().numpy()
         if want_crops:
-            out["crops_rgb"] = crops_out
+            out["crops_rgb"] = crops_dev.cpu().numpy()
         return out
+
+    def run_resident(self, buckets: Dict[Tuple[int, int], Tuple[torch.Tensor, torch.Tensor, torch.Tensor]], n: int,
+                     records: torch.Tensor, logp: torch.Tensor):
+        """Steady-state form for throughput measurement: the clip's frames are already in HBM,
+        grouped per resolution as ``{(H, W): (frames[m,H,W,3], boxes[m,F,4], ids int32[m])}`` with
+        ``m`` a multiple of the batch size; every batch is one device copy into the graph's static
+        buffers and one graph replay. Nothing synchronises; results land in ``records`` / ``logp``."""
+        eng = self.engine
+        eng.clip_begin(n)
+        for shape, (fr, bx, ids) in buckets.items():
+            bk = self.buckets.get(shape)
+            if bk is None:
+                bk = self.buckets[shape] = _Bucket(eng, shape, self.batch)
+            assert fr.shape[0] % self.batch == 0
+            for k in range(0, fr.shape[0], self.batch):
+                b = bk.slots[bk.next]
+                bk.next ^= 1
+                b.frames.copy_(fr[k : k + self.batch])
+                b.boxes.copy_(bx[k : k + self.batch])
+                b.ids.copy_(ids[k : k + self.batch])
+                self._launch(b)
+        eng.clip_mark_ready(list(range(n)))
+        eng.head_frames(1, n, records, logp)

@@ -280,3 +280,57 @@ def make_stub_log(path: str, n_frames: int) -> None:
                     "can_act": True,
                 }
                 f.write(json.dumps(rec) + "\n")
+
+
+# ----------------------------------------------------------------------------
+# the same frames, generated where they will be consumed
+# ----------------------------------------------------------------------------
+
+def _hash_u32_torch(idx, seed: int):
+    """``hash_u32`` on an int64 torch tensor (values < 2**32; every product stays below 2**63)."""
+    m = 0xFFFFFFFF
+    x = (idx + ((seed * 0x9E3779B1) & m)) & m
+    x = x ^ (x >> 16)
+    x = (x * 0x7FEB352D) & m
+    x = x ^ (x >> 15)
+    x = (x * 0x846CA68B) & m
+    return x ^ (x >> 16)
+
+
+def make_frames_torch(n: int, height: int, width: int, seed: int = 7, first_frame: int = 0, device="cuda", out=None):
+    """``make_frames`` computed with torch ops on ``device``: bit-identical frames (same integer
+    hash, same rectangles) without synthesising and uploading gigabytes on the host -- the
+    8192-frame clip of BASELINE.json configs[3] is 51 GB of raw BGR."""
+    import torch
+
+    dev = torch.device(device)
+    frames = out if out is not None else torch.empty((n, height, width, 3), dtype=torch.uint8, device=dev)
+    ys = torch.arange(height, dtype=torch.int64, device=dev)[:, None]
+    xs = torch.arange(width, dtype=torch.int64, device=dev)[None, :]
+    pix3 = (ys * width + xs) * 3
+    g0 = (xs * 200 // width).expand(height, width)
+    g1 = (ys * 200 // height).expand(height, width)
+    for i in range(n):
+        f = first_frame + i
+        g2 = ((xs + ys + 3 * f) % 512) * 200 // 512
+        img = torch.empty((height, width, 3), dtype=torch.int64, device=dev)
+        for c, g in enumerate((g0, g1, g2)):
+            img[:, :, c] = g + (_hash_u32_torch(pix3 + c, seed * 7919 + f) & 31)
+        for p in range(2):
+            cx, cy, w, h = fighter_box(f, p, height, width)
+            x0, x1 = int((cx - w / 2) * width), int((cx + w / 2) * width)
+            y0, y1 = int((cy - h / 2) * height), int((cy + h / 2) * height)
+            x0c, x1c, y0c, y1c = max(x0, 0), min(x1, width), max(y0, 0), min(y1, height)
+            if x1c <= x0c or y1c <= y0c:
+                continue
+            yy = torch.arange(y0c, y1c, dtype=torch.int64, device=dev)[:, None] - y0
+            xx = torch.arange(x0c, x1c, dtype=torch.int64, device=dev)[None, :] - x0
+            blk3 = ((yy // 12) * 64 + (xx // 12)) * 3
+            fine3 = (yy * 4096 + xx) * 3
+            phase = f // 4
+            for c in range(3):
+                base = _hash_u32_torch(blk3 + c, seed * 131 + p * 17 + phase * 1009) & 127
+                fine = _hash_u32_torch(fine3 + c, seed + p) & 15
+                img[y0c:y1c, x0c:x1c, c] = 96 + base + fine
+        frames[i] = img.clamp_(0, 255).to(torch.uint8)
+    return frames

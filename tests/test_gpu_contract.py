@@ -333,17 +333,118 @@ def test_mixed_resolution_stream_with_hipgraph(engine, state_dict):
             assert ok
             crops_ref[i, p] = yolo_crop.runner_input_from_crop(c)
     ref = pipeline.run_action_recognition(np.zeros((n, 1, 1, 3), np.uint8), boxes, state_dict, mode="cached", crops_rgb=crops_ref)
-    runner = MixedResolutionRunner(engine, batch_frames=8, use_graphs=True)
+    # 32 frames = 64 crops per captured batch: the engine's side-stream fork/join (max-pool of one half batch
+    # under the stem of the other, pa_api.hip) is INSIDE the captured graph
+    runner = MixedResolutionRunner(engine, batch_frames=32, use_graphs=True)
     got = runner.run(frames, boxes, want_crops=True)
-    assert runner.captures == 2 and runner.replays == 4 + 2  # 27 frames @1080p -> 4 batches, 13 @720p -> 2
+    assert runner.captures == 2 and runner.replays == 1 + 1  # 27 frames @1080p -> 1 padded batch, 13 @720p -> 1
     assert np.array_equal(got["crops_rgb"], crops_ref)
     assert np.abs(got["logp"] - ref["logp"]).max() <= 1e-4
     assert np.array_equal(got["action_id"], ref["action_id"])
-    # steady state: a second clip replays the captured graphs only, and eager mode agrees bitwise
+    # the second clip lands in each bucket's other staging slot (one more capture each); from the third
+    # clip on only replays happen; eager mode agrees bitwise
     again = runner.run(frames, boxes)
-    assert runner.captures == 2 and np.array_equal(again["logp"], got["logp"])
-    eager = MixedResolutionRunner(engine, batch_frames=8, use_graphs=False).run(frames, boxes)
+    assert runner.captures == 4 and np.array_equal(again["logp"], got["logp"])
+    third = runner.run(frames, boxes)
+    assert runner.captures == 4 and runner.replays == 6 and np.array_equal(third["logp"], got["logp"])
+    eager = MixedResolutionRunner(engine, batch_frames=32, use_graphs=False).run(frames, boxes)
     assert np.array_equal(eager["logp"], got["logp"])
+    # steady-state form with the frames resident in HBM: same results, no host synchronisation inside
+    by_shape = {}
+    for i, (h, w) in enumerate(res):
+        by_shape.setdefault((h, w), []).append(i)
+    resident = {}
+    for shape, idx in by_shape.items():
+        idx = idx + [idx[-1]] * (-len(idx) % 32)
+        resident[shape] = (torch.from_numpy(np.stack([frames[i] for i in idx])).cuda(),
+                           torch.from_numpy(boxes[idx]).cuda(), torch.tensor(idx, dtype=torch.int32).cuda())
+    rec, lp = engine.alloc_records(n - 1), engine.alloc_logp(n - 1)
+    runner.run_resident(resident, n, rec, lp)
+    torch.cuda.synchronize()
+    assert runner.captures == 4 and np.array_equal(lp.cpu().numpy(), got["logp"])
+
+
+@pytest.mark.parametrize("n_total", [40, 90])
+def test_frame_parallel_hip_engine_two_ranks(engine, tmp_path, n_total):
+    """BASELINE.json configs[3] in miniature on the real HIP engine: two ranks (sharing this box's one
+    GPU, gloo transport) shard one clip, exchange the 27-frame feature halo and gather the records;
+    compared with single-process infer_clip. n_total = 40: shards (20 frames) shorter than the reach,
+    no interior frames at all; n_total = 90: 45-frame shards with interior frames whose head runs under
+    the halo exchange. Rank 1 builds its engine from rank 0's broadcast weight arena."""
+    import socket
+    import subprocess
+    import sys
+
+    h, w = 720, 1280
+    out = str(tmp_path / "two_rank.npz")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "helpers", "two_rank_worker.py"), str(n_total), str(h), str(w), out]
+    subprocess.run(cmd, check=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="4"))
+    got = np.load(out)
+    single = engine.infer_clip(synth.make_frames(n_total, h, w), synth.make_boxes(n_total, h, w))
+    assert got["logp"].shape == (n_total - 1, 2, 63)
+    # the batch a crop travels in differs (shards of 20 / 45 in chunks of 16 vs one 64-chunked clip), so tiles
+    # and split-K may differ: fp32 rounding, not bitwise
+    assert np.abs(got["logp"] - single["logp"]).max() <= 1e-5
+    assert np.array_equal(got["rec"][..., 1], single["action_id"])
+    assert np.array_equal(got["rec"][..., 0], single["char_id"])
+    assert np.array_equal(got["logp_p"], got["logp"]) and np.array_equal(got["rec_p"], got["rec"])  # pipelined == serial
+    has_interior = (got["interior"][:, 1] > got["interior"][:, 0]).any()
+    assert has_interior == (n_total == 90)
+
+
+def test_indexed_backbone_rejects_frame_ids_outside_the_clip(engine):
+    """a bad id must not become an out-of-bounds device write. The host path refuses it
+    (pa_clip_mark_ready -> PA_ERR_CAPACITY); ids that only exist on the device are skipped by the
+    scatter kernel and reported by pa_device_errors."""
+    from playaid_core_amd import _lib
+    from playaid_core_amd.engine import EngineError
+
+    n, h, w = 4, 720, 1280
+    fr = torch.from_numpy(synth.make_frames(n, h, w)).cuda()
+    bx = torch.from_numpy(synth.make_boxes(n, h, w)).cuda()
+    engine.clip_begin(8)
+    with pytest.raises(EngineError) as ei:
+        engine.clip_mark_ready([0, 1, 8])
+    assert ei.value.code == _lib.PA_ERR_CAPACITY
+    guard = engine.features_buffer(1)  # the row a wild id 8 would have hit first: cache rows 16, 17
+    engine.clip_mark_ready(list(range(8)))
+    before = engine.features_export(7, 1).clone()
+    engine.backbone_frames_indexed(fr, bx, torch.tensor([0, 1, 8, -3], dtype=torch.int32).cuda())
+    with pytest.raises(EngineError) as ei:
+        engine.check_device_errors()
+    assert ei.value.code == _lib.PA_ERR_CAPACITY and "2 frame id" in str(ei.value)
+    engine.check_device_errors()  # the counter was cleared
+    assert torch.equal(engine.features_export(7, 1), before)  # nothing was written for the bad ids
+    assert engine.features_export(0, 2).abs().sum() > 0
+    # features of a frame that is not cached in this clip cannot be exported (stale rows of an earlier clip)
+    engine.clip_begin(8)
+    with pytest.raises(EngineError) as ei:
+        engine.features_export(0, 1)
+    assert ei.value.code == _lib.PA_ERR_NOT_READY
+    del guard
+
+
+def test_repaired_gap_crops_come_from_their_source_frames(engine, state_dict):
+    """pa_backbone_frames_src: crop (i, p) cut from frames[src[i, p]] in ONE pass == cutting each
+    fighter column from its own re-indexed frame stack (what the runner did in two passes before)."""
+    n, h, w = 12, 720, 1280
+    frames = synth.make_frames(n, h, w)
+    boxes = synth.make_boxes(n, h, w)
+    src = np.tile(np.arange(n, dtype=np.int32)[:, None], (1, 2))
+    src[4, 0], src[5, 0], src[9, 1] = 5, 6, 10  # repaired gaps read VideoCapture position j (one frame late)
+    got = engine.infer_clip(frames, boxes, want_crops=True, src=src)
+    for p in range(2):
+        ref = engine.infer_clip(frames[src[:, p]], boxes, want_crops=True)
+        assert np.array_equal(got["crops_rgb"][:, p], ref["crops_rgb"][:, p])
+        assert np.array_equal(got["logp"][:, p], ref["logp"][:, p])
+    bad = src.copy()
+    bad[3, 1] = n  # outside the frame buffer: never dereferenced, reported per crop
+    st = engine.infer_clip(frames, boxes, want_crops=True, src=bad)["crop_status"]
+    assert st[3, 1] == 5 and (np.delete(st.ravel(), 3 * 2 + 1) == 0).all()
 
 
 def test_log_projection_boxes(engine, tmp_path):

@@ -15,7 +15,7 @@ from playaid_core_amd import parallel, synth
 
 
 def test_shard_and_halo_plans_cover_every_window():
-    for n_total, world in [(60, 2), (61, 3), (128, 8), (40, 4), (30, 8)]:
+    for n_total, world in [(60, 2), (61, 3), (128, 8), (40, 4), (30, 8), (70, 2), (8192, 8), (300, 3), (56, 1)]:
         owned = []
         for r in range(world):
             lo, hi = parallel.owned_frame_nums(n_total, world, r)
@@ -30,6 +30,14 @@ def test_shard_and_halo_plans_cover_every_window():
         sends = {(r, p, f0, c) for r in range(world) for (p, f0, c) in parallel.halo_plan(n_total, world, r, 27)[1]}
         recvs = {(p, r, f0, c) for r in range(world) for (p, f0, c) in parallel.halo_plan(n_total, world, r, 27)[0]}
         assert sends == recvs
+        # interior frames: exactly those whose window stays inside the rank's own shard
+        for r in range(world):
+            own = set(range(*parallel.shard_range(n_total, world, r)))
+            f_lo, f_hi = parallel.owned_frame_nums(n_total, world, r)
+            brute = [f for f in range(f_lo, f_hi)
+                     if set(range(max(1, f - 27) - 1, min(n_total - 1, f + 27))) <= own]
+            i_lo, i_hi = parallel.interior_frame_nums(n_total, world, r, 27)
+            assert list(range(i_lo, i_hi)) == brute, (n_total, world, r)
 
 
 class OracleEngine:
@@ -114,11 +122,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_frame_parallel_equals_single_process(world, tmp_path, state_dict):
+@pytest.mark.parametrize("world,n_total", [(2, 70), (3, 34)])
+def test_frame_parallel_equals_single_process(world, n_total, tmp_path, state_dict):
+    """(2, 70): each rank has interior frames (head under the halo exchange) and edge frames;
+    (3, 34): shards shorter than the 27-frame reach, multi-peer halos, no interior at all."""
     from oracle import pipeline
 
-    n_total, h, w = 34, 720, 1280  # shards shorter than the 27-frame reach: multi-peer halos
+    h, w = 720, 1280
     out = str(tmp_path / "par.npz")
     mp.spawn(_worker, args=(world, _free_port(), n_total, h, w, out), nprocs=world, join=True)
     got = np.load(out)
