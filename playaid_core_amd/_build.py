@@ -21,6 +21,7 @@ SOURCES = [
     ("igemm.hip", []),
     ("igemm_bf16.hip", []),
     ("patchconv.hip", []),
+    ("patchconv_bf16.hip", []),
     ("stem.hip", []),
     ("misc.hip", []),
     ("preprocess.hip", ["-ffp-contract=off"]),

@@ -372,8 +372,12 @@ int run_conv(pa_engine* e, const ConvLayer& L, int crop0, int ncrops, size_t sla
     // stride-1 3x3 layers: input patch resident in LDS across the nine taps (patchconv.hip);
     // PA_PATCH=0 keeps the generic im2col engine for A/B runs
     static const int use_patch = getenv("PA_PATCH") ? atoi(getenv("PA_PATCH")) : 1;
+    static const int use_bf16_patch = getenv("PA_BF16_PATCH") ? atoi(getenv("PA_BF16_PATCH")) : 1;
     if (bf) {
-        HIPCHK(e, launch_igemm_bf16(p, tile, s));
+        hipError_t pe = hipErrorInvalidValue;
+        if (use_bf16_patch && L.stride == 1 && !L.in2) pe = launch_conv3x3_bf16_patch(p, s);
+        if (pe == hipErrorInvalidValue) pe = launch_igemm_bf16(p, tile, s);  // stride-2 convs, fused 1x1/2 second source
+        HIPCHK(e, pe);
     } else if (use_patch && L.kh == 3 && L.stride == 1) {
         int bm = tile == TILE_64x64 || tile == TILE_64x64_K64 ? 64 : 128;
         const int howo = L.out_hw * L.out_hw, in_w2 = L.out_hw + 2;

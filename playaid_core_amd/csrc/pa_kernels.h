@@ -58,6 +58,9 @@ hipError_t launch_igemm(const GemmParams& p, GemmTile tile, hipStream_t s);
 // f32 accumulate on v_mfma_f32_32x32x16_bf16; conv mode only (igemm_bf16.hip)
 hipError_t launch_igemm_bf16(const GemmParams& p, GemmTile tile, hipStream_t s);
 
+// stride-1 3x3 convolution on bf16 with the activation patch resident in LDS (patchconv_bf16.hip); no second source
+hipError_t launch_conv3x3_bf16_patch(const GemmParams& p, hipStream_t s);
+
 // Persistent direct 7x7/2 stem (stem.hip): x = [crops][134][134][4] fp32 (3-pixel zero border,
 // channel 3 = 0), wgt = [64][7 ky][8 px][4 ch] (the igemm stem layout), out = [crops][66][66][64].
 struct StemParams {

@@ -1,0 +1,389 @@
+// Stride-1 3x3 convolution on bf16 activations / weights for gfx950 with the activation patch
+// resident in LDS across the nine taps (BASELINE.json configs[2], "bf16 conv path").
+//
+// igemm_bf16.hip stages an im2col tile and a weight tile per 64-deep k-step, so every activation
+// byte crosses L2 -> LDS nine times and a 128 x 64 tile pays 24 KB of LDS fill for 8 matrix
+// instructions per wave: the matrix pipe idles at ~0.19 (rocprofv3, round 1). This kernel turns the
+// K loop inside out like the fp32 patch kernel (patchconv.hip), with what bf16 rates demand on top:
+//
+//  * tile = 64*WAVES output pixels x 64 output channels; one wave = 64 pixels x 64 channels
+//    (2 x 2 accumulators of v_mfma_f32_32x32x16_bf16): the weight stage of a k-step is shared by
+//    every wave of the workgroup, so weight fill per matrix instruction falls with the pixel tile;
+//  * K runs over 32-channel chunks; per chunk the tile's input patch -- (rows + 2) x (W + 2) padded
+//    pixels x 64 B, a CONTIGUOUS pixel range of the zero-bordered NHWC buffer (whole padded images
+//    for the 16-, 8- and 4-wide maps) -- is copied to LDS once (double buffered) and the nine taps
+//    read their operands from it at pixel offset ky*(W+2)+kx: 1/9 of the activation fill;
+//  * weights go through LDS in stages of THREE taps (one ky row, 12 KB) in a three-deep ring, one
+//    workgroup barrier per stage = per 24 matrix instructions of a wave; every copy is LDS-DMA
+//    (buffer_load ... lds) with counted vmcnt waits and a raw s_barrier, so the copies of stage
+//    t+2 and of the next chunk's patch stay in flight across the barriers;
+//  * the matrix instruction takes the WEIGHTS as its row operand and the pixels as its column
+//    operand: a lane then owns one pixel and runs of four consecutive output channels, which two
+//    v_permlane32_swap turn into eight consecutive channels = one 16-byte store per lane. No LDS
+//    transposition, no barrier, no second pass in the epilogue;
+//  * 16-byte slots of a pixel / weight row are XOR-swizzled on the DMA source so that every
+//    ds_read_b128 lane group hits 16 distinct bank slots for all nine taps on every map width
+//    (keys brute-forced by scripts/lds_swizzle_search.py).
+//
+// fp32 accumulation, bias + residual + ReLU in fp32, one rounding to bf16 at the store.
+#include "pa_kernels.h"
+
+namespace pa {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint16_t bf16_t;  // storage
+
+namespace {
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, int voff_bytes, int soff_bytes, uint8_t* lds_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_base, 16, voff_bytes,
+                                             soff_bytes, 0, 0);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {  // round to nearest even (finite inputs)
+    uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
+    ua += 0x7fffu + ((ua >> 16) & 1u);
+    ub += 0x7fffu + ((ub >> 16) & 1u);
+    return (ua >> 16) | (ub & 0xffff0000u);
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    // counted wait: all but the N youngest vector-memory operations of this wave are done
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if constexpr (N == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+}
+
+// Geometry of one map width. A tile is 64*WAVES consecutive output pixels in (image, row, column)
+// raster order: a band of rows of one image (W = 32), or whole images (W <= 16).
+template <int W, int WAVES> struct PatchGeom {
+    static constexpr int PXT = 64 * WAVES;
+    static constexpr int PITCH = W + 2;
+    static constexpr int IMG_PX = PITCH * PITCH;
+    static constexpr int HW = W * W;
+    static constexpr bool BAND = HW > PXT;                       // tile = rows of one image
+    static constexpr int ROWS = BAND ? PXT / W : W;              // image rows per tile (band) / per image
+    static constexpr int IMGS = BAND ? 1 : PXT / HW;             // images per tile
+    static constexpr int TILES_PER_IMG = BAND ? HW / PXT : 1;
+    static constexpr int PATCH_PX = BAND ? (ROWS + 2) * PITCH : IMGS * IMG_PX;
+    static constexpr int NPIECE = (PATCH_PX + 15) / 16;          // 1 KB DMA pieces (16 pixels x 64 B)
+    static constexpr int PATCH_BYTES = NPIECE * 1024;
+    // swizzle key of padded pixel (row r, column c): ((c >> 2) * KA + r * KB) & 3 (lds_swizzle_search.py)
+    static constexpr int KA = W == 32 ? 1 : (W == 16 ? 2 : 0);
+    static constexpr int KB = W == 32 ? 0 : 1;
+    static_assert(W == 32 || W == 16 || W == 8 || W == 4, "map widths of the ResNet-18 stages at 128 x 128 input");
+    static_assert(BAND ? (PXT % W == 0 && HW % PXT == 0) : (PXT % HW == 0), "tile must be whole rows / whole images");
+};
+
+constexpr int WSTAGE_BYTES = 3 * 64 * 64;  // three taps x 64 output channels x 32 bf16
+constexpr int NSTG = 3;                    // weight ring depth
+
+}  // namespace
+
+// LDS: [patch 0][patch 1][weight ring]. One array (a second __shared__ object makes hipcc drain vmcnt
+// in front of the operand reads).
+template <int W, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void conv3x3_bf16_patch_kernel(const GemmParams p) {
+    using G = PatchGeom<W, WAVES>;
+    constexpr int NT = 64 * WAVES;
+    constexpr int LDS_BYTES = 2 * G::PATCH_BYTES + NSTG * WSTAGE_BYTES;
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[LDS_BYTES];
+    uint8_t* const wring = lds + 2 * G::PATCH_BYTES;
+
+    const bf16_t* residual = reinterpret_cast<const bf16_t*>(p.residual);
+    bf16_t* out = reinterpret_cast<bf16_t*>(p.out);
+    const int C = p.chunk;          // input channels
+    const int n_ch = C >> 5;        // 32-channel chunks
+
+    // XCD-aware (bijective) remap: blocks with equal b % 8 share an XCD and get a contiguous run of tiles
+    const int nwg = gridDim.x;
+    const int b = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+    const int tile_m = wg / p.tiles_n;
+    const int tile_n = wg - tile_m * p.tiles_n;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+
+    // first padded pixel of this tile's patch
+    const int p0 = G::BAND ? (tile_m / G::TILES_PER_IMG) * G::IMG_PX + (tile_m % G::TILES_PER_IMG) * G::ROWS * G::PITCH
+                           : tile_m * G::IMGS * G::IMG_PX;
+
+    const __amdgpu_buffer_rsrc_t act_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.act), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wgt_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wgt), 0, -1, 0x00020000);
+
+    // ---- DMA jobs. A stage's copies are a flat list: 12 weight pieces (3 taps x 4 groups of 16 output
+    // channels), then -- in the ky = 0 and ky = 1 stages -- half of the next chunk's patch pieces. Wave w
+    // takes jobs w, w + WAVES, ...; every wave issues the same NUMBER of copies per stage (the counted
+    // vmcnt waits rely on it), surplus slots repeat the list's last piece.
+    constexpr int HALF = (G::NPIECE + 1) / 2;
+    constexpr int CNT_P = (12 + HALF + WAVES - 1) / WAVES;  // copies per wave in a stage that also moves patch pieces
+    constexpr int CNT_W = (12 + WAVES - 1) / WAVES;         // ... in the ky = 2 stage
+    static_assert(CNT_P <= 12, "extend wait_vmcnt");
+    // lane-constant part of the source address of a weight piece: output channel 16*grp + (lane >> 2),
+    // slot (lane & 3) ^ key, key = (n >> 2) & 3
+    const int wl_n = lane >> 2;  // + 16 * grp
+    // patch piece q: pixel 16 q + (lane >> 2), slot lane & 3
+    auto patch_voff = [&](int q) -> int {
+        int gpx = p0 + 16 * q + (lane >> 2);
+        gpx = gpx < p.total_px ? gpx : p.total_px - 1;
+        const int rem = gpx % G::IMG_PX;
+        const int r = rem / G::PITCH, c = rem - r * G::PITCH;
+        const int key = ((c >> 2) * G::KA + r * G::KB) & 3;
+        return gpx * C * 2 + (((lane & 3) ^ key) << 4);
+    };
+    int pvoff[2][CNT_P];  // [half][slot]: -1 = this slot is a weight piece
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < CNT_P; ++i) {
+            int job = wave + WAVES * i;
+            job = job < 12 + HALF ? job : 12 + HALF - 1;
+            int q = job - 12 + h * HALF;
+            q = q < G::NPIECE ? q : G::NPIECE - 1;
+            pvoff[h][i] = job >= 12 ? patch_voff(q) : -1;
+        }
+
+    // copies of stage (chunk ch, tap row KY) into ring slot SLOT, plus patch pieces of chunk ch_next into patch buffer PB
+#define BP_ISSUE(CH, KY, SLOT, WITH_PATCH, HALF_IDX, CH_NEXT, PB)                                                             \
+    {                                                                                                                \
+        constexpr int CNT_ = (WITH_PATCH) ? CNT_P : CNT_W;                                                           \
+        _Pragma("unroll") for (int i_ = 0; i_ < CNT_; ++i_) {                                                        \
+            int job_ = wave + WAVES * i_;                                                                            \
+            const int last_ = (WITH_PATCH) ? 12 + HALF - 1 : 11;                                                     \
+            job_ = job_ < last_ ? job_ : last_;                                                                      \
+            if (job_ < 12) {                                                                                         \
+                const int kx_ = job_ >> 2, grp_ = job_ & 3;                                                          \
+                const int n_ = 16 * grp_ + wl_n;                                                                     \
+                const int voff_ = ((tile_n * 64 + n_) * p.ktot) * 2 + (((lane & 3) ^ ((n_ >> 2) & 3)) << 4);         \
+                dma16(wgt_rs, voff_, (((KY) * 3 + kx_) * C + (CH) * 32) * 2, wring + (SLOT) * WSTAGE_BYTES + job_ * 1024); \
+            } else {                                                                                                 \
+                int q_ = job_ - 12 + (HALF_IDX) * HALF;                                                            \
+                q_ = q_ < G::NPIECE ? q_ : G::NPIECE - 1;                                                            \
+                dma16(act_rs, pvoff[HALF_IDX][i_], (CH_NEXT) * 64, lds + (PB) * G::PATCH_BYTES + q_ * 1024);         \
+            }                                                                                                        \
+        }                                                                                                            \
+    }
+
+    // ---- operand addresses ---------------------------------------------------------------------
+    // activation fragment of pixel block pi (32 pixels), tap (ky, kx), k group kg: lane reads slot
+    // (2 kg + lh) ^ key of patch pixel pbase[pi] + ky*PITCH + kx
+    int pbase[2], prow[2], pcol[2];
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+        int m = tile_m * G::PXT + wave * 64 + pi * 32 + lr;
+        m = m < p.M ? m : p.M - 1;
+        const int img = m / G::HW, rem = m - img * G::HW;
+        const int oy = rem / W, ox = rem - oy * W;
+        pbase[pi] = (img * G::IMG_PX + oy * G::PITCH + ox - p0) * 64;
+        prow[pi] = oy;
+        pcol[pi] = ox;
+    }
+    // weight fragment of channel block ci: row n = 32 ci + lr of the stage, slot (2 kg + lh) ^ ((n >> 2) & 3)
+    int wbase[2][2];
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg) {
+            const int n = 32 * ci + lr;
+            wbase[ci][kg] = n * 64 + (((2 * kg + lh) ^ ((n >> 2) & 3)) << 4);
+        }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[pi][ci][e] = 0.f;
+
+    u32x4 fa[2][2], fw[2][2];  // [set][pi | ci]
+#define BP_LOAD(SET, PATCH, WST, KY, KX, KG)                                                                         \
+    {                                                                                                                \
+        _Pragma("unroll") for (int pi_ = 0; pi_ < 2; ++pi_) {                                                        \
+            const int key_ = (((pcol[pi_] + (KX)) >> 2) * G::KA + (prow[pi_] + (KY)) * G::KB) & 3;                   \
+            fa[SET][pi_] = *reinterpret_cast<const u32x4*>((PATCH) + pbase[pi_] + ((KY) * G::PITCH + (KX)) * 64 +    \
+                                                           (((2 * (KG) + lh) ^ key_) << 4));                         \
+        }                                                                                                            \
+        _Pragma("unroll") for (int ci_ = 0; ci_ < 2; ++ci_)                                                          \
+            fw[SET][ci_] = *reinterpret_cast<const u32x4*>((WST) + (KX) * 4096 + wbase[ci_][KG]);                    \
+    }
+#define BP_MFMA(SET)                                                                                                 \
+    {                                                                                                                \
+        _Pragma("unroll") for (int pi_ = 0; pi_ < 2; ++pi_)                                                          \
+            _Pragma("unroll") for (int ci_ = 0; ci_ < 2; ++ci_)                                                      \
+                acc[pi_][ci_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[SET][ci_]),    \
+                                                                        __builtin_bit_cast(bf16x8, fa[SET][pi_]),    \
+                                                                        acc[pi_][ci_], 0, 0, 0);                     \
+    }
+
+    // ---- prologue: patch of chunk 0, weight stages 0 and 1 -------------------------------------------
+    {
+        for (int q = wave; q < G::NPIECE; q += WAVES) dma16(act_rs, patch_voff(q), 0, lds + q * 1024);
+        for (int job = wave; job < 12; job += WAVES) {
+            const int kx = job >> 2, grp = job & 3;
+            const int n = 16 * grp + wl_n;
+            const int voff = ((tile_n * 64 + n) * p.ktot) * 2 + (((lane & 3) ^ ((n >> 2) & 3)) << 4);
+            dma16(wgt_rs, voff, ((0 * 3 + kx) * C) * 2, wring + 0 * WSTAGE_BYTES + job * 1024);
+            dma16(wgt_rs, voff, ((1 * 3 + kx) * C) * 2, wring + 1 * WSTAGE_BYTES + job * 1024);
+        }
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+    }
+    BP_LOAD(0, lds, wring, 0, 0, 0);
+
+    // ---- main loop: chunk outermost, the three tap rows unrolled (ring slot of stage 3 ch + ky is ky) --
+    for (int ch = 0; ch < n_ch; ++ch) {
+        const uint8_t* patch = lds + (ch & 1) * G::PATCH_BYTES;
+        const int pb_next = (ch & 1) ^ 1;
+        const int ch_next = ch + 1 < n_ch ? ch + 1 : ch;   // behind the last chunk: re-fetch it (unused)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            // stage t = 3 ch + ky. Copies of stage t + 2 -> ring slot (ky + 2) % 3 (last read in stage t - 1,
+            // whose closing barrier every wave has passed); in ky = 0, 1 also half of the next patch
+            {
+                const int t2ky = (ky + 2) % 3;
+                int ch2 = ky == 0 ? ch : ch + 1;
+                ch2 = ch2 < n_ch ? ch2 : n_ch - 1;  // behind the end: re-fetch an existing stage (unused)
+                if (ky < 2) {
+                    BP_ISSUE(ch2, t2ky, t2ky, true, ky, ch_next, pb_next);
+                } else {
+                    BP_ISSUE(ch2, t2ky, t2ky, false, 0, ch_next, pb_next);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const uint8_t* wst = wring + ky * WSTAGE_BYTES;
+#pragma unroll
+            for (int g = 0; g < 6; ++g) {  // k group g = (kx, kg)
+                const int kx = g >> 1, kg = g & 1;
+                (void)kx; (void)kg;
+                if (g < 5) {
+                    // operands of the next group before this group's matrix instructions
+                    BP_LOAD((g + 1) & 1, patch, wst, ky, (g + 1) >> 1, (g + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    BP_MFMA(g & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    // last group of the stage: its operands were requested one group ago. Close the stage --
+                    // the copies of stage t + 1 (issued a stage ago) have landed once only this stage's own
+                    // copies are outstanding; every wave's reads of this stage are in registers -- then
+                    // request the next stage's first operands and cover their latency with the last
+                    // matrix instructions.
+                    if (ky < 2) wait_vmcnt<CNT_P>(); else wait_vmcnt<CNT_W>();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ky < 2) {
+                        BP_LOAD(0, patch, wring + (ky + 1) * WSTAGE_BYTES, ky + 1, 0, 0);
+                    } else if (ch + 1 < n_ch) {
+                        BP_LOAD(0, lds + pb_next * G::PATCH_BYTES, wring, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    BP_MFMA(1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+#undef BP_LOAD
+#undef BP_MFMA
+#undef BP_ISSUE
+    wait_vmcnt<0>();  // the tail's unused re-fetches must not outlive the workgroup's LDS
+
+    // ---- epilogue: lane = one pixel; accumulator element e of block (pi, ci) is output channel
+    // 32 ci + 8 (e >> 2) + 4 lh + (e & 3). Swapping halves between lanes l and l + 32 gives each lane
+    // eight consecutive channels: 32 ci + 16 j + 8 lh + 0..7 (j = 0, 1) -> one 16-byte store.
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+        const int m = tile_m * G::PXT + wave * 64 + pi * 32 + lr;
+        const bool valid = m < p.M;
+        const int mm = valid ? m : p.M - 1;
+        const int img = mm / G::HW, rem = mm - img * G::HW;
+        const int oy = rem / W, ox = rem - oy * W;
+        const int o_px = img * p.out_img_stride + (oy + p.out_pad) * p.out_row_stride + (ox + p.out_pad) * p.out_px_stride +
+                         tile_n * 64 + 8 * lh;
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    // X = element group 2j (channels 16j + 4lh + i), Y = group 2j + 1 (channels 16j + 8 + 4lh + i)
+                    const uint32_t x = __float_as_uint(acc[pi][ci][8 * j + i]);
+                    const uint32_t y = __float_as_uint(acc[pi][ci][8 * j + 4 + i]);
+                    const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+                    v[i] = __uint_as_float(r[0]);      // lh = 0: own X (16j + i)      | lh = 1: partner's Y (16j + 8 + i)
+                    v[4 + i] = __uint_as_float(r[1]);  // lh = 0: partner's X (16j+4+i) | lh = 1: own Y (16j + 12 + i)
+                }
+                const int o = o_px + 32 * ci + 16 * j;
+                const int cb = tile_n * 64 + 32 * ci + 16 * j + 8 * lh;
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + cb);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + cb + 4);
+                const float bs[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                u32x4 rv = {0u, 0u, 0u, 0u};
+                if (residual) rv = *reinterpret_cast<const u32x4*>(residual + o);
+                uint32_t pk[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float a0 = v[2 * k] + bs[2 * k] + __uint_as_float(rv[k] << 16);
+                    float a1 = v[2 * k + 1] + bs[2 * k + 1] + __uint_as_float(rv[k] & 0xffff0000u);
+                    if (p.relu) {
+                        a0 = a0 > 0.f ? a0 : 0.f;
+                        a1 = a1 > 0.f ? a1 : 0.f;
+                    }
+                    pk[k] = pack_bf16x2(a0, a1);
+                }
+                if (valid) *reinterpret_cast<u32x4*>(out + o) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+            }
+    }
+}
+
+// p: GemmParams as for launch_igemm_bf16 (conv mode, 3x3, stride 1, no second source, chunk = Cin, ktot = 9 Cin,
+// N % 64 == 0, bias != nullptr). Returns hipErrorInvalidValue for a geometry it does not cover (the caller
+// then uses igemm_bf16.hip).
+hipError_t launch_conv3x3_bf16_patch(const GemmParams& p_in, hipStream_t s) {
+    GemmParams p = p_in;
+    if (p.gather || p.taps != 9 || p.kw_taps != 3 || p.stride != 1 || p.chunk % 32 != 0 || p.N % 64 != 0 || p.M <= 0 ||
+        p.k2_steps != 0 || p.ktot != 9 * p.chunk || !p.bias || p.wo * p.wo != p.howo || p.M % p.howo != 0)
+        return hipErrorInvalidValue;
+    const int W = p.wo;
+    if (p.in_row_stride != (W + 2) * p.in_px_stride || p.in_img_stride != (W + 2) * (W + 2) * p.in_px_stride ||
+        p.in_px_stride != p.chunk || p.off_y != 0 || p.off_x != 0)
+        return hipErrorInvalidValue;
+    p.total_px = (p.M / p.howo) * (W + 2) * (W + 2);
+    static const int waves8 = getenv("PA_BF16_WAVES8") ? atoi(getenv("PA_BF16_WAVES8")) : 0;  // bit mask over {32,16,8}: 512-thread tiles
+    p.tiles_n = p.N / 64;
+#define BPL(W_, WV_)                                                                                                 \
+    {                                                                                                                \
+        p.tiles_m = (p.M + 64 * WV_ - 1) / (64 * WV_);                                                               \
+        hipLaunchKernelGGL((conv3x3_bf16_patch_kernel<W_, WV_>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WV_), 0, s, p); \
+    }
+    switch (W) {
+        case 32: if (waves8 & 1) BPL(32, 8) else BPL(32, 4) break;
+        case 16: if (waves8 & 2) BPL(16, 8) else BPL(16, 4) break;
+        case 8: if (waves8 & 4) BPL(8, 4) else BPL(8, 8) break;
+        case 4: BPL(4, 4) break;
+        default: return hipErrorInvalidValue;
+    }
+#undef BPL
+    return hipGetLastError();
+}
+
+}  // namespace pa
