@@ -196,7 +196,10 @@ def main():
     eng = broadcast_engine(make_engine, sd, device) if world > 1 else make_engine(sd)
     # this rank's shard of the synthetic clip, generated on the device it will be read from (bit-identical to
     # synth.make_frames) and resident in HBM before timing
-    frames = synth.make_frames_torch(hi - lo, args.height, args.width, first_frame=lo, device=device)
+    if long_clip or os.environ.get("PA_BENCH_DEVICE_SYNTH") == "1":
+        frames = synth.make_frames_torch(hi - lo, args.height, args.width, first_frame=lo, device=device)
+    else:  # short clips: the host generator (rocprofv3 counter passes crash in the torch integer kernels of the device one)
+        frames = torch.from_numpy(synth.make_frames(hi - lo, args.height, args.width, first_frame=lo)).to(device)
     boxes = torch.from_numpy(synth.make_boxes(hi - lo, args.height, args.width, first_frame=lo)).to(device)
     runner = FrameParallelClip(eng, S, DELTA)
 

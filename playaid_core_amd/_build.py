@@ -23,6 +23,7 @@ SOURCES = [
     ("patchconv.hip", []),
     ("patchconv_bf16.hip", []),
     ("stem.hip", []),
+    ("stem_pool.hip", []),
     ("misc.hip", []),
     ("preprocess.hip", ["-ffp-contract=off"]),
     ("pa_api.hip", []),

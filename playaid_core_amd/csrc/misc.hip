@@ -10,7 +10,7 @@ namespace pa {
 
 // x[n][3][128][128] (NCHW fp32, the tensor `model(x)` receives,
 // cnn_action_detector.py:29-31) -> zero-bordered NHWC4 [n][134][134][4].
-__global__ __launch_bounds__(256) void nchw_to_padded_kernel(const float* __restrict__ x, float* __restrict__ out, int n) {
+__global__ __launch_bounds__(256) void nchw_to_padded_kernel(const float* __restrict__ x, float* __restrict__ out, int n, int out_bf16) {
     const size_t total = (size_t)n * 128 * 128;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int img = (int)(i >> 14);
@@ -22,15 +22,23 @@ __global__ __launch_bounds__(256) void nchw_to_padded_kernel(const float* __rest
         v.y = s[16384];
         v.z = s[32768];
         v.w = 0.f;
-        reinterpret_cast<float4*>(out)[((size_t)img * 134 + (y + 3)) * 134 + (xx + 3)] = v;
+        const size_t o = ((size_t)img * 134 + (y + 3)) * 134 + (xx + 3);
+        if (out_bf16) {  // bf16 conv path: the stem multiplies bf16 pixels (round to nearest even)
+            uint32_t u[3] = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z)};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) u[k] = (u[k] + 0x7fffu + ((u[k] >> 16) & 1u)) >> 16;
+            reinterpret_cast<uint2*>(out)[o] = make_uint2(u[0] | (u[1] << 16), u[2]);
+        } else {
+            reinterpret_cast<float4*>(out)[o] = v;
+        }
     }
 }
 
-hipError_t launch_nchw_to_padded(const float* x, float* out, int32_t n, hipStream_t s) {
+hipError_t launch_nchw_to_padded(const float* x, float* out, int32_t n, int32_t out_bf16, hipStream_t s) {
     const size_t total = (size_t)n * 16384;
     int grid = (int)((total + 255) / 256);
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(nchw_to_padded_kernel, dim3(grid), dim3(256), 0, s, x, out, n);
+    hipLaunchKernelGGL(nchw_to_padded_kernel, dim3(grid), dim3(256), 0, s, x, out, n, out_bf16);
     return hipGetLastError();
 }
 

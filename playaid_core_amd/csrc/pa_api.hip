@@ -37,6 +37,10 @@ struct ConvLayer {
     // fused 1x1 stride-2 downsample branch (block 0 of layers 2-4): extra K read from `in2`
     float* in2 = nullptr;
     int in2_c = 0, in2_hw = 0, in2_stride = 1;
+    // bf16 path: the downsample branch is its own small GEMM into `ds_out` (bf16, same padded layout as `out`),
+    // which the 3x3 conv then adds as its residual (patchconv_bf16.hip has no second source)
+    float* ds_wgt = nullptr;  // [cout][in2_c] bf16
+    float* ds_out = nullptr;
     double k_alg = 0;  // algorithmic K (unpadded) for FLOP accounting
 };
 
@@ -81,7 +85,8 @@ struct pa_engine {
     size_t slab_floats = 0;
     std::vector<ConvLayer> convs;  // stem + 19 convs
     ConvLayer fc;
-    float* c1 = nullptr;  // stem output [max_crops][66][66][64]
+    float* stem_wgt_bf16 = nullptr;  // bf16 path: the folded stem weights [64][224] as bf16
+    float* c1 = nullptr;  // stem output [max_crops][66][66][64] (only the unfused stem + pool fallback writes it)
     float* p1 = nullptr;  // maxpool output [max_crops][34][34][64]
     float* layer4_out = nullptr;
     // head weights
@@ -319,6 +324,7 @@ int run_conv(pa_engine* e, const ConvLayer& L, int crop0, int ncrops, size_t sla
     const size_t in_crop = (size_t)in_w * in_w * L.in_px_stride;
     const size_t out_crop = (size_t)out_w * out_w * L.cout;
     const bool bf = e->bf16 && L.kh == 3;  // bf16 conv path: the 3x3 stack (buffers addressed in 2-byte elements)
+    const bool bf_ds = bf && L.in2 && L.ds_wgt;  // downsample branch as its own GEMM, added as the residual
     const size_t es = bf ? 2 : 4;
     auto at = [es](float* base, size_t elems) { return reinterpret_cast<float*>(reinterpret_cast<char*>(base) + elems * es); };
     p.act = at(L.in, crop0 * in_crop);
@@ -348,7 +354,27 @@ int run_conv(pa_engine* e, const ConvLayer& L, int crop0, int ncrops, size_t sla
     p.out_img_stride = (int)out_crop;
     p.out_pad = L.out_pad;
     p.relu = L.relu;
-    if (L.in2) {
+    if (bf_ds) {
+        GemmParams d;
+        memset(&d, 0, sizeof(d));
+        const int w2 = L.in2_hw + 2;  // zero-bordered block input
+        d.act = at(L.in2, (size_t)crop0 * w2 * w2 * L.in2_c);
+        d.wgt = L.ds_wgt;
+        d.out = at(L.ds_out, crop0 * out_crop);
+        d.slab = p.slab;
+        d.M = p.M; d.N = p.N;
+        d.taps = 1; d.kw_taps = 1; d.chunk = L.in2_c; d.ktot = L.in2_c;
+        d.howo = p.howo; d.wo = p.wo;
+        d.in_px_stride = L.in2_c; d.in_row_stride = w2 * L.in2_c; d.in_img_stride = w2 * w2 * L.in2_c;
+        d.stride = L.in2_stride; d.off_y = 1; d.off_x = 1;
+        d.out_px_stride = p.out_px_stride; d.out_row_stride = p.out_row_stride; d.out_img_stride = p.out_img_stride;
+        d.out_pad = p.out_pad;
+        d.relu = 0; d.splitk = 1;
+        ProfScope ps(e, s, prof_name, 2.0 * d.M * d.N * L.in2_c,
+                     2.0 * ((double)ncrops * L.in2_hw * L.in2_hw * L.in2_c / (L.in2_stride * L.in2_stride) + (double)d.M * d.N + (double)d.N * L.in2_c));
+        HIPCHK(e, launch_igemm_bf16(d, TILE_128x64, s));
+        p.residual = d.out;
+    } else if (L.in2) {
         const int w2 = L.in2_hw + 2;  // zero-bordered block input
         p.act2 = at(L.in2, (size_t)crop0 * w2 * w2 * L.in2_c);
         p.k2_steps = L.in2_c / (bf ? 64 : 32);
@@ -365,9 +391,10 @@ int run_conv(pa_engine* e, const ConvLayer& L, int crop0, int ncrops, size_t sla
     p.splitk = splitk;
     const size_t slab_avail = e->slab_floats > slab_off ? e->slab_floats - slab_off : 0;
     if ((size_t)p.splitk * p.M * p.N > slab_avail) p.splitk = 1;
-    const double flops = 2.0 * p.M * p.N * L.k_alg;
-    const double bytes = (double)es * ((double)ncrops * L.in_hw * L.in_hw * L.cin + (double)p.M * p.N * (L.residual ? 2 : 1) +
-                                       (double)p.N * L.k_alg + (L.in2 ? (double)ncrops * L.in2_hw * L.in2_hw * L.in2_c : 0.0));
+    const double k_main = bf_ds ? L.k_alg - L.in2_c : L.k_alg;  // (the branch's own launch carries its FLOPs and bytes)
+    const double flops = 2.0 * p.M * p.N * k_main;
+    const double bytes = (double)es * ((double)ncrops * L.in_hw * L.in_hw * L.cin + (double)p.M * p.N * ((L.residual || bf_ds) ? 2 : 1) +
+                                       (double)p.N * k_main + ((L.in2 && !bf_ds) ? (double)ncrops * L.in2_hw * L.in2_hw * L.in2_c : 0.0));
     ProfScope ps(e, s, prof_name, flops, bytes);
     // stride-1 3x3 layers: input patch resident in LDS across the nine taps (patchconv.hip);
     // PA_PATCH=0 keeps the generic im2col engine for A/B runs
@@ -375,7 +402,7 @@ int run_conv(pa_engine* e, const ConvLayer& L, int crop0, int ncrops, size_t sla
     static const int use_bf16_patch = getenv("PA_BF16_PATCH") ? atoi(getenv("PA_BF16_PATCH")) : 1;
     if (bf) {
         hipError_t pe = hipErrorInvalidValue;
-        if (use_bf16_patch && L.stride == 1 && !L.in2) pe = launch_conv3x3_bf16_patch(p, s);
+        if (use_bf16_patch && L.stride == 1 && !p.act2) pe = launch_conv3x3_bf16_patch(p, s);
         if (pe == hipErrorInvalidValue) pe = launch_igemm_bf16(p, tile, s);  // stride-2 convs, fused 1x1/2 second source
         HIPCHK(e, pe);
     } else if (use_patch && L.kh == 3 && L.stride == 1) {
@@ -421,11 +448,28 @@ int run_backbone_part(pa_engine* e, int crop0, int ncrops, const float* x_in, fl
             HIPCHK(e, launch_maxpool(e->c1 + (size_t)c0 * 66 * 66 * 64, e->p1 + (size_t)c0 * 34 * 34 * 64, n, st));
         return PA_OK;
     };
-    // The max-pool is pure HBM/L2 streaming and the stem pure matrix work: with the batch cut in two,
-    // the pool of the first half runs on the side stream underneath the stem of the second half.
-    // (Not while kernels are being timed one by one, and not inside the two-stream interleave.)
+    // Default: stem + BatchNorm + ReLU + max-pool in one persistent kernel (stem_pool.hip), the 64 x 64 stem map never
+    // reaches memory. PA_STEM_POOL=0 keeps the two-kernel form for A/B runs: there the max-pool (pure HBM/L2
+    // streaming) of one half batch runs on the side stream underneath the stem (pure matrix work) of the other.
+    static const int fused_pool = getenv("PA_STEM_POOL") ? atoi(getenv("PA_STEM_POOL")) : 1;
     static const int overlap_pool = getenv("PA_POOL_OVERLAP") ? atoi(getenv("PA_POOL_OVERLAP")) : 1;
-    if (overlap_pool && !e->profiling && !e->interleave && e->side && s != e->side && ncrops >= 64) {
+    if (fused_pool && !stem_igemm) {
+        StemPoolParams sp;
+        memset(&sp, 0, sizeof(sp));
+        const size_t es_in = e->bf16 ? 2 : 4;
+        sp.x = reinterpret_cast<const char*>(x_in) + (size_t)crop0 * 134 * 134 * 4 * es_in;
+        sp.wgt = e->bf16 ? e->stem_wgt_bf16 : stem.wgt;
+        sp.bias = stem.bias;
+        sp.out = reinterpret_cast<char*>(e->p1) + (size_t)crop0 * 34 * 34 * 64 * es_in;
+        sp.crops = ncrops;
+        sp.in_bf16 = sp.out_bf16 = e->bf16 ? 1 : 0;
+        const double px = (double)ncrops * 64 * 64;
+        ProfScope ps(e, s, "stem_conv7x7_pool", 2.0 * px * 64 * 147,
+                     (double)es_in * ((double)ncrops * 128 * 128 * 4 + (double)ncrops * 32 * 32 * 64 + 64.0 * 147));
+        HIPCHK(e, launch_stem_pool(sp, s));
+    } else if (e->bf16) {
+        return fail(e, PA_ERR_INVALID_ARG, "the bf16 path has no unfused stem (PA_STEM_POOL=0 / PA_STEM_IGEMM=1 are fp32 A/B knobs)");
+    } else if (overlap_pool && !e->profiling && !e->interleave && e->side && s != e->side && ncrops >= 64) {
         const int half = (ncrops / 2 + 7) & ~7;
         if ((rc = stem_part(crop0, half, s))) return rc;
         HIPCHK(e, hipEventRecord(e->ev_fork, s));
@@ -561,6 +605,7 @@ int run_preprocess(pa_engine* e, const uint8_t* frames, int n, int height, int w
     p.t_stride = e->t_stride;
     p.crops_u8 = crops_u8;
     p.crops_f32 = crops_f32;
+    p.crops_f32_is_bf16 = e->bf16 ? 1 : 0;
     p.status = status;
     p.fallback_count = e->fallback;
     p.fallback_list = e->fallback + 4;
@@ -709,6 +754,7 @@ int create_impl(const pa_config* cfg, const void* blob, size_t src_bytes, const 
         } else {
             r2 = (e->bf16 && k == 3) ? upload_bf16(e, &L.wgt, w) : upload(e, &L.wgt, w);
             if (r2) return r2;
+            if (e->bf16 && k == 7 && (r2 = upload_bf16(e, &e->stem_wgt_bf16, w))) return r2;
             r2 = upload(e, &L.bias, b);
             if (r2) return r2;
         }
@@ -765,8 +811,16 @@ int create_impl(const pa_config* cfg, const void* blob, size_t src_bytes, const 
                     memcpy(&wf[(size_t)o * k_all + k_main], &wd[(size_t)o * cin], sizeof(float) * cin);
                     bf[o] = (float)((double)keep_b[o] + (double)bd[o]);
                 }
-                rc = e->bf16 ? upload_bf16(e, &L.wgt, wf) : upload(e, &L.wgt, wf);
-                if (rc) return rc;
+                if (e->bf16) {
+                    rc = upload_bf16(e, &L.wgt, keep_w);  // [co][9 co]: the 3x3 alone
+                    if (rc) return rc;
+                    rc = upload_bf16(e, &L.ds_wgt, wd);   // [co][cin]
+                    if (rc) return rc;
+                    ALLOC(L.ds_out, buf, true);
+                } else {
+                    rc = upload(e, &L.wgt, wf);
+                    if (rc) return rc;
+                }
                 rc = upload(e, &L.bias, bf);
                 if (rc) return rc;
                 L.in2 = cur;
@@ -931,7 +985,7 @@ int pa_infer_windows(pa_engine* e, const float* x, int32_t batch, float* logp, v
         const int ncrops = nw * S;
         {
             ProfScope ps(e, s, "nchw_to_nhwc4", 0.0, ncrops * (49152.0 * 4 + 134.0 * 134 * 16));
-            HIPCHK(e, launch_nchw_to_padded(x + (size_t)w0 * S * 3 * 128 * 128, e->x0, ncrops, s));
+            HIPCHK(e, launch_nchw_to_padded(x + (size_t)w0 * S * 3 * 128 * 128, e->x0, ncrops, e->bf16 ? 1 : 0, s));
         }
         int rc = run_backbone(e, ncrops, e->x0, e->feats_tmp, s);
         if (rc) return rc;

@@ -73,6 +73,19 @@ struct StemParams {
     unsigned long long* clk;  // stamp builds only
 };
 hipError_t launch_stem7x7(const StemParams& p, hipStream_t s);
+// Stem + BatchNorm + ReLU + 3x3/2 max-pool in one persistent kernel (stem_pool.hip): x as above (fp32) or bf16
+// [crops][134][134][4]; wgt fp32 or bf16 [64][224]; out = pooled map [crops][34][34][64], fp32 or bf16.
+struct StemPoolParams {
+    const void* x;
+    const void* wgt;
+    const float* bias;
+    void* out;
+    int32_t crops;
+    int32_t run;       // row pairs per run (set by the launcher)
+    int32_t in_bf16;   // x and wgt are bf16: multiply on the bf16 matrix cores
+    int32_t out_bf16;
+};
+hipError_t launch_stem_pool(const StemPoolParams& p, hipStream_t s);
 hipError_t launch_splitk_reduce(const GemmParams& p, hipStream_t s);
 // stride-1 3x3 convolution with the input patch resident in LDS across the nine taps (patchconv.hip); bm = 128 | 64
 hipError_t launch_conv3x3_patch(const GemmParams& p, int bm, hipStream_t s);
@@ -120,6 +133,7 @@ struct PreprocParams {
     size_t t_stride;
     uint8_t* crops_u8;      // [ncrops][128][128][3] or nullptr
     float* crops_f32;       // [ncrops][134][134][4] zero-bordered, or nullptr
+    int32_t crops_f32_is_bf16;  // the model input is stored as bf16 [ncrops][134][134][4] instead (bf16 conv path)
     int32_t* status;        // [ncrops] or nullptr
     int32_t* fallback_count;  // [1] number of crops routed to the multi-kernel fallback (zeroed per call)
     int32_t* fallback_list;   // [ncrops] their indices
@@ -139,7 +153,7 @@ hipError_t launch_project_boxes(const double* log, double* boxes, int32_t n, hip
 // small kernels (misc.hip)
 // ---------------------------------------------------------------------------
 // x[n][3][128][128] f32 -> zero-bordered [n][134][134][4]
-hipError_t launch_nchw_to_padded(const float* x, float* out, int32_t n, hipStream_t s);
+hipError_t launch_nchw_to_padded(const float* x, float* out, int32_t n, int32_t out_bf16, hipStream_t s);
 // 3x3/2 max pool, padded [n][66][66][64] -> padded [n][34][34][64]
 hipError_t launch_maxpool(const float* in, float* out, int32_t n, hipStream_t s);
 // global average pool, padded [n][6][6][512] -> [n][512]

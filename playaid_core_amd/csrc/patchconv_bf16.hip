@@ -95,10 +95,16 @@ constexpr int NSTG = 3;                    // weight ring depth
 
 // LDS: [patch 0][patch 1][weight ring]. One array (a second __shared__ object makes hipcc drain vmcnt
 // in front of the operand reads).
+//
+// Workgroups are PERSISTENT over a run of consecutive pixel tiles of one 64-channel column: the stage
+// sequence simply continues into the next tile (same weights, next tile's patch), so a tile's first
+// patch and first weight stages arrive under the previous tile's last stages and the pipeline never
+// drains; the epilogue stores straight from the accumulators in between. Everything lane-dependent
+// (patch pixel of a lane, swizzle keys, DMA source offsets) is tile-independent; a tile contributes only
+// scalar offsets.
 template <int W, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void conv3x3_bf16_patch_kernel(const GemmParams p) {
     using G = PatchGeom<W, WAVES>;
-    constexpr int NT = 64 * WAVES;
     constexpr int LDS_BYTES = 2 * G::PATCH_BYTES + NSTG * WSTAGE_BYTES;
     __shared__ __attribute__((aligned(1024))) uint8_t lds[LDS_BYTES];
     uint8_t* const wring = lds + 2 * G::PATCH_BYTES;
@@ -108,47 +114,56 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_bf16_patch_kernel(const Ge
     const int C = p.chunk;          // input channels
     const int n_ch = C >> 5;        // 32-channel chunks
 
-    // XCD-aware (bijective) remap: blocks with equal b % 8 share an XCD and get a contiguous run of tiles
+    // XCD-aware (bijective) remap: blocks with equal b % 8 share an XCD and get a contiguous run of work
+    // items; item v = (tile group, channel column): the columns of one tile group sit on one XCD (they
+    // read the same patches), the weights of a column stay in that XCD's L2 for the whole group.
     const int nwg = gridDim.x;
     const int b = blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
-    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
-    const int tile_m = wg / p.tiles_n;
-    const int tile_n = wg - tile_m * p.tiles_n;
+    const int v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+    const int grp = v / p.tiles_n;
+    const int tile_n = v - grp * p.tiles_n;
+    const int tile_first = grp * p.tiles_per_img;                      // (field reused: tiles per workgroup)
+    int tile_cnt = p.tiles_m - tile_first;
+    tile_cnt = tile_cnt < p.tiles_per_img ? tile_cnt : p.tiles_per_img;
+    if (tile_cnt <= 0) return;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 31, lh = lane >> 5;
 
-    // first padded pixel of this tile's patch
-    const int p0 = G::BAND ? (tile_m / G::TILES_PER_IMG) * G::IMG_PX + (tile_m % G::TILES_PER_IMG) * G::ROWS * G::PITCH
-                           : tile_m * G::IMGS * G::IMG_PX;
-
-    const __amdgpu_buffer_rsrc_t act_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.act), 0, -1, 0x00020000);
+    // out-of-range bytes of the activation buffer (the last tile's patch pieces run past it) read as zero
+    const __amdgpu_buffer_rsrc_t act_rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.act), 0, p.total_px * C * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t wgt_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wgt), 0, -1, 0x00020000);
 
+    // byte offset of tile t's patch origin (its first padded pixel) in the activation buffer
+    auto patch_origin = [&](int t) -> int {
+        const int p0 = G::BAND ? (t / G::TILES_PER_IMG) * G::IMG_PX + (t % G::TILES_PER_IMG) * G::ROWS * G::PITCH
+                               : t * G::IMGS * G::IMG_PX;
+        return p0 * C * 2;
+    };
+
     // ---- DMA jobs. A stage's copies are a flat list: 12 weight pieces (3 taps x 4 groups of 16 output
-    // channels), then -- in the ky = 0 and ky = 1 stages -- half of the next chunk's patch pieces. Wave w
-    // takes jobs w, w + WAVES, ...; every wave issues the same NUMBER of copies per stage (the counted
-    // vmcnt waits rely on it), surplus slots repeat the list's last piece.
+    // channels), then -- in the ky = 0 and ky = 1 stages -- half of the next patch's pieces. Wave w takes
+    // jobs w, w + WAVES, ...; every wave issues the same NUMBER of copies per stage (the counted vmcnt
+    // waits rely on it), surplus slots repeat the list's last piece.
     constexpr int HALF = (G::NPIECE + 1) / 2;
     constexpr int CNT_P = (12 + HALF + WAVES - 1) / WAVES;  // copies per wave in a stage that also moves patch pieces
     constexpr int CNT_W = (12 + WAVES - 1) / WAVES;         // ... in the ky = 2 stage
     static_assert(CNT_P <= 12, "extend wait_vmcnt");
-    // lane-constant part of the source address of a weight piece: output channel 16*grp + (lane >> 2),
-    // slot (lane & 3) ^ key, key = (n >> 2) & 3
-    const int wl_n = lane >> 2;  // + 16 * grp
-    // patch piece q: pixel 16 q + (lane >> 2), slot lane & 3
+    // patch piece q: patch pixel 16 q + (lane >> 2), slot lane & 3. The swizzle key of a pixel depends on
+    // its padded (row, column); with the tile origins this geometry allows it is the same for every tile.
     auto patch_voff = [&](int q) -> int {
-        int gpx = p0 + 16 * q + (lane >> 2);
-        gpx = gpx < p.total_px ? gpx : p.total_px - 1;
-        const int rem = gpx % G::IMG_PX;
+        const int pp = 16 * q + (lane >> 2);
+        const int rem = pp % G::IMG_PX;             // BAND: patch rows of one image, origin at column 0
         const int r = rem / G::PITCH, c = rem - r * G::PITCH;
         const int key = ((c >> 2) * G::KA + r * G::KB) & 3;
-        return gpx * C * 2 + (((lane & 3) ^ key) << 4);
+        return pp * C * 2 + (((lane & 3) ^ key) << 4);
     };
-    int pvoff[2][CNT_P];  // [half][slot]: -1 = this slot is a weight piece
+    static_assert(!G::BAND || G::KB == 0, "a row band's origin row must not enter the swizzle key");
+    int pvoff[2][CNT_P];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -157,11 +172,14 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_bf16_patch_kernel(const Ge
             job = job < 12 + HALF ? job : 12 + HALF - 1;
             int q = job - 12 + h * HALF;
             q = q < G::NPIECE ? q : G::NPIECE - 1;
-            pvoff[h][i] = job >= 12 ? patch_voff(q) : -1;
+            pvoff[h][i] = job >= 12 ? patch_voff(q) : 0;
         }
+    // weight piece job: tap kx = job >> 2, output channels 16 (job & 3) + (lane >> 2), slot (lane & 3) ^ ((n >> 2) & 3)
+    const int wvoff_base = (tile_n * 64 + (lane >> 2)) * p.ktot * 2;
 
-    // copies of stage (chunk ch, tap row KY) into ring slot SLOT, plus patch pieces of chunk ch_next into patch buffer PB
-#define BP_ISSUE(CH, KY, SLOT, WITH_PATCH, HALF_IDX, CH_NEXT, PB)                                                             \
+    // copies of weight stage (chunk CH, tap row KY) into ring slot SLOT, plus -- WITH_PATCH -- half HALF_IDX of the
+    // patch at byte offset PSOFF of the activation buffer into patch buffer PB
+#define BP_ISSUE(CH, KY, SLOT, WITH_PATCH, HALF_IDX, PSOFF, PB)                                                      \
     {                                                                                                                \
         constexpr int CNT_ = (WITH_PATCH) ? CNT_P : CNT_W;                                                           \
         _Pragma("unroll") for (int i_ = 0; i_ < CNT_; ++i_) {                                                        \
@@ -170,31 +188,37 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_bf16_patch_kernel(const Ge
             job_ = job_ < last_ ? job_ : last_;                                                                      \
             if (job_ < 12) {                                                                                         \
                 const int kx_ = job_ >> 2, grp_ = job_ & 3;                                                          \
-                const int n_ = 16 * grp_ + wl_n;                                                                     \
-                const int voff_ = ((tile_n * 64 + n_) * p.ktot) * 2 + (((lane & 3) ^ ((n_ >> 2) & 3)) << 4);         \
+                const int n_ = 16 * grp_ + (lane >> 2);                                                              \
+                const int voff_ = wvoff_base + 16 * grp_ * p.ktot * 2 + (((lane & 3) ^ ((n_ >> 2) & 3)) << 4);       \
                 dma16(wgt_rs, voff_, (((KY) * 3 + kx_) * C + (CH) * 32) * 2, wring + (SLOT) * WSTAGE_BYTES + job_ * 1024); \
             } else {                                                                                                 \
-                int q_ = job_ - 12 + (HALF_IDX) * HALF;                                                            \
+                int q_ = job_ - 12 + (HALF_IDX) * HALF;                                                              \
                 q_ = q_ < G::NPIECE ? q_ : G::NPIECE - 1;                                                            \
-                dma16(act_rs, pvoff[HALF_IDX][i_], (CH_NEXT) * 64, lds + (PB) * G::PATCH_BYTES + q_ * 1024);         \
+                dma16(act_rs, pvoff[HALF_IDX][i_], (PSOFF), lds + (PB) * G::PATCH_BYTES + q_ * 1024);                \
             }                                                                                                        \
         }                                                                                                            \
     }
 
-    // ---- operand addresses ---------------------------------------------------------------------
+    // ---- operand addresses (tile-independent) ---------------------------------------------------
     // activation fragment of pixel block pi (32 pixels), tap (ky, kx), k group kg: lane reads slot
     // (2 kg + lh) ^ key of patch pixel pbase[pi] + ky*PITCH + kx
-    int pbase[2], prow[2], pcol[2];
+    int pbase[2], prow[2], pcol[2], obase[2];
 #pragma unroll
     for (int pi = 0; pi < 2; ++pi) {
-        int m = tile_m * G::PXT + wave * 64 + pi * 32 + lr;
-        m = m < p.M ? m : p.M - 1;
-        const int img = m / G::HW, rem = m - img * G::HW;
+        const int ml = wave * 64 + pi * 32 + lr;         // pixel inside the tile
+        const int img = ml / G::HW, rem = ml - img * G::HW;   // BAND: img == 0, rem = row * W + column inside the band
         const int oy = rem / W, ox = rem - oy * W;
-        pbase[pi] = (img * G::IMG_PX + oy * G::PITCH + ox - p0) * 64;
+        pbase[pi] = (img * G::IMG_PX + oy * G::PITCH + ox) * 64;
         prow[pi] = oy;
         pcol[pi] = ox;
+        obase[pi] = img * p.out_img_stride + (oy + p.out_pad) * p.out_row_stride + (ox + p.out_pad) * p.out_px_stride +
+                    tile_n * 64 + 8 * lh;
     }
+    // output offset of tile t's first pixel
+    auto out_origin = [&](int t) -> int {
+        return G::BAND ? (t / G::TILES_PER_IMG) * p.out_img_stride + (t % G::TILES_PER_IMG) * G::ROWS * p.out_row_stride
+                       : t * G::IMGS * p.out_img_stride;
+    };
     // weight fragment of channel block ci: row n = 32 ci + lr of the stage, slot (2 kg + lh) ^ ((n >> 2) & 3)
     int wbase[2][2];
 #pragma unroll
@@ -203,6 +227,17 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_bf16_patch_kernel(const Ge
         for (int kg = 0; kg < 2; ++kg) {
             const int n = 32 * ci + lr;
             wbase[ci][kg] = n * 64 + (((2 * kg + lh) ^ ((n >> 2) & 3)) << 4);
+        }
+    // bias of this lane's 4 x 8 output channels (channel column fixed for the workgroup)
+    float bias8[2][2][8];
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float* bp = p.bias + tile_n * 64 + 32 * ci + 16 * j + 8 * lh;
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+            bias8[ci][j][0] = b0.x; bias8[ci][j][1] = b0.y; bias8[ci][j][2] = b0.z; bias8[ci][j][3] = b0.w;
+            bias8[ci][j][4] = b1.x; bias8[ci][j][5] = b1.y; bias8[ci][j][6] = b1.z; bias8[ci][j][7] = b1.w;
         }
 
     f32x16 acc[2][2];
@@ -233,13 +268,14 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_bf16_patch_kernel(const Ge
                                                                         acc[pi_][ci_], 0, 0, 0);                     \
     }
 
-    // ---- prologue: patch of chunk 0, weight stages 0 and 1 -------------------------------------------
+    // ---- prologue: patch of the first tile's chunk 0, weight stages 0 and 1 ----------------------------
     {
-        for (int q = wave; q < G::NPIECE; q += WAVES) dma16(act_rs, patch_voff(q), 0, lds + q * 1024);
+        const int ps0 = patch_origin(tile_first);
+        for (int q = wave; q < G::NPIECE; q += WAVES) dma16(act_rs, patch_voff(q), ps0, lds + q * 1024);
         for (int job = wave; job < 12; job += WAVES) {
-            const int kx = job >> 2, grp = job & 3;
-            const int n = 16 * grp + wl_n;
-            const int voff = ((tile_n * 64 + n) * p.ktot) * 2 + (((lane & 3) ^ ((n >> 2) & 3)) << 4);
+            const int kx = job >> 2, grp_ = job & 3;
+            const int n = 16 * grp_ + (lane >> 2);
+            const int voff = wvoff_base + 16 * grp_ * p.ktot * 2 + (((lane & 3) ^ ((n >> 2) & 3)) << 4);
             dma16(wgt_rs, voff, ((0 * 3 + kx) * C) * 2, wring + 0 * WSTAGE_BYTES + job * 1024);
             dma16(wgt_rs, voff, ((1 * 3 + kx) * C) * 2, wring + 1 * WSTAGE_BYTES + job * 1024);
         }
@@ -248,111 +284,127 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_bf16_patch_kernel(const Ge
     }
     BP_LOAD(0, lds, wring, 0, 0, 0);
 
-    // ---- main loop: chunk outermost, the three tap rows unrolled (ring slot of stage 3 ch + ky is ky) --
-    for (int ch = 0; ch < n_ch; ++ch) {
-        const uint8_t* patch = lds + (ch & 1) * G::PATCH_BYTES;
-        const int pb_next = (ch & 1) ^ 1;
-        const int ch_next = ch + 1 < n_ch ? ch + 1 : ch;   // behind the last chunk: re-fetch it (unused)
+    // ---- main loop over (tile, chunk); the three tap rows unrolled (ring slot of a stage is its ky) -----
+    int pb = 0;  // patch buffer of the current chunk
+    u32x4 res[2][2][2];
+    for (int tk = 0; tk < tile_cnt; ++tk) {
+        const int tile = tile_first + tk;
+        const int ps_tile = patch_origin(tile);
+        const bool more_tiles = tk + 1 < tile_cnt;
+        const int ps_next_tile = patch_origin(more_tiles ? tile + 1 : tile);
+        for (int ch = 0; ch < n_ch; ++ch) {
+            const uint8_t* patch = lds + pb * G::PATCH_BYTES;
+            const int pb_next = pb ^ 1;
+            const bool last_ch = ch + 1 == n_ch;
+            // the patch that follows: next chunk of this tile, or chunk 0 of the next tile; behind the very
+            // last chunk the current one is fetched again (unused) so that every stage issues the same copies
+            const int ps_next = last_ch ? (more_tiles ? ps_next_tile : ps_tile + ch * 64) : ps_tile + (ch + 1) * 64;
+            const bool has_next = !last_ch || more_tiles;
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            // stage t = 3 ch + ky. Copies of stage t + 2 -> ring slot (ky + 2) % 3 (last read in stage t - 1,
-            // whose closing barrier every wave has passed); in ky = 0, 1 also half of the next patch
-            {
-                const int t2ky = (ky + 2) % 3;
-                int ch2 = ky == 0 ? ch : ch + 1;
-                ch2 = ch2 < n_ch ? ch2 : n_ch - 1;  // behind the end: re-fetch an existing stage (unused)
-                if (ky < 2) {
-                    BP_ISSUE(ch2, t2ky, t2ky, true, ky, ch_next, pb_next);
-                } else {
-                    BP_ISSUE(ch2, t2ky, t2ky, false, 0, ch_next, pb_next);
+            for (int ky = 0; ky < 3; ++ky) {
+                // stage (ch, ky). Copies of the stage after next -> ring slot (ky + 2) % 3 (last read one stage
+                // ago, whose closing barrier every wave has passed); in ky = 0, 1 also half of the next patch.
+                // The weights wrap around at the end of a tile (same channel column).
+                if (last_ch && ky == 2 && residual) {
+                    // residual of this tile, requested before this stage's copies so that the stage's counted
+                    // wait also covers it
+                    const int oo = out_origin(tile);
+#pragma unroll
+                    for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+                        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+                                res[pi][ci][j] = *reinterpret_cast<const u32x4*>(residual + oo + obase[pi] + 32 * ci + 16 * j);
                 }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            const uint8_t* wst = wring + ky * WSTAGE_BYTES;
-#pragma unroll
-            for (int g = 0; g < 6; ++g) {  // k group g = (kx, kg)
-                const int kx = g >> 1, kg = g & 1;
-                (void)kx; (void)kg;
-                if (g < 5) {
-                    // operands of the next group before this group's matrix instructions
-                    BP_LOAD((g + 1) & 1, patch, wst, ky, (g + 1) >> 1, (g + 1) & 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                    BP_MFMA(g & 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                } else {
-                    // last group of the stage: its operands were requested one group ago. Close the stage --
-                    // the copies of stage t + 1 (issued a stage ago) have landed once only this stage's own
-                    // copies are outstanding; every wave's reads of this stage are in registers -- then
-                    // request the next stage's first operands and cover their latency with the last
-                    // matrix instructions.
-                    if (ky < 2) wait_vmcnt<CNT_P>(); else wait_vmcnt<CNT_W>();
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    __builtin_amdgcn_sched_barrier(0);
+                {
+                    const int t2ky = (ky + 2) % 3;
+                    int ch2 = ky == 0 ? ch : ch + 1;
+                    ch2 = ch2 < n_ch ? ch2 : 0;
                     if (ky < 2) {
-                        BP_LOAD(0, patch, wring + (ky + 1) * WSTAGE_BYTES, ky + 1, 0, 0);
-                    } else if (ch + 1 < n_ch) {
-                        BP_LOAD(0, lds + pb_next * G::PATCH_BYTES, wring, 0, 0, 0);
+                        BP_ISSUE(ch2, t2ky, t2ky, true, ky, ps_next, pb_next);
+                    } else {
+                        BP_ISSUE(ch2, t2ky, t2ky, false, 0, ps_next, pb_next);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
-                    BP_MFMA(1);
-                    __builtin_amdgcn_sched_barrier(0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const uint8_t* wst = wring + ky * WSTAGE_BYTES;
+#pragma unroll
+                for (int g = 0; g < 6; ++g) {  // k group g = (kx, kg)
+                    if (g < 5) {
+                        // operands of the next group before this group's matrix instructions
+                        BP_LOAD((g + 1) & 1, patch, wst, ky, (g + 1) >> 1, (g + 1) & 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        BP_MFMA(g & 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else {
+                        // last group of the stage: its operands were requested one group ago. Close the stage --
+                        // the copies of the next stage (issued a stage ago) have landed once only this stage's
+                        // own copies are outstanding; every wave's reads of this stage are in registers -- then
+                        // request the next stage's first operands and cover their latency with the last
+                        // matrix instructions.
+                        if (ky < 2) wait_vmcnt<CNT_P>(); else wait_vmcnt<CNT_W>();
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (ky < 2) {
+                            BP_LOAD(0, patch, wring + (ky + 1) * WSTAGE_BYTES, ky + 1, 0, 0);
+                        } else if (has_next) {
+                            BP_LOAD(0, lds + pb_next * G::PATCH_BYTES, wring, 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        BP_MFMA(1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
+            pb = pb_next;
+        }
+        // ---- epilogue of this tile: lane = one pixel; accumulator element e of block (pi, ci) is output
+        // channel 32 ci + 8 (e >> 2) + 4 lh + (e & 3). Swapping halves between lanes l and l + 32 gives each
+        // lane eight consecutive channels: 32 ci + 16 j + 8 lh + 0..7 (j = 0, 1) -> one 16-byte store. The next
+        // tile's first copies are in flight meanwhile.
+        const int oo = out_origin(tile);
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) {
+            const bool valid = tile * G::PXT + wave * 64 + pi * 32 + lr < p.M;
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float vv[8];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        // X = element group 2j (channels 16j + 4lh + i), Y = group 2j + 1 (channels 16j + 8 + 4lh + i)
+                        const uint32_t x = __float_as_uint(acc[pi][ci][8 * j + i]);
+                        const uint32_t y = __float_as_uint(acc[pi][ci][8 * j + 4 + i]);
+                        const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+                        vv[i] = __uint_as_float(r[0]);      // lh = 0: own X (16j + i)       | lh = 1: partner's Y (16j + 8 + i)
+                        vv[4 + i] = __uint_as_float(r[1]);  // lh = 0: partner's X (16j+4+i) | lh = 1: own Y (16j + 12 + i)
+                    }
+                    u32x4 rv = {0u, 0u, 0u, 0u};
+                    if (residual) rv = res[pi][ci][j];
+                    uint32_t pk[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float a0 = vv[2 * k] + bias8[ci][j][2 * k] + __uint_as_float(rv[k] << 16);
+                        float a1 = vv[2 * k + 1] + bias8[ci][j][2 * k + 1] + __uint_as_float(rv[k] & 0xffff0000u);
+                        if (p.relu) {
+                            a0 = a0 > 0.f ? a0 : 0.f;
+                            a1 = a1 > 0.f ? a1 : 0.f;
+                        }
+                        pk[k] = pack_bf16x2(a0, a1);
+                    }
+                    if (valid) *reinterpret_cast<u32x4*>(out + oo + obase[pi] + 32 * ci + 16 * j) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[pi][ci][8 * j + e] = 0.f;
+                }
         }
     }
 #undef BP_LOAD
 #undef BP_MFMA
 #undef BP_ISSUE
     wait_vmcnt<0>();  // the tail's unused re-fetches must not outlive the workgroup's LDS
-
-    // ---- epilogue: lane = one pixel; accumulator element e of block (pi, ci) is output channel
-    // 32 ci + 8 (e >> 2) + 4 lh + (e & 3). Swapping halves between lanes l and l + 32 gives each lane
-    // eight consecutive channels: 32 ci + 16 j + 8 lh + 0..7 (j = 0, 1) -> one 16-byte store.
-#pragma unroll
-    for (int pi = 0; pi < 2; ++pi) {
-        const int m = tile_m * G::PXT + wave * 64 + pi * 32 + lr;
-        const bool valid = m < p.M;
-        const int mm = valid ? m : p.M - 1;
-        const int img = mm / G::HW, rem = mm - img * G::HW;
-        const int oy = rem / W, ox = rem - oy * W;
-        const int o_px = img * p.out_img_stride + (oy + p.out_pad) * p.out_row_stride + (ox + p.out_pad) * p.out_px_stride +
-                         tile_n * 64 + 8 * lh;
-#pragma unroll
-        for (int ci = 0; ci < 2; ++ci)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                float v[8];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    // X = element group 2j (channels 16j + 4lh + i), Y = group 2j + 1 (channels 16j + 8 + 4lh + i)
-                    const uint32_t x = __float_as_uint(acc[pi][ci][8 * j + i]);
-                    const uint32_t y = __float_as_uint(acc[pi][ci][8 * j + 4 + i]);
-                    const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
-                    v[i] = __uint_as_float(r[0]);      // lh = 0: own X (16j + i)      | lh = 1: partner's Y (16j + 8 + i)
-                    v[4 + i] = __uint_as_float(r[1]);  // lh = 0: partner's X (16j+4+i) | lh = 1: own Y (16j + 12 + i)
-                }
-                const int o = o_px + 32 * ci + 16 * j;
-                const int cb = tile_n * 64 + 32 * ci + 16 * j + 8 * lh;
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + cb);
-                const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + cb + 4);
-                const float bs[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-                u32x4 rv = {0u, 0u, 0u, 0u};
-                if (residual) rv = *reinterpret_cast<const u32x4*>(residual + o);
-                uint32_t pk[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float a0 = v[2 * k] + bs[2 * k] + __uint_as_float(rv[k] << 16);
-                    float a1 = v[2 * k + 1] + bs[2 * k + 1] + __uint_as_float(rv[k] & 0xffff0000u);
-                    if (p.relu) {
-                        a0 = a0 > 0.f ? a0 : 0.f;
-                        a1 = a1 > 0.f ? a1 : 0.f;
-                    }
-                    pk[k] = pack_bf16x2(a0, a1);
-                }
-                if (valid) *reinterpret_cast<u32x4*>(out + o) = u32x4{pk[0], pk[1], pk[2], pk[3]};
-            }
-    }
 }
 
 // p: GemmParams as for launch_igemm_bf16 (conv mode, 3x3, stride 1, no second source, chunk = Cin, ktot = 9 Cin,
@@ -368,12 +420,29 @@ hipError_t launch_conv3x3_bf16_patch(const GemmParams& p_in, hipStream_t s) {
         p.in_px_stride != p.chunk || p.off_y != 0 || p.off_x != 0)
         return hipErrorInvalidValue;
     p.total_px = (p.M / p.howo) * (W + 2) * (W + 2);
-    static const int waves8 = getenv("PA_BF16_WAVES8") ? atoi(getenv("PA_BF16_WAVES8")) : 0;  // bit mask over {32,16,8}: 512-thread tiles
+    if ((long long)p.total_px * p.chunk * 2 >= (1ll << 31)) return hipErrorInvalidValue;  // 32-bit buffer offsets
+    static const int waves8 = getenv("PA_BF16_WAVES8") ? atoi(getenv("PA_BF16_WAVES8")) : 0;  // bit mask over {32,16,8}: flips the default
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidValue;
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
     p.tiles_n = p.N / 64;
+    // persistent workgroups: WGPC per CU (what the LDS image allows), each a run of consecutive pixel tiles
+    // of one channel column
 #define BPL(W_, WV_)                                                                                                 \
     {                                                                                                                \
-        p.tiles_m = (p.M + 64 * WV_ - 1) / (64 * WV_);                                                               \
-        hipLaunchKernelGGL((conv3x3_bf16_patch_kernel<W_, WV_>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WV_), 0, s, p); \
+        using G_ = PatchGeom<W_, WV_>;                                                                               \
+        constexpr int lds_ = 2 * G_::PATCH_BYTES + NSTG * WSTAGE_BYTES;                                              \
+        const int wgpc_ = lds_ <= 81920 ? 2 : 1;                                                                     \
+        p.tiles_m = (p.M + G_::PXT - 1) / G_::PXT;                                                                   \
+        int slots_ = n_cu * wgpc_ / p.tiles_n;                                                                       \
+        slots_ = slots_ > 0 ? slots_ : 1;                                                                            \
+        p.tiles_per_img = (p.tiles_m + slots_ - 1) / slots_;          /* tiles per workgroup */                     \
+        const int groups_ = (p.tiles_m + p.tiles_per_img - 1) / p.tiles_per_img;                                     \
+        hipLaunchKernelGGL((conv3x3_bf16_patch_kernel<W_, WV_>), dim3(groups_ * p.tiles_n), dim3(64 * WV_), 0, s, p); \
     }
     switch (W) {
         case 32: if (waves8 & 1) BPL(32, 8) else BPL(32, 4) break;

@@ -617,8 +617,15 @@ __device__ __forceinline__ void write_crop_pixel(const PreprocParams& p, int cro
         v.z = (float)o2 / 255.0f;
         v.w = 0.f;
         const int dy = i >> 7, dx = i & 127;
-        float4* o = reinterpret_cast<float4*>(p.crops_f32) + ((size_t)crop * 134 + (dy + 3)) * 134 + (dx + 3);
-        *o = v;
+        const size_t o = ((size_t)crop * 134 + (dy + 3)) * 134 + (dx + 3);
+        if (p.crops_f32_is_bf16) {  // bf16 conv path: the /255 quotient rounded to bf16 (nearest even)
+            uint32_t u[3] = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z)};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) u[k] = (u[k] + 0x7fffu + ((u[k] >> 16) & 1u)) >> 16;
+            reinterpret_cast<uint2*>(p.crops_f32)[o] = make_uint2(u[0] | (u[1] << 16), u[2]);
+        } else {
+            reinterpret_cast<float4*>(p.crops_f32)[o] = v;
+        }
     }
 }
 

@@ -288,7 +288,7 @@ def test_profile_rows(engine):
     rows = engine.profile_read()
     engine.profile_enable(False)
     names = {r["name"] for r in rows}
-    assert {"preprocess_crops", "igemm_conv3x3", "stem_conv7x7", "head_mlp_logsoftmax"} <= names
+    assert {"preprocess_crops", "igemm_conv3x3", "stem_conv7x7_pool", "head_mlp_logsoftmax"} <= names
     conv = next(r for r in rows if r["name"] == "igemm_conv3x3")
     assert conv["launches"] == 16 and conv["total_ms"] > 0 and conv["flops"] > 1e9
 
