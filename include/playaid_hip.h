@@ -157,6 +157,33 @@ int pa_square_crops(pa_engine* e, const uint8_t* frames, int32_t n, int32_t heig
                     const double* boxes, int32_t padding, int32_t swap_rb, uint8_t* crops,
                     int32_t* status, void* stream);
 
+/* ---- a5: the runner's own input branch ----------------------------------- */
+
+/* One crop image inside a byte buffer: what YOLOv5 --save-crop wrote and cv2.imread returns
+ * (ai_runner.py:445-446), uint8 [height][width][3], BGR, rows packed. */
+typedef struct pa_crop_image {
+    int64_t offset;  /* byte offset of the image in `images` */
+    int32_t height;
+    int32_t width;
+} pa_crop_image;
+
+/* Replaces the per-frame body of AIRunner.get_action_recognition_input_for_frame (ai_runner.py:446-459)
+ * for n_crops crop images of ANY size at once: BGR2RGB (swap_rb = 1) -> imutils.resize(width=128)
+ * = cv2.resize(INTER_AREA) to (128, int(h * (128 / w))) -> ImageOps.pad((128, 128), black) when that is
+ * not 128 rows (tall crops are BICUBIC-shrunk and letterboxed left/right, wide ones letterboxed top/bottom).
+ * images: device bytes; desc: device pa_crop_image[n_crops]; inputs_u8: uint8[n_crops][128][128][3] (the
+ * `frames` list of :459-464); status: int32[n_crops] PA_CROP_* (PA_CROP_BAD_BOX: descriptor outside the
+ * buffer or larger than max_frame_height x max_frame_width; PA_CROP_EMPTY: int(h*128/w) == 0, where
+ * cv2.resize raises; PA_CROP_FILTER_TOO_WIDE: taller than 3.5 x 128 rows after the resize). */
+int pa_runner_inputs(pa_engine* e, const uint8_t* images, size_t images_bytes, const pa_crop_image* desc, int32_t n_crops,
+                     int32_t swap_rb, uint8_t* inputs_u8, int32_t* status, void* stream);
+
+/* pa_backbone_frames for a clip that arrives as crop IMAGES instead of frames + boxes (the reference's
+ * actual on-disk hand-off, crops/<Fighter>/<video>_<n>.jpg after decoding): n frames x num_fighters images in
+ * (frame, fighter) order -> runner inputs -> ResNet-18 features in the cache rows of frames frame0... */
+int pa_backbone_crop_images(pa_engine* e, const uint8_t* images, size_t images_bytes, const pa_crop_image* desc, int32_t n,
+                            int32_t frame0, uint8_t* crops_rgb, int32_t* status, void* stream);
+
 /* Boxes from the game log instead of a detector. Replaces the
  * projection half of Fighter.set_from_json (fighter.py:494-539: calculate_lookat_matrix,
  * calculate_intrinsic_matrix, project_point_to_pixel on four corners, all for the

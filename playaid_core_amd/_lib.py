@@ -65,6 +65,10 @@ class pa_record(C.Structure):
     ]
 
 
+class pa_crop_image(C.Structure):
+    _fields_ = [("offset", C.c_int64), ("height", C.c_int32), ("width", C.c_int32)]
+
+
 class pa_kernel_stat(C.Structure):
     _fields_ = [
         ("name", C.c_char * 48),
@@ -89,6 +93,8 @@ SYMBOLS = [
     ("pa_weight_blob_bytes", C.c_size_t, [C.c_int, C.c_int]),
     ("pa_infer_windows", C.c_int, [_P, _P, C.c_int32, _P, _P]),
     ("pa_square_crops", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, _P]),
+    ("pa_runner_inputs", C.c_int, [_P, _P, C.c_size_t, _P, C.c_int32, C.c_int32, _P, _P, _P]),
+    ("pa_backbone_crop_images", C.c_int, [_P, _P, C.c_size_t, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     ("pa_project_boxes", C.c_int, [_P, _P, C.c_int32, _P, _P]),
     ("pa_clip_begin", C.c_int, [_P, C.c_int32]),
     ("pa_backbone_frames", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, _P]),

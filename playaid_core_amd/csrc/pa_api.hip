@@ -920,7 +920,9 @@ int create_impl(const pa_config* cfg, const void* blob, size_t src_bytes, const 
     }
     // preprocess scratch
     e->coef_dim = std::max(cfg->max_frame_height, cfg->max_frame_width);
-    e->t_stride = (size_t)cfg->max_frame_height * cfg->max_frame_width * 3;
+    // per-crop scratch of the resamplers: a whole frame slice, and at least the runner-input branch's worst
+    // case (INTER_AREA result of 448 rows + the 128 rows behind the vertical pass, 128 px x 3 B each)
+    e->t_stride = std::max((size_t)cfg->max_frame_height * cfg->max_frame_width * 3, (size_t)(448 + 128) * PA_CROP * 3);
     ALLOC(e->plans, (size_t)NC, true);
     ALLOC(e->fallback, (size_t)NC + 4, true);
     ALLOC(e->coef, (size_t)NC * 2 * e->coef_dim * (2 + PA_KSIZE_MAX), false);
@@ -1004,6 +1006,53 @@ int pa_square_crops(pa_engine* e, const uint8_t* frames, int32_t n, int32_t heig
     if (n > e->cfg.max_batch_frames || height > e->cfg.max_frame_height || width > e->cfg.max_frame_width)
         return fail(e, PA_ERR_CAPACITY, "pa_square_crops: frames exceed engine capacity");
     return run_preprocess(e, frames, n, height, width, boxes, padding, swap_rb, crops, nullptr, status, (hipStream_t)stream);
+}
+
+namespace {
+int run_runner_inputs(pa_engine* e, const uint8_t* images, size_t images_bytes, const pa_crop_image* desc, int n, int swap_rb,
+                      uint8_t* inputs_u8, float* inputs_f32, int32_t* status, hipStream_t s) {
+    RunnerInParams q;
+    memset(&q, 0, sizeof(q));
+    q.images = images;
+    q.images_bytes = (long long)images_bytes;
+    q.desc = reinterpret_cast<const CropImageDesc*>(desc);
+    q.n = n;
+    q.swap_rb = swap_rb;
+    q.max_h = e->cfg.max_frame_height;
+    q.max_w = e->cfg.max_frame_width;
+    q.t1 = e->t1;
+    q.t2 = e->t2;
+    q.t_stride = e->t_stride;
+    q.inputs_u8 = inputs_u8;
+    q.inputs_f32 = inputs_f32;
+    q.inputs_f32_is_bf16 = e->bf16 ? 1 : 0;
+    q.status = status;
+    ProfScope ps(e, s, "runner_inputs", 0.0, (double)images_bytes + (double)n * 49152.0 * 5);
+    HIPCHK(e, launch_runner_inputs(q, s));
+    return PA_OK;
+}
+}  // namespace
+
+int pa_runner_inputs(pa_engine* e, const uint8_t* images, size_t images_bytes, const pa_crop_image* desc, int32_t n_crops,
+                     int32_t swap_rb, uint8_t* inputs_u8, int32_t* status, void* stream) {
+    static_assert(sizeof(pa_crop_image) == sizeof(CropImageDesc), "descriptor layouts must agree");
+    if (!e || !images || !desc || !inputs_u8 || n_crops < 1) return fail(e, PA_ERR_INVALID_ARG, "pa_runner_inputs: bad argument");
+    if (n_crops > e->max_crops) return fail(e, PA_ERR_CAPACITY, "pa_runner_inputs: more crops than max_batch_frames * num_fighters");
+    return run_runner_inputs(e, images, images_bytes, desc, n_crops, swap_rb, inputs_u8, nullptr, status, (hipStream_t)stream);
+}
+
+int pa_backbone_crop_images(pa_engine* e, const uint8_t* images, size_t images_bytes, const pa_crop_image* desc, int32_t n,
+                            int32_t frame0, uint8_t* crops_rgb, int32_t* status, void* stream) {
+    if (!e || !images || !desc || n < 1 || frame0 < 0) return fail(e, PA_ERR_INVALID_ARG, "pa_backbone_crop_images: bad argument");
+    if (e->clip_frames < 1) return fail(e, PA_ERR_INVALID_ARG, "pa_backbone_crop_images: call pa_clip_begin first");
+    if (n > e->cfg.max_batch_frames || frame0 + n > e->clip_frames)
+        return fail(e, PA_ERR_CAPACITY, "pa_backbone_crop_images: frames exceed engine / clip capacity");
+    hipStream_t s = (hipStream_t)stream;
+    const int F = e->cfg.num_fighters;
+    int rc = run_runner_inputs(e, images, images_bytes, desc, n * F, 1, crops_rgb, e->x0_slot[0], e->pre_status[0], s);
+    if (rc) return rc;
+    if (status) HIPCHK(e, hipMemcpyAsync(status, e->pre_status[0], sizeof(int32_t) * n * F, hipMemcpyDeviceToDevice, s));
+    return pa_backbone_slot(e, 0, n, frame0, stream);
 }
 
 int pa_project_boxes(pa_engine* e, const double* log_rows, int32_t n_rows, double* boxes, void* stream) {

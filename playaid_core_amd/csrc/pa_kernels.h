@@ -144,6 +144,26 @@ struct PreprocParams {
 };
 
 hipError_t launch_preprocess(const PreprocParams& p, hipStream_t s);
+
+// crop images of any size -> runner inputs (ai_runner.py:446-459), see runner_input_kernel
+struct CropImageDesc {  // == pa_crop_image of the public header
+    int64_t offset;     // byte offset of the image inside `images`
+    int32_t height, width;
+};
+struct RunnerInParams {
+    const uint8_t* images;      // concatenated uint8 [h][w][3] images
+    long long images_bytes;
+    const CropImageDesc* desc;  // [n] (device)
+    int32_t n, swap_rb, max_h, max_w;
+    uint8_t* t1;                // scratch, t_stride bytes per image each
+    uint8_t* t2;
+    size_t t_stride;
+    uint8_t* inputs_u8;         // [n][128][128][3] or nullptr
+    float* inputs_f32;          // [n][134][134][4] zero-bordered model input (fp32, or bf16 storage) or nullptr
+    int32_t inputs_f32_is_bf16;
+    int32_t* status;            // [n] PA_CROP_* or nullptr
+};
+hipError_t launch_runner_inputs(const RunnerInParams& q, hipStream_t s);
 // per-device one-time setup of the crop stage (dynamic-LDS attribute); call with the device current
 hipError_t preprocess_init_device();
 // log rows [n][9] (pos_x,pos_y,cam xyz,target xyz,fov deg) -> normalised boxes [n][4]

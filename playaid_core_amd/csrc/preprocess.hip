@@ -1102,6 +1102,301 @@ hipError_t launch_project_boxes(const double* log, double* boxes, int32_t n, hip
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// The runner's own input branch (playaid/ai_runner.py:446-459): a crop IMAGE of any size -- what
+// YOLOv5 --save-crop writes and cv2.imread returns, uint8 [h][w][3] BGR -- becomes the 128 x 128 model
+// input by  BGR2RGB -> imutils.resize(width=128) = cv2.resize(INTER_AREA) to (128, int(h * (128 / w)))
+// -> ImageOps.pad((128, 128), black) when that is not 128 rows (Pillow: aspect-preserving BICUBIC
+// "contain", pasted centred). The order of the two resamplers is the reverse of square_crop's, and the
+// INTER_AREA source is not square, so this is its own kernel: one workgroup per image, the three
+// passes over L2-resident scratch (t1: INTER_AREA result, t2: after the horizontal bicubic pass, then
+// t1's second half: after the vertical pass), coefficient tables in LDS. Same integer / IEEE arithmetic
+// as the fused path (shared helpers above), bit-exact against oracle/yolo_crop.runner_input_from_crop.
+struct RunnerInPlan {
+    int status;
+    int sw, sh;          // source image
+    int oh;              // INTER_AREA destination height (width 128)
+    int mode;            // 0 copy, 1 2x2, 2 integer, 3 general, 4 enlarging (bilinear emulation)
+    int isx, isy;
+    double scale_x, scale_y;
+    int rw, rh, px, py;  // ImageOps.pad: size after contain, paste offset (rw == 128 && rh == 128: no pad step)
+    int need_h, need_v;
+};
+
+struct WhCanvas {  // plain [rows][cols][3] bytes
+    const uint8_t* src;
+    int pitch;
+    __device__ __forceinline__ void load(int y, int x, int& c0, int& c1, int& c2) const {
+        const uint8_t* s = src + (size_t)y * pitch + x * 3;
+        c0 = s[0]; c1 = s[1]; c2 = s[2];
+    }
+};
+
+// One destination pixel of cv::resize(INTER_AREA) from an sw x sh image to 128 x oh (area_pixel() with
+// separate axes; the source is a plain image, no paste window).
+__device__ __forceinline__ void area_pixel_wh(const RunnerInPlan& pl, const WhCanvas& cv, int dy, int dx, int& o0, int& o1, int& o2) {
+    if (pl.mode == 0) {
+        cv.load(dy, dx, o0, o1, o2);
+    } else if (pl.mode == 1) {
+        int s0 = 2, s1 = 2, s2 = 2;
+        for (int yy = 0; yy < 2; ++yy)
+            for (int xx = 0; xx < 2; ++xx) {
+                int c0, c1, c2;
+                cv.load(dy * 2 + yy, dx * 2 + xx, c0, c1, c2);
+                s0 += c0; s1 += c1; s2 += c2;
+            }
+        o0 = s0 >> 2; o1 = s1 >> 2; o2 = s2 >> 2;
+    } else if (pl.mode == 2) {
+        int s0 = 0, s1 = 0, s2 = 0;
+        for (int yy = 0; yy < pl.isy; ++yy)
+            for (int xx = 0; xx < pl.isx; ++xx) {
+                int c0, c1, c2;
+                cv.load(dy * pl.isy + yy, dx * pl.isx + xx, c0, c1, c2);
+                s0 += c0; s1 += c1; s2 += c2;
+            }
+        const float scale = 1.f / (float)(pl.isx * pl.isy);
+        o0 = cv_saturate_u8((float)s0 * scale);
+        o1 = cv_saturate_u8((float)s1 * scale);
+        o2 = cv_saturate_u8((float)s2 * scale);
+    } else if (pl.mode == 4) {
+        // cv::resize's 8-bit bilinear resizer with area-mode coefficients (see area_pixel())
+        const double inv_x = 128.0 / (double)pl.sw, inv_y = (double)pl.oh / (double)pl.sh;
+        int sx = (int)floor((double)dx * pl.scale_x);
+        float fx = (float)((double)(dx + 1) - (double)(sx + 1) * inv_x);
+        fx = fx <= 0.f ? 0.f : fx - floorf(fx);
+        const bool plain = sx + 1 >= pl.sw;
+        if (sx >= pl.sw - 1) {
+            fx = 0.f;
+            sx = pl.sw - 1;
+        }
+        const int a0 = (int)rintf((1.f - fx) * 2048.f), a1 = (int)rintf(fx * 2048.f);
+        const int sy = (int)floor((double)dy * pl.scale_y);
+        float fy = (float)((double)(dy + 1) - (double)(sy + 1) * inv_y);
+        fy = fy <= 0.f ? 0.f : fy - floorf(fy);
+        const int b0 = (int)rintf((1.f - fy) * 2048.f), b1 = (int)rintf(fy * 2048.f);
+        const int r0 = sy < pl.sh - 1 ? sy : pl.sh - 1;
+        const int r1 = sy + 1 < pl.sh - 1 ? sy + 1 : pl.sh - 1;
+        int h0[3], h1[3];
+        int c0, c1, c2, e0 = 0, e1 = 0, e2 = 0;
+        cv.load(r0, sx, c0, c1, c2);
+        if (!plain) cv.load(r0, sx + 1, e0, e1, e2);
+        h0[0] = plain ? c0 * 2048 : c0 * a0 + e0 * a1;
+        h0[1] = plain ? c1 * 2048 : c1 * a0 + e1 * a1;
+        h0[2] = plain ? c2 * 2048 : c2 * a0 + e2 * a1;
+        cv.load(r1, sx, c0, c1, c2);
+        if (!plain) cv.load(r1, sx + 1, e0, e1, e2);
+        h1[0] = plain ? c0 * 2048 : c0 * a0 + e0 * a1;
+        h1[1] = plain ? c1 * 2048 : c1 * a0 + e1 * a1;
+        h1[2] = plain ? c2 * 2048 : c2 * a0 + e2 * a1;
+        o0 = ((((b0 * (h0[0] >> 4)) >> 16) + ((b1 * (h1[0] >> 4)) >> 16) + 2) >> 2) & 0xff;
+        o1 = ((((b0 * (h0[1] >> 4)) >> 16) + ((b1 * (h1[1] >> 4)) >> 16) + 2) >> 2) & 0xff;
+        o2 = ((((b0 * (h0[2] >> 4)) >> 16) + ((b1 * (h1[2] >> 4)) >> 16) + 2) >> 2) & 0xff;
+    } else {
+        const AreaTab tx = area_tab(dx, pl.scale_x, pl.sw);
+        const AreaTab ty = area_tab(dy, pl.scale_y, pl.sh);
+        float sum0 = 0.f, sum1 = 0.f, sum2 = 0.f;
+        for (int j = 0; j < ty.n; ++j) {
+            const float beta = area_alpha(ty, j);
+            float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+            for (int k = 0; k < tx.n; ++k) {
+                const float alpha = area_alpha(tx, k);
+                int c0, c1, c2;
+                cv.load(ty.s_first + j, tx.s_first + k, c0, c1, c2);
+                b0 = b0 + (float)c0 * alpha;
+                b1 = b1 + (float)c1 * alpha;
+                b2 = b2 + (float)c2 * alpha;
+            }
+            sum0 = sum0 + beta * b0;
+            sum1 = sum1 + beta * b1;
+            sum2 = sum2 + beta * b2;
+        }
+        o0 = cv_saturate_u8(sum0);
+        o1 = cv_saturate_u8(sum1);
+        o2 = cv_saturate_u8(sum2);
+    }
+}
+
+// Pillow precompute_coeffs + normalize_coeffs_8bpc for output coordinate xx of a pass in_size -> out_size
+// (the arithmetic of crop_coef_kernel), into row[0] = first tap, row[1] = tap count, row[2..] = coefficients.
+__device__ void bicubic_coef_row(int in_size, int out_size, int xx, int32_t* row) {
+    const double scale = (double)(float)in_size / out_size;
+    const double filterscale = scale < 1.0 ? 1.0 : scale;
+    const double support = 2.0 * filterscale;
+    const double ss = 1.0 / filterscale;
+    const double center = 0.0 + (xx + 0.5) * scale;
+    int xmin = (int)(center - support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5);
+    if (xmax > in_size) xmax = in_size;
+    xmax -= xmin;
+    double k[PA_KSIZE_MAX];
+    double ww = 0.0;
+    for (int x = 0; x < PA_KSIZE_MAX; ++x) {
+        double w = 0.0;
+        if (x < xmax) {
+            w = bicubic_filter((x + xmin - center + 0.5) * ss);
+            ww += w;
+        }
+        k[x] = w;
+    }
+    row[0] = xmin;
+    row[1] = xmax;
+    for (int x = 0; x < PA_KSIZE_MAX; ++x) {
+        double v = k[x];
+        if (x < xmax && ww != 0.0) v = v / ww;
+        row[2 + x] = v < 0 ? (int)(-0.5 + v * (double)(1 << PRECISION_BITS)) : (int)(0.5 + v * (double)(1 << PRECISION_BITS));
+    }
+}
+
+__global__ __launch_bounds__(256) void runner_input_kernel(const RunnerInParams q) {
+    __shared__ int32_t coef[2][PA_CROP][COEF_ROW];  // [axis][output coordinate]: both passes end at <= 128 outputs
+    const int crop = blockIdx.x;
+    const int tid = threadIdx.x;
+    PreprocParams out;  // write_crop_pixel() only reads these fields
+    out.swap_rb = q.swap_rb;
+    out.crops_u8 = q.inputs_u8;
+    out.crops_f32 = q.inputs_f32;
+    out.crops_f32_is_bf16 = q.inputs_f32_is_bf16;
+    RunnerInPlan pl;
+    pl.status = PA_CROP_OK;
+    const long long off = q.desc[crop].offset;
+    pl.sh = q.desc[crop].height;
+    pl.sw = q.desc[crop].width;
+    pl.oh = 0; pl.mode = 0; pl.isx = pl.isy = 1; pl.scale_x = pl.scale_y = 1.0;
+    pl.rw = pl.rh = PA_CROP; pl.px = pl.py = 0; pl.need_h = pl.need_v = 0;
+    if (pl.sh < 1 || pl.sw < 1 || pl.sh > q.max_h || pl.sw > q.max_w || off < 0 ||
+        off + (long long)pl.sh * pl.sw * 3 > q.images_bytes)
+        pl.status = PA_CROP_BAD_BOX;
+    if (pl.status == PA_CROP_OK) {
+        // imutils.resize(width=128): dim = (128, int(h * (128 / float(w))))
+        const double r = 128.0 / (double)pl.sw;
+        const double ohd = (double)pl.sh * r;
+        pl.oh = ohd < 2.0e9 ? (int)ohd : 0;
+        if (pl.oh < 1) pl.status = PA_CROP_EMPTY;  // cv2.resize raises for an empty destination
+    }
+    if (pl.status == PA_CROP_OK) {
+        const double inv_sx = 128.0 / (double)pl.sw, inv_sy = (double)pl.oh / (double)pl.sh;
+        pl.scale_x = 1.0 / inv_sx;
+        pl.scale_y = 1.0 / inv_sy;
+        if (pl.sw == PA_CROP && pl.sh == pl.oh) {
+            pl.mode = 0;
+        } else if (pl.scale_x < 1.0 || pl.scale_y < 1.0) {
+            pl.mode = 4;
+        } else {
+            pl.isx = (int)rint(pl.scale_x);
+            pl.isy = (int)rint(pl.scale_y);
+            const bool fast = fabs(pl.scale_x - pl.isx) < 2.220446049250313e-16 && fabs(pl.scale_y - pl.isy) < 2.220446049250313e-16;
+            pl.mode = fast ? ((pl.isx == 2 && pl.isy == 2) ? 1 : 2) : 3;
+        }
+        if (pl.oh != PA_CROP) {
+            // ImageOps.pad(img 128 x oh, (128, 128)): contain keeps the aspect ratio (ImageOps.py)
+            const double im_ratio = 128.0 / (double)pl.oh;
+            if (im_ratio > 1.0) {
+                const int nh = (int)rint((double)pl.oh / 128.0 * 128.0);
+                if (nh != PA_CROP) pl.rh = nh;
+            } else {
+                const int nw = (int)rint(128.0 / (double)pl.oh * 128.0);
+                if (nw != PA_CROP) pl.rw = nw;
+            }
+            if (pl.rw < 1 || pl.rh < 1) pl.status = PA_CROP_EMPTY;
+            pl.need_h = pl.rw != PA_CROP;
+            pl.need_v = pl.rh != pl.oh;
+            if (pl.rw != PA_CROP)
+                pl.px = (int)rint((double)(PA_CROP - pl.rw) * 0.5);
+            else if (pl.rh != PA_CROP)
+                pl.py = (int)rint((double)(PA_CROP - pl.rh) * 0.5);
+            if ((pl.need_h && bicubic_ksize(PA_CROP, pl.rw) > PA_KSIZE_MAX) || (pl.need_v && bicubic_ksize(pl.oh, pl.rh) > PA_KSIZE_MAX))
+                pl.status = PA_CROP_FILTER_TOO_WIDE;
+        }
+        if ((size_t)(pl.oh + (pl.need_v ? pl.rh : 0)) * PA_CROP * 3 > q.t_stride) pl.status = PA_CROP_FILTER_TOO_WIDE;  // scratch
+    }
+    if (tid == 0 && q.status) q.status[crop] = pl.status;
+    if (pl.status != PA_CROP_OK) {
+        for (int i = tid; i < PA_CROP * PA_CROP; i += 256) write_crop_pixel(out, crop, i, 0, 0, 0);
+        return;
+    }
+    // ---- INTER_AREA: image -> A = t1[crop] as [oh][128][3]
+    uint8_t* A = q.t1 + (size_t)crop * q.t_stride;
+    {
+        WhCanvas cv;
+        cv.src = q.images + off;
+        cv.pitch = pl.sw * 3;
+        for (int i = tid; i < pl.oh * PA_CROP; i += 256) {
+            const int dy = i >> 7, dx = i & 127;
+            int o0, o1, o2;
+            area_pixel_wh(pl, cv, dy, dx, o0, o1, o2);
+            uint8_t* o = A + (size_t)i * 3;
+            o[0] = (uint8_t)o0; o[1] = (uint8_t)o1; o[2] = (uint8_t)o2;
+        }
+    }
+    // coefficient tables of the pad step (fp64, one output coordinate per thread)
+    if (pl.need_h && tid < pl.rw) bicubic_coef_row(PA_CROP, pl.rw, tid, coef[0][tid]);
+    if (pl.need_v && tid >= 128 && tid - 128 < pl.rh) bicubic_coef_row(pl.oh, pl.rh, tid - 128, coef[1][tid - 128]);
+    __threadfence();
+    __syncthreads();
+    const uint8_t* cur = A;
+    int cur_w = PA_CROP, cur_h = pl.oh;
+    if (pl.need_h) {  // ImagingResampleHorizontal_8bpc: [oh][128] -> B = t2[crop] as [oh][rw]
+        uint8_t* B = q.t2 + (size_t)crop * q.t_stride;
+        for (int i = tid; i < pl.oh * pl.rw; i += 256) {
+            const int y = i / pl.rw, xx = i - y * pl.rw;
+            const int32_t* row = coef[0][xx];
+            const uint8_t* sp = cur + ((size_t)y * cur_w + row[0]) * 3;
+            int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
+            for (int t = 0; t < row[1]; ++t) {
+                const int k = row[2 + t];
+                a0 += __mul24((int)sp[3 * t + 0], k);
+                a1 += __mul24((int)sp[3 * t + 1], k);
+                a2 += __mul24((int)sp[3 * t + 2], k);
+            }
+            uint8_t* o = B + (size_t)i * 3;
+            o[0] = (uint8_t)clip8(a0); o[1] = (uint8_t)clip8(a1); o[2] = (uint8_t)clip8(a2);
+        }
+        __threadfence();
+        __syncthreads();
+        cur = B;
+        cur_w = pl.rw;
+    }
+    if (pl.need_v) {  // ImagingResampleVertical_8bpc: [oh][cur_w] -> C = second half of t1[crop] as [rh][cur_w]
+        uint8_t* Cb = A + (size_t)pl.oh * PA_CROP * 3;
+        for (int i = tid; i < pl.rh * cur_w; i += 256) {
+            const int yy = i / cur_w, x = i - yy * cur_w;
+            const int32_t* row = coef[1][yy];
+            const uint8_t* sp = cur + ((size_t)row[0] * cur_w + x) * 3;
+            int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
+            for (int t = 0; t < row[1]; ++t) {
+                const int k = row[2 + t];
+                a0 += __mul24((int)sp[0], k);
+                a1 += __mul24((int)sp[1], k);
+                a2 += __mul24((int)sp[2], k);
+                sp += (size_t)cur_w * 3;
+            }
+            uint8_t* o = Cb + (size_t)i * 3;
+            o[0] = (uint8_t)clip8(a0); o[1] = (uint8_t)clip8(a1); o[2] = (uint8_t)clip8(a2);
+        }
+        __threadfence();
+        __syncthreads();
+        cur = Cb;
+        cur_h = pl.rh;
+    }
+    // paste on the black 128 x 128 canvas, channel swap, u8 + model input
+    for (int i = tid; i < PA_CROP * PA_CROP; i += 256) {
+        const int y = (i >> 7) - pl.py, x = (i & 127) - pl.px;
+        int o0 = 0, o1 = 0, o2 = 0;
+        if ((unsigned)y < (unsigned)cur_h && (unsigned)x < (unsigned)cur_w) {
+            const uint8_t* sp = cur + ((size_t)y * cur_w + x) * 3;
+            o0 = sp[0]; o1 = sp[1]; o2 = sp[2];
+        }
+        write_crop_pixel(out, crop, i, o0, o1, o2);
+    }
+}
+
+hipError_t launch_runner_inputs(const RunnerInParams& q, hipStream_t s) {
+    if (q.n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(runner_input_kernel, dim3(q.n), dim3(256), 0, s, q);
+    return hipGetLastError();
+}
+
 hipError_t preprocess_init_device() {
     // dynamic LDS beyond the 64 KiB default; the attribute is per device, so pa_create sets it for its own
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&crop_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -195,6 +195,67 @@ class Engine:
         torch.cuda.synchronize(self.device)
         return crops[:, :nf].cpu().numpy(), status[:, :nf].cpu().numpy()
 
+    # -- a5: crop images -> runner inputs ------------------------------------
+    def _pack_crop_images(self, images):
+        """list of uint8[h_i, w_i, 3] -> (device byte tensor, device descriptor tensor int64[n, 2])."""
+        flat, desc, off = [], np.zeros((len(images), 2), dtype=np.int64), 0
+        for i, im in enumerate(images):
+            im = np.ascontiguousarray(im, dtype=np.uint8)
+            if im.ndim != 3 or im.shape[2] != 3:
+                raise ValueError("crop images are uint8[h, w, 3]")
+            desc[i, 0] = off
+            desc[i, 1] = (im.shape[1] << 32) | im.shape[0]  # int32 height, int32 width (little endian struct)
+            flat.append(im.reshape(-1))
+            off += (im.size + 15) & ~15
+            flat.append(np.zeros(((im.size + 15) & ~15) - im.size, np.uint8))
+        buf = torch.from_numpy(np.concatenate(flat) if flat else np.zeros(16, np.uint8)).to(self.device)
+        return buf, torch.from_numpy(desc).to(self.device)
+
+    def runner_inputs(self, images, swap_rb: bool = True):
+        """``AIRunner.get_action_recognition_input_for_frame``'s per-frame preprocessing
+        (``ai_runner.py:446-459``) for a list of BGR crop images of any size ->
+        (uint8[n,128,128,3] RGB, status int32[n]) on the host."""
+        out_c, out_s = [], []
+        step = self.max_batch_frames * self.F
+        for i0 in range(0, len(images), step):
+            chunk = images[i0 : i0 + step]
+            buf, desc = self._pack_crop_images(chunk)
+            out = torch.empty((len(chunk), 128, 128, 3), dtype=torch.uint8, device=self.device)
+            st = torch.empty((len(chunk),), dtype=torch.int32, device=self.device)
+            self._check(self._lib.pa_runner_inputs(self._h, _ptr(buf), buf.numel(), _ptr(desc), len(chunk), int(swap_rb),
+                                                   _ptr(out), _ptr(st), self._stream()))
+            torch.cuda.synchronize(self.device)
+            out_c.append(out.cpu().numpy())
+            out_s.append(st.cpu().numpy())
+        return np.concatenate(out_c), np.concatenate(out_s)
+
+    def infer_clip_from_crop_images(self, images, want_crops: bool = False):
+        """A clip given as crop images, ``images[frame][fighter]`` uint8[h, w, 3] BGR (the reference's on-disk
+        hand-off between YOLOv5 and the runner): same result dict as ``infer_clip``."""
+        n = len(images)
+        records = self.alloc_records(n - 1)
+        logp = torch.empty((n - 1, self.F, self.A), dtype=torch.float32, device=self.device)
+        status = torch.empty((n, self.F), dtype=torch.int32, device=self.device)
+        crops = torch.empty((n, self.F, 128, 128, 3), dtype=torch.uint8, device=self.device) if want_crops else None
+        self.clip_begin(n)
+        step = self.max_batch_frames
+        for f0 in range(0, n, step):
+            chunk = [im for fr in images[f0 : f0 + step] for im in fr]
+            cnt = len(chunk) // self.F
+            buf, desc = self._pack_crop_images(chunk)
+            self._check(self._lib.pa_backbone_crop_images(self._h, _ptr(buf), buf.numel(), _ptr(desc), cnt, f0,
+                                                          _ptr(crops[f0 : f0 + cnt]) if want_crops else C.c_void_p(0),
+                                                          _ptr(status[f0 : f0 + cnt]), self._stream()))
+            torch.cuda.synchronize(self.device)  # buf / desc are freed when this iteration ends
+        self.head_frames(1, n, records, logp)
+        torch.cuda.synchronize(self.device)
+        out = self.decode_records(records)
+        out["logp"] = logp.cpu().numpy()
+        out["crop_status"] = status.cpu().numpy()
+        if want_crops:
+            out["crops_rgb"] = crops.cpu().numpy()
+        return out
+
     # -- boxes from the game log ----------------------------------------------
     def project_boxes(self, log_rows) -> torch.Tensor:
         """log_rows float64[..., 9] (pos_x,pos_y,cam xyz,target xyz,fov deg) -> boxes float64[..., 4] on device."""
