@@ -62,12 +62,19 @@ class ClipSource:
     """Decoded frames + per-frame YOLO label text (stand-in for VideoCapture +
     the ``labels/<video>_<n>.txt`` files, 1-indexed like them)."""
 
-    def __init__(self, frames: np.ndarray, labels: List[str], name: str = "clip"):
+    def __init__(self, frames: np.ndarray, labels: List[str], name: str = "clip", crop_images=None):
+        """``crop_images`` (optional): ``crop_images[i][p]`` = the BGR crop image YOLOv5 ``--save-crop`` wrote for
+        fighter slot p (sorted class ids) of frame i (``crops/<Fighter>/<video>_<i+1>.jpg`` after
+        ``cv2.imread``), any size, or None where the detector saved none. With them the runner takes the
+        reference's own input branch (``ai_runner.py:446-459``) from the images instead of cutting crops from
+        ``frames``; ``frames`` may then be an empty ``uint8[n, 0, 0, 3]`` array."""
         assert frames.ndim == 4 and frames.shape[3] == 3 and frames.dtype == np.uint8
         assert len(labels) == frames.shape[0]
+        assert crop_images is None or len(crop_images) == len(labels)
         self.frames = frames
         self.labels = list(labels)
         self.name = name
+        self.crop_images = crop_images
 
     @classmethod
     def load(cls, path: str) -> "ClipSource":
@@ -186,11 +193,19 @@ class AIRunner:
         if eng.S != self.num_frames_per_sample:
             raise ValueError(f"model was trained with sequence_length {eng.S}, runner asked for {self.num_frames_per_sample}")
         if eng.cfg.frame_delta != self.frame_delta or list(eng.cfg.fighter_class_ids)[:2] != self._class_ids:
+            hs, ws = [self.clip.frames.shape[1], 128], [self.clip.frames.shape[2], 128]
+            for row in self.clip.crop_images or []:
+                for im in row:
+                    if im is not None:
+                        hs.append(im.shape[0])
+                        ws.append(im.shape[1])
             eng = eng.reconfigured(frame_delta=self.frame_delta, fighter_class_ids=tuple(self._class_ids),
-                                   max_clip_frames=max(self.max_frames, 64),
-                                   max_frame_height=self.clip.frames.shape[1], max_frame_width=self.clip.frames.shape[2])
+                                   max_clip_frames=max(self.max_frames, 64), max_frame_height=max(hs), max_frame_width=max(ws))
         boxes, src, missing = self._boxes()
         n = self.max_frames
+        if self.clip.crop_images is not None:
+            self._results = self._run_clip_from_crop_images(eng, boxes, src, missing)
+            return self._results
         for p, fighter in enumerate(self.fighters):
             # every frame in [1, max_frames) is the middle of its own window (ai_runner.py:443-447)
             bad = np.nonzero(missing[: n - 1, p])[0]
@@ -208,6 +223,37 @@ class AIRunner:
         bad = np.argwhere(st != 0)
         assert len(bad) == 0, f"Failed to get square crop from frame {bad[0][0] + 1}"  # ai_runner.py:418
         self._results = out
+        return out
+
+    def _run_clip_from_crop_images(self, eng, boxes, src, missing):
+        """The clip's crops are the detector's saved crop images: every (frame, fighter) goes through the
+        runner-input branch on the device (``pa_backbone_crop_images``). A crop that the label repair made up
+        by duplicating the last detection (``ai_runner.py:270-289``) re-uses that detection's image, like the
+        file copy the reference makes; an interpolated gap (``:389-418``) is re-cut from the video by the
+        reference and therefore needs ``frames`` -- not available from crop images alone."""
+        n = self.max_frames
+        cl = self.cleaned
+        images = []
+        for i in range(n):
+            row = []
+            for p, fighter in enumerate(self.fighters):
+                j = int(src[i, p])
+                if missing[i, p]:
+                    assert i == n - 1, f"Failed to get frame crops/{fighter}/{self.video_name}_{i + 1}.jpg"
+                    j = int(np.nonzero(~missing[:, p])[0][-1])  # never reported (frame max_frames has no window)
+                same = cl.pixel_frame[j, p] == j and np.array_equal(cl.pixel_box[j, p], boxes[i, p])
+                img = self.clip.crop_images[j][p] if same or missing[i, p] else None
+                if img is None:
+                    raise NotImplementedError(
+                        f"crop of {fighter} for frame {i + 1} was interpolated by the label repair; the reference re-cuts it "
+                        "from the video (ai_runner.py:404-418): give the ClipSource its frames as well")
+                row.append(img)
+            images.append(row)
+        out = eng.infer_clip_from_crop_images(images, want_crops=True)
+        st = out["crop_status"].copy()
+        st[missing] = 0
+        bad = np.argwhere(st != 0)
+        assert len(bad) == 0, f"Bad shape of crop image for frame {bad[0][0] + 1}"  # ai_runner.py:458
         return out
 
     def get_action_recognition_input_for_frame(self, frame: int, fighter: str):

@@ -83,3 +83,37 @@ def test_clip_from_crop_images_equals_clip_from_frames(engine):
         for p in range(2):
             assert np.array_equal(got["crops_rgb"][i, p], yolo_crop.runner_input_from_crop(images[i][p]))
     assert np.isfinite(got["logp"]).all()
+
+
+@pytest.mark.gpu
+def test_airunner_on_a_crop_image_clip(tmp_path, state_dict, engine):
+    """b2 with the reference's real hand-off: the runner is given the detector's saved crop images (plus the
+    label text) instead of decoded frames and produces the same ai_output.yaml."""
+    import yaml
+
+    from playaid_core_amd import synth
+    from playaid_core_amd.ai_runner import AIRunner, ClipSource
+    from playaid_core_amd.anim_ontology import MOVE_TO_CLASS_ID
+    from playaid_core_amd.cnn_action_detector import CNNActionDetector
+
+    ckpt = str(tmp_path / "seeded.ckpt")
+    synth.save_checkpoint(ckpt, seed=1234)
+    model = CNNActionDetector.load_from_checkpoint(ckpt, actions=list(MOVE_TO_CLASS_ID.keys()), max_batch_frames=32,
+                                                   max_clip_frames=64, max_frame_height=720, max_frame_width=1280)
+    clip = ClipSource.synthetic(20, 720, 1280)
+    by_frames = AIRunner(clip, model=model, output_dir=str(tmp_path / "a"))
+    by_frames.run_action_recognition()
+    by_frames.write_output()
+    # what YOLOv5 --save-crop would have stored: here the 128 x 128 BGR square crops of the same boxes
+    bgr, status = engine.square_crops(clip.frames, synth.make_boxes(20, 720, 1280), padding=30, swap_rb=False)
+    assert (status == 0).all()
+    crops = [[np.ascontiguousarray(bgr[i, p]) for p in range(2)] for i in range(20)]
+    clip2 = ClipSource(np.zeros((20, 0, 0, 3), np.uint8), clip.labels, name="crops_only", crop_images=crops)
+    by_images = AIRunner(clip2, model=model, output_dir=str(tmp_path / "b"))
+    by_images.run_action_recognition()
+    by_images.write_output()
+    a = yaml.safe_load(open(by_frames.ai_output_file))
+    b = yaml.safe_load(open(by_images.ai_output_file))
+    assert a == b and len(a["Pikachu"]) == 19
+    inp, frames7 = by_images.get_action_recognition_input_for_frame(5, "Joker")
+    assert inp.shape == (1, 7, 3, 128, 128) and np.array_equal(frames7[3], by_frames.get_action_recognition_input_for_frame(5, "Joker")[1][3])
