@@ -184,6 +184,24 @@ int pa_runner_inputs(pa_engine* e, const uint8_t* images, size_t images_bytes, c
 int pa_backbone_crop_images(pa_engine* e, const uint8_t* images, size_t images_bytes, const pa_crop_image* desc, int32_t n,
                             int32_t frame0, uint8_t* crops_rgb, int32_t* status, void* stream);
 
+/* ---- f1: detection post-processing --------------------------------------- */
+
+/* Replaces the post-network half of the YOLOv5 subprocess AIRunner.run_yolo starts (ai_runner.py:191-224:
+ * detect.py --max-det 2 --save-txt --save-conf --classes 2 3): from the detection head's decoded rows
+ * pred[n_frames][rows][5 + num_classes] (cx cy w h in network-input pixels, objectness, class scores; device
+ * float32) to the numbers of the label files the reference parses (ai_runner.py:53-94): objectness and
+ * confidence gates (conf_thres, default 0.25), best class per row, class filter (class_mask bit c = class c
+ * allowed; the reference passes classes 2 and 3), class-aware IoU NMS (iou_thres, default 0.45), at most
+ * max_det (<= 8) boxes, mapped from the letterboxed net_height x net_width input back to the img_height x
+ * img_width frame, rounded to pixels and normalised.
+ * dets: float32[n_frames][max_det][6] = cls cx cy w h conf in LABEL-FILE order (detect.py writes
+ * reversed(det): lowest confidence first); counts: int32[n_frames]. The host writes each row as six '%g'
+ * fields (playaid_core_amd/detect.py). The arithmetic is the un-vendored ultralytics/yolov5 checkout's; the
+ * contract is restated in oracle/detect.py ("parity unpinned"). */
+int pa_detect_postprocess(pa_engine* e, const float* pred, int32_t n_frames, int32_t rows, int32_t num_classes,
+                          float conf_thres, float iou_thres, uint32_t class_mask, int32_t max_det, int32_t net_height,
+                          int32_t net_width, int32_t img_height, int32_t img_width, float* dets, int32_t* counts, void* stream);
+
 /* Boxes from the game log instead of a detector. Replaces the
  * projection half of Fighter.set_from_json (fighter.py:494-539: calculate_lookat_matrix,
  * calculate_intrinsic_matrix, project_point_to_pixel on four corners, all for the

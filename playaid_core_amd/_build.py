@@ -26,6 +26,7 @@ SOURCES = [
     ("stem_pool.hip", []),
     ("misc.hip", []),
     ("preprocess.hip", ["-ffp-contract=off"]),
+    ("detect.hip", ["-ffp-contract=off"]),
     ("pa_api.hip", []),
 ]
 

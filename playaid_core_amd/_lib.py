@@ -95,6 +95,8 @@ SYMBOLS = [
     ("pa_square_crops", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     ("pa_runner_inputs", C.c_int, [_P, _P, C.c_size_t, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     ("pa_backbone_crop_images", C.c_int, [_P, _P, C.c_size_t, _P, C.c_int32, C.c_int32, _P, _P, _P]),
+    ("pa_detect_postprocess", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_uint32, C.c_int32,
+                                        C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     ("pa_project_boxes", C.c_int, [_P, _P, C.c_int32, _P, _P]),
     ("pa_clip_begin", C.c_int, [_P, C.c_int32]),
     ("pa_backbone_frames", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, _P]),

@@ -1055,6 +1055,29 @@ int pa_backbone_crop_images(pa_engine* e, const uint8_t* images, size_t images_b
     return pa_backbone_slot(e, 0, n, frame0, stream);
 }
 
+int pa_detect_postprocess(pa_engine* e, const float* pred, int32_t n_frames, int32_t rows, int32_t num_classes, float conf_thres,
+                          float iou_thres, uint32_t class_mask, int32_t max_det, int32_t net_height, int32_t net_width,
+                          int32_t img_height, int32_t img_width, float* dets, int32_t* counts, void* stream) {
+    if (!e || !pred || !dets || !counts || n_frames < 1 || rows < 1 || num_classes < 1 || num_classes > 32 || max_det < 1 ||
+        max_det > 8 || net_height < 1 || net_width < 1 || img_height < 1 || img_width < 1)
+        return fail(e, PA_ERR_INVALID_ARG, "pa_detect_postprocess: bad argument");
+    DetectParams q;
+    memset(&q, 0, sizeof(q));
+    q.pred = pred;
+    q.n_frames = n_frames; q.rows = rows; q.nc = num_classes; q.max_det = max_det;
+    q.conf_thres = conf_thres; q.iou_thres = iou_thres; q.class_mask = class_mask;
+    // scale_boxes: gain and pad in double (Python floats), applied as float32 scalars to the float32 boxes
+    const double gain = std::min((double)net_height / img_height, (double)net_width / img_width);
+    q.gain = (float)gain;
+    q.pad_x = (float)(((double)net_width - img_width * gain) / 2.0);
+    q.pad_y = (float)(((double)net_height - img_height * gain) / 2.0);
+    q.img_w = (float)img_width; q.img_h = (float)img_height;
+    q.dets = dets; q.counts = counts;
+    ProfScope ps(e, (hipStream_t)stream, "detect_nms", 0.0, (double)n_frames * rows * (5 + num_classes) * 4.0 * max_det);
+    HIPCHK(e, launch_detect_nms(q, (hipStream_t)stream));
+    return PA_OK;
+}
+
 int pa_project_boxes(pa_engine* e, const double* log_rows, int32_t n_rows, double* boxes, void* stream) {
     if (!e || !log_rows || !boxes || n_rows < 1) return fail(e, PA_ERR_INVALID_ARG, "pa_project_boxes: bad argument");
     HIPCHK(e, launch_project_boxes(log_rows, boxes, n_rows, (hipStream_t)stream));

@@ -170,6 +170,21 @@ hipError_t preprocess_init_device();
 hipError_t launch_project_boxes(const double* log, double* boxes, int32_t n, hipStream_t s);
 
 // ---------------------------------------------------------------------------
+// detection post-processing (detect.hip): head rows -> class filter, confidence, NMS, max_det, image-space boxes
+// ---------------------------------------------------------------------------
+struct DetectParams {
+    const float* pred;   // [n_frames][rows][5 + nc]: cx cy w h (network-input pixels), objectness, class scores
+    int32_t n_frames, rows, nc, max_det;
+    float conf_thres, iou_thres;
+    uint32_t class_mask;
+    float pad_x, pad_y, gain;  // letterbox of the network input inside the image (scale_boxes)
+    float img_w, img_h;
+    float* dets;         // [n_frames][max_det][6]: cls cx cy w h conf, label-file order (lowest confidence first)
+    int32_t* counts;     // [n_frames]
+};
+hipError_t launch_detect_nms(const DetectParams& q, hipStream_t s);
+
+// ---------------------------------------------------------------------------
 // small kernels (misc.hip)
 // ---------------------------------------------------------------------------
 // x[n][3][128][128] f32 -> zero-bordered [n][134][134][4]

@@ -256,6 +256,23 @@ class Engine:
             out["crops_rgb"] = crops.cpu().numpy()
         return out
 
+    # -- f1: detection post-processing ------------------------------------------
+    def detect_postprocess(self, pred, net_hw, img_hw, conf_thres: float = 0.25, iou_thres: float = 0.45,
+                           classes=(2, 3), max_det: int = 2):
+        """pred float32[n, rows, 5 + nc] (decoded head rows) -> (dets float32[n, max_det, 6], counts int32[n]) on
+        the device; dets rows are ``cls cx cy w h conf`` in label-file order."""
+        pd = self._dev(pred, torch.float32)
+        n, rows, width = pd.shape
+        mask = 0
+        for c in classes:
+            mask |= 1 << int(c)
+        dets = torch.empty((n, max_det, 6), dtype=torch.float32, device=self.device)
+        counts = torch.empty((n,), dtype=torch.int32, device=self.device)
+        self._check(self._lib.pa_detect_postprocess(self._h, _ptr(pd), n, rows, width - 5, conf_thres, iou_thres, mask, max_det,
+                                                    int(net_hw[0]), int(net_hw[1]), int(img_hw[0]), int(img_hw[1]), _ptr(dets),
+                                                    _ptr(counts), self._stream()))
+        return dets, counts
+
     # -- boxes from the game log ----------------------------------------------
     def project_boxes(self, log_rows) -> torch.Tensor:
         """log_rows float64[..., 9] (pos_x,pos_y,cam xyz,target xyz,fov deg) -> boxes float64[..., 4] on device."""
