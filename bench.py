@@ -139,6 +139,54 @@ def pcie_inclusive(eng, frames_dev, boxes_dev, steps=8):
     }
 
 
+def pcie_inclusive_windows(eng, frames_dev, boxes_dev, steps=8):
+    """PCIe-inclusive again, but only the crops' source slices cross the link (pa_upload_crop_windows: ~0.42 MB per
+    1080p crop instead of 6.2 MB per frame), double buffered like above."""
+    dev = eng.device
+    n, h, w, _ = frames_dev.shape
+    host = frames_dev.cpu().pin_memory()
+    boxes_host = boxes_dev.cpu().numpy()
+    stages = [eng.make_window_stage(n), eng.make_window_stage(n)]
+    rec = eng.alloc_records(n - 1)
+    side, main = torch.cuda.Stream(dev), torch.cuda.current_stream(dev)
+    ready = [torch.cuda.Event(), torch.cuda.Event()]
+    free = [torch.cuda.Event(), torch.cuda.Event()]
+
+    def run(k_steps):
+        for e in free:
+            e.record(main)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for k in range(k_steps + 1):
+            if k < k_steps:
+                with torch.cuda.stream(side):
+                    side.wait_event(free[k & 1])
+                    eng.upload_crop_windows(host, boxes_host, stages[k & 1])
+                    ready[k & 1].record(side)
+            if k > 0:
+                j = (k - 1) & 1
+                main.wait_event(ready[j])
+                eng.clip_begin(n)
+                eng.preprocess_windows(stages[j], n, h, w, boxes_dev, 0)
+                free[j].record(main)  # the windows are consumed once the crop stage has run
+                eng.backbone_slot(0, n, 0)
+                eng.head_frames(1, n, rec, None)
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / k_steps
+
+    run(2)
+    dt = run(steps)
+    return {
+        "value": round(n / dt, 1),
+        "unit": "frames/s",
+        "ms_per_clip": round(dt * 1e3, 3),
+        "h2d_MB_per_clip": round(stages[0]["used"] / 1e6, 1),
+        "method": f"{steps} clips, frames in pinned host memory; only every crop's source slice crosses PCIe, read straight out of "
+        "the host frames by one upload kernel per clip (slice geometry computed on the host with the device plan's arithmetic), "
+        "uploads of clip k+1 on a side stream under the compute of clip k; no decode",
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -367,6 +415,7 @@ def main():
                 }
         if world == 1 and not long_clip and not args.no_pcie:
             result["pcie_inclusive"] = pcie_inclusive(eng, frames, boxes)
+            result["pcie_inclusive_windows"] = pcie_inclusive_windows(eng, frames, boxes)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(sd, args.height, args.width, args.cpu_sample_frames)
         print(json.dumps(result), flush=True)

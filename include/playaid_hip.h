@@ -245,6 +245,30 @@ int pa_preprocess_frames(pa_engine* e, const uint8_t* frames, int32_t n, int32_t
                          void* stream);
 int pa_backbone_slot(pa_engine* e, int32_t slot, int32_t n, int32_t frame0, void* stream);
 
+/* ---- f2 / a1: ingest without hardware decode ----------------------------- */
+
+/* This image has no hardware decode path (no rocDecode / rocJPEG / VCN libraries, no cv2), so "decode" is the
+ * hand-over of raw BGR frames (cv2.VideoCapture.read's output, ai_runner.py:404-405). When those
+ * frames sit in HOST memory, uploading them whole costs 6.2 MB per 1080p frame of PCIe for the ~0.84 MB the two
+ * crops read. pa_upload_crop_windows copies only each crop's slice -- the square_crop region fighter.py:335-343
+ * cuts, computed on the host with the device plan's own arithmetic -- into a packed device buffer: one kernel
+ * whose waves read the slice rows straight out of the host frames over PCIe (frames_host must be pinned,
+ * device-visible memory: hipHostMalloc / torch pin_memory; desc_host too) and writes one descriptor per crop; pa_preprocess_windows is
+ * pa_preprocess_frames reading those windows (bit-identical crops). height / width stay the FRAME's. */
+typedef struct pa_crop_window {
+    int64_t offset;      /* first byte of the slice in the window buffer (16-byte aligned) */
+    int32_t pitch;       /* bytes per slice row in the window buffer (row_bytes rounded up to 16) */
+    int32_t rows;        /* slice rows */
+    int64_t src_offset;  /* first byte of the slice in the host frame buffer */
+    int32_t src_pitch;   /* bytes per frame row */
+    int32_t row_bytes;   /* slice width * 3 */
+} pa_crop_window;
+int pa_upload_crop_windows(pa_engine* e, const uint8_t* frames_host, int32_t n, int32_t height, int32_t width,
+                           const double* boxes_host, int32_t padding, uint8_t* windows_dev, size_t windows_capacity,
+                           pa_crop_window* desc_host, pa_crop_window* desc_dev, size_t* bytes_used, void* stream);
+int pa_preprocess_windows(pa_engine* e, const uint8_t* windows_dev, const pa_crop_window* desc_dev, int32_t n, int32_t height,
+                          int32_t width, const double* boxes, int32_t slot, uint8_t* crops_rgb, int32_t* status, void* stream);
+
 /* pa_backbone_frames for frames that are NOT consecutive in the clip (a resolution bucket of a
  * mixed-resolution stream, BASELINE.json configs[4]): frame_ids[n] (device, int32, 0-based)
  * says where each frame's features go in the cache. The call does not touch host-side clip

@@ -69,6 +69,11 @@ class pa_crop_image(C.Structure):
     _fields_ = [("offset", C.c_int64), ("height", C.c_int32), ("width", C.c_int32)]
 
 
+class pa_crop_window(C.Structure):
+    _fields_ = [("offset", C.c_int64), ("pitch", C.c_int32), ("rows", C.c_int32), ("src_offset", C.c_int64),
+                ("src_pitch", C.c_int32), ("row_bytes", C.c_int32)]
+
+
 class pa_kernel_stat(C.Structure):
     _fields_ = [
         ("name", C.c_char * 48),
@@ -102,6 +107,9 @@ SYMBOLS = [
     ("pa_backbone_frames", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, _P]),
     ("pa_preprocess_frames", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, _P]),
     ("pa_backbone_slot", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P]),
+    ("pa_upload_crop_windows", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_size_t, _P, _P,
+                                         C.POINTER(C.c_size_t), _P]),
+    ("pa_preprocess_windows", C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, _P]),
     ("pa_backbone_frames_indexed", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
     ("pa_clip_mark_ready", C.c_int, [_P, _P, C.c_int32]),
     ("pa_device_errors", C.c_int, [_P, C.POINTER(C.c_int32), _P]),

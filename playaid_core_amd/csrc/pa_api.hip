@@ -584,10 +584,11 @@ int run_head(pa_engine* e, int nwin, const float* feats, const int32_t* gather, 
 
 int run_preprocess(pa_engine* e, const uint8_t* frames, int n, int height, int width, const double* boxes, int padding,
                    int swap_rb, uint8_t* crops_u8, float* crops_f32, int32_t* status, hipStream_t s,
-                   const int32_t* src_frame = nullptr, int n_src = 0) {
+                   const int32_t* src_frame = nullptr, int n_src = 0, const pa_crop_window* windows = nullptr) {
     PreprocParams p;
     memset(&p, 0, sizeof(p));
     p.frames = frames;
+    p.windows = reinterpret_cast<const CropWindow*>(windows);
     p.boxes = boxes;
     p.src_frame = src_frame;
     p.n_src = src_frame ? n_src : n;
@@ -1053,6 +1054,86 @@ int pa_backbone_crop_images(pa_engine* e, const uint8_t* images, size_t images_b
     if (rc) return rc;
     if (status) HIPCHK(e, hipMemcpyAsync(status, e->pre_status[0], sizeof(int32_t) * n * F, hipMemcpyDeviceToDevice, s));
     return pa_backbone_slot(e, 0, n, frame0, stream);
+}
+
+namespace {
+// The slice of YoloCrop.square_crop (fighter.py:305-343) on the host: the arithmetic of crop_plan_kernel up to the
+// numpy slice, so that the window the host uploads is exactly the region the device plan will read.
+void host_slice(const double* b, int W, int H, int pad, int* sy0, int* sx0, int* sh, int* sw) {
+    *sy0 = *sx0 = *sh = *sw = 0;
+    const double v[4] = {b[0] * W, b[1] * H, b[2] * W, b[3] * H};
+    int iv[4];
+    for (int k = 0; k < 4; ++k) {
+        if (!(v[k] > -2.0e9 && v[k] < 2.0e9)) return;
+        iv[k] = (int)v[k];
+    }
+    const int cx = iv[0], cy = iv[1], d = iv[2] > iv[3] ? iv[2] : iv[3];
+    if (d <= 0 || d > 16384) return;
+    const int half = d / 2;
+    auto np_slice = [](int start, int stop, int size, int* s0, int* len) {
+        if (start > size) start = size;
+        if (stop < 0) {
+            stop += size;
+            if (stop < 0) stop = 0;
+        }
+        if (stop > size) stop = size;
+        *s0 = start;
+        *len = stop > start ? stop - start : 0;
+    };
+    np_slice(std::max(cy - half - pad, 0), std::min(cy + half + pad, H), H, sy0, sh);
+    np_slice(std::max(cx - half - pad, 0), std::min(cx + half + pad, W), W, sx0, sw);
+}
+}  // namespace
+
+int pa_upload_crop_windows(pa_engine* e, const uint8_t* frames_host, int32_t n, int32_t height, int32_t width,
+                           const double* boxes_host, int32_t padding, uint8_t* windows_dev, size_t windows_capacity,
+                           pa_crop_window* desc_host, pa_crop_window* desc_dev, size_t* bytes_used, void* stream) {
+    static_assert(sizeof(pa_crop_window) == sizeof(CropWindow), "descriptor layouts must agree");
+    if (!e || !frames_host || !boxes_host || !windows_dev || !desc_host || !desc_dev || n < 1 || height < 1 || width < 1 || padding < 0)
+        return fail(e, PA_ERR_INVALID_ARG, "pa_upload_crop_windows: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int F = e->cfg.num_fighters;
+    size_t off = 0;
+    for (int i = 0; i < n * F; ++i) {
+        int sy0, sx0, sh, sw;
+        host_slice(boxes_host + (size_t)i * 4, width, height, padding, &sy0, &sx0, &sh, &sw);
+        pa_crop_window& d = desc_host[i];
+        d.offset = (int64_t)off;
+        d.row_bytes = sw * 3;
+        d.pitch = (sw * 3 + 15) & ~15;
+        d.rows = sh;
+        d.src_offset = (int64_t)((((size_t)(i / F) * height + sy0) * width + sx0) * 3);
+        d.src_pitch = width * 3;
+        const size_t bytes = (size_t)sh * d.pitch;
+        if (sh == 0 || sw == 0) {  // empty / bad box: the device plan reports it and reads nothing
+            d.rows = d.row_bytes = d.pitch = 0;
+            continue;
+        }
+        if (off + bytes + 16 > windows_capacity) return fail(e, PA_ERR_CAPACITY, "pa_upload_crop_windows: window buffer too small");
+        off += bytes;
+    }
+    // descriptors first (tiny, from the caller's pinned array), then ONE kernel that pulls every slice row out of
+    // the pinned host frames over PCIe
+    HIPCHK(e, hipMemcpyAsync(desc_dev, desc_host, sizeof(pa_crop_window) * n * F, hipMemcpyHostToDevice, s));
+    HIPCHK(e, launch_slice_upload(frames_host, (long long)n * height * width * 3, reinterpret_cast<const CropWindow*>(desc_dev), windows_dev,
+                                  n * F, s));
+    if (bytes_used) *bytes_used = off;
+    return PA_OK;
+}
+
+int pa_preprocess_windows(pa_engine* e, const uint8_t* windows_dev, const pa_crop_window* desc_dev, int32_t n, int32_t height,
+                          int32_t width, const double* boxes, int32_t slot, uint8_t* crops_rgb, int32_t* status, void* stream) {
+    if (!e || !windows_dev || !desc_dev || !boxes || n < 1 || height < 1 || width < 1 || slot < 0 || slot > 1)
+        return fail(e, PA_ERR_INVALID_ARG, "pa_preprocess_windows: bad argument");
+    if (n > e->cfg.max_batch_frames || height > e->cfg.max_frame_height || width > e->cfg.max_frame_width)
+        return fail(e, PA_ERR_CAPACITY, "pa_preprocess_windows: frames exceed engine capacity");
+    hipStream_t s = (hipStream_t)stream;
+    const int F = e->cfg.num_fighters;
+    int rc = run_preprocess(e, windows_dev, n, height, width, boxes, e->cfg.crop_padding, 1, crops_rgb, e->x0_slot[slot],
+                            e->pre_status[slot], s, nullptr, 0, desc_dev);
+    if (rc) return rc;
+    if (status) HIPCHK(e, hipMemcpyAsync(status, e->pre_status[slot], sizeof(int32_t) * n * F, hipMemcpyDeviceToDevice, s));
+    return PA_OK;
 }
 
 int pa_detect_postprocess(pa_engine* e, const float* pred, int32_t n_frames, int32_t rows, int32_t num_classes, float conf_thres,

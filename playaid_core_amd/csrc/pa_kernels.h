@@ -119,8 +119,20 @@ struct CropPlan {
     double scale_x, scale_y;
 };
 
+struct CropWindow {  // == pa_crop_window of the public header
+    int64_t offset;      // first byte of the crop's slice inside the window buffer
+    int32_t pitch;       // bytes per slice row in the window buffer (row_bytes rounded up to 16)
+    int32_t rows;        // slice rows
+    int64_t src_offset;  // first byte of the slice inside the host frame buffer
+    int32_t src_pitch;   // bytes per frame row
+    int32_t row_bytes;   // slice width * 3
+};
+hipError_t launch_slice_upload(const uint8_t* frames_host, long long frames_bytes, const CropWindow* desc, uint8_t* windows, int ncrops,
+                               hipStream_t s);
+
 struct PreprocParams {
-    const uint8_t* frames;  // [n_src][H][W][3]
+    const uint8_t* frames;  // [n_src][H][W][3]; with `windows`: the packed window buffer
+    const CropWindow* windows;  // [ncrops] or nullptr: every crop's slice was uploaded on its own
     const double* boxes;    // [ncrops][4]
     const int32_t* src_frame;  // [ncrops] frame each crop is cut from, or nullptr = crop / fighters
     int32_t n_src;             // frames in the buffer (bound of src_frame)

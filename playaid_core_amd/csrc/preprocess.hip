@@ -187,6 +187,17 @@ __device__ __forceinline__ BandRows band_rows(const CropPlan& pl, int r0, int r1
 }
 
 __device__ __forceinline__ int kk_dbg(const int32_t* row, int t) { return row[2 + t]; }
+
+// First byte and row pitch of a crop's slice: inside the whole frame, or -- window ingest (pa_preprocess_windows) --
+// inside the packed copy of just that slice that the host uploaded.
+__device__ __forceinline__ const uint8_t* slice_ptr(const PreprocParams& p, int crop, const CropPlan& pl, size_t* pitch) {
+    if (p.windows) {
+        *pitch = (size_t)p.windows[crop].pitch;
+        return p.frames + p.windows[crop].offset;
+    }
+    *pitch = (size_t)p.width * 3;
+    return p.frames + ((size_t)pl.frame * p.height + pl.sy0) * p.width * 3 + (size_t)pl.sx0 * 3;
+}
 __device__ __forceinline__ int align_up(int v, int a) { return (v + a - 1) / a * a; }
 
 // LDS layout of one sub-band: B0 source rows | B1 after the horizontal pass; B2 (after the
@@ -238,7 +249,7 @@ __global__ __launch_bounds__(64) void crop_plan_kernel(const PreprocParams p) {
     pl.scale_x = pl.scale_y = 1.0;
     const double* b = p.boxes + (size_t)crop * 4;
     const int W = p.width, H = p.height, pad = p.padding;
-    if ((unsigned)pl.frame >= (unsigned)p.n_src) {  // a source index outside the frame buffer: never dereferenced
+    if (!p.windows && (unsigned)pl.frame >= (unsigned)p.n_src) {  // a source index outside the frame buffer: never dereferenced
         pl.frame = 0;
         pl.status = PA_CROP_BAD_FRAME;
     }
@@ -421,8 +432,8 @@ __device__ __forceinline__ uint32_t clip8(int v) {
 __device__ void fallback_h(const PreprocParams& p, int crop, const CropPlan& pl) {
     if (!pl.need_h) return;
     const int total = pl.sh * pl.rw;
-    const uint8_t* src = p.frames + ((size_t)pl.frame * p.height + pl.sy0) * p.width * 3 + (size_t)pl.sx0 * 3;
-    const size_t src_pitch = (size_t)p.width * 3;
+    size_t src_pitch;
+    const uint8_t* src = slice_ptr(p, crop, pl, &src_pitch);
     uint8_t* dst = p.t1 + (size_t)crop * p.t_stride;
     const int32_t* coef = p.coef + (size_t)(crop * 2 + 0) * p.coef_dim * COEF_ROW;
     for (int i = threadIdx.x; i < total; i += blockDim.x) {
@@ -455,8 +466,7 @@ __device__ void fallback_v(const PreprocParams& p, int crop, const CropPlan& pl)
         src = p.t1 + (size_t)crop * p.t_stride;
         src_pitch = (size_t)pl.rw * 3;
     } else {
-        src = p.frames + ((size_t)pl.frame * p.height + pl.sy0) * p.width * 3 + (size_t)pl.sx0 * 3;
-        src_pitch = (size_t)p.width * 3;
+        src = slice_ptr(p, crop, pl, &src_pitch);
     }
     uint8_t* dst = p.t2 + (size_t)crop * p.t_stride;
     const int32_t* coef = p.coef + (size_t)(crop * 2 + 1) * p.coef_dim * COEF_ROW;
@@ -640,8 +650,7 @@ __device__ void fallback_area(const PreprocParams& p, int crop, const CropPlan& 
         cv.src = p.t1 + (size_t)crop * p.t_stride;
         cv.pitch = (size_t)pl.rw * 3;
     } else {
-        cv.src = p.frames + ((size_t)pl.frame * p.height + pl.sy0) * p.width * 3 + (size_t)pl.sx0 * 3;
-        cv.pitch = (size_t)p.width * 3;
+        cv.src = slice_ptr(p, crop, pl, &cv.pitch);
     }
     for (int i = threadIdx.x; i < PA_CROP * PA_CROP; i += blockDim.x) {
         const int dy = i >> 7, dx = i & 127;
@@ -722,8 +731,8 @@ __global__ __launch_bounds__(CF_NT) void crop_fused_kernel(const PreprocParams p
         return;
     }
     if (!pl.fused_rb) return;
-    const uint8_t* slice = p.frames + ((size_t)pl.frame * p.height + pl.sy0) * p.width * 3 + (size_t)pl.sx0 * 3;
-    const size_t frame_pitch = (size_t)p.width * 3;
+    size_t frame_pitch;
+    const uint8_t* slice = slice_ptr(p, crop, pl, &frame_pitch);
     const int32_t* coef_h = p.coef + (size_t)(crop * 2 + 0) * p.coef_dim * COEF_ROW;
     const int32_t* coef_v = p.coef + (size_t)(crop * 2 + 1) * p.coef_dim * COEF_ROW;
     const int rb = pl.fused_rb;
@@ -1394,6 +1403,57 @@ __global__ __launch_bounds__(256) void runner_input_kernel(const RunnerInParams 
 hipError_t launch_runner_inputs(const RunnerInParams& q, hipStream_t s) {
     if (q.n <= 0) return hipSuccess;
     hipLaunchKernelGGL(runner_input_kernel, dim3(q.n), dim3(256), 0, s, q);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Window ingest: the frames stay in (pinned, device-visible) HOST memory and only every crop's source slice
+// crosses PCIe. One wave copies one slice row at a time straight out of host memory -- coalesced dword reads
+// from the 4-byte-aligned address below the row start, re-aligned with v_alignbyte like stage 0 of the fused
+// kernel -- into the packed window buffer (row pitch padded to 16 bytes). A 2-D hipMemcpy per crop was measured
+// at ~2 ms each on this stack; this kernel is one launch for all crops and is bound by the link.
+__global__ __launch_bounds__(256) void slice_upload_kernel(const uint8_t* __restrict__ frames_host, const CropWindow* __restrict__ desc,
+                                                           uint8_t* __restrict__ windows, long long frames_bytes) {
+    const int crop = blockIdx.y;
+    const CropWindow w = desc[crop];
+    const int rows = w.rows;
+    const int row_bytes = w.row_bytes;
+    if (rows <= 0 || row_bytes <= 0) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int row_dwords = (row_bytes + 3) >> 2;
+    for (int y = wave; y < rows; y += nwaves) {
+        const long long so = w.src_offset + (long long)y * w.src_pitch;
+        const uintptr_t ga = (uintptr_t)(frames_host + so);
+        const uint32_t* g4 = reinterpret_cast<const uint32_t*>(ga & ~(uintptr_t)3);
+        const uint32_t sh = (uint32_t)(ga & 3);
+        // bytes of the frame buffer left from the aligned address on: never read past its end
+        const long long left = frames_bytes - (so - (long long)sh);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(windows + w.offset + (size_t)y * w.pitch);
+        // the link's latency is microseconds: every lane requests up to six dwords (a 1.5 KB row per pass) before the
+        // first one is used
+        for (int j0 = 0; j0 < row_dwords; j0 += 384) {
+            uint32_t lo[6], hi[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int j = j0 + lane + 64 * u;
+                lo[u] = j < row_dwords ? g4[j] : 0u;
+                hi[u] = (sh && j < row_dwords && 4ll * (j + 1) < (long long)sh + row_bytes && 4ll * (j + 2) <= left) ? g4[j + 1] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int j = j0 + lane + 64 * u;
+                if (j < row_dwords) dst[j] = __builtin_amdgcn_alignbyte(hi[u], lo[u], sh);
+            }
+        }
+    }
+}
+
+hipError_t launch_slice_upload(const uint8_t* frames_host, long long frames_bytes, const CropWindow* desc, uint8_t* windows, int ncrops,
+                               hipStream_t s) {
+    if (ncrops <= 0) return hipSuccess;
+    hipLaunchKernelGGL(slice_upload_kernel, dim3(32, ncrops), dim3(256), 0, s, frames_host, desc, windows, frames_bytes);
     return hipGetLastError();
 }
 

@@ -320,6 +320,37 @@ class Engine:
 
     supports_pipelining = True
 
+    # -- ingest from host memory: only the crops' slices cross PCIe ------------------
+    def make_window_stage(self, n_frames: int, bytes_per_crop: int = 1 << 20):
+        """Reusable staging for ``upload_crop_windows``: a device window buffer, a pinned host and a device
+        descriptor array for ``n_frames`` frames."""
+        nc = n_frames * self.F
+        return {
+            "windows": torch.empty(nc * bytes_per_crop + 16, dtype=torch.uint8, device=self.device),
+            "desc_host": torch.zeros((nc, 4), dtype=torch.int64).pin_memory(),  # pa_crop_window is 32 bytes
+            "desc_dev": torch.zeros((nc, 4), dtype=torch.int64, device=self.device),
+            "used": 0,
+        }
+
+    def upload_crop_windows(self, frames_host: torch.Tensor, boxes_host, stage, padding: int = None):
+        """frames_host: uint8[n,H,W,3] CPU tensor in PINNED memory (the upload kernel reads it from the device);
+        boxes_host: float64[n,F,4] numpy. Enqueues the descriptor copy and the slice-upload kernel on the current stream."""
+        if not frames_host.is_pinned():
+            raise ValueError("frames_host must be pinned host memory (tensor.pin_memory())")
+        n, h, w, _ = frames_host.shape
+        bx = np.ascontiguousarray(boxes_host, dtype=np.float64)
+        used = C.c_size_t(0)
+        self._check(self._lib.pa_upload_crop_windows(
+            self._h, C.c_void_p(frames_host.data_ptr()), n, h, w, bx.ctypes.data_as(C.c_void_p),
+            self.cfg.crop_padding if padding is None else padding, _ptr(stage["windows"]), stage["windows"].numel(),
+            C.c_void_p(stage["desc_host"].data_ptr()), _ptr(stage["desc_dev"]), C.byref(used), self._stream()))
+        stage["used"] = int(used.value)
+        return stage
+
+    def preprocess_windows(self, stage, n: int, height: int, width: int, boxes_dev: torch.Tensor, slot: int, crops_rgb=None, status=None):
+        self._check(self._lib.pa_preprocess_windows(self._h, _ptr(stage["windows"]), _ptr(stage["desc_dev"]), n, height, width,
+                                                    _ptr(boxes_dev), slot, _ptr(crops_rgb), _ptr(status), self._stream()))
+
     def backbone_frames_indexed(self, frames_dev, boxes_dev, ids_dev, crops_rgb=None, status=None):
         """Crop + backbone for frames whose clip positions are given by ids_dev (int32, device)."""
         n, h, w, _ = frames_dev.shape
