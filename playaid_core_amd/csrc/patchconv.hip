@@ -254,8 +254,8 @@ __global__ __launch_bounds__(KS2 ? 512 : 256, 2) void conv3x3_patch_kernel(const
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
                     const f32x4 a4 = af[g & 1][mi], b4 = breg[tap % 3][kk];
-                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[mi], 0, 0, 0);
-                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[mi], 0, 0, 0);
+                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4.x, a4.x, acc[mi], 0, 0, 0);
+                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4.y, a4.y, acc[mi], 0, 0, 0);
                     if (mi == 0) {
                         // next group's operands (next tap's first group at kk == 3): same patch
                         // buffer, no barrier in between
@@ -267,8 +267,8 @@ __global__ __launch_bounds__(KS2 ? 512 : 256, 2) void conv3x3_patch_kernel(const
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[mi], 0, 0, 0);
-                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[mi], 0, 0, 0);
+                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4.z, a4.z, acc[mi], 0, 0, 0);
+                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4.w, a4.w, acc[mi], 0, 0, 0);
                 }
             }
         }
@@ -311,15 +311,15 @@ __global__ __launch_bounds__(KS2 ? 512 : 256, 2) void conv3x3_patch_kernel(const
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi) {
                         const f32x4 a4 = a2[kk & 1][mi], b4 = breg[j % 3][kk];
-                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[mi], 0, 0, 0);
-                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[mi], 0, 0, 0);
+                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4.x, a4.x, acc[mi], 0, 0, 0);
+                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4.y, a4.y, acc[mi], 0, 0, 0);
                         if (mi == 0 && kk + 1 < 4) {
                             __builtin_amdgcn_sched_barrier(0);
                             PC_LOAD_A2((kk + 1) & 1, kk + 1);
                             __builtin_amdgcn_sched_barrier(0);
                         }
-                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[mi], 0, 0, 0);
-                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[mi], 0, 0, 0);
+                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4.z, a4.z, acc[mi], 0, 0, 0);
+                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4.w, a4.w, acc[mi], 0, 0, 0);
                     }
                 }
 #undef PC_LOAD_A2
@@ -336,62 +336,63 @@ __global__ __launch_bounds__(KS2 ? 512 : 256, 2) void conv3x3_patch_kernel(const
     const unsigned long long st2 = __builtin_amdgcn_s_memrealtime();
 #endif
 
-    // Epilogue. The accumulators hold one output channel per lane (32x32 C/D map: col = lane & 31,
-    // row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5)), which would mean 32 four-byte stores per lane,
-    // and with every workgroup of the launch reaching its epilogue together the stores queue up
-    // (timeline stamps: 8 us median, 16 us worst, of a 46 us workgroup lifetime). So the tile is
-    // transposed through the (now idle) patch buffers: rows of 64 channels, then each
-    // thread moves 16 bytes: BM/16 residual loads + stores of dwordx4 instead of 32 of a dword.
-    constexpr int TS = 64;  // unpadded: conflict-free for ds_read_b128's lane groups (see igemm.hip)
-    constexpr int ET = KS2 ? 512 : 256;      // threads sharing the stores (both halves under KS2)
-    constexpr int EP_IT = BM * 16 / ET;      // 16-byte stores per thread
+    // Epilogue. The matrix instructions take the WEIGHTS as their row operand and the pixels as their column
+    // operand, so a lane owns ONE pixel (lane & 31 of its 32-pixel block) and, per accumulator group g = e >> 2,
+    // FOUR CONSECUTIVE output channels 8 g + 4 (lane >> 5) + (e & 3) = 16 contiguous bytes of the NHWC output:
+    // bias + residual + ReLU and the store happen straight from the accumulators with dwordx4 accesses (4 MI per
+    // lane), no transposition through LDS, no barrier. (With the pixels as the row operand a lane held one channel
+    // of 16 pixels = 32 four-byte stores, which queued up when a whole launch reached its epilogue together -- 8 us
+    // median of a 46 us workgroup -- and the LDS transposition that replaced them still cost two barriers.)
     const bool direct_out = KS2 || p.splitk <= 1;
-    const int et = KS2 ? (int)threadIdx.x : tid;
-    const int c4 = (et & 15) * 4;   // first of this thread's 4 channels inside the tile
-    const int r_t = et >> 4;        // its row in each (ET / 16)-row slice
-    int o_t[EP_IT];
-    f32x4 res_t[EP_IT];
+    if (KS2) {
+        // the two halves of K meet in LDS: half 1 parks its accumulators lane-for-lane, half 0 adds them
+        f32x4* xb = reinterpret_cast<f32x4*>(pc_lds);  // every wave left the k loop through the final barrier
+        if (half == 1) {
 #pragma unroll
-    for (int i = 0; i < EP_IT; ++i) {
-        int m = tile_m * BM + r_t + (ET / 16) * i;
-        m = m < p.M ? m : p.M - 1;
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    xb[(mi * 4 + g) * 256 + tid] = f32x4{acc[mi][4 * g], acc[mi][4 * g + 1], acc[mi][4 * g + 2], acc[mi][4 * g + 3]};
+        }
+        __syncthreads();
+        if (half == 1) return;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 o = xb[(mi * 4 + g) * 256 + tid];
+                acc[mi][4 * g] += o.x; acc[mi][4 * g + 1] += o.y; acc[mi][4 * g + 2] += o.z; acc[mi][4 * g + 3] += o.w;
+            }
+    }
+    const int ch0 = tile_n * BN + wn * 32 + 4 * lh;  // this lane's channels: ch0 + 8 g + 0..3
+    f32x4 bias4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        bias4[g] = (direct_out && p.bias) ? *reinterpret_cast<const f32x4*>(p.bias + ch0 + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = tile_m * BM + wm * (BM / 2) + mi * 32 + lr;
+        if (m >= p.M) continue;
         int img, oy, ox;
         split_m(p, m, img, oy, ox);
-        o_t[i] = img * p.out_img_stride + (oy + p.out_pad) * p.out_row_stride + (ox + p.out_pad) * p.out_px_stride +
-                 tile_n * BN + c4;
-        res_t[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    if (direct_out && p.residual) {
+        const int o_px = img * p.out_img_stride + (oy + p.out_pad) * p.out_row_stride + (ox + p.out_pad) * p.out_px_stride + ch0;
+        f32x4 res4[4];
 #pragma unroll
-        for (int i = 0; i < EP_IT; ++i) res_t[i] = *reinterpret_cast<const f32x4*>(p.residual + o_t[i]);
-    }
-    f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (direct_out && p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + tile_n * BN + c4);
-    float* const tbuf = patch0;  // (this half's buffers) every wave left the k loop through the final barrier
+        for (int g = 0; g < 4; ++g)
+            res4[g] = (direct_out && p.residual) ? *reinterpret_cast<const f32x4*>(p.residual + o_px + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = wm * (BM / 2) + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            tbuf[row * TS + wn * 32 + lr] = acc[mi][e];
-        }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < EP_IT; ++i) {
-        const int row = r_t + (ET / 16) * i;
-        const int m = tile_m * BM + row;
-        if (m >= p.M) continue;
-        f32x4 v = *reinterpret_cast<const f32x4*>(pc_lds + row * TS + c4);
-        if (KS2) v += *reinterpret_cast<const f32x4*>(pc_lds + 2 * PP + row * TS + c4);  // + the other half of K
-        if (!direct_out) {
-            *reinterpret_cast<f32x4*>(p.slab + ((size_t)z * p.M + m) * p.N + tile_n * BN + c4) = v;
-        } else {
-            v += bias4 + res_t[i];
-            if (p.relu) {
-                v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
-                v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v = f32x4{acc[mi][4 * g], acc[mi][4 * g + 1], acc[mi][4 * g + 2], acc[mi][4 * g + 3]};
+            if (!direct_out) {
+                *reinterpret_cast<f32x4*>(p.slab + ((size_t)z * p.M + m) * p.N + ch0 + 8 * g) = v;
+            } else {
+                v += bias4[g] + res4[g];
+                if (p.relu) {
+                    v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+                    v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+                }
+                *reinterpret_cast<f32x4*>(p.out + o_px + 8 * g) = v;
             }
-            *reinterpret_cast<f32x4*>(p.out + o_t[i]) = v;
         }
     }
 #ifdef PA_STAMP_BUILD

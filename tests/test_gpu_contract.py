@@ -495,3 +495,44 @@ def test_fighter_kat_box_on_gpu(engine):
                              list(data["camera_target_position"].values()), 50)
     assert got == want
     assert Fighter(frame_num=0, data=data).crop.yolo_crop() == want
+
+
+def test_bf16_full_size_configs2_properties(state_dict):
+    """BASELINE.json configs[2] at its full size (256 x 720p frames = 512 crops per backbone batch) -- far
+    beyond what the CPU oracle finishes in seconds, so checked through properties: the bf16 path's crops are
+    bit-identical to the fp32 engine's (whose parity with the oracle the small tests pin), its log-probs stay
+    within the bf16 tolerance of the fp32 engine's on every one of the 510 windows, the run is bitwise
+    repeatable (no atomics, fixed tile order), and chunking the clip into 4 x 64 frames changes nothing beyond
+    that tolerance."""
+    from playaid_core_amd.engine import Engine
+
+    n, h, w = 256, 720, 1280
+    frames = synth.make_frames_torch(n, h, w, device="cuda")
+    boxes = torch.from_numpy(synth.make_boxes(n, h, w)).cuda()
+    outs = {}
+    for dt, mb in (("f32", 64), ("bf16", 256), ("bf16", 64)):
+        eng = Engine(state_dict, max_batch_frames=mb, max_clip_frames=n, max_frame_height=h, max_frame_width=w, compute_dtype=dt)
+        try:
+            rec, lp = eng.alloc_records(n - 1), eng.alloc_logp(n - 1)
+            crops = torch.empty((n, 2, 128, 128, 3), dtype=torch.uint8, device="cuda")
+            st = torch.empty((n, 2), dtype=torch.int32, device="cuda")
+            eng.infer_clip_device(frames, boxes, rec, lp, crops, st)
+            torch.cuda.synchronize()
+            first = lp.clone()
+            eng.infer_clip_device(frames, boxes, rec, lp, crops, st)
+            torch.cuda.synchronize()
+            assert torch.equal(first, lp), "not bitwise repeatable"
+            assert (st == 0).all() and torch.isfinite(lp).all()
+            outs[(dt, mb)] = (lp.cpu().numpy(), crops.cpu().numpy(), eng.decode_records(rec)["action_id"])
+        finally:
+            eng.close()
+    ref_lp, ref_crops, ref_act = outs[("f32", 64)]
+    for key in (("bf16", 256), ("bf16", 64)):
+        lp, crops, act = outs[key]
+        assert np.array_equal(crops, ref_crops)
+        d = np.abs(lp - ref_lp)
+        assert d.max() <= BF16_LOGP_TOL and d.max() > 1e-4, d.max()
+        top2 = np.sort(ref_lp, axis=-1)[..., -2:]
+        clear = (top2[..., 1] - top2[..., 0]) > 2 * BF16_LOGP_TOL
+        assert clear.sum() > 100 and np.array_equal(act[clear], ref_act[clear])
+    assert np.abs(outs[("bf16", 256)][0] - outs[("bf16", 64)][0]).max() <= BF16_LOGP_TOL
