@@ -25,8 +25,9 @@ resamplers the reference's crop path calls. Neither library's source lives in
    fp32). PARITY UNPINNED: cv2 is not installed here, so this restatement is
    checked only through properties (constant images, integer-scale box means,
    weights summing to one) -- see DESIGN.md. The enlarging branch
-   (scale < 1, which OpenCV routes to its linear resizer) is NOT restated;
-   callers must keep the square side >= 128 px.
+   (scale < 1, which OpenCV routes to its fixed-point linear resizer with
+   area-mode coefficients) is restated in ``_cv_resize_area_enlarge`` below,
+   equally unpinned.
 """
 from __future__ import annotations
 

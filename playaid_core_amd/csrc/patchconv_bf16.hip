@@ -102,10 +102,16 @@ constexpr int NSTG = 3;                    // weight ring depth
 // drains; the epilogue stores straight from the accumulators in between. Everything lane-dependent
 // (patch pixel of a lane, swizzle keys, DMA source offsets) is tile-independent; a tile contributes only
 // scalar offsets.
-template <int W, int WAVES>
+//
+// WRES (the 64 -> 64 channel convolutions of layer 1, whose whole filter bank is 73.7 KB): the weights are copied to
+// LDS ONCE per workgroup and stay there, [chunk][tap][64 channels][64 B]; only activation patches stream, the
+// stage ring, its copies, counted waits and per-stage barriers disappear (one barrier per chunk = 72 matrix
+// instructions per wave), and a 512-pixel tile amortises the halo rows. These layers are HBM-bound.
+template <int W, int WAVES, bool WRES>
 __global__ __launch_bounds__(64 * WAVES) void conv3x3_bf16_patch_kernel(const GemmParams p) {
     using G = PatchGeom<W, WAVES>;
-    constexpr int LDS_BYTES = 2 * G::PATCH_BYTES + NSTG * WSTAGE_BYTES;
+    constexpr int WRES_BYTES = 2 * 9 * 4096;  // two 32-channel chunks x nine taps x (64 rows x 64 B)
+    constexpr int LDS_BYTES = 2 * G::PATCH_BYTES + (WRES ? WRES_BYTES : NSTG * WSTAGE_BYTES);
     __shared__ __attribute__((aligned(1024))) uint8_t lds[LDS_BYTES];
     uint8_t* const wring = lds + 2 * G::PATCH_BYTES;
 
@@ -149,9 +155,10 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_bf16_patch_kernel(const Ge
     // channels), then -- in the ky = 0 and ky = 1 stages -- half of the next patch's pieces. Wave w takes
     // jobs w, w + WAVES, ...; every wave issues the same NUMBER of copies per stage (the counted vmcnt
     // waits rely on it), surplus slots repeat the list's last piece.
-    constexpr int HALF = (G::NPIECE + 1) / 2;
-    constexpr int CNT_P = (12 + HALF + WAVES - 1) / WAVES;  // copies per wave in a stage that also moves patch pieces
-    constexpr int CNT_W = (12 + WAVES - 1) / WAVES;         // ... in the ky = 2 stage
+    constexpr int HALF = WRES ? G::NPIECE : (G::NPIECE + 1) / 2;   // WRES: the whole next patch in the ky = 0 stage
+    constexpr int NWJ = WRES ? 0 : 12;                              // weight pieces per stage
+    constexpr int CNT_P = (NWJ + HALF + WAVES - 1) / WAVES;  // copies per wave in a stage that also moves patch pieces
+    constexpr int CNT_W = (NWJ + WAVES - 1) / WAVES;         // ... in the ky = 2 stage
     static_assert(CNT_P <= 12, "extend wait_vmcnt");
     // patch piece q: patch pixel 16 q + (lane >> 2), slot lane & 3. The swizzle key of a pixel depends on
     // its padded (row, column); with the tile origins this geometry allows it is the same for every tile.
@@ -169,10 +176,10 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_bf16_patch_kernel(const Ge
 #pragma unroll
         for (int i = 0; i < CNT_P; ++i) {
             int job = wave + WAVES * i;
-            job = job < 12 + HALF ? job : 12 + HALF - 1;
-            int q = job - 12 + h * HALF;
+            job = job < NWJ + HALF ? job : NWJ + HALF - 1;
+            int q = job - NWJ + h * HALF;
             q = q < G::NPIECE ? q : G::NPIECE - 1;
-            pvoff[h][i] = job >= 12 ? patch_voff(q) : 0;
+            pvoff[h][i] = job >= NWJ ? patch_voff(q) : 0;
         }
     // weight piece job: tap kx = job >> 2, output channels 16 (job & 3) + (lane >> 2), slot (lane & 3) ^ ((n >> 2) & 3)
     const int wvoff_base = (tile_n * 64 + (lane >> 2)) * p.ktot * 2;
@@ -184,15 +191,15 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_bf16_patch_kernel(const Ge
         constexpr int CNT_ = (WITH_PATCH) ? CNT_P : CNT_W;                                                           \
         _Pragma("unroll") for (int i_ = 0; i_ < CNT_; ++i_) {                                                        \
             int job_ = wave + WAVES * i_;                                                                            \
-            const int last_ = (WITH_PATCH) ? 12 + HALF - 1 : 11;                                                     \
+            const int last_ = (WITH_PATCH) ? NWJ + HALF - 1 : NWJ - 1;                                               \
             job_ = job_ < last_ ? job_ : last_;                                                                      \
-            if (job_ < 12) {                                                                                         \
+            if (job_ < NWJ) {                                                                                        \
                 const int kx_ = job_ >> 2, grp_ = job_ & 3;                                                          \
                 const int n_ = 16 * grp_ + (lane >> 2);                                                              \
                 const int voff_ = wvoff_base + 16 * grp_ * p.ktot * 2 + (((lane & 3) ^ ((n_ >> 2) & 3)) << 4);       \
                 dma16(wgt_rs, voff_, (((KY) * 3 + kx_) * C + (CH) * 32) * 2, wring + (SLOT) * WSTAGE_BYTES + job_ * 1024); \
             } else {                                                                                                 \
-                int q_ = job_ - 12 + (HALF_IDX) * HALF;                                                              \
+                int q_ = job_ - NWJ + (HALF_IDX) * HALF;                                                             \
                 q_ = q_ < G::NPIECE ? q_ : G::NPIECE - 1;                                                            \
                 dma16(act_rs, pvoff[HALF_IDX][i_], (PSOFF), lds + (PB) * G::PATCH_BYTES + q_ * 1024);                \
             }                                                                                                        \
@@ -272,12 +279,22 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_bf16_patch_kernel(const Ge
     {
         const int ps0 = patch_origin(tile_first);
         for (int q = wave; q < G::NPIECE; q += WAVES) dma16(act_rs, patch_voff(q), ps0, lds + q * 1024);
-        for (int job = wave; job < 12; job += WAVES) {
-            const int kx = job >> 2, grp_ = job & 3;
-            const int n = 16 * grp_ + (lane >> 2);
-            const int voff = wvoff_base + 16 * grp_ * p.ktot * 2 + (((lane & 3) ^ ((n >> 2) & 3)) << 4);
-            dma16(wgt_rs, voff, ((0 * 3 + kx) * C) * 2, wring + 0 * WSTAGE_BYTES + job * 1024);
-            dma16(wgt_rs, voff, ((1 * 3 + kx) * C) * 2, wring + 1 * WSTAGE_BYTES + job * 1024);
+        if constexpr (WRES) {
+            // the whole filter bank: piece j = (chunk * 9 + tap) * 4 + group of 16 output channels
+            for (int j = wave; j < 2 * 9 * 4; j += WAVES) {
+                const int tc = j >> 2, grp_ = j & 3, chn = tc / 9, tap = tc - chn * 9;
+                const int n = 16 * grp_ + (lane >> 2);
+                const int voff = wvoff_base + 16 * grp_ * p.ktot * 2 + (((lane & 3) ^ ((n >> 2) & 3)) << 4);
+                dma16(wgt_rs, voff, (tap * C + chn * 32) * 2, wring + j * 1024);
+            }
+        } else {
+            for (int job = wave; job < 12; job += WAVES) {
+                const int kx = job >> 2, grp_ = job & 3;
+                const int n = 16 * grp_ + (lane >> 2);
+                const int voff = wvoff_base + 16 * grp_ * p.ktot * 2 + (((lane & 3) ^ ((n >> 2) & 3)) << 4);
+                dma16(wgt_rs, voff, ((0 * 3 + kx) * C) * 2, wring + 0 * WSTAGE_BYTES + job * 1024);
+                dma16(wgt_rs, voff, ((1 * 3 + kx) * C) * 2, wring + 1 * WSTAGE_BYTES + job * 1024);
+            }
         }
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
@@ -305,19 +322,24 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_bf16_patch_kernel(const Ge
                 // stage (ch, ky). Copies of the stage after next -> ring slot (ky + 2) % 3 (last read one stage
                 // ago, whose closing barrier every wave has passed); in ky = 0, 1 also half of the next patch.
                 // The weights wrap around at the end of a tile (same channel column).
-                if (last_ch && ky == 2 && residual) {
-                    // residual of this tile, requested before this stage's copies so that the stage's counted
-                    // wait also covers it
-                    const int oo = out_origin(tile);
-#pragma unroll
-                    for (int pi = 0; pi < 2; ++pi)
-#pragma unroll
-                        for (int ci = 0; ci < 2; ++ci)
-#pragma unroll
-                            for (int j = 0; j < 2; ++j)
-                                res[pi][ci][j] = *reinterpret_cast<const u32x4*>(residual + oo + obase[pi] + 32 * ci + 16 * j);
-                }
-                {
+#define BP_RESIDUAL()                                                                                                \
+    {                                                                                                                \
+        const int oo_ = out_origin(tile);                                                                            \
+        _Pragma("unroll") for (int pi = 0; pi < 2; ++pi)                                                             \
+            _Pragma("unroll") for (int ci = 0; ci < 2; ++ci)                                                         \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                        \
+                    res[pi][ci][j] = *reinterpret_cast<const u32x4*>(residual + oo_ + obase[pi] + 32 * ci + 16 * j); \
+    }
+                // residual of this tile. Ring kernel: requested in the tile's last stage BEFORE that stage's copies, so
+                // that the stage's counted wait also covers it (vmcnt is in order). WRES: one wait per chunk, so it is
+                // requested at the start of the tile's last chunk, behind the patch copies, a whole chunk ahead.
+                if (!WRES && last_ch && ky == 2 && residual) BP_RESIDUAL();
+                if constexpr (WRES) {
+                    if (ky == 0) {
+                        BP_ISSUE(0, 0, 0, true, 0, ps_next, pb_next);  // (only patch jobs exist)
+                        if (last_ch && residual) BP_RESIDUAL();
+                    }
+                } else {
                     const int t2ky = (ky + 2) % 3;
                     int ch2 = ky == 0 ? ch : ch + 1;
                     ch2 = ch2 < n_ch ? ch2 : 0;
@@ -328,7 +350,10 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_bf16_patch_kernel(const Ge
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                const uint8_t* wst = wring + ky * WSTAGE_BYTES;
+                // weights of this stage: ring slot ky, or the resident bank's (chunk, tap row)
+                const uint8_t* wst = WRES ? wring + (ch * 9 + ky * 3) * 4096 : wring + ky * WSTAGE_BYTES;
+                const uint8_t* wst_next = WRES ? wring + (ch * 9 + (ky + 1) * 3) * 4096 : wring + (ky + 1) * WSTAGE_BYTES;
+                const uint8_t* wst_wrap = WRES ? wring + (last_ch ? 0 : (ch + 1) * 9) * 4096 : wring;  // first stage of the next chunk
 #pragma unroll
                 for (int g = 0; g < 6; ++g) {  // k group g = (kx, kg)
                     if (g < 5) {
@@ -342,15 +367,24 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_bf16_patch_kernel(const Ge
                         // the copies of the next stage (issued a stage ago) have landed once only this stage's
                         // own copies are outstanding; every wave's reads of this stage are in registers -- then
                         // request the next stage's first operands and cover their latency with the last
-                        // matrix instructions.
-                        if (ky < 2) wait_vmcnt<CNT_P>(); else wait_vmcnt<CNT_W>();
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        __builtin_amdgcn_s_barrier();
+                        // matrix instructions. (WRES: nothing to wait for inside a chunk; at its end the next
+                        // patch -- and, behind a tile's last chunk, the residual -- must be there.)
+                        if constexpr (WRES) {
+                            if (ky == 2) {
+                                wait_vmcnt<0>();
+                                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                                __builtin_amdgcn_s_barrier();
+                            }
+                        } else {
+                            if (ky < 2) wait_vmcnt<CNT_P>(); else wait_vmcnt<CNT_W>();
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            __builtin_amdgcn_s_barrier();
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                         if (ky < 2) {
-                            BP_LOAD(0, patch, wring + (ky + 1) * WSTAGE_BYTES, ky + 1, 0, 0);
+                            BP_LOAD(0, patch, wst_next, ky + 1, 0, 0);
                         } else if (has_next) {
-                            BP_LOAD(0, lds + pb_next * G::PATCH_BYTES, wring, 0, 0, 0);
+                            BP_LOAD(0, lds + pb_next * G::PATCH_BYTES, wst_wrap, 0, 0, 0);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                         BP_MFMA(1);
@@ -404,6 +438,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_bf16_patch_kernel(const Ge
 #undef BP_LOAD
 #undef BP_MFMA
 #undef BP_ISSUE
+#undef BP_RESIDUAL
     wait_vmcnt<0>();  // the tail's unused re-fetches must not outlive the workgroup's LDS
 }
 
@@ -422,6 +457,7 @@ hipError_t launch_conv3x3_bf16_patch(const GemmParams& p_in, hipStream_t s) {
     p.total_px = (p.M / p.howo) * (W + 2) * (W + 2);
     if ((long long)p.total_px * p.chunk * 2 >= (1ll << 31)) return hipErrorInvalidValue;  // 32-bit buffer offsets
     static const int waves8 = getenv("PA_BF16_WAVES8") ? atoi(getenv("PA_BF16_WAVES8")) : 0;  // bit mask over {32,16,8}: flips the default
+    static const int wres = getenv("PA_BF16_WRES") ? atoi(getenv("PA_BF16_WRES")) : 1;
     static int n_cu = 0;
     if (!n_cu) {
         int dev = 0;
@@ -432,26 +468,31 @@ hipError_t launch_conv3x3_bf16_patch(const GemmParams& p_in, hipStream_t s) {
     p.tiles_n = p.N / 64;
     // persistent workgroups: WGPC per CU (what the LDS image allows), each a run of consecutive pixel tiles
     // of one channel column
-#define BPL(W_, WV_)                                                                                                 \
+#define BPL(W_, WV_) BPLX(W_, WV_, false)
+#define BPLX(W_, WV_, WRES_)                                                                                         \
     {                                                                                                                \
         using G_ = PatchGeom<W_, WV_>;                                                                               \
-        constexpr int lds_ = 2 * G_::PATCH_BYTES + NSTG * WSTAGE_BYTES;                                              \
+        constexpr int lds_ = 2 * G_::PATCH_BYTES + ((WRES_) ? 2 * 9 * 4096 : NSTG * WSTAGE_BYTES);                   \
         const int wgpc_ = lds_ <= 81920 ? 2 : 1;                                                                     \
         p.tiles_m = (p.M + G_::PXT - 1) / G_::PXT;                                                                   \
         int slots_ = n_cu * wgpc_ / p.tiles_n;                                                                       \
         slots_ = slots_ > 0 ? slots_ : 1;                                                                            \
         p.tiles_per_img = (p.tiles_m + slots_ - 1) / slots_;          /* tiles per workgroup */                     \
         const int groups_ = (p.tiles_m + p.tiles_per_img - 1) / p.tiles_per_img;                                     \
-        hipLaunchKernelGGL((conv3x3_bf16_patch_kernel<W_, WV_>), dim3(groups_ * p.tiles_n), dim3(64 * WV_), 0, s, p); \
+        hipLaunchKernelGGL((conv3x3_bf16_patch_kernel<W_, WV_, WRES_>), dim3(groups_ * p.tiles_n), dim3(64 * WV_), 0, s, p); \
     }
     switch (W) {
-        case 32: if (waves8 & 1) BPL(32, 8) else BPL(32, 4) break;
+        case 32:
+            // layer 1 (64 -> 64 channels): the filter bank stays in LDS (PA_BF16_WRES=0: the ring kernel, for A/B runs)
+            if (p.chunk == 64 && p.N == 64 && wres) BPLX(32, 8, true) else if (waves8 & 1) BPL(32, 8) else BPL(32, 4)
+            break;
         case 16: if (waves8 & 2) BPL(16, 8) else BPL(16, 4) break;
         case 8: if (waves8 & 4) BPL(8, 4) else BPL(8, 8) break;
         case 4: BPL(4, 4) break;
         default: return hipErrorInvalidValue;
     }
 #undef BPL
+#undef BPLX
     return hipGetLastError();
 }
 

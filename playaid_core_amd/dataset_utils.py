@@ -3,7 +3,7 @@
 Mirrors ``playaid/dataset_utils.py:109-138``: S (odd) frame numbers around a
 middle frame with quadratic spacing ``delta * (mid - i)**2``, clamped to
 ``[min_frame, max_frames - 1]``. The device-side head kernel gathers cached
-feature rows with exactly these indices (``csrc/head.hip``); this function is
+feature rows with exactly these indices (``window_gather_kernel`` in ``csrc/misc.hip``); this function is
 the host mirror used by ``AIRunner`` and by the tests.
 """
 from typing import List

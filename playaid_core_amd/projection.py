@@ -13,10 +13,11 @@ from typing import Dict, List
 
 import numpy as np
 
+from .anim_ontology import STAGE_ENUM_TO_DATA
+
 # STAGE_ENUM_TO_DATA[...]["fov"] (playaid/anim_ontology.py:497-570): 50 everywhere except
 # TOWN_AND_CITY (95) = 30; unknown stages fall back to stage 0 (fighter.py:479-480).
-STAGE_FOV = {0: 50, 3: 50, 44: 50, 51: 50, 86: 50, 89: 50, 95: 30, 107: 50, 118: 50, 242: 50, 257: 50, 268: 50,
-             293: 50, 295: 50, 330: 50, 347: 50, 351: 50, 361: 50}
+STAGE_FOV = {sid: d["fov"] for sid, d in STAGE_ENUM_TO_DATA.items()}
 
 
 def log_rows_from_timeline(timeline: List[List[Dict]]) -> np.ndarray:
