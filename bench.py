@@ -187,6 +187,56 @@ def pcie_inclusive_windows(eng, frames_dev, boxes_dev, steps=8):
     }
 
 
+def bench_mixed(args):
+    """BASELINE.json configs[4]: a 1080p/720p interleaved clip, frames resident in HBM per resolution bucket, fixed-size
+    batches through hipGraph-captured "crop + backbone + scatter into the feature cache" sequences, one head pass per
+    clip. Reports the graph-replay rate with the eager rate of the same launches beside it. Single GPU, own metric."""
+    from playaid_core_amd.stream_runner import MixedResolutionRunner
+
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(device)
+    n, batch = 192, 32  # 128 frames at 1080p + 64 at 720p: 4 + 2 batches of 32 frames (64 crops each)
+    res = [(1080, 1920) if (i % 3) != 1 else (720, 1280) for i in range(n)]
+    sd = synth.make_state_dict(seed=1234)
+    eng = Engine(sd, device=str(device), max_batch_frames=batch, max_clip_frames=n, compute_dtype=args.dtype)
+    buckets = {}
+    for shape in sorted(set(res)):
+        idx = [i for i in range(n) if res[i] == shape]
+        assert len(idx) % batch == 0
+        fr = torch.stack([torch.from_numpy(synth.make_frame(i, *shape)) for i in idx]).to(device)
+        bx = torch.from_numpy(np.stack([[synth.fighter_box(i, p, *shape) for p in range(2)] for i in idx]).astype(np.float64)).to(device)
+        buckets[shape] = (fr, bx, torch.tensor(idx, dtype=torch.int32, device=device))
+    rec, lp = eng.alloc_records(n - 1), eng.alloc_logp(n - 1)
+    out = {}
+    for mode, use_graphs in (("graph", True), ("eager", False)):
+        runner = MixedResolutionRunner(eng, batch_frames=batch, use_graphs=use_graphs)
+        for _ in range(max(args.warmup, 2)):  # two passes: both staging slots of every bucket get captured
+            runner.run_resident(buckets, n, rec, lp)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            runner.run_resident(buckets, n, rec, lp)
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        assert torch.isfinite(lp).all()
+        out[mode] = {"frames_per_s": round(n * args.steps / dt, 1), "ms_per_clip": round(1e3 * dt / args.steps, 3),
+                     "graph_captures": runner.captures, "graph_replays": runner.replays}
+    eng.check_device_errors()
+    result = {
+        "metric": "mixed-resolution frames/sec (1080p + 720p interleaved), frames resident in HBM -> per-frame labels",
+        "value": out["graph"]["frames_per_s"], "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": max(args.warmup, 2),
+        "ms_per_step": out["graph"]["ms_per_clip"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"configs[4]: {n}-frame clip, 2/3 at 1920x1080 and 1/3 at 1280x720 interleaved, bucketed by resolution into "
+                   f"batches of {batch} frames, each batch one hipGraph replay (crop stage + backbone + "
+                   "scatter into the feature cache), one temporal-head pass per clip; seeded weights",
+                   "ingest": "frames resident in HBM per bucket; no decode"},
+        "hipgraph": out["graph"], "eager": out["eager"],
+    }
+    print(json.dumps(result), flush=True)
+    eng.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,6 +250,9 @@ def main():
                     "--gpus > 1, off (configs[1]: a 64-frame clip per step) when --gpus 1; 0 = a --frames clip per rank (weak scaling)")
     ap.add_argument("--inner-repeat", type=int, default=20,
                     help="configs[1]/[2] only: clips per timed step (ms_per_step stays per clip)")
+    ap.add_argument("--workload", default="clip", choices=["clip", "mixed"],
+                    help="clip = the headline / configs[1-3] workloads; mixed = BASELINE.json configs[4] (mixed-resolution stream, "
+                    "bucketing + hipGraph replay; single GPU, reported under its own metric)")
     ap.add_argument("--cpu-sample-frames", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive side measurement")
@@ -210,6 +263,8 @@ def main():
                     help="f32 = the headline (reference arithmetic); bf16 = BASELINE.json configs[2]'s conv path, reported under its own dtype, never as the headline")
     args = ap.parse_args()
 
+    if args.workload == "mixed":
+        return bench_mixed(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -62,7 +62,7 @@ __device__ __forceinline__ int bicubic_ksize(int in_size, int out_size) {
 
 
 // Pillow precompute_coeffs bounds (first tap, tap count) of output coordinate
-// xx for a pass in_size -> out_size: the same arithmetic as crop_coef_kernel.
+// xx for a pass in_size -> out_size: the same arithmetic as bicubic_coef_row.
 __device__ __forceinline__ void bicubic_bounds(int in_size, int out_size, int xx, int* xmin, int* cnt) {
     const double scale = (double)(float)in_size / out_size;
     const double filterscale = scale < 1.0 ? 1.0 : scale;
@@ -230,10 +230,53 @@ __device__ __forceinline__ BandLds band_lds(const CropPlan& pl, const BandRows& 
     return l;
 }
 
+__device__ __forceinline__ double bicubic_filter(double x) {
+    const double a = -0.5;
+    if (x < 0.0) x = -x;
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+    return 0.0;
+}
+
+// Pillow precompute_coeffs + normalize_coeffs_8bpc for output coordinate xx of a pass in_size -> out_size
+// into row[0] = first tap, row[1] = tap count, row[2..] = coefficients.
+__device__ void bicubic_coef_row(int in_size, int out_size, int xx, int32_t* row) {
+    const double scale = (double)(float)in_size / out_size;
+    const double filterscale = scale < 1.0 ? 1.0 : scale;
+    const double support = 2.0 * filterscale;
+    const double ss = 1.0 / filterscale;
+    const double center = 0.0 + (xx + 0.5) * scale;
+    int xmin = (int)(center - support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5);
+    if (xmax > in_size) xmax = in_size;
+    xmax -= xmin;
+    double k[PA_KSIZE_MAX];
+    double ww = 0.0;
+    for (int x = 0; x < PA_KSIZE_MAX; ++x) {
+        double w = 0.0;
+        if (x < xmax) {
+            w = bicubic_filter((x + xmin - center + 0.5) * ss);
+            ww += w;
+        }
+        k[x] = w;
+    }
+    row[0] = xmin;
+    row[1] = xmax;
+    for (int x = 0; x < PA_KSIZE_MAX; ++x) {
+        double v = k[x];
+        if (x < xmax && ww != 0.0) v = v / ww;
+        row[2 + x] = v < 0 ? (int)(-0.5 + v * (double)(1 << PRECISION_BITS)) : (int)(0.5 + v * (double)(1 << PRECISION_BITS));
+    }
+}
+
 // One wave per crop: every lane derives the geometry (cheap, identical), then the lanes
 // share the search for the largest LDS sub-band (128 candidate sub-bands in parallel).
-__global__ __launch_bounds__(64) void crop_plan_kernel(const PreprocParams p) {
+// Workgroup = one crop: wave 0 plans, then all four waves fill the crop's two Pillow coefficient tables.
+__global__ __launch_bounds__(256) void crop_plan_kernel(const PreprocParams p) {
+    __shared__ CropPlan plan_sh;
     const int crop = blockIdx.x;
+    if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
     CropPlan pl;
     pl.status = PA_CROP_OK;
@@ -355,62 +398,25 @@ __global__ __launch_bounds__(64) void crop_plan_kernel(const PreprocParams p) {
             if (worst <= p.fused_lds) pl.fused_rb = rb;
         }
     }
-    if (lane != 0) return;
-    if (pl.status == PA_CROP_OK && pl.fused_rb == 0) {
-        const int slot = atomicAdd(p.fallback_count, 1);
-        p.fallback_list[slot] = crop;
-    }
-    p.plans[crop] = pl;
-    if (p.status) p.status[crop] = pl.status;
-}
-
-__device__ __forceinline__ double bicubic_filter(double x) {
-    const double a = -0.5;
-    if (x < 0.0) x = -x;
-    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
-    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
-    return 0.0;
-}
-
-// Pillow precompute_coeffs + normalize_coeffs_8bpc, one thread per output coordinate.
-__global__ void crop_coef_kernel(const PreprocParams p) {
-    const int crop = blockIdx.y >> 1;
-    const int axis = blockIdx.y & 1;
-    const int xx = blockIdx.x * blockDim.x + threadIdx.x;
-    const CropPlan pl = p.plans[crop];
-    if (pl.status != PA_CROP_OK) return;
-    const int need = axis ? pl.need_v : pl.need_h;
-    if (!need) return;
-    const int in_size = axis ? pl.sh : pl.sw;
-    const int out_size = axis ? pl.rh : pl.rw;
-    if (xx >= out_size) return;
-    const double scale = (double)(float)in_size / out_size;
-    const double filterscale = scale < 1.0 ? 1.0 : scale;
-    const double support = 2.0 * filterscale;
-    const double ss = 1.0 / filterscale;
-    const double center = 0.0 + (xx + 0.5) * scale;
-    int xmin = (int)(center - support + 0.5);
-    if (xmin < 0) xmin = 0;
-    int xmax = (int)(center + support + 0.5);
-    if (xmax > in_size) xmax = in_size;
-    xmax -= xmin;
-    double k[PA_KSIZE_MAX];
-    double ww = 0.0;
-    for (int x = 0; x < PA_KSIZE_MAX; ++x) {
-        double w = 0.0;
-        if (x < xmax) {
-            w = bicubic_filter((x + xmin - center + 0.5) * ss);
-            ww += w;
+    if (lane == 0) {
+        if (pl.status == PA_CROP_OK && pl.fused_rb == 0) {
+            const int slot = atomicAdd(p.fallback_count, 1);
+            p.fallback_list[slot] = crop;
         }
-        k[x] = w;
+        p.plans[crop] = pl;
+        plan_sh = pl;
+        if (p.status) p.status[crop] = pl.status;
     }
-    int32_t* row = p.coef + ((size_t)(crop * 2 + axis) * p.coef_dim + xx) * COEF_ROW;
-    row[0] = xmin;
-    row[1] = xmax;
-    for (int x = 0; x < PA_KSIZE_MAX; ++x) {
-        double v = k[x];
-        if (x < xmax && ww != 0.0) v = v / ww;
-        row[2 + x] = v < 0 ? (int)(-0.5 + v * (double)(1 << PRECISION_BITS)) : (int)(0.5 + v * (double)(1 << PRECISION_BITS));
+    }
+    __syncthreads();
+    // Pillow precompute_coeffs + normalize_coeffs_8bpc for both passes (one thread per output coordinate)
+    const CropPlan pl = plan_sh;
+    if (pl.status != PA_CROP_OK) return;
+    for (int axis = 0; axis < 2; ++axis) {
+        if (!(axis ? pl.need_v : pl.need_h)) continue;
+        const int in_size = axis ? pl.sh : pl.sw, out_size = axis ? pl.rh : pl.rw;
+        for (int xx = threadIdx.x; xx < out_size; xx += 256)
+            bicubic_coef_row(in_size, out_size, xx, p.coef + ((size_t)(crop * 2 + axis) * p.coef_dim + xx) * COEF_ROW);
     }
 }
 
@@ -1225,38 +1231,6 @@ __device__ __forceinline__ void area_pixel_wh(const RunnerInPlan& pl, const WhCa
     }
 }
 
-// Pillow precompute_coeffs + normalize_coeffs_8bpc for output coordinate xx of a pass in_size -> out_size
-// (the arithmetic of crop_coef_kernel), into row[0] = first tap, row[1] = tap count, row[2..] = coefficients.
-__device__ void bicubic_coef_row(int in_size, int out_size, int xx, int32_t* row) {
-    const double scale = (double)(float)in_size / out_size;
-    const double filterscale = scale < 1.0 ? 1.0 : scale;
-    const double support = 2.0 * filterscale;
-    const double ss = 1.0 / filterscale;
-    const double center = 0.0 + (xx + 0.5) * scale;
-    int xmin = (int)(center - support + 0.5);
-    if (xmin < 0) xmin = 0;
-    int xmax = (int)(center + support + 0.5);
-    if (xmax > in_size) xmax = in_size;
-    xmax -= xmin;
-    double k[PA_KSIZE_MAX];
-    double ww = 0.0;
-    for (int x = 0; x < PA_KSIZE_MAX; ++x) {
-        double w = 0.0;
-        if (x < xmax) {
-            w = bicubic_filter((x + xmin - center + 0.5) * ss);
-            ww += w;
-        }
-        k[x] = w;
-    }
-    row[0] = xmin;
-    row[1] = xmax;
-    for (int x = 0; x < PA_KSIZE_MAX; ++x) {
-        double v = k[x];
-        if (x < xmax && ww != 0.0) v = v / ww;
-        row[2 + x] = v < 0 ? (int)(-0.5 + v * (double)(1 << PRECISION_BITS)) : (int)(0.5 + v * (double)(1 << PRECISION_BITS));
-    }
-}
-
 __global__ __launch_bounds__(256) void runner_input_kernel(const RunnerInParams q) {
     __shared__ int32_t coef[2][PA_CROP][COEF_ROW];  // [axis][output coordinate]: both passes end at <= 128 outputs
     const int crop = blockIdx.x;
@@ -1470,8 +1444,7 @@ hipError_t launch_preprocess(const PreprocParams& p_in, hipStream_t s) {
     p.ablate = ablate;
     const int ncrops = p.n_frames * p.fighters;
     if (ncrops <= 0) return hipSuccess;
-    hipLaunchKernelGGL(crop_plan_kernel, dim3(ncrops), dim3(64), 0, s, p);
-    hipLaunchKernelGGL(crop_coef_kernel, dim3((p.coef_dim + 127) / 128, ncrops * 2), dim3(128), 0, s, p);
+    hipLaunchKernelGGL(crop_plan_kernel, dim3(ncrops), dim3(256), 0, s, p);
 #ifdef PA_STAMP_BUILD
     static int calls = 0;
     static unsigned long long* sd = nullptr;

@@ -18,7 +18,7 @@ for r in rows:
     d[r["Counter_Name"]] = float(r["Counter_Value"])
 ds = [disp[k] for k in sorted(disp)]
 if dtype == "bf16":
-    conv = [d for d in ds if "igemm_bf16_kernel" in d["name"]]
+    conv = [d for d in ds if "igemm_bf16_kernel" in d["name"] or "conv3x3_bf16_patch_kernel" in d["name"]]
 else:
     ig = [d for d in ds if "igemm_f32_kernel" in d["name"] and ", true," not in d["name"]]
     assert len(ig) % 4 == 0, len(ig)

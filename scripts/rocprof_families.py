@@ -8,7 +8,11 @@ non-gather igemm launches of a bench step come in a fixed order (layer2.0.conv1,
 layer4.0.conv1, fc; the gather-mode Conv1d is a different instantiation), which this script uses
 to split them, so that bench.py's roofline.avg_launch_ms can be checked against the profiler.
 
-  python scripts/rocprof_families.py <dir>/<host>/<pid>_kernel_trace.csv out.json"""
+  python scripts/rocprof_families.py <dir>/<host>/<pid>_kernel_trace.csv out.json [f32|bf16]
+
+bf16 (configs[2]): the conv3x3 family = every conv3x3_bf16_patch_kernel launch (the stride-1 convs) + every
+igemm_bf16_kernel launch (the stride-2 convs and the three 1x1/2 downsample GEMMs that feed the patch kernel as
+its residual): 19 launches per step; igemm_f32_kernel then only runs the fc."""
 import collections, csv, json, sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
@@ -25,13 +29,14 @@ for r in rows:
             ig.append(dur)
     elif name.startswith("pa::") or " pa::" in name:
         fam[name.split("(")[0].replace("void ", "").replace("pa::", "")].append(dur)
-per = 4
+dtype = sys.argv[3] if len(sys.argv) > 3 else "f32"
+per = 4 if dtype == "f32" else 1
 assert len(ig) % per == 0, len(ig)
 for s in range(len(ig) // per):
     step = ig[s * per:(s + 1) * per]
-    fam["igemm_conv3x3"] += step[0:3]
-    fam["igemm_fc"].append(step[3])
-for k in [k for k in fam if k.startswith("conv3x3_patch_kernel")]:
+    fam["igemm_conv3x3"] += step[0:per - 1]
+    fam["igemm_fc"].append(step[per - 1])
+for k in [k for k in fam if k.startswith(("conv3x3_patch_kernel", "conv3x3_bf16_patch_kernel", "igemm_bf16_kernel"))]:
     fam["igemm_conv3x3"] += fam.pop(k)
 out = {k: {"launches": len(v), "avg_us": round(sum(v) / len(v) / 1e3, 2), "total_ms": round(sum(v) / 1e6, 3)} for k, v in sorted(fam.items())}
 json.dump(out, open(sys.argv[2], "w"), indent=1)

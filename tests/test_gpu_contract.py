@@ -333,8 +333,8 @@ def test_mixed_resolution_stream_with_hipgraph(engine, state_dict):
             assert ok
             crops_ref[i, p] = yolo_crop.runner_input_from_crop(c)
     ref = pipeline.run_action_recognition(np.zeros((n, 1, 1, 3), np.uint8), boxes, state_dict, mode="cached", crops_rgb=crops_ref)
-    # 32 frames = 64 crops per captured batch: the engine's side-stream fork/join (max-pool of one half batch
-    # under the stem of the other, pa_api.hip) is INSIDE the captured graph
+    # 32 frames = 64 crops per captured batch (the size from which the engine used to fork a side stream inside
+    # the backbone; stem and max-pool are one kernel now, the captured sequence is a single stream)
     runner = MixedResolutionRunner(engine, batch_frames=32, use_graphs=True)
     got = runner.run(frames, boxes, want_crops=True)
     assert runner.captures == 2 and runner.replays == 1 + 1  # 27 frames @1080p -> 1 padded batch, 13 @720p -> 1
