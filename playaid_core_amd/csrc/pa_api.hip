@@ -1093,6 +1093,16 @@ int pa_upload_crop_windows(pa_engine* e, const uint8_t* frames_host, int32_t n, 
         return fail(e, PA_ERR_INVALID_ARG, "pa_upload_crop_windows: bad argument");
     hipStream_t s = (hipStream_t)stream;
     const int F = e->cfg.num_fighters;
+    // the upload kernel dereferences frames_host on the device: it must be pinned (device-visible) host memory,
+    // a pageable pointer would be a GPU page fault
+    for (const void* hp : {(const void*)frames_host, (const void*)(frames_host + (size_t)n * height * width * 3 - 1), (const void*)desc_host}) {
+        hipPointerAttribute_t attr;
+        const hipError_t pe = hipPointerGetAttributes(&attr, hp);
+        if (pe != hipSuccess || (attr.type != hipMemoryTypeHost && attr.type != hipMemoryTypeManaged && attr.type != hipMemoryTypeDevice)) {
+            (void)hipGetLastError();
+            return fail(e, PA_ERR_INVALID_ARG, "pa_upload_crop_windows: frames_host / desc_host must be pinned host memory (hipHostMalloc, torch pin_memory)");
+        }
+    }
     size_t off = 0;
     for (int i = 0; i < n * F; ++i) {
         int sy0, sx0, sh, sw;

@@ -47,3 +47,24 @@ def test_window_ingest_equals_whole_frame_ingest(engine):
     engine.preprocess_windows(stage, n, h, w, torch.from_numpy(boxes2).to(engine.device), 1, crops, status)
     torch.cuda.synchronize()
     assert np.array_equal(crops.cpu().numpy(), ref2["crops_rgb"])
+
+
+def test_pageable_host_memory_is_refused(engine):
+    """The upload kernel reads the frames from the device: a pageable pointer must come back as a status code,
+    never as a GPU page fault."""
+    import ctypes as C
+
+    from playaid_core_amd import _lib
+
+    n, h, w = 2, 720, 1280
+    frames = torch.from_numpy(synth.make_frames(n, h, w))  # NOT pinned
+    stage = engine.make_window_stage(n)
+    with pytest.raises(ValueError):
+        engine.upload_crop_windows(frames, synth.make_boxes(n, h, w), stage)
+    boxes = np.ascontiguousarray(synth.make_boxes(n, h, w))
+    used = C.c_size_t(0)
+    rc = engine._lib.pa_upload_crop_windows(
+        engine._h, C.c_void_p(frames.data_ptr()), n, h, w, boxes.ctypes.data_as(C.c_void_p), 30,
+        C.c_void_p(stage["windows"].data_ptr()), stage["windows"].numel(), C.c_void_p(stage["desc_host"].data_ptr()),
+        C.c_void_p(stage["desc_dev"].data_ptr()), C.byref(used), None)
+    assert rc == _lib.PA_ERR_INVALID_ARG and b"pinned" in engine._lib.pa_last_error(engine._h)
