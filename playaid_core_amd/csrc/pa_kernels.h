@@ -47,6 +47,7 @@ struct GemmParams {
     // input row pitch and image size in pixels, tile -> first patch pixel, pixels in the whole buffer
     int32_t patch_slots, patch_pitch, img_px, tiles_per_img, p0_img, p0_row, total_px;
     int32_t swz_a, magic_pitch, magic_img, img_px_patch;  // chunk-swizzle key of a patch pixel (see patchconv.hip)
+    int32_t xcd_m, xcd_n;  // the 8 XCDs as an xcd_m x xcd_n grid over (pixel tiles, channel tiles); 0 = contiguous runs of tiles
     unsigned long long* clk;  // ablation builds only: in-kernel clock stamps
 };
 

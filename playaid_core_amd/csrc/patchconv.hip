@@ -86,8 +86,19 @@ __global__ __launch_bounds__(KS2 ? 512 : 256, 2) void conv3x3_patch_kernel(const
     const int tiles_mn = p.tiles_m * p.tiles_n;
     const int z = KS2 ? half : wg / tiles_mn;   // which share of K this group of four waves sums
     const int t_id = KS2 ? wg : wg - (wg / tiles_mn) * tiles_mn;
-    const int tile_m = t_id / p.tiles_n;
-    const int tile_n = t_id - tile_m * p.tiles_n;
+    int tile_m = t_id / p.tiles_n;
+    int tile_n = t_id - tile_m * p.tiles_n;
+    if (p.xcd_m) {
+        // Each XCD has its own L2, so every XCD fetches the activations AND the weights of its tiles from HBM once.
+        // A contiguous run of tiles gives an XCD 1/8 of the pixels and ALL channel columns = the whole filter bank
+        // (layer 4: 9.4 MB of weights x 8 XCDs = 75 of the 85 MB fetched per launch, rocprofv3 FETCH_SIZE). Arranging
+        // the XCDs as an xcd_m x xcd_n grid over (pixel tiles, channel tiles) fetches acts / xcd_m + weights / xcd_n each.
+        const int local = b >> 3;                      // this workgroup's rank inside its XCD
+        const int tn_per = p.tiles_n / p.xcd_n, tm_per = p.tiles_m / p.xcd_m;
+        const int lm = local / tn_per;
+        tile_m = (xcd / p.xcd_n) * tm_per + lm;
+        tile_n = (xcd % p.xcd_n) * tn_per + (local - lm * tn_per);
+    }
 
     const int tid = threadIdx.x & 255;
 #ifdef PA_STAMP_BUILD
@@ -468,6 +479,24 @@ hipError_t launch_conv3x3_patch(const GemmParams& p_in, int bm, hipStream_t s) {
         p.ksteps_per_split = n_ch / 2;
     }
     const int grid = p.tiles_m * p.tiles_n * p.splitk;
+    p.xcd_m = p.xcd_n = 0;
+    if (p.splitk == 1 && grid % 8 == 0) {
+        // bytes an XCD fetches for an (a x b) arrangement: input activations / a + weights / b; keep the default
+        // (a = 8: contiguous runs) unless another divisor pair is at least 10 % cheaper
+        const double act = (double)p.total_px * p.chunk * 4.0, wgt = (double)p.N * p.ktot * 4.0;
+        double best = act / 8 + wgt;
+        static const int use_grid = getenv("PA_XCD_GRID") ? atoi(getenv("PA_XCD_GRID")) : 1;
+        for (int a = 4; a >= 1 && use_grid; a >>= 1) {
+            const int bb = 8 / a;
+            if (p.tiles_m % a || p.tiles_n % bb) continue;
+            const double cost = act / a + wgt / bb;
+            if (cost < 0.9 * best) {
+                best = cost;
+                p.xcd_m = a;
+                p.xcd_n = bb;
+            }
+        }
+    }
 #ifdef PA_STAMP_BUILD
     // timeline stamps of every workgroup of launch number PA_STAMP_CALL, written to PA_STAMP_FILE
     static int stamp_calls = 0;
