@@ -41,7 +41,7 @@ import torch.distributed as dist
 
 from playaid_core_amd import synth
 from playaid_core_amd.engine import Engine
-from playaid_core_amd.parallel import FrameParallelClip, broadcast_engine, halo_plan, shard_range
+from playaid_core_amd.parallel import ClipLanes, FrameParallelClip, broadcast_engine, halo_plan, shard_range
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, = fp32 vector peak
 PEAK_HBM_GBS = 8000.0
@@ -253,6 +253,12 @@ def main():
     ap.add_argument("--workload", default="clip", choices=["clip", "mixed"],
                     help="clip = the headline / configs[1-3] workloads; mixed = BASELINE.json configs[4] (mixed-resolution stream, "
                     "bucketing + hipGraph replay; single GPU, reported under its own metric)")
+    ap.add_argument("--lanes", type=int, default=2,
+                    help="configs[1]/[2] at N = 1: independent clips alternate over this many engines / streams (ClipLanes); "
+                    "1 = one engine with the crop stage of clip k+1 under the backbone of clip k")
+    ap.add_argument("--long-clip-batch", type=int, default=256,
+                    help="configs[3]: frames per backbone batch of the long clip (the 64-frame batch is configs[1]'s workload, "
+                    "not a property of the 8192-frame clip)")
     ap.add_argument("--cpu-sample-frames", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive side measurement")
@@ -284,7 +290,7 @@ def main():
     F, S, A, DELTA = 2, 7, 63, 3
     clip_frames = args.clip_frames if args.clip_frames is not None else (8192 if world > 1 else 0)
     long_clip = clip_frames > 0
-    n_batch = args.frames
+    n_batch = args.long_clip_batch if long_clip else args.frames
     n_total = clip_frames if long_clip else n_batch * world
     lo, hi = shard_range(n_total, world, rank)
     repeat = 1 if (long_clip or world > 1) else max(args.inner_repeat, 1)
@@ -305,8 +311,13 @@ def main():
         frames = torch.from_numpy(synth.make_frames(hi - lo, args.height, args.width, first_frame=lo)).to(device)
     boxes = torch.from_numpy(synth.make_boxes(hi - lo, args.height, args.width, first_frame=lo)).to(device)
     runner = FrameParallelClip(eng, S, DELTA)
+    lanes = None
+    if world == 1 and not long_clip and args.lanes > 1 and not args.no_pipeline:
+        lanes = ClipLanes(eng, S, DELTA, lanes=args.lanes)
 
     def step(pipeline=None):
+        if lanes is not None and pipeline is None:
+            return lanes.submit(frames, boxes, n_total)[1:]
         pipeline = (not args.no_pipeline) if pipeline is None else pipeline
         return runner.run(frames, boxes, n_total, gather=True, pipeline=pipeline, reuse_buffers=True)
 
@@ -388,7 +399,11 @@ def main():
                 "inner_repeat": repeat,
                 "inner_repeat_note": "clips per timed step; ms_per_step = timed region / (steps x inner_repeat) = one clip",
                 "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU",
-                "pipeline": "crop stage of batch k+1 overlaps the backbone of batch k (2 streams, 2 input slots)" if not args.no_pipeline else "none",
+                "pipeline": (f"{args.lanes} lanes: independent clips alternate over {args.lanes} engines (own activation buffers, own HIP stream), "
+                             "so one clip's launch ramps / kernel tails run under another clip's steady state; inside a lane the crop stage "
+                             "and the backbone run in stream order") if lanes is not None
+                else ("crop stage of batch k+1 overlaps the backbone of batch k (2 streams, 2 input slots)" if not args.no_pipeline else "none"),
+                "lanes": args.lanes if lanes is not None else 1,
             },
         }
         if world > 1:
@@ -477,6 +492,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if lanes is not None:
+        lanes.close()
     eng.close()
 
 

@@ -119,6 +119,13 @@ class Engine:
                 self._h = C.c_void_p(0)
             raise EngineError(rc, msg)
 
+    def clone(self, **overrides) -> "Engine":
+        """A second engine on the same device with the same (already folded) weights: its own activation buffers,
+        feature cache and scratch. Built from this engine's weight arena (``pa_create_from_arena``): no second fold."""
+        kw = dict(self._ctor_kwargs)
+        kw.update(overrides)
+        return Engine(self.weights_arena(), **kw)
+
     def reconfigured(self, **overrides) -> "Engine":
         """A new engine on the same device and weights with some geometry changed."""
         kw = dict(self._ctor_kwargs)

@@ -536,3 +536,36 @@ def test_bf16_full_size_configs2_properties(state_dict):
         clear = (top2[..., 1] - top2[..., 0]) > 2 * BF16_LOGP_TOL
         assert clear.sum() > 100 and np.array_equal(act[clear], ref_act[clear])
     assert np.abs(outs[("bf16", 256)][0] - outs[("bf16", 64)][0]).max() <= BF16_LOGP_TOL
+
+
+def test_clip_lanes_equal_single_engine(engine):
+    """ClipLanes (independent clips alternating over two engines / streams, the second engine cloned from the
+    first one's weight arena) returns bitwise what the single engine returns for every clip, whatever the lane,
+    with clips of both lanes in flight at the same time."""
+    from playaid_core_amd.parallel import ClipLanes
+
+    n, h, w = 24, 720, 1280
+    clips = []
+    for seed in (3, 4, 5, 6, 7):
+        f = torch.from_numpy(synth.make_frames(n, h, w, seed=seed)).cuda()
+        b = torch.from_numpy(synth.make_boxes(n, h, w, first_frame=10 * seed)).cuda()
+        clips.append((f, b))
+    torch.cuda.synchronize()
+    want = [engine.infer_clip(f, b)["logp"] for f, b in clips]
+    lanes = ClipLanes(engine, 7, 3, lanes=2)
+    try:
+        assert len(lanes.engines) == 2 and lanes.engines[1] is not engine
+        for rounds in range(2):
+            pending = []
+            for i, (f, b) in enumerate(clips):
+                lane, rec, lp = lanes.submit(f, b, n)
+                pending.append((i, lane, lp))
+                if len(pending) == 2:  # both lanes busy: drain the older one before its lane is reused
+                    j, lj, lpj = pending.pop(0)
+                    lanes.streams[lj].synchronize()
+                    assert np.array_equal(lpj.cpu().numpy(), want[j]), (rounds, j, lj)
+            lanes.synchronize()
+            for j, lj, lpj in pending:
+                assert np.array_equal(lpj.cpu().numpy(), want[j])
+    finally:
+        lanes.close()
