@@ -314,6 +314,7 @@ def main():
     lanes = None
     if world == 1 and not long_clip and args.lanes > 1 and not args.no_pipeline:
         lanes = ClipLanes(eng, S, DELTA, lanes=args.lanes)
+        lanes.calibrate(frames, boxes, n_total)   # untimed: which of the concurrent streams overlap best on this clip shape
 
     def step(pipeline=None):
         if lanes is not None and pipeline is None:
@@ -404,6 +405,7 @@ def main():
                              "and the backbone run in stream order") if lanes is not None
                 else ("crop stage of batch k+1 overlaps the backbone of batch k (2 streams, 2 input slots)" if not args.no_pipeline else "none"),
                 "lanes": args.lanes if lanes is not None else 1,
+                "lane_stream_calibration": lanes.calibration if lanes is not None else None,
             },
         }
         if world > 1:

@@ -34,8 +34,9 @@
 extern "C" {
 #endif
 
-#define PA_ABI_VERSION 3
+#define PA_ABI_VERSION 4
 #define PA_WEIGHT_MAGIC 0x31574150 /* "PAW1" */
+#define PA_LSTM_MAGIC 0x314c4150   /* "PAL1" */
 #define PA_FEATURE_STRIDE 1024     /* floats per cached feature row (1000 used) */
 #define PA_CROP 128
 
@@ -313,6 +314,33 @@ int pa_infer_clip(pa_engine* e, const uint8_t* frames, int32_t n, int32_t height
  * feats: float32[n,num_fighters,PA_FEATURE_STRIDE]. */
 int pa_features_export(pa_engine* e, int32_t frame0, int32_t n, float* feats, void* stream);
 int pa_features_import(pa_engine* e, int32_t frame0, int32_t n, const float* feats, void* stream);
+
+/* ---- the alternative temporal model --------
+ *
+ * RNNActionDetector (playaid/models/rnn_action_detector.py:55-95): the same torchvision resnet18 with
+ * fc = Linear(512, 300), then nn.LSTM(300, 512, num_layers=3), Linear(512,128) + ReLU, Linear(128, A),
+ * log_softmax -- one output row per (window, frame). The backbone half reuses an engine's kernels:
+ *
+ * pa_backbone_windows: x float32[n_crops,3,128,128] (NCHW, values k/255, device) -> feats
+ * float32[n_crops,PA_FEATURE_STRIDE] (device), the engine's resnet18 output per crop (fc included; an
+ * engine built from a state dict whose fc rows 300..999 are zero yields the 300 features and zeros). */
+int pa_backbone_windows(pa_engine* e, const float* x, int32_t n_crops, float* feats, void* stream);
+
+/* The recurrent head. blob: int32 header {PA_LSTM_MAGIC, 1, input_dim, hidden_dim, num_layers, num_actions, 0, 0},
+ * then float32 per layer l: weight_ih_l [4H, in_l], weight_hh_l [4H, H], bias_ih_l [4H], bias_hh_l [4H] (torch
+ * gate order i, f, g, o; in_0 = input_dim, in_l = H), then action_decoder.0.weight [128, H], .0.bias [128],
+ * .2.weight [A, 128], .2.bias [A]. hidden_dim % 8 == 0, <= 512; max_rows bounds seq_len * batch. */
+typedef struct pa_lstm pa_lstm;
+size_t pa_lstm_blob_bytes(int32_t input_dim, int32_t hidden_dim, int32_t num_layers, int32_t num_actions);
+int pa_lstm_create(int32_t device, int32_t input_dim, int32_t hidden_dim, int32_t num_layers, int32_t num_actions,
+                   int32_t max_rows, const void* blob_host, size_t blob_bytes, pa_lstm** out);
+void pa_lstm_destroy(pa_lstm* h);
+const char* pa_lstm_last_error(const pa_lstm* h);
+/* x float32[seq_len, batch, ld] (device; the first input_dim of every ld-float row are read), zero initial
+ * state -> logp float32[seq_len * batch, num_actions] (device). As in the reference (:88-90, an nn.LSTM
+ * without batch_first fed [B, S, 300]) seq_len is the number of WINDOWS and batch (<= 16) the frames of a
+ * window: the state runs from one window to the next. */
+int pa_lstm_forward(pa_lstm* h, const float* x, int32_t ld, int32_t seq_len, int32_t batch, float* logp, void* stream);
 
 /* ---- measurement -------------------------------------------------------- */
 

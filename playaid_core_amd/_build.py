@@ -27,6 +27,7 @@ SOURCES = [
     ("misc.hip", []),
     ("preprocess.hip", ["-ffp-contract=off"]),
     ("detect.hip", ["-ffp-contract=off"]),
+    ("lstm.hip", []),
     ("pa_api.hip", []),
 ]
 

@@ -12,10 +12,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # PA_LIB_PATH: load a differently built library (e.g. the ablation build used by scripts/)
 LIB_PATH = os.environ.get("PA_LIB_PATH") or os.path.join(HERE, "libplayaid_hip.so")
 
-PA_ABI_VERSION = 3
+PA_ABI_VERSION = 4
 PA_DTYPE_F32 = 0
 PA_DTYPE_BF16 = 1
 PA_WEIGHT_MAGIC = 0x31574150
+PA_LSTM_MAGIC = 0x314C4150
 PA_FEATURE_STRIDE = 1024
 
 PA_OK = 0
@@ -121,6 +122,12 @@ SYMBOLS = [
     ("pa_profile_enable", C.c_int, [_P, C.c_int32]),
     ("pa_profile_read", C.c_int, [_P, C.POINTER(pa_kernel_stat), C.c_int32, C.POINTER(C.c_int32)]),
     ("pa_stream_sync", C.c_int, [_P, _P]),
+    ("pa_backbone_windows", C.c_int, [_P, _P, C.c_int32, _P, _P]),
+    ("pa_lstm_blob_bytes", C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    ("pa_lstm_create", C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_size_t, C.POINTER(_P)]),
+    ("pa_lstm_destroy", None, [_P]),
+    ("pa_lstm_last_error", C.c_char_p, [_P]),
+    ("pa_lstm_forward", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
 ]
 
 _lib = None

@@ -1,0 +1,262 @@
+// Temporal head of the reference's alternative model, RNNActionDetector
+// (playaid/models/rnn_action_detector.py:55-95): ResNet-18 features (fc -> 300) ->
+// nn.LSTM(300, 512, num_layers=3) -> Linear(512,128) + ReLU -> Linear(128, A) -> log_softmax, one output row per
+// (window, frame). The backbone runs on the engine's convolution kernels (pa_backbone_windows); this file is the
+// recurrent part and its decoder.
+//
+// The reference feeds the LSTM a [B, S, 300] tensor WITHOUT batch_first, so torch treats dimension 0 -- the
+// windows -- as time and dimension 1 -- the S frames of a window -- as the batch (:88-90): the state runs from
+// one window to the next. That is reproduced as is: pa_lstm_forward takes (seq_len, batch) in torch's order.
+//
+// Per layer: the input projection of every time step is one GEMM ([L*N, in] x [in, 4H], bias b_ih), then one
+// small launch per time step adds h(t-1) W_hh^T + b_hh, applies the gates (torch order i, f, g, o) and writes
+// h(t), c(t). All fp32; gates with expf / tanhf. This is a side path (7-row batches, launch-latency bound), not
+// the hot loop: no MFMA tiling here on purpose.
+#include "pa_kernels.h"
+#include "../../include/playaid_hip.h"
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace pa {
+namespace {
+
+constexpr int LSTM_NMAX = 16;  // batch rows of a time step (the reference's S <= 15)
+
+// C[m][n] = sum_k X[m*ld + k] * W[n*K + k] + bias[n]     (M x K) x (N x K)^T, 64 x 64 tiles, 4 x 4 per thread
+__global__ __launch_bounds__(256) void lstm_proj_kernel(const float* __restrict__ X, int ld, const float* __restrict__ W,
+                                                        const float* __restrict__ bias, float* __restrict__ Cm, int M, int N, int K) {
+    __shared__ float xs[16][65], ws[16][65];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    float acc[4][4] = {};
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+            const int r = i >> 4, k = i & 15;
+            xs[k][r] = (m0 + r < M && k0 + k < K) ? X[(size_t)(m0 + r) * ld + k0 + k] : 0.f;
+            ws[k][r] = (n0 + r < N && k0 + k < K) ? W[(size_t)(n0 + r) * K + k0 + k] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = xs[k][ty * 4 + i];
+                b[i] = ws[k][tx * 4 + i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
+            if (m < M && n < N) Cm[(size_t)m * N + n] = acc[i][j] + bias[n];
+        }
+}
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+
+// One time step of one layer. Workgroup = 8 hidden units (32 gate rows), wave g = gate g (i, f, g, o).
+// pre: [N][4H] input projection (+ b_ih) of this step; h_prev: [N][H] or nullptr at t = 0 (zero state).
+__global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict__ pre, const float* __restrict__ w_hh,
+                                                        const float* __restrict__ b_hh, const float* __restrict__ h_prev,
+                                                        float* __restrict__ c, float* __restrict__ h_out, int N, int H) {
+    extern __shared__ float sm[];
+    float* hs = sm;                         // [N][H]
+    float* gs = sm + (size_t)N * H;         // [4][8][LSTM_NMAX]
+    const int j0 = blockIdx.x * 8;
+    const int lane = threadIdx.x & 63, gate = threadIdx.x >> 6;
+    if (h_prev) {
+        for (int i = threadIdx.x; i < N * H; i += 256) hs[i] = h_prev[i];
+        __syncthreads();
+        for (int u = 0; u < 8; ++u) {
+            const float* wr = w_hh + (size_t)(gate * H + j0 + u) * H;
+            float acc[LSTM_NMAX];
+#pragma unroll
+            for (int n = 0; n < LSTM_NMAX; ++n) acc[n] = 0.f;
+            for (int k = lane; k < H; k += 64) {
+                const float w = wr[k];
+#pragma unroll
+                for (int n = 0; n < LSTM_NMAX; ++n)
+                    if (n < N) acc[n] = fmaf(w, hs[n * H + k], acc[n]);
+            }
+#pragma unroll
+            for (int n = 0; n < LSTM_NMAX; ++n) {
+                float v = acc[n];
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+                if (lane == 0 && n < N) gs[(gate * 8 + u) * LSTM_NMAX + n] = v;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 8 * LSTM_NMAX) {
+        const int u = threadIdx.x / LSTM_NMAX, n = threadIdx.x % LSTM_NMAX;
+        if (n < N) {
+            const int j = j0 + u;
+            float g4[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                // torch: (x W_ih^T + b_ih) + (h W_hh^T + b_hh)
+                const float rec = (h_prev ? gs[(g * 8 + u) * LSTM_NMAX + n] : 0.f) + b_hh[g * H + j];
+                g4[g] = pre[(size_t)n * 4 * H + g * H + j] + rec;
+            }
+            const float ig = sigmoidf(g4[0]), fg = sigmoidf(g4[1]), gg = tanhf(g4[2]), og = sigmoidf(g4[3]);
+            const float c_prev = h_prev ? c[n * H + j] : 0.f;
+            const float cn = fg * c_prev + ig * gg;
+            c[n * H + j] = cn;
+            h_out[n * H + j] = og * tanhf(cn);
+        }
+    }
+}
+
+// action_decoder + log_softmax for one row: Linear(H,128) + ReLU -> Linear(128,A) -> log_softmax
+__global__ __launch_bounds__(128) void lstm_decode_kernel(const float* __restrict__ h, const float* __restrict__ w1,
+                                                          const float* __restrict__ b1, const float* __restrict__ w2,
+                                                          const float* __restrict__ b2, float* __restrict__ logp, int H, int A) {
+    __shared__ float hid[128];
+    __shared__ float lg[64];
+    const int row = blockIdx.x, t = threadIdx.x;
+    const float* hr = h + (size_t)row * H;
+    {
+        const float* w = w1 + (size_t)t * H;
+        float a = 0.f;
+        for (int k = 0; k < H; ++k) a = fmaf(w[k], hr[k], a);
+        a += b1[t];
+        hid[t] = a > 0.f ? a : 0.f;
+    }
+    __syncthreads();
+    if (t < A) {
+        const float* w = w2 + (size_t)t * 128;
+        float a = 0.f;
+        for (int k = 0; k < 128; ++k) a = fmaf(w[k], hid[k], a);
+        lg[t] = a + b2[t];
+    }
+    __syncthreads();
+    if (t < A) {
+        float mx = -INFINITY;
+        for (int k = 0; k < A; ++k) mx = fmaxf(mx, lg[k]);
+        float sum = 0.f;
+        for (int k = 0; k < A; ++k) sum += expf(lg[k] - mx);
+        logp[(size_t)row * A + t] = lg[t] - mx - logf(sum);
+    }
+}
+
+}  // namespace
+}  // namespace pa
+
+struct pa_lstm {
+    int in_dim = 0, hid = 0, layers = 0, actions = 0, max_rows = 0, device = 0;
+    std::vector<float*> w_ih, w_hh, b_ih, b_hh;
+    float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
+    float *weights = nullptr;            // one allocation behind all of the above
+    float *pre = nullptr, *hseq[2] = {nullptr, nullptr}, *c = nullptr;
+    std::string last_error;
+};
+
+namespace {
+size_t lstm_float_count(int in_dim, int hid, int layers, int actions) {
+    size_t n = 0;
+    for (int l = 0; l < layers; ++l) n += (size_t)4 * hid * (l == 0 ? in_dim : hid) + (size_t)4 * hid * hid + 8 * (size_t)hid;
+    n += (size_t)128 * hid + 128 + (size_t)actions * 128 + actions;
+    return n;
+}
+}  // namespace
+
+extern "C" {
+
+size_t pa_lstm_blob_bytes(int32_t input_dim, int32_t hidden_dim, int32_t num_layers, int32_t num_actions) {
+    return 8 * sizeof(int32_t) + lstm_float_count(input_dim, hidden_dim, num_layers, num_actions) * sizeof(float);
+}
+
+const char* pa_lstm_last_error(const pa_lstm* h) { return h ? h->last_error.c_str() : "null handle"; }
+
+int pa_lstm_create(int32_t device, int32_t input_dim, int32_t hidden_dim, int32_t num_layers, int32_t num_actions, int32_t max_rows,
+                   const void* blob_host, size_t blob_bytes, pa_lstm** out) {
+    if (!out) return PA_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!blob_host || input_dim < 1 || hidden_dim < 8 || hidden_dim % 8 != 0 || hidden_dim > 512 || num_layers < 1 || num_layers > 8 ||
+        num_actions < 1 || num_actions > 64 || max_rows < 1)
+        return PA_ERR_INVALID_ARG;
+    const int32_t* hdr = reinterpret_cast<const int32_t*>(blob_host);
+    if (blob_bytes != pa_lstm_blob_bytes(input_dim, hidden_dim, num_layers, num_actions) || hdr[0] != PA_LSTM_MAGIC || hdr[1] != 1 ||
+        hdr[2] != input_dim || hdr[3] != hidden_dim || hdr[4] != num_layers || hdr[5] != num_actions)
+        return PA_ERR_BAD_WEIGHTS;
+    pa_lstm* h = new pa_lstm();
+    *out = h;  // handed back on failure too (pa_lstm_last_error, then pa_lstm_destroy)
+    h->in_dim = input_dim; h->hid = hidden_dim; h->layers = num_layers; h->actions = num_actions; h->max_rows = max_rows;
+    h->device = device;
+    auto chk = [&](hipError_t e, const char* what) -> bool {
+        if (e == hipSuccess) return true;
+        h->last_error = std::string(what) + ": " + hipGetErrorString(e);
+        return false;
+    };
+    if (!chk(hipSetDevice(device), "hipSetDevice")) return PA_ERR_NO_DEVICE;
+    const size_t nw = lstm_float_count(input_dim, hidden_dim, num_layers, num_actions);
+    const size_t H = hidden_dim;
+    if (!chk(hipMalloc(&h->weights, nw * sizeof(float)), "hipMalloc weights")) return PA_ERR_HIP;
+    if (!chk(hipMemcpy(h->weights, hdr + 8, nw * sizeof(float), hipMemcpyHostToDevice), "upload weights")) return PA_ERR_HIP;
+    float* p = h->weights;
+    for (int l = 0; l < num_layers; ++l) {
+        const size_t in_l = l == 0 ? input_dim : hidden_dim;
+        h->w_ih.push_back(p); p += 4 * H * in_l;
+        h->w_hh.push_back(p); p += 4 * H * H;
+        h->b_ih.push_back(p); p += 4 * H;
+        h->b_hh.push_back(p); p += 4 * H;
+    }
+    h->w1 = p; p += 128 * H;
+    h->b1 = p; p += 128;
+    h->w2 = p; p += (size_t)num_actions * 128;
+    h->b2 = p;
+    if (!chk(hipMalloc(&h->pre, (size_t)max_rows * 4 * H * sizeof(float)), "hipMalloc pre")) return PA_ERR_HIP;
+    for (int i = 0; i < 2; ++i)
+        if (!chk(hipMalloc(&h->hseq[i], (size_t)max_rows * H * sizeof(float)), "hipMalloc h")) return PA_ERR_HIP;
+    if (!chk(hipMalloc(&h->c, (size_t)pa::LSTM_NMAX * H * sizeof(float)), "hipMalloc c")) return PA_ERR_HIP;
+    return PA_OK;
+}
+
+void pa_lstm_destroy(pa_lstm* h) {
+    if (!h) return;
+    (void)hipFree(h->weights);
+    (void)hipFree(h->pre);
+    (void)hipFree(h->hseq[0]);
+    (void)hipFree(h->hseq[1]);
+    (void)hipFree(h->c);
+    delete h;
+}
+
+int pa_lstm_forward(pa_lstm* h, const float* x, int32_t ld, int32_t seq_len, int32_t batch, float* logp, void* stream) {
+    if (!h) return PA_ERR_INVALID_ARG;
+    auto bad = [&](int code, const char* msg) { h->last_error = msg; return code; };
+    if (!x || !logp || seq_len < 1 || batch < 1 || ld < h->in_dim) return bad(PA_ERR_INVALID_ARG, "pa_lstm_forward: bad argument");
+    if (batch > pa::LSTM_NMAX) return bad(PA_ERR_CAPACITY, "pa_lstm_forward: more than 16 rows per time step");
+    const long long rows = (long long)seq_len * batch;
+    if (rows > h->max_rows) return bad(PA_ERR_CAPACITY, "pa_lstm_forward: seq_len * batch exceeds max_rows");
+    hipStream_t s = (hipStream_t)stream;
+    const int H = h->hid, M = (int)rows;
+    const size_t step_lds = ((size_t)batch * H + 4 * 8 * pa::LSTM_NMAX) * sizeof(float);
+    for (int l = 0; l < h->layers; ++l) {
+        const float* in = l == 0 ? x : h->hseq[(l - 1) & 1];
+        const int in_ld = l == 0 ? ld : H, K = l == 0 ? h->in_dim : H;
+        hipLaunchKernelGGL(pa::lstm_proj_kernel, dim3((4 * H + 63) / 64, (M + 63) / 64), dim3(256), 0, s, in, in_ld, h->w_ih[l], h->b_ih[l],
+                           h->pre, M, 4 * H, K);
+        float* hs = h->hseq[l & 1];
+        for (int t = 0; t < seq_len; ++t)
+            hipLaunchKernelGGL(pa::lstm_step_kernel, dim3(H / 8), dim3(256), step_lds, s, h->pre + (size_t)t * batch * 4 * H, h->w_hh[l],
+                               h->b_hh[l], t ? hs + (size_t)(t - 1) * batch * H : nullptr, h->c, hs + (size_t)t * batch * H, batch, H);
+    }
+    hipLaunchKernelGGL(pa::lstm_decode_kernel, dim3(M), dim3(128), 0, s, h->hseq[(h->layers - 1) & 1], h->w1, h->b1, h->w2, h->b2, logp, H,
+                       h->actions);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return bad(PA_ERR_HIP, hipGetErrorString(e));
+    return PA_OK;
+}
+
+}  // extern "C"

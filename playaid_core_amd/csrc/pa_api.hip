@@ -1000,6 +1000,21 @@ int pa_infer_windows(pa_engine* e, const float* x, int32_t batch, float* logp, v
     return PA_OK;
 }
 
+int pa_backbone_windows(pa_engine* e, const float* x, int32_t n_crops, float* feats, void* stream) {
+    if (!e || !x || !feats || n_crops < 1) return fail(e, PA_ERR_INVALID_ARG, "pa_backbone_windows: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    for (int c0 = 0; c0 < n_crops; c0 += e->max_crops) {  // the backbone scratch holds max_crops crops
+        const int n = std::min(e->max_crops, n_crops - c0);
+        {
+            ProfScope ps(e, s, "nchw_to_nhwc4", 0.0, n * (49152.0 * 4 + 134.0 * 134 * 16));
+            HIPCHK(e, launch_nchw_to_padded(x + (size_t)c0 * 3 * 128 * 128, e->x0, n, e->bf16 ? 1 : 0, s));
+        }
+        const int rc = run_backbone(e, n, e->x0, feats + (size_t)c0 * PA_FEATURE_STRIDE, s);
+        if (rc) return rc;
+    }
+    return PA_OK;
+}
+
 int pa_square_crops(pa_engine* e, const uint8_t* frames, int32_t n, int32_t height, int32_t width, const double* boxes,
                     int32_t padding, int32_t swap_rb, uint8_t* crops, int32_t* status, void* stream) {
     if (!e || !frames || !boxes || !crops || n < 1 || height < 1 || width < 1 || padding < 0)

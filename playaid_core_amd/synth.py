@@ -334,3 +334,41 @@ def make_frames_torch(n: int, height: int, width: int, seed: int = 7, first_fram
                 img[y0c:y1c, x0c:x1c, c] = 96 + base + fine
         frames[i] = img.clamp_(0, 255).to(torch.uint8)
     return frames
+
+
+def make_rnn_state_dict(seed: int = 4321, num_actions: int = 63) -> Dict[str, np.ndarray]:
+    """Seeded fp32 weights in the key layout of the reference's ``RNNActionDetector``
+    (``playaid/models/rnn_action_detector.py:55-65``): ``resnet.*`` (torchvision resnet18 whose ``fc`` is
+    ``nn.Sequential(nn.Linear(512, 300))`` -> ``resnet.fc.0.*``), ``lstm.{weight,bias}_{ih,hh}_l{0,1,2}``
+    (``nn.LSTM(300, 512, num_layers=3)``), ``action_decoder.{0,2}.*``. Same distributions as
+    ``make_state_dict``; LSTM tensors ~ U(+-1/sqrt(512)) like ``nn.LSTM.reset_parameters``."""
+    sd: Dict[str, np.ndarray] = {}
+
+    def dense(key, shape):
+        a = math.sqrt(3.0 / int(np.prod(shape[1:])))
+        sd[key] = uniform(shape, _name_seed(key, seed), -a, a)
+
+    for key, shape in resnet18_param_shapes():
+        if key.startswith("fc."):
+            continue
+        full = "resnet." + key
+        if key.endswith("running_var") or (key.endswith(".weight") and len(shape) == 1):
+            sd[full] = uniform(shape, _name_seed(full, seed), 0.5, 1.5)
+        elif len(shape) == 1:
+            sd[full] = uniform(shape, _name_seed(full, seed), -0.1, 0.1)
+        else:
+            dense(full, shape)
+    dense("resnet.fc.0.weight", (300, 512))
+    sd["resnet.fc.0.bias"] = uniform((300,), _name_seed("resnet.fc.0.bias", seed), -0.05, 0.05)
+    k = 1.0 / math.sqrt(512.0)
+    for layer in range(3):
+        in_dim = 300 if layer == 0 else 512
+        for name, shape in (("weight_ih", (2048, in_dim)), ("weight_hh", (2048, 512)), ("bias_ih", (2048,)), ("bias_hh", (2048,))):
+            key = f"lstm.{name}_l{layer}"
+            sd[key] = uniform(shape, _name_seed(key, seed), -k, k)
+    dense("action_decoder.0.weight", (128, 512))
+    sd["action_decoder.0.bias"] = uniform((128,), _name_seed("action_decoder.0.bias", seed), -0.05, 0.05)
+    a = 4.0 * math.sqrt(3.0 / 128)
+    sd["action_decoder.2.weight"] = uniform((num_actions, 128), _name_seed("action_decoder.2.weight", seed), -a, a)
+    sd["action_decoder.2.bias"] = uniform((num_actions,), _name_seed("action_decoder.2.bias", seed), -0.5, 0.5)
+    return sd
