@@ -211,15 +211,31 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const GemmParams p) {
             bf[SET][ni] = *reinterpret_cast<const f32x4*>((STAGE_PTR) + b_rd_off + ni * 32 * ROW_F + ch);     \
     }
 
+    // Every wave issues the same number of copies per stage, so the stage boundaries can use COUNTED waits
+    // (vector-memory operations retire in order): stage ks+1 has landed once only the copies of stage ks+2 -- issued
+    // at the top of this k-step -- are outstanding. A __syncthreads() here would drain vmcnt to 0 and with it the
+    // whole ring (every copy would be waited for one k-step after its issue: the round-2 profile of this kernel).
+    constexpr int NCOPY = A_ROWS + B_ROWS;
+    static_assert(NCOPY == 12 || NCOPY == 8 || NCOPY == 6 || NCOPY == 4, "extend the counted wait below");
     if (ks_begin < ks_end) PA_ISSUE_STAGE(0);
     if (ks_begin + 1 < ks_end) PA_ISSUE_STAGE(1);
-    __syncthreads();
+    if (ks_begin + 1 < ks_end) {
+        if constexpr (NCOPY == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if constexpr (NCOPY == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if constexpr (NCOPY == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
     if (ks_begin < ks_end) PA_LOAD_FRAGS(0, lds, 0);
     int buf = 0;
     for (int ks = ks_begin; ks < ks_end; ++ks) {
         const int buf1 = buf == 2 ? 0 : buf + 1;
         const int buf2 = buf1 == 2 ? 0 : buf1 + 1;
-        if (ks + 2 < ks_end) PA_ISSUE_STAGE(buf2);
+        // slot buf2 held stage ks-1: every wave passed the barrier of k-step ks-1 with those reads in registers
+        const bool issued = ks + 2 < ks_end;
+        if (issued) PA_ISSUE_STAGE(buf2);
         const bool has_next = ks + 1 < ks_end;
         __builtin_amdgcn_sched_barrier(0);
         const float* st_cur = lds + buf * STAGE;
@@ -231,8 +247,21 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const GemmParams p) {
             __builtin_amdgcn_sched_barrier(0);
             if (g + 1 < KG) {
                 PA_LOAD_FRAGS((g + 1) & 1, st_cur, g + 1);
-            } else if (has_next) {
-                PA_LOAD_FRAGS((g + 1) & 1, st_next, 0);
+            } else {
+                // close the stage: this wave's reads of it are in registers; the next stage has landed for this
+                // wave once only the newest copies are outstanding, and for everyone behind the barrier
+                if (issued) {
+                    if constexpr (NCOPY == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                    else if constexpr (NCOPY == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    else if constexpr (NCOPY == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                if (has_next) PA_LOAD_FRAGS((g + 1) & 1, st_next, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -242,9 +271,9 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const GemmParams p) {
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                         __builtin_bit_cast(bf16x8, af[g & 1][mi]), __builtin_bit_cast(bf16x8, bf[g & 1][ni]), acc[mi][ni], 0, 0, 0);
         }
-        __syncthreads();
         buf = buf1;
     }
+    __syncthreads();  // (the transposed tile below reuses the ring)
 #undef PA_LOAD_FRAGS
 #undef PA_ISSUE_STAGE
 
