@@ -37,6 +37,7 @@ extern "C" {
 #define PA_ABI_VERSION 4
 #define PA_WEIGHT_MAGIC 0x31574150 /* "PAW1" */
 #define PA_LSTM_MAGIC 0x314c4150   /* "PAL1" */
+#define PA_ENCODER_MAGIC 0x31454150 /* "PAE1" */
 #define PA_FEATURE_STRIDE 1024     /* floats per cached feature row (1000 used) */
 #define PA_CROP 128
 
@@ -341,6 +342,52 @@ const char* pa_lstm_last_error(const pa_lstm* h);
  * without batch_first fed [B, S, 300]) seq_len is the number of WINDOWS and batch (<= 16) the frames of a
  * window: the state runs from one window to the next. */
 int pa_lstm_forward(pa_lstm* h, const float* x, int32_t ld, int32_t seq_len, int32_t batch, float* logp, void* stream);
+
+/* A conv-net given as a table (the ResNet-50 backbone of ResnetTransformerDetector,
+ * playaid/models/resnet_transformer_detector.py:37), run on the engine's fp32 convolution kernels. Weights arrive
+ * BatchNorm-folded: per convolution [cout][ky][kx][cin] at w_off and the bias [cout] at b_off (float offsets into
+ * one blob); the 7x7/2 stem as [64][7 ky][8 px][4 ch] (kx >= 7 and channel 3 zero). Activations: `n_bufs` device
+ * buffers of buf_floats_per_crop[b] floats per crop, NHWC with a zero border of `pad` pixels; a bordered buffer
+ * must keep one geometry for the whole table. Layers run in table order. */
+typedef struct pa_conv_desc {
+    int32_t kind;               /* 0 convolution, 1 stem 7x7/2 + ReLU + max-pool 3x3/2 of the 128x128x3 input, 2 global average pool */
+    int32_t cin, cout;          /* kind 0: cin % 32 == 0, cout % 64 == 0; kind 2: cin = channels */
+    int32_t ksize, stride;      /* 1 | 3, 1 | 2 */
+    int32_t in_hw;              /* spatial size of the input interior (square) */
+    int32_t in_buf, in_pad;     /* in_pad >= (ksize - 1) / 2 */
+    int32_t out_buf, out_pad;
+    int32_t res_buf;            /* residual added before the ReLU (geometry of the output), or -1 */
+    int32_t relu;
+    int64_t w_off, b_off;
+} pa_conv_desc;
+typedef struct pa_convnet pa_convnet;
+int pa_convnet_create(int32_t device, const pa_conv_desc* descs, int32_t n_descs, const int64_t* buf_floats_per_crop,
+                      int32_t n_bufs, const float* weights_host, size_t n_weights, int32_t max_crops, pa_convnet** out);
+void pa_convnet_destroy(pa_convnet* h);
+const char* pa_convnet_last_error(const pa_convnet* h);
+/* x float32[n,3,128,128] (NCHW, device) -> out: the last layer's output buffer, float32[n, out_floats_per_crop]. */
+int pa_convnet_forward(pa_convnet* h, const float* x, int32_t n, float* out, int32_t out_floats_per_crop, void* stream);
+
+/* Head of ResnetTransformerDetector (resnet_transformer_detector.py:41-93,141): Linear(in_dim, hidden_dim), the
+ * enc_dim-value time encoding of the frame slot appended (d_model = hidden_dim + enc_dim, 32 per head),
+ * num_layers post-norm nn.TransformerEncoderLayer (ReLU feed-forward of ff_dim), Linear(d_model, num_actions),
+ * log_softmax. blob: int32[16] header {PA_ENCODER_MAGIC, 1, in_dim, hidden_dim, slots, enc_dim, num_heads,
+ * num_layers, ff_dim, num_actions, 0...}, then float32: resnet_ffn.weight [hidden, in_dim], .bias, freq_encoding
+ * [slots, enc_dim], per layer self_attn.in_proj_weight [3D, D], in_proj_bias, out_proj.weight [D, D], .bias,
+ * linear1.weight [ff, D], .bias, linear2.weight [D, ff], .bias, norm1.weight, .bias, norm2.weight, .bias, then
+ * classifier.weight [A, D], .bias. */
+typedef struct pa_encoder pa_encoder;
+size_t pa_encoder_blob_bytes(int32_t in_dim, int32_t hidden_dim, int32_t slots, int32_t enc_dim, int32_t num_layers,
+                             int32_t ff_dim, int32_t num_actions);
+int pa_encoder_create(int32_t device, int32_t in_dim, int32_t hidden_dim, int32_t slots, int32_t enc_dim, int32_t num_heads,
+                      int32_t num_layers, int32_t ff_dim, int32_t num_actions, int32_t max_rows, const void* blob_host,
+                      size_t blob_bytes, pa_encoder** out);
+void pa_encoder_destroy(pa_encoder* h);
+const char* pa_encoder_last_error(const pa_encoder* h);
+/* feats float32[seq_len * batch, ld] (device, row r = l * batch + n; the first in_dim values of a row are read) ->
+ * logp float32[seq_len * batch, num_actions]. As in the reference (an encoder without batch_first fed
+ * [B, S, 256], :82-84) seq_len is the number of WINDOWS and batch = slots the frames of a window. */
+int pa_encoder_forward(pa_encoder* h, const float* feats, int32_t ld, int32_t seq_len, int32_t batch, float* logp, void* stream);
 
 /* ---- measurement -------------------------------------------------------- */
 

@@ -28,6 +28,8 @@ SOURCES = [
     ("preprocess.hip", ["-ffp-contract=off"]),
     ("detect.hip", ["-ffp-contract=off"]),
     ("lstm.hip", []),
+    ("convnet.hip", []),
+    ("transformer.hip", []),
     ("pa_api.hip", []),
 ]
 

@@ -17,6 +17,7 @@ PA_DTYPE_F32 = 0
 PA_DTYPE_BF16 = 1
 PA_WEIGHT_MAGIC = 0x31574150
 PA_LSTM_MAGIC = 0x314C4150
+PA_ENCODER_MAGIC = 0x31454150
 PA_FEATURE_STRIDE = 1024
 
 PA_OK = 0
@@ -75,6 +76,11 @@ class pa_crop_window(C.Structure):
                 ("src_pitch", C.c_int32), ("row_bytes", C.c_int32)]
 
 
+class pa_conv_desc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("kind", "cin", "cout", "ksize", "stride", "in_hw", "in_buf", "in_pad", "out_buf", "out_pad",
+                                        "res_buf", "relu")] + [("w_off", C.c_int64), ("b_off", C.c_int64)]
+
+
 class pa_kernel_stat(C.Structure):
     _fields_ = [
         ("name", C.c_char * 48),
@@ -128,6 +134,16 @@ SYMBOLS = [
     ("pa_lstm_destroy", None, [_P]),
     ("pa_lstm_last_error", C.c_char_p, [_P]),
     ("pa_lstm_forward", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    ("pa_convnet_create", C.c_int, [C.c_int32, C.POINTER(pa_conv_desc), C.c_int32, C.POINTER(C.c_int64), C.c_int32, _P, C.c_size_t,
+                                    C.c_int32, C.POINTER(_P)]),
+    ("pa_convnet_destroy", None, [_P]),
+    ("pa_convnet_last_error", C.c_char_p, [_P]),
+    ("pa_convnet_forward", C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P]),
+    ("pa_encoder_blob_bytes", C.c_size_t, [C.c_int32] * 7),
+    ("pa_encoder_create", C.c_int, [C.c_int32] * 10 + [_P, C.c_size_t, C.POINTER(_P)]),
+    ("pa_encoder_destroy", None, [_P]),
+    ("pa_encoder_last_error", C.c_char_p, [_P]),
+    ("pa_encoder_forward", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
 ]
 
 _lib = None

@@ -23,9 +23,10 @@ namespace {
 
 constexpr int LSTM_NMAX = 16;  // batch rows of a time step (the reference's S <= 15)
 
-// C[m][n] = sum_k X[m*ld + k] * W[n*K + k] + bias[n]     (M x K) x (N x K)^T, 64 x 64 tiles, 4 x 4 per thread
-__global__ __launch_bounds__(256) void lstm_proj_kernel(const float* __restrict__ X, int ld, const float* __restrict__ W,
-                                                        const float* __restrict__ bias, float* __restrict__ Cm, int M, int N, int K) {
+// C[m*ldc + n] = act(sum_k X[m*ld + k] * W[n*K + k] + bias[n])   (M x K) x (N x K)^T, 64 x 64 tiles, 4 x 4 per thread
+__global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict__ X, int ld, const float* __restrict__ W,
+                                                         const float* __restrict__ bias, float* __restrict__ Cm, int ldc, int M, int N, int K,
+                                                         int relu) {
     __shared__ float xs[16][65], ws[16][65];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
@@ -57,7 +58,11 @@ __global__ __launch_bounds__(256) void lstm_proj_kernel(const float* __restrict_
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
-            if (m < M && n < N) Cm[(size_t)m * N + n] = acc[i][j] + bias[n];
+            if (m < M && n < N) {
+                float v = acc[i][j] + (bias ? bias[n] : 0.f);
+                if (relu) v = v > 0.f ? v : 0.f;
+                Cm[(size_t)m * ldc + n] = v;
+            }
         }
 }
 
@@ -150,6 +155,13 @@ __global__ __launch_bounds__(128) void lstm_decode_kernel(const float* __restric
 }
 
 }  // namespace
+
+hipError_t launch_linear_f32(const float* X, int ld, const float* W, const float* bias, float* Cm, int ldc, int M, int N, int K, int relu,
+                             hipStream_t s) {
+    hipLaunchKernelGGL(linear_f32_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, s, X, ld, W, bias, Cm, ldc, M, N, K, relu);
+    return hipGetLastError();
+}
+
 }  // namespace pa
 
 struct pa_lstm {
@@ -245,8 +257,7 @@ int pa_lstm_forward(pa_lstm* h, const float* x, int32_t ld, int32_t seq_len, int
     for (int l = 0; l < h->layers; ++l) {
         const float* in = l == 0 ? x : h->hseq[(l - 1) & 1];
         const int in_ld = l == 0 ? ld : H, K = l == 0 ? h->in_dim : H;
-        hipLaunchKernelGGL(pa::lstm_proj_kernel, dim3((4 * H + 63) / 64, (M + 63) / 64), dim3(256), 0, s, in, in_ld, h->w_ih[l], h->b_ih[l],
-                           h->pre, M, 4 * H, K);
+        (void)pa::launch_linear_f32(in, in_ld, h->w_ih[l], h->b_ih[l], h->pre, 4 * H, M, 4 * H, K, 0, s);
         float* hs = h->hseq[l & 1];
         for (int t = 0; t < seq_len; ++t)
             hipLaunchKernelGGL(pa::lstm_step_kernel, dim3(H / 8), dim3(256), step_lds, s, h->pre + (size_t)t * batch * 4 * H, h->w_hh[l],

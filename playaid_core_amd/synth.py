@@ -372,3 +372,60 @@ def make_rnn_state_dict(seed: int = 4321, num_actions: int = 63) -> Dict[str, np
     sd["action_decoder.2.weight"] = uniform((num_actions, 128), _name_seed("action_decoder.2.weight", seed), -a, a)
     sd["action_decoder.2.bias"] = uniform((num_actions,), _name_seed("action_decoder.2.bias", seed), -0.5, 0.5)
     return sd
+
+
+def make_resformer_state_dict(seed: int = 2468, num_actions: int = 63, sequence_length: int = 7) -> Dict[str, np.ndarray]:
+    """Seeded fp32 weights in the key layout of the reference's ``ResnetTransformerDetector``
+    (``playaid/models/resnet_transformer_detector.py:26-66,127``): ``model.resnet.*`` (timm ``resnet50`` without
+    classifier), ``model.resnet_ffn``, the ``model.freq_encoding`` buffer, ``model.transformer.layers.{0,1,2}.*``
+    (``nn.TransformerEncoderLayer(256, 8)``: ``self_attn.in_proj_*``, ``self_attn.out_proj``, ``linear1``,
+    ``linear2``, ``norm1``, ``norm2``), ``model.classifier``; also the tensors the forward never reads
+    (``model.encoder_layer.*``, ``model.resnet_classifier``) because a real checkpoint holds them. The last
+    BatchNorm of every bottleneck gets a small gamma so that 16 residual additions keep the activations O(1)."""
+    from .resnet_transformer_detector import D_MODEL, FF_DIM, HIDDEN_DIM, NUM_LAYERS, resnet50_param_shapes, time_encoding
+
+    sd: Dict[str, np.ndarray] = {}
+
+    def dense(key, shape, gain=1.0):
+        a = gain * math.sqrt(3.0 / int(np.prod(shape[1:])))
+        sd[key] = uniform(shape, _name_seed(key, seed), -a, a)
+
+    def small(key, shape, a=0.05):
+        sd[key] = uniform(shape, _name_seed(key, seed), -a, a)
+
+    for key, shape in resnet50_param_shapes():
+        full = "model.resnet." + key
+        if key.endswith("running_var"):
+            sd[full] = uniform(shape, _name_seed(full, seed), 0.5, 1.5)
+        elif key.endswith(".weight") and len(shape) == 1:
+            lo, hi = (0.1, 0.3) if ".bn3." in key else (0.5, 1.5)
+            sd[full] = uniform(shape, _name_seed(full, seed), lo, hi)
+        elif len(shape) == 1:
+            sd[full] = uniform(shape, _name_seed(full, seed), -0.1, 0.1)
+        else:
+            dense(full, shape, gain=math.sqrt(2.0))
+    dense("model.resnet_ffn.weight", (HIDDEN_DIM, 2048))
+    small("model.resnet_ffn.bias", (HIDDEN_DIM,))
+    sd["model.freq_encoding"] = time_encoding(sequence_length)
+
+    def encoder_layer(prefix):
+        dense(prefix + "self_attn.in_proj_weight", (3 * D_MODEL, D_MODEL))
+        small(prefix + "self_attn.in_proj_bias", (3 * D_MODEL,))
+        dense(prefix + "self_attn.out_proj.weight", (D_MODEL, D_MODEL))
+        small(prefix + "self_attn.out_proj.bias", (D_MODEL,))
+        dense(prefix + "linear1.weight", (FF_DIM, D_MODEL))
+        small(prefix + "linear1.bias", (FF_DIM,))
+        dense(prefix + "linear2.weight", (D_MODEL, FF_DIM))
+        small(prefix + "linear2.bias", (D_MODEL,))
+        for nm in ("norm1", "norm2"):
+            sd[prefix + nm + ".weight"] = uniform((D_MODEL,), _name_seed(prefix + nm + ".weight", seed), 0.8, 1.2)
+            small(prefix + nm + ".bias", (D_MODEL,), 0.1)
+
+    encoder_layer("model.encoder_layer.")
+    for layer in range(NUM_LAYERS):
+        encoder_layer(f"model.transformer.layers.{layer}.")
+    dense("model.resnet_classifier.weight", (num_actions, HIDDEN_DIM))
+    small("model.resnet_classifier.bias", (num_actions,))
+    dense("model.classifier.weight", (num_actions, D_MODEL), gain=4.0)
+    small("model.classifier.bias", (num_actions,), 0.5)
+    return sd

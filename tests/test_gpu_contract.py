@@ -555,7 +555,15 @@ def test_clip_lanes_equal_single_engine(engine):
     lanes = ClipLanes(engine, 7, 3, lanes=2)
     try:
         assert len(lanes.engines) == 2 and lanes.engines[1] is not engine
+        assert lanes.streams[0] is not lanes.streams[1]
         for rounds in range(2):
+            if rounds == 1:
+                # the second round on streams picked by measurement; a calibration leaves results unchanged
+                rates = lanes.calibrate(clips[0][0], clips[0][1], n, clips=4)
+                if rates:
+                    assert lanes.calibration["picked"] == list(max(rates, key=rates.get))
+                    assert all(v > 0 for v in rates.values())
+                lanes.synchronize()
             pending = []
             for i, (f, b) in enumerate(clips):
                 lane, rec, lp = lanes.submit(f, b, n)
