@@ -316,6 +316,16 @@ int pa_infer_clip(pa_engine* e, const uint8_t* frames, int32_t n, int32_t height
 int pa_features_export(pa_engine* e, int32_t frame0, int32_t n, float* feats, void* stream);
 int pa_features_import(pa_engine* e, int32_t frame0, int32_t n, const float* feats, void* stream);
 
+/* Damage HUD crops (AIRunner.run_damage_detection, ai_runner.py:556-571 +
+ * damage_crop_to_percent :114): YoloCrop.crop_img (fighter.py:316-321) = image[y1:y2, x1:x2] followed by
+ * imutils.resize(width=out_w) = cv2.resize(INTER_AREA) to (out_w, int(h * (out_w / float(w)))), for up to four pixel
+ * rectangles per frame (rects_host int32[n_rects][4] = x1, y1, x2, y2 from YoloCrop.xyxy_pixels). frames
+ * uint8[n,H,W,3] (device) -> out uint8[n,n_rects,out_h_cap,out_w,3] (device, channel order kept; rows beyond a
+ * rectangle's height untouched); the heights are returned in out_h_host[n_rects]. The recogniser the reference
+ * then calls (PaddleOCR) is an external model and is not part of this library. */
+int pa_crop_resize_width(pa_engine* e, const uint8_t* frames, int32_t n, int32_t height, int32_t width, const int32_t* rects_host,
+                         int32_t n_rects, int32_t out_w, uint8_t* out, int32_t out_h_cap, int32_t* out_h_host, void* stream);
+
 /* ---- the alternative temporal model --------
  *
  * RNNActionDetector (playaid/models/rnn_action_detector.py:55-95): the same torchvision resnet18 with

@@ -1015,6 +1015,37 @@ int pa_backbone_windows(pa_engine* e, const float* x, int32_t n_crops, float* fe
     return PA_OK;
 }
 
+int pa_crop_resize_width(pa_engine* e, const uint8_t* frames, int32_t n, int32_t height, int32_t width, const int32_t* rects_host,
+                         int32_t n_rects, int32_t out_w, uint8_t* out, int32_t out_h_cap, int32_t* out_h_host, void* stream) {
+    if (!e || !frames || !rects_host || !out || !out_h_host || n < 1 || height < 1 || width < 1 || n_rects < 1 || n_rects > 4 || out_w < 1 ||
+        out_h_cap < 1)
+        return fail(e, PA_ERR_INVALID_ARG, "pa_crop_resize_width: bad argument");
+    RectResizeParams q;
+    memset(&q, 0, sizeof(q));
+    q.frames = frames;
+    q.height = height;
+    q.width = width;
+    q.n_rects = n_rects;
+    q.out_w = out_w;
+    q.out_h_cap = out_h_cap;
+    q.out = out;
+    for (int r = 0; r < n_rects; ++r) {
+        const int x1 = rects_host[4 * r], y1 = rects_host[4 * r + 1], x2 = rects_host[4 * r + 2], y2 = rects_host[4 * r + 3];
+        if (x1 < 0 || y1 < 0 || x2 > width || y2 > height || x2 <= x1 || y2 <= y1)
+            return fail(e, PA_ERR_INVALID_ARG, "pa_crop_resize_width: empty rectangle or outside the frame (cv2.resize raises on an empty image)");
+        // imutils.resize: r = width / float(w); dim = (width, int(h * r))
+        const double ratio = (double)out_w / (double)(x2 - x1);
+        const int oh = (int)((double)(y2 - y1) * ratio);
+        if (oh < 1) return fail(e, PA_ERR_INVALID_ARG, "pa_crop_resize_width: destination height 0");
+        if (oh > out_h_cap) return fail(e, PA_ERR_CAPACITY, "pa_crop_resize_width: out_h_cap too small");
+        q.x1[r] = x1; q.y1[r] = y1; q.x2[r] = x2; q.y2[r] = y2;
+        q.out_h[r] = oh;
+        out_h_host[r] = oh;
+    }
+    HIPCHK(e, launch_rect_resize(q, n, (hipStream_t)stream));
+    return PA_OK;
+}
+
 int pa_square_crops(pa_engine* e, const uint8_t* frames, int32_t n, int32_t height, int32_t width, const double* boxes,
                     int32_t padding, int32_t swap_rb, uint8_t* crops, int32_t* status, void* stream) {
     if (!e || !frames || !boxes || !crops || n < 1 || height < 1 || width < 1 || padding < 0)

@@ -177,6 +177,18 @@ struct RunnerInParams {
     int32_t* status;            // [n] PA_CROP_* or nullptr
 };
 hipError_t launch_runner_inputs(const RunnerInParams& q, hipStream_t s);
+
+// crop_img + imutils.resize(width) of up to four pixel rectangles per frame (the damage HUD crops), see rect_resize_kernel
+struct RectResizeParams {
+    const uint8_t* frames;       // [n][height][width][3]
+    int32_t height, width;
+    int32_t n_rects;
+    int32_t x1[4], y1[4], x2[4], y2[4];  // numpy slice image[y1:y2, x1:x2]
+    int32_t out_w, out_h[4];     // destination width, int(h * (out_w / float(w))) per rectangle
+    int32_t out_h_cap;           // rows per rectangle in `out`
+    uint8_t* out;                // [n][n_rects][out_h_cap][out_w][3]
+};
+hipError_t launch_rect_resize(const RectResizeParams& q, int n_frames, hipStream_t s);
 // per-device one-time setup of the crop stage (dynamic-LDS attribute); call with the device current
 hipError_t preprocess_init_device();
 // log rows [n][9] (pos_x,pos_y,cam xyz,target xyz,fov deg) -> normalised boxes [n][4]

@@ -1130,7 +1130,7 @@ hipError_t launch_project_boxes(const double* log, double* boxes, int32_t n, hip
 struct RunnerInPlan {
     int status;
     int sw, sh;          // source image
-    int oh;              // INTER_AREA destination height (width 128)
+    int ow, oh;          // INTER_AREA destination width (128 for runner inputs) and height
     int mode;            // 0 copy, 1 2x2, 2 integer, 3 general, 4 enlarging (bilinear emulation)
     int isx, isy;
     double scale_x, scale_y;
@@ -1147,7 +1147,7 @@ struct WhCanvas {  // plain [rows][cols][3] bytes
     }
 };
 
-// One destination pixel of cv::resize(INTER_AREA) from an sw x sh image to 128 x oh (area_pixel() with
+// One destination pixel of cv::resize(INTER_AREA) from an sw x sh image to ow x oh (area_pixel() with
 // separate axes; the source is a plain image, no paste window).
 __device__ __forceinline__ void area_pixel_wh(const RunnerInPlan& pl, const WhCanvas& cv, int dy, int dx, int& o0, int& o1, int& o2) {
     if (pl.mode == 0) {
@@ -1175,7 +1175,7 @@ __device__ __forceinline__ void area_pixel_wh(const RunnerInPlan& pl, const WhCa
         o2 = cv_saturate_u8((float)s2 * scale);
     } else if (pl.mode == 4) {
         // cv::resize's 8-bit bilinear resizer with area-mode coefficients (see area_pixel())
-        const double inv_x = 128.0 / (double)pl.sw, inv_y = (double)pl.oh / (double)pl.sh;
+        const double inv_x = (double)pl.ow / (double)pl.sw, inv_y = (double)pl.oh / (double)pl.sh;
         int sx = (int)floor((double)dx * pl.scale_x);
         float fx = (float)((double)(dx + 1) - (double)(sx + 1) * inv_x);
         fx = fx <= 0.f ? 0.f : fx - floorf(fx);
@@ -1245,7 +1245,7 @@ __global__ __launch_bounds__(256) void runner_input_kernel(const RunnerInParams 
     const long long off = q.desc[crop].offset;
     pl.sh = q.desc[crop].height;
     pl.sw = q.desc[crop].width;
-    pl.oh = 0; pl.mode = 0; pl.isx = pl.isy = 1; pl.scale_x = pl.scale_y = 1.0;
+    pl.ow = PA_CROP; pl.oh = 0; pl.mode = 0; pl.isx = pl.isy = 1; pl.scale_x = pl.scale_y = 1.0;
     pl.rw = pl.rh = PA_CROP; pl.px = pl.py = 0; pl.need_h = pl.need_v = 0;
     if (pl.sh < 1 || pl.sw < 1 || pl.sh > q.max_h || pl.sw > q.max_w || off < 0 ||
         off + (long long)pl.sh * pl.sw * 3 > q.images_bytes)
@@ -1428,6 +1428,53 @@ hipError_t launch_slice_upload(const uint8_t* frames_host, long long frames_byte
                                hipStream_t s) {
     if (ncrops <= 0) return hipSuccess;
     hipLaunchKernelGGL(slice_upload_kernel, dim3(32, ncrops), dim3(256), 0, s, frames_host, desc, windows, frames_bytes);
+    return hipGetLastError();
+}
+
+// YoloCrop.crop_img (fighter.py:316-321) + imutils.resize(width = out_w) (= cv2.resize INTER_AREA to
+// (out_w, int(h * (out_w / float(w)))), imutils 0.5.4) for up to four fixed pixel rectangles per frame: the damage
+// HUD crops of AIRunner.run_damage_detection (ai_runner.py:556-571, damage_crop_to_percent :114). One workgroup per
+// (rectangle, frame), one thread per destination pixel, every INTER_AREA branch of area_pixel_wh (the HUD boxes are
+// ENLARGED at 720p / 1080p: OpenCV's bilinear emulation). Channel order is kept (BGR in, BGR out).
+__global__ __launch_bounds__(256) void rect_resize_kernel(const RectResizeParams q) {
+    const int r = blockIdx.x, f = blockIdx.y;
+    RunnerInPlan pl;
+    pl.status = PA_CROP_OK;
+    pl.sw = q.x2[r] - q.x1[r];
+    pl.sh = q.y2[r] - q.y1[r];
+    pl.ow = q.out_w;
+    pl.oh = q.out_h[r];
+    pl.rw = pl.rh = pl.px = pl.py = pl.need_h = pl.need_v = 0;
+    pl.isx = pl.isy = 1;
+    const double inv_sx = (double)pl.ow / (double)pl.sw, inv_sy = (double)pl.oh / (double)pl.sh;
+    pl.scale_x = 1.0 / inv_sx;
+    pl.scale_y = 1.0 / inv_sy;
+    if (pl.sw == pl.ow && pl.sh == pl.oh) {
+        pl.mode = 0;
+    } else if (pl.scale_x < 1.0 || pl.scale_y < 1.0) {
+        pl.mode = 4;
+    } else {
+        pl.isx = (int)rint(pl.scale_x);
+        pl.isy = (int)rint(pl.scale_y);
+        const bool fast = fabs(pl.scale_x - pl.isx) < 2.220446049250313e-16 && fabs(pl.scale_y - pl.isy) < 2.220446049250313e-16;
+        pl.mode = fast ? ((pl.isx == 2 && pl.isy == 2) ? 1 : 2) : 3;
+    }
+    WhCanvas cv;
+    cv.pitch = q.width * 3;
+    cv.src = q.frames + ((size_t)f * q.height + q.y1[r]) * q.width * 3 + (size_t)q.x1[r] * 3;
+    uint8_t* dst = q.out + ((size_t)f * q.n_rects + r) * q.out_h_cap * q.out_w * 3;
+    for (int i = threadIdx.x; i < pl.oh * pl.ow; i += 256) {
+        const int dy = i / pl.ow, dx = i - dy * pl.ow;
+        int o0, o1, o2;
+        area_pixel_wh(pl, cv, dy, dx, o0, o1, o2);
+        uint8_t* o = dst + (size_t)i * 3;
+        o[0] = (uint8_t)o0; o[1] = (uint8_t)o1; o[2] = (uint8_t)o2;
+    }
+}
+
+hipError_t launch_rect_resize(const RectResizeParams& q, int n_frames, hipStream_t s) {
+    if (n_frames <= 0 || q.n_rects <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rect_resize_kernel, dim3(q.n_rects, n_frames), dim3(256), 0, s, q);
     return hipGetLastError();
 }
 

@@ -178,6 +178,28 @@ class Engine:
         self._check(self._lib.pa_infer_windows(self._h, _ptr(xd), xd.shape[0], _ptr(out), self._stream()))
         return out
 
+    # -- f4: damage HUD crops -------------------------------------------------
+    def crop_resize_width(self, frames, rects, out_w: int = 256):
+        """``YoloCrop.crop_img`` + ``imutils.resize(width=out_w)`` (``ai_runner.py:114,556-571``) for up to four pixel
+        rectangles ``(x1, y1, x2, y2)`` per frame: frames uint8[n,H,W,3] -> list of uint8[n, oh_j, out_w, 3] on the
+        host, one array per rectangle, channel order kept."""
+        fd = self._dev(frames, torch.uint8)
+        n, h, w, _ = fd.shape
+        rects = [tuple(int(v) for v in r) for r in rects]
+        if not 1 <= len(rects) <= 4:
+            raise ValueError("1..4 rectangles per call")
+        cap = 1
+        for (x1, y1, x2, y2) in rects:
+            if x2 > x1 and y2 > y1:
+                cap = max(cap, int((y2 - y1) * (out_w / float(x2 - x1))))
+        out = torch.zeros((n, len(rects), cap, out_w, 3), dtype=torch.uint8, device=self.device)
+        flat = (C.c_int32 * (4 * len(rects)))(*[v for r in rects for v in r])
+        oh = (C.c_int32 * len(rects))()
+        self._check(self._lib.pa_crop_resize_width(self._h, _ptr(fd), n, h, w, flat, len(rects), out_w, _ptr(out), cap, oh, self._stream()))
+        torch.cuda.synchronize(self.device)
+        host = out.cpu().numpy()
+        return [np.ascontiguousarray(host[:, j, : oh[j]]) for j in range(len(rects))]
+
     # -- a6: crops -----------------------------------------------------------
     def square_crops(self, frames, boxes, padding: int = constants.CROP_PADDING, swap_rb: bool = False):
         """frames uint8[n,H,W,3], boxes float64[n,F',4] -> (crops uint8[n,F',128,128,3], status int32[n,F']) on host."""
