@@ -237,6 +237,56 @@ def bench_mixed(args):
     eng.close()
 
 
+def clip_batch_side(eng, n_clip, kb, height, width, S, delta, lanes_n, clips=160):
+    """Side measurement (not `value`): the same 64-frame clips, `kb` of them concatenated per backbone batch
+    (pa_clip_begin_batch: every window stays inside its own clip; results equal the per-clip ones to fp32 rounding,
+    tests/test_gpu_contract.py::test_clip_batch_equals_separate_clips), two lanes as in the headline. More crops per
+    launch amortise the ~8 us a convolution launch costs outside its steady state."""
+    big = eng.clone(max_batch_frames=n_clip * kb, max_clip_frames=max(n_clip * kb, 64))
+    lanes = None
+    try:
+        n = n_clip * kb
+        frames = torch.from_numpy(synth.make_frames(n, height, width)).to(eng.device)
+        boxes = torch.from_numpy(synth.make_boxes(n, height, width)).to(eng.device)
+        lanes = ClipLanes(big, S, delta, lanes=lanes_n)
+        lanes.calibrate(frames, boxes, n, batch_of=kb)
+        calls = max(clips // kb, 4)
+        for _ in range(4):
+            lanes.submit(frames, boxes, n, kb)
+        torch.cuda.synchronize(eng.device)
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            lanes.submit(frames, boxes, n, kb)
+        torch.cuda.synchronize(eng.device)
+        dt = time.perf_counter() - t0
+        # kernel pass on one stream
+        runner = FrameParallelClip(big, S, delta)
+        big.profile_enable(True)
+        for _ in range(6):
+            runner.run(frames, boxes, n, gather=False, pipeline=False, reuse_buffers=True, batch_of=kb)
+        torch.cuda.synchronize(eng.device)
+        big.profile_enable(False)
+        stats = big.profile_read()
+        dom = max(stats, key=lambda s: s["total_ms"])
+        tf = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
+        return {
+            "clips_per_backbone_batch": kb,
+            "crops_per_launch": n * 2,
+            "lanes": lanes_n,
+            "value": round(n * calls / dt, 2),
+            "unit": "frames/s",
+            "ms_per_clip": round(1000.0 * dt / (calls * kb), 4),
+            "roofline_frac": round(tf / PEAK_FP32_MATRIX_TFLOPS, 4) if big.compute_dtype == "f32" else None,
+            "dominant_family_tflops": round(tf, 2),
+            "avg_launch_ms": round(dom["total_ms"] / max(dom["launches"], 1), 5),
+            "note": "side measurement, NOT `value`: the headline keeps BASELINE configs[1]'s batch of 64 frames per backbone pass",
+        }
+    finally:
+        if lanes is not None:
+            lanes.close()
+        big.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -256,6 +306,12 @@ def main():
     ap.add_argument("--lanes", type=int, default=2,
                     help="configs[1]/[2] at N = 1: independent clips alternate over this many engines / streams (ClipLanes); "
                     "1 = one engine with the crop stage of clip k+1 under the backbone of clip k")
+    ap.add_argument("--clips-per-batch", type=int, default=1,
+                    help="configs[1]/[2] at N = 1: this many independent clips go through the backbone as ONE batch "
+                    "(pa_clip_begin_batch: windows stay inside their own clip, results equal the per-clip ones) -- more crops per launch")
+    ap.add_argument("--clip-batch-side", type=int, default=4,
+                    help="side measurement `clip_batches` of the default run: this many clips per backbone batch (0 / 1: skip; also skipped "
+                    "with --no-pcie)")
     ap.add_argument("--long-clip-batch", type=int, default=256,
                     help="configs[3]: frames per backbone batch of the long clip (the 64-frame batch is configs[1]'s workload, "
                     "not a property of the 8192-frame clip)")
@@ -290,10 +346,12 @@ def main():
     F, S, A, DELTA = 2, 7, 63, 3
     clip_frames = args.clip_frames if args.clip_frames is not None else (8192 if world > 1 else 0)
     long_clip = clip_frames > 0
-    n_batch = args.long_clip_batch if long_clip else args.frames
+    kb = max(args.clips_per_batch, 1) if (world == 1 and not long_clip) else 1   # independent clips per backbone batch
+    n_clip = args.frames                                                           # frames of one clip (short-clip workloads)
+    n_batch = args.long_clip_batch if long_clip else n_clip * kb
     n_total = clip_frames if long_clip else n_batch * world
     lo, hi = shard_range(n_total, world, rank)
-    repeat = 1 if (long_clip or world > 1) else max(args.inner_repeat, 1)
+    repeat = 1 if (long_clip or world > 1) else max(args.inner_repeat // kb, 1)   # step() calls per timed step
 
     # weights: rank 0 folds them once; the prepared device arena crosses xGMI in one RCCL broadcast
     sd = synth.make_state_dict(seed=1234) if rank == 0 else None
@@ -314,13 +372,14 @@ def main():
     lanes = None
     if world == 1 and not long_clip and args.lanes > 1 and not args.no_pipeline:
         lanes = ClipLanes(eng, S, DELTA, lanes=args.lanes)
-        lanes.calibrate(frames, boxes, n_total)   # untimed: which of the concurrent streams overlap best on this clip shape
+        lanes.calibrate(frames, boxes, n_total, batch_of=kb if kb > 1 else 0)   # untimed: which of the concurrent streams overlap best on this shape
+    batch_of = kb if kb > 1 else 0
 
     def step(pipeline=None):
         if lanes is not None and pipeline is None:
-            return lanes.submit(frames, boxes, n_total)[1:]
+            return lanes.submit(frames, boxes, n_total, batch_of)[1:]
         pipeline = (not args.no_pipeline) if pipeline is None else pipeline
-        return runner.run(frames, boxes, n_total, gather=True, pipeline=pipeline, reuse_buffers=True)
+        return runner.run(frames, boxes, n_total, gather=True, pipeline=pipeline, reuse_buffers=True, batch_of=batch_of)
 
     def fence():
         torch.cuda.synchronize(device)
@@ -342,14 +401,15 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    n_clips = args.steps * repeat
+    n_calls = args.steps * repeat       # step() calls in the timed region
+    n_clips = n_calls * kb              # clips they processed
     # ---- kernel pass: clips again with every launch bracketed by HIP events on the launch stream
     # (pa_profile_enable). Kept out of the timed region because the event pairs serialise
     # neighbouring kernels and cost ~10 % throughput; its own wall time is reported as
     # profiled_ms_per_step.
     stats, dt_prof, prof_clips = [], None, 0
     if not args.no_profile:
-        prof_clips = args.steps if long_clip else min(n_clips, 40)
+        prof_clips = args.steps if long_clip else min(n_calls, 40)   # (step() calls of the kernel pass)
         if long_clip:
             prof_clips = min(prof_clips, 2)
         eng.profile_enable(True)
@@ -364,15 +424,15 @@ def main():
     if rank == 0:
         # sanity: results are finite and complete
         assert rec.shape[0] == n_total - 1 and torch.isfinite(lp).all()
-        fps = n_total * n_clips / dt
-        shape = (n_batch, args.height, args.width, args.dtype)
+        fps = n_total * n_calls / dt
+        shape = (n_clip, args.height, args.width, args.dtype)
         if long_clip:
             cfg_name = "configs[3]" if (clip_frames, args.height, args.width, args.dtype) == (8192, 1080, 1920, "f32") else "custom long clip"
             what = (f"ONE {clip_frames}-frame {args.height}x{args.width} BGR clip sharded frame-parallel over {world} rank(s) "
                     f"({hi - lo} frames on rank 0, backbone batches of {n_batch})")
         else:
             cfg_name = {(64, 1080, 1920, "f32"): "configs[1]", (256, 720, 1280, "bf16"): "configs[2]"}.get(shape, "custom shape")
-            what = f"{n_batch} x {args.height}x{args.width} BGR frames per GPU per clip"
+            what = f"{n_clip} x {args.height}x{args.width} BGR frames per GPU per clip"
         reach = DELTA * (S // 2) ** 2
         result = {
             "metric": f"{args.height}p frames/sec end-to-end (decode->labels; 'decode' here = ingest of raw BGR frames already resident in HBM)",
@@ -394,10 +454,14 @@ def main():
                 f"{'fp32' if args.dtype == 'f32' else 'bf16-conv (3x3 stack in bf16, fp32 accumulate; stem, fc, head fp32)'} "
                 f"CNNActionDetector (ResNet-18 + Conv1d/MLP head, 63 actions), seeded weights",
                 "ingest": "frames resident in HBM before the timed region; no decode (BASELINE metric's 'decode' = ingest of raw BGR frames, SURVEY.md 8a1)",
-                "clip_frames": n_total,
+                "clip_frames": n_total if long_clip else n_clip,
+                "clips_per_backbone_batch": kb,
+                "clips_per_backbone_batch_note": ("independent clips concatenated for the backbone launches; every window is clamped to its own "
+                                                  "clip (pa_clip_begin_batch), results equal the per-clip ones to fp32 rounding "
+                                                  "(tests/test_gpu_contract.py::test_clip_batch_equals_separate_clips)") if kb > 1 else None,
                 "frames_per_backbone_batch": n_batch,
                 "crops_per_backbone_batch": n_batch * F,
-                "inner_repeat": repeat,
+                "inner_repeat": repeat * kb,
                 "inner_repeat_note": "clips per timed step; ms_per_step = timed region / (steps x inner_repeat) = one clip",
                 "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU",
                 "pipeline": (f"{args.lanes} lanes: independent clips alternate over {args.lanes} engines (own activation buffers, own HIP stream), "
@@ -486,8 +550,10 @@ def main():
                     "frac": round(gbs / PEAK_HBM_GBS, 4),
                 }
         if world == 1 and not long_clip and not args.no_pcie:
-            result["pcie_inclusive"] = pcie_inclusive(eng, frames, boxes)
-            result["pcie_inclusive_windows"] = pcie_inclusive_windows(eng, frames, boxes)
+            result["pcie_inclusive"] = pcie_inclusive(eng, frames[:n_clip], boxes[:n_clip])
+            result["pcie_inclusive_windows"] = pcie_inclusive_windows(eng, frames[:n_clip], boxes[:n_clip])
+        if world == 1 and not long_clip and kb == 1 and not args.no_pcie and not args.no_pipeline and args.clip_batch_side > 1:
+            result["clip_batches"] = clip_batch_side(eng, n_clip, args.clip_batch_side, args.height, args.width, S, DELTA, max(args.lanes, 1))
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(sd, args.height, args.width, args.cpu_sample_frames)
         print(json.dumps(result), flush=True)

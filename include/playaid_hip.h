@@ -219,6 +219,13 @@ int pa_project_boxes(pa_engine* e, const double* log_rows, int32_t n_rows, doubl
  * ai_runner.py:244-245): sets the clamp range of the window sampler and marks
  * the feature cache empty. */
 int pa_clip_begin(pa_engine* e, int32_t clip_frames);
+/* A batch of n_clips INDEPENDENT clips of clip_frames frames each, processed as one clip of n_clips * clip_frames
+ * frames (clip c = frames c * clip_frames ...): the backbone calls see one long clip -- more crops per launch --
+ * while every window is clamped to its own clip's frame numbers, so each clip's records equal what it gets alone up
+ * to fp32 rounding (launch sizes pick tiles / split-K factors) (the reference runs clips one after another; ai_runner.py:493-520 has no cross-clip state). Records of frame
+ * numbers that are a multiple of clip_frames belong to no clip (a clip's frame numbers run 1 .. clip_frames - 1)
+ * and are to be ignored. */
+int pa_clip_begin_batch(pa_engine* e, int32_t n_clips, int32_t clip_frames);
 
 /* Crop + backbone for frames frame0 .. frame0+n-1 (0-based) of the clip:
  * square_crop(pad) -> BGR2RGB -> /255 -> ResNet-18 -> 1000-d feature per

@@ -111,6 +111,7 @@ SYMBOLS = [
                                         C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     ("pa_project_boxes", C.c_int, [_P, _P, C.c_int32, _P, _P]),
     ("pa_clip_begin", C.c_int, [_P, C.c_int32]),
+    ("pa_clip_begin_batch", C.c_int, [_P, C.c_int32, C.c_int32]),
     ("pa_backbone_frames", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, _P]),
     ("pa_preprocess_frames", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, _P]),
     ("pa_backbone_slot", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P]),

@@ -176,8 +176,11 @@ hipError_t launch_avgpool(const float* in, float* out, int32_t n, hipStream_t s)
 // window w = (frame_num_lo + w / fighters, fighter w % fighters); slot t reads
 // frame number clamp(f -/+ delta*(mid-t)^2) and hence feature-cache row
 // (frame_num - 1) * fighters + fighter.
+// sub_frames > 0: the clip is a batch of independent clips of sub_frames frames each (pa_clip_begin_batch); frame
+// number f belongs to clip c = (f - 1) / sub_frames and its window is clamped to that clip's own frame numbers
+// c * sub_frames + 1 .. c * sub_frames + sub_frames - 1.
 __global__ void window_gather_kernel(int32_t* gather, int frame_num_lo, int count, int fighters, int seq, int delta,
-                                     int max_frames, int min_frame) {
+                                     int max_frames, int min_frame, int sub_frames) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int total = count * fighters * seq;
     if (i >= total) return;
@@ -185,6 +188,11 @@ __global__ void window_gather_kernel(int32_t* gather, int frame_num_lo, int coun
     const int w = i / seq;
     const int fighter = w % fighters;
     const int f = frame_num_lo + w / fighters;
+    if (sub_frames > 0) {
+        const int c = (f - 1) / sub_frames;
+        min_frame = c * sub_frames + 1;
+        max_frames = (c + 1) * sub_frames;
+    }
     const int mid = seq / 2;
     int off = delta * (mid - t) * (mid - t);
     if (off < 0) off = -off;
@@ -200,10 +208,10 @@ __global__ void window_gather_kernel(int32_t* gather, int frame_num_lo, int coun
 }
 
 hipError_t launch_window_gather(int32_t* gather, int32_t frame_num_lo, int32_t count, int32_t fighters, int32_t seq,
-                                int32_t delta, int32_t max_frames, int32_t min_frame, hipStream_t s) {
+                                int32_t delta, int32_t max_frames, int32_t min_frame, int32_t sub_frames, hipStream_t s) {
     const int total = count * fighters * seq;
     hipLaunchKernelGGL(window_gather_kernel, dim3((total + 255) / 256), dim3(256), 0, s, gather, frame_num_lo, count,
-                       fighters, seq, delta, max_frames, min_frame);
+                       fighters, seq, delta, max_frames, min_frame, sub_frames);
     return hipGetLastError();
 }
 

@@ -60,6 +60,7 @@ struct pa_engine {
     int cache_rows = 0;  // feature-cache rows
     // clip state
     int clip_frames = 0;
+    int sub_frames = 0;  // > 0: the clip is a batch of independent clips of this many frames (pa_clip_begin_batch)
     std::vector<char> ready;
     // device memory (all freed in pa_destroy)
     std::vector<void*> allocs;
@@ -80,7 +81,7 @@ struct pa_engine {
     int32_t* cache_status = nullptr;  // [cache_rows]
     float* h1 = nullptr;              // [max_crops][512]
     int32_t* gather = nullptr;        // [max_crops][S]
-    int gather_key[3] = {-1, -1, -1}; // (f0, cnt, clip_frames) the table in `gather` was built for; -1 = none (other users of the buffer reset it)
+    int gather_key[4] = {-1, -1, -1, -1}; // (f0, cnt, clip_frames, sub_frames) the table in `gather` was built for; -1 = none (other users of the buffer reset it)
     float* slab = nullptr;
     size_t slab_floats = 0;
     std::vector<ConvLayer> convs;  // stem + 19 convs
@@ -1225,7 +1226,18 @@ int pa_clip_begin(pa_engine* e, int32_t clip_frames) {
     if (!e || clip_frames < 1) return fail(e, PA_ERR_INVALID_ARG, "pa_clip_begin: bad argument");
     if (clip_frames > e->cfg.max_clip_frames) return fail(e, PA_ERR_CAPACITY, "pa_clip_begin: clip longer than max_clip_frames");
     e->clip_frames = clip_frames;
+    e->sub_frames = 0;
     e->ready.assign(clip_frames, 0);
+    return PA_OK;
+}
+
+int pa_clip_begin_batch(pa_engine* e, int32_t n_clips, int32_t clip_frames) {
+    if (!e || n_clips < 1 || clip_frames < 2) return fail(e, PA_ERR_INVALID_ARG, "pa_clip_begin_batch: bad argument");
+    if ((long long)n_clips * clip_frames > e->cfg.max_clip_frames)
+        return fail(e, PA_ERR_CAPACITY, "pa_clip_begin_batch: n_clips * clip_frames exceeds max_clip_frames");
+    const int rc = pa_clip_begin(e, n_clips * clip_frames);
+    if (rc) return rc;
+    e->sub_frames = clip_frames;
     return PA_OK;
 }
 
@@ -1345,9 +1357,9 @@ int pa_head_frames(pa_engine* e, int32_t lo, int32_t hi, pa_record* records, flo
         const int cnt = std::min(frames_per_pass, hi - f0);
         // the index table only depends on (first frame, count, clip length): a steady stream of
         // equal clips (bench.py, the frame-parallel runner) re-uses it instead of re-launching
-        if (e->gather_key[0] != f0 || e->gather_key[1] != cnt || e->gather_key[2] != e->clip_frames) {
-            HIPCHK(e, launch_window_gather(e->gather, f0, cnt, F, S, D, e->clip_frames, 1, s));
-            e->gather_key[0] = f0; e->gather_key[1] = cnt; e->gather_key[2] = e->clip_frames;
+        if (e->gather_key[0] != f0 || e->gather_key[1] != cnt || e->gather_key[2] != e->clip_frames || e->gather_key[3] != e->sub_frames) {
+            HIPCHK(e, launch_window_gather(e->gather, f0, cnt, F, S, D, e->clip_frames, 1, e->sub_frames, s));
+            e->gather_key[0] = f0; e->gather_key[1] = cnt; e->gather_key[2] = e->clip_frames; e->gather_key[3] = e->sub_frames;
         }
         const size_t o = (size_t)(f0 - lo) * F;
         int rc = run_head(e, cnt * F, e->cache, e->gather, e->cache_status, records ? records + o : nullptr,

@@ -225,8 +225,7 @@ hipError_t launch_maxpool_bf16(const void* in, void* out, int32_t n, hipStream_t
 hipError_t launch_avgpool_bf16(const void* in, float* out, int32_t n, hipStream_t s);  // bf16 in, fp32 out
 // window gather table: rows into the feature cache, see head_gather_kernel
 hipError_t launch_window_gather(int32_t* gather, int32_t frame_num_lo, int32_t count, int32_t fighters,
-                                int32_t seq, int32_t delta, int32_t max_frames, int32_t min_frame,
-                                hipStream_t s);
+                                int32_t seq, int32_t delta, int32_t max_frames, int32_t min_frame, int32_t sub_frames, hipStream_t s);
 hipError_t launch_identity_gather(int32_t* gather, int32_t n, hipStream_t s);
 hipError_t launch_scatter_rows(const float* feats, const int32_t* st, const int32_t* ids, float* cache, int32_t* cache_st,
                                int32_t n, int32_t fighters, int32_t clip_frames, int32_t* bad_ids, hipStream_t s);

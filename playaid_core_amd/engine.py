@@ -311,8 +311,15 @@ class Engine:
         return out
 
     # -- b2: clip ------------------------------------------------------------
-    def clip_begin(self, clip_frames: int):
-        self._check(self._lib.pa_clip_begin(self._h, clip_frames))
+    def clip_begin(self, clip_frames: int, batch_of: int = 0):
+        """``batch_of`` = n > 0: the ``clip_frames`` frames are n independent clips of ``clip_frames // n`` frames
+        each (``pa_clip_begin_batch``): windows never cross from one clip into the next."""
+        if batch_of:
+            if clip_frames % batch_of:
+                raise ValueError("the batch must hold whole clips")
+            self._check(self._lib.pa_clip_begin_batch(self._h, batch_of, clip_frames // batch_of))
+        else:
+            self._check(self._lib.pa_clip_begin(self._h, clip_frames))
 
     def backbone_frames(self, frames_dev: torch.Tensor, boxes_dev: torch.Tensor, frame0: int, crops_rgb=None, status=None):
         n, h, w, _ = frames_dev.shape

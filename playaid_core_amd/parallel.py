@@ -211,10 +211,13 @@ class FrameParallelClip:
         self.finish_halo(self.post_halo(n_total))
 
     def run(self, frames_local, boxes_local, n_total: int, gather: bool = True, pipeline: bool = False,
-            reuse_buffers: bool = False):
+            reuse_buffers: bool = False, batch_of: int = 0):
         """frames_local / boxes_local: this rank's shard (device tensors for the HIP engine).
         Returns on every rank ``(records int32[count,F,4], logp float32[count,F,A])`` for frame
         numbers 1..n_total-1 in order (``gather=False`` or one rank: the local part only).
+
+        ``batch_of`` = k: the frames are k independent clips of ``n_total // k`` frames (see ``Engine.clip_begin``);
+        clip c's rows are ``[c * L : c * L + L - 1]`` of the result, row ``c * L + L - 1`` belongs to no clip.
 
         Result tensors: the local part lives in buffers this object keeps between calls. With
         ``reuse_buffers=False`` (default) the caller gets its own copies; ``reuse_buffers=True``
@@ -222,7 +225,13 @@ class FrameParallelClip:
         eng = self.engine
         lo, hi = shard_range(n_total, self.world, self.rank)
         assert frames_local.shape[0] == hi - lo, "shard size mismatch"
-        eng.clip_begin(n_total)
+        if batch_of:
+            # n_total frames = batch_of independent clips (one rank only: a clip is not cut across ranks); rows whose
+            # frame number is a multiple of the clip length belong to no clip
+            assert self.world == 1, "clip batches are a single-GPU throughput mode"
+            eng.clip_begin(n_total, batch_of=batch_of)
+        else:
+            eng.clip_begin(n_total)
         self.backbone_shard(frames_local, boxes_local, lo, pipeline=pipeline)
         pending = self.post_halo(n_total)
         f_lo, f_hi = owned_frame_nums(n_total, self.world, self.rank)
@@ -332,7 +341,7 @@ class ClipLanes:
         self.calibration = None
         self._next = 0
 
-    def calibrate(self, frames, boxes, n_total: int, clips: int = 12):
+    def calibrate(self, frames, boxes, n_total: int, clips: int = 12, batch_of: int = 0):
         """Pick the lanes' streams by measurement on the caller's own clip shape. Streams that overlap on the
         spin-kernel probe can still sit on hardware queues that share a dispatch pipe: such a pair ran real clips at
         45.2 k frames/s where the other pairs of the same process ran at 47.9 k. Every combination of the
@@ -346,11 +355,11 @@ class ClipLanes:
         for combo in itertools.combinations(range(len(self._candidates)), n):
             self.streams = [self._candidates[i] for i in combo]
             for k in range(2 * n):
-                self.submit(frames, boxes, n_total)
+                self.submit(frames, boxes, n_total, batch_of)
             torch.cuda.synchronize(self.engines[0].device)
             t0 = time.perf_counter()
             for k in range(clips):
-                self.submit(frames, boxes, n_total)
+                self.submit(frames, boxes, n_total, batch_of)
             torch.cuda.synchronize(self.engines[0].device)
             rates[combo] = n_total * clips / (time.perf_counter() - t0)
         best = max(rates, key=rates.get)
@@ -358,12 +367,14 @@ class ClipLanes:
         self.calibration = {"picked": list(best), "rates": {",".join(map(str, c)): round(v, 1) for c, v in rates.items()}}
         return rates
 
-    def submit(self, frames, boxes, n_total: int):
-        """Enqueue one clip on the next lane -> (lane index, records view, logp view)."""
+    def submit(self, frames, boxes, n_total: int, batch_of: int = 0):
+        """Enqueue one clip (``batch_of`` = k: k independent clips concatenated, see ``FrameParallelClip.run``) on the
+        next lane -> (lane index, records view, logp view)."""
         lane = self._next
         self._next = (self._next + 1) % len(self.engines)
         with torch.cuda.stream(self.streams[lane]):
-            rec, lp = self.runners[lane].run(frames, boxes, n_total, gather=False, pipeline=False, reuse_buffers=True)
+            rec, lp = self.runners[lane].run(frames, boxes, n_total, gather=False, pipeline=False, reuse_buffers=True,
+                                             batch_of=batch_of)
         return lane, rec, lp
 
     def synchronize(self):

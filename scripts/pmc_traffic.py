@@ -2,7 +2,7 @@
 """HBM traffic of the conv3x3 kernel family from two rocprofv3 PMC passes
 (FETCH_SIZE and WRITE_SIZE collected separately, as MI355X_MICROARCH.md prescribes).
 
-  python scripts/pmc_traffic.py <dir with pmc_fetch/ and pmc_write/> <out.json> [f32|bf16]
+  python scripts/pmc_traffic.py <dir with pmc_fetch/ and pmc_write/> <out.json> [f32|bf16] [frames height width]
 
 Units: both counters are in KiB. On gfx950 FETCH_SIZE reports half the bytes of a wide
 coalesced read stream (guide, section HBM), so it is doubled; WRITE_SIZE is taken as is.
@@ -39,9 +39,12 @@ f = conv3x3_values(dispatches(d + "/pmc_fetch", "FETCH_SIZE"), dtype)
 w = conv3x3_values(dispatches(d + "/pmc_write", "WRITE_SIZE"), dtype)
 fetch = 2.0 * sum(f) / len(f) * 1024.0
 write = sum(w) / len(w) * 1024.0
+# the workload the passes ran (bench.py replays the figure only for this shape): defaults = the two profiled configs
+shape = [int(v) for v in sys.argv[4:7]] if len(sys.argv) >= 7 else ([256, 720, 1280] if dtype == "bf16" else [64, 1080, 1920])
 out = {
     "kernel": "igemm_conv3x3",
     "dtype": dtype,
+    "workload": {"frames": shape[0], "height": shape[1], "width": shape[2]},
     "launches_sampled": len(f),
     "fetch_bytes_per_launch": round(fetch),
     "write_bytes_per_launch": round(write),

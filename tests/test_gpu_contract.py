@@ -577,3 +577,39 @@ def test_clip_lanes_equal_single_engine(engine):
                 assert np.array_equal(lpj.cpu().numpy(), want[j])
     finally:
         lanes.close()
+
+
+def test_clip_batch_equals_separate_clips(engine):
+    """pa_clip_begin_batch: k independent clips run as ONE long clip through the backbone (more crops per launch)
+    give every clip the records it gets alone (to fp32 rounding) -- windows are clamped to the clip's own frame
+    numbers, never into a neighbour -- for clip lengths below and above the 27-frame reach of the window."""
+    from playaid_core_amd.parallel import FrameParallelClip
+
+    h, w = 720, 1280
+    for L, k in ((20, 3), (40, 2)):
+        clips = []
+        for c in range(k):
+            f = torch.from_numpy(synth.make_frames(L, h, w, seed=11 + c)).cuda()
+            b = torch.from_numpy(synth.make_boxes(L, h, w, first_frame=7 * c)).cuda()
+            clips.append((f, b))
+        torch.cuda.synchronize()
+        want = [engine.infer_clip(f, b) for f, b in clips]
+        runner = FrameParallelClip(engine, 7, 3)
+        frames = torch.cat([f for f, _ in clips])
+        boxes = torch.cat([b for _, b in clips])
+        rec, lp = runner.run(frames, boxes, L * k, gather=False, batch_of=k)
+        torch.cuda.synchronize()
+        lp = lp.cpu().numpy()
+        assert lp.shape[0] == L * k - 1
+        for c in range(k):
+            got = lp[c * L: c * L + L - 1]
+            # same windows, same weights; a launch over more crops picks other tiles / split-K factors, so the
+            # sums differ in the last bits only (2e-6 here against the 1e-4 bar)
+            assert np.abs(got - want[c]["logp"]).max() <= 1e-5, (L, k, c, np.abs(got - want[c]["logp"]).max())
+            assert np.array_equal(got.argmax(-1), want[c]["logp"].argmax(-1))
+        # the same frames as ONE clip differ near the seams: the batch flag is what keeps the clips apart
+        rec1, lp1 = runner.run(frames, boxes, L * k, gather=False)
+        torch.cuda.synchronize()
+        assert np.abs(lp1.cpu().numpy()[L - 4: L - 1] - want[0]["logp"][L - 4: L - 1]).max() > 1e-3
+    with pytest.raises(ValueError):
+        engine.clip_begin(50, batch_of=3)
