@@ -279,7 +279,7 @@ def clip_batch_side(eng, n_clip, kb, height, width, S, delta, lanes_n, clips=160
             "roofline_frac": round(tf / PEAK_FP32_MATRIX_TFLOPS, 4) if big.compute_dtype == "f32" else None,
             "dominant_family_tflops": round(tf, 2),
             "avg_launch_ms": round(dom["total_ms"] / max(dom["launches"], 1), 5),
-            "note": "side measurement, NOT `value`: the headline keeps BASELINE configs[1]'s batch of 64 frames per backbone pass",
+            "note": "side measurement, NOT `value`: the headline keeps the batch size BASELINE.json names (one clip per backbone pass)",
         }
     finally:
         if lanes is not None:
