@@ -72,6 +72,58 @@ def test_create_rejects_bad_arguments_without_gpu(lib):
     assert lib.pa_create(ctypes.byref(cfg), buf, 64, ctypes.byref(h)) == _lib.PA_ERR_INVALID_ARG
 
 
+def test_side_model_handles_reject_bad_tables_without_gpu(lib):
+    """pa_lstm_create / pa_encoder_create / pa_convnet_create check their blobs and tables before any device call."""
+    import numpy as np
+
+    from playaid_core_amd import _lib, synth
+    from playaid_core_amd.rnn_action_detector import pack_lstm_blob
+
+    h = ctypes.c_void_p(0)
+    blob = pack_lstm_blob(synth.make_rnn_state_dict(seed=3, num_actions=9), 9)
+    ptr = blob.ctypes.data_as(ctypes.c_void_p)
+    assert lib.pa_lstm_create(0, 300, 512, 3, 10, 64, ptr, blob.nbytes, ctypes.byref(h)) == _lib.PA_ERR_BAD_WEIGHTS   # A mismatch
+    assert lib.pa_lstm_create(0, 300, 520, 3, 9, 64, ptr, blob.nbytes, ctypes.byref(h)) == _lib.PA_ERR_INVALID_ARG    # hidden > 512
+    assert lib.pa_lstm_create(0, 300, 512, 3, 9, 0, ptr, blob.nbytes, ctypes.byref(h)) == _lib.PA_ERR_INVALID_ARG
+    assert lib.pa_encoder_create(0, 2048, 247, 7, 9, 8, 3, 2048, 63, 64, ptr, blob.nbytes, ctypes.byref(h)) == _lib.PA_ERR_BAD_WEIGHTS
+    assert lib.pa_encoder_create(0, 2048, 247, 7, 9, 4, 3, 2048, 63, 64, ptr, blob.nbytes, ctypes.byref(h)) == _lib.PA_ERR_INVALID_ARG  # 64-wide heads
+    assert lib.pa_encoder_blob_bytes(2048, 247, 7, 9, 3, 2048, 63) > 4 * 3 * (3 * 256 * 256 + 2 * 256 * 2048)
+
+    def conv(**kw):
+        d = dict(kind=0, cin=64, cout=64, ksize=3, stride=1, in_hw=32, in_buf=0, in_pad=1, out_buf=1, out_pad=0, res_buf=-1, relu=1,
+                 w_off=0, b_off=64 * 9 * 64)
+        d.update(kw)
+        return d
+
+    def create(descs, bufs, n_weights=64 * 9 * 64 + 64):
+        arr = (_lib.pa_conv_desc * len(descs))()
+        for i, d in enumerate(descs):
+            for k, v in d.items():
+                setattr(arr[i], k, v)
+        w = np.zeros(n_weights, np.float32)
+        hh = ctypes.c_void_p(0)
+        rc = lib.pa_convnet_create(0, arr, len(descs), (ctypes.c_int64 * len(bufs))(*bufs), len(bufs), w.ctypes.data_as(ctypes.c_void_p),
+                                   w.size, 4, ctypes.byref(hh))
+        msg = lib.pa_convnet_last_error(hh).decode() if hh else ""
+        if hh:
+            lib.pa_convnet_destroy(hh)
+        return rc, msg
+
+    big = 34 * 34 * 64
+    rc, msg = create([conv(cin=48)], [big, big])
+    assert rc == _lib.PA_ERR_INVALID_ARG and "unsupported convolution" in msg          # cin % 32
+    rc, msg = create([conv(in_pad=0)], [big, big])
+    assert rc == _lib.PA_ERR_INVALID_ARG                                               # a 3x3 needs a border
+    rc, msg = create([conv()], [big, big], n_weights=100)
+    assert rc == _lib.PA_ERR_BAD_WEIGHTS and "outside the blob" in msg
+    rc, msg = create([conv()], [1000, big])
+    assert rc == _lib.PA_ERR_INVALID_ARG and "too small" in msg
+    rc, msg = create([conv(), conv(in_hw=16, out_buf=1)], [big, big])
+    assert rc == _lib.PA_ERR_INVALID_ARG and "two geometries" in msg                   # bordered buffer 0 reused at 16 x 16
+    rc, msg = create([conv(kind=7)], [big, big])
+    assert rc == _lib.PA_ERR_INVALID_ARG and "unknown kind" in msg
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from playaid_core_amd import _lib
 
