@@ -195,7 +195,7 @@ def bench_mixed(args):
 
     device = torch.device("cuda", 0)
     torch.cuda.set_device(device)
-    n, batch = 192, 32  # 128 frames at 1080p + 64 at 720p: 4 + 2 batches of 32 frames (64 crops each)
+    n, batch = 192, args.mixed_batch  # 128 frames at 1080p + 64 at 720p: with 32-frame batches 4 + 2 graph replays per clip
     res = [(1080, 1920) if (i % 3) != 1 else (720, 1280) for i in range(n)]
     sd = synth.make_state_dict(seed=1234)
     eng = Engine(sd, device=str(device), max_batch_frames=batch, max_clip_frames=n, compute_dtype=args.dtype)
@@ -309,6 +309,7 @@ def main():
     ap.add_argument("--clips-per-batch", type=int, default=1,
                     help="configs[1]/[2] at N = 1: this many independent clips go through the backbone as ONE batch "
                     "(pa_clip_begin_batch: windows stay inside their own clip, results equal the per-clip ones) -- more crops per launch")
+    ap.add_argument("--mixed-batch", type=int, default=64, help="--workload mixed: frames per resolution bucket batch (divides 64)")
     ap.add_argument("--clip-batch-side", type=int, default=4,
                     help="side measurement `clip_batches` of the default run: this many clips per backbone batch (0 / 1: skip; also skipped "
                     "with --no-pcie)")
