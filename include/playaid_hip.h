@@ -414,6 +414,11 @@ int pa_encoder_forward(pa_encoder* h, const float* feats, int32_t ld, int32_t se
 int pa_profile_enable(pa_engine* e, int32_t on);
 int pa_profile_read(pa_engine* e, pa_kernel_stat* stats, int32_t max_stats, int32_t* n_stats);
 
+/* Keeps `stream` busy for about `microseconds` (one spinning thread; 0..100000). A probe, not a workload: two
+ * HIP streams that the runtime multiplexed onto one hardware queue run such kernels strictly in turn, two that sit
+ * on different queues side by side (playaid_core_amd/parallel.py picks the streams of its lanes with it). */
+int pa_stream_spin(pa_engine* e, int32_t microseconds, void* stream);
+
 /* Blocks until all work enqueued on `stream` is done (hipStreamSynchronize). */
 int pa_stream_sync(pa_engine* e, void* stream);
 

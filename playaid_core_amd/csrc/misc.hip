@@ -360,4 +360,20 @@ hipError_t launch_head_mlp(const HeadParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
+// A single-thread kernel that keeps its stream busy for `ticks` of the 100 MHz real-time clock: the probe
+// parallel._concurrent_streams uses to find out whether two HIP streams execute side by side (streams multiplexed
+// onto one hardware queue run strictly in turn).
+__global__ void spin_kernel(long long ticks, int* sink) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    int n = 0;
+    // (the iteration cap bounds the kernel to about a second whatever the clock does)
+    while ((long long)(__builtin_amdgcn_s_memrealtime() - t0) < ticks && n < (1 << 24)) ++n;
+    if (ticks < 0) *sink = n;  // (never true: keeps the loop observable)
+}
+
+hipError_t launch_spin(int32_t microseconds, hipStream_t s) {
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(1), 0, s, (long long)microseconds * 100, (int*)nullptr);
+    return hipGetLastError();
+}
+
 }  // namespace pa

@@ -1441,6 +1441,12 @@ int pa_profile_read(pa_engine* e, pa_kernel_stat* stats, int32_t max_stats, int3
     return PA_OK;
 }
 
+int pa_stream_spin(pa_engine* e, int32_t microseconds, void* stream) {
+    if (!e || microseconds < 0 || microseconds > 100000) return fail(e, PA_ERR_INVALID_ARG, "pa_stream_spin: 0..100000 us");
+    HIPCHK(e, launch_spin(microseconds, (hipStream_t)stream));
+    return PA_OK;
+}
+
 int pa_stream_sync(pa_engine* e, void* stream) {
     HIPCHK(e, hipStreamSynchronize((hipStream_t)stream));
     return PA_OK;

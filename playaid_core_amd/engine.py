@@ -144,6 +144,11 @@ class Engine:
         except Exception:
             pass
 
+    def stream_spin(self, microseconds: int, stream: "torch.cuda.Stream"):
+        """Keep ``stream`` busy for that long with one spinning thread (``pa_stream_spin``): the concurrency probe of
+        ``parallel.ClipLanes``."""
+        self._check(self._lib.pa_stream_spin(self._h, int(microseconds), C.c_void_p(stream.cuda_stream)))
+
     def _check(self, rc: int):
         if rc != _lib.PA_OK:
             raise EngineError(rc, self._lib.pa_last_error(self._h).decode())

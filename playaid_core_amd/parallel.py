@@ -285,22 +285,20 @@ class FrameParallelClip:
         return rec, lp
 
 
-def _concurrent_streams(device, count: int, tries: int = 16, allow_sharing: bool = True):
+def _concurrent_streams(engine, count: int, tries: int = 16, allow_sharing: bool = True):
     """``count`` HIP streams that really run side by side. The HIP runtime multiplexes streams onto a few hardware
     queues (four by default) and two streams that land on the same queue execute strictly in turn: measured on
     MI355X, torch's first and second pool streams shared one (two lanes then ran at the one-lane rate, 43.0 k
     frames/s against 47.9 k for any pair on distinct queues). So each candidate is probed against the streams already
     taken with two ~1 ms single-thread spin kernels: overlapping pairs finish in one kernel time, serialised ones
     in two. Candidates that fail are dropped (they stay in torch's pool)."""
+    device = engine.device
     with torch.cuda.device(device):
-        spin = 2_000_000
-
         def elapsed(streams):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for st in streams:
-                with torch.cuda.stream(st):
-                    torch.cuda._sleep(spin)
+                engine.stream_spin(1000, st)     # ~1 ms single-thread kernel (pa_stream_spin)
             torch.cuda.synchronize()
             return time.perf_counter() - t0
 
@@ -335,8 +333,8 @@ class ClipLanes:
         self.engines = [engine] + [engine.clone() for _ in range(max(lanes, 1) - 1)]
         self.runners = [FrameParallelClip(e, sequence_length, frame_delta) for e in self.engines]
         # a few more mutually concurrent streams than lanes: calibrate() picks among them
-        self._candidates = _concurrent_streams(engine.device, max(len(self.engines), 4), allow_sharing=False)
-        self.streams = _concurrent_streams(engine.device, len(self.engines)) if len(self._candidates) < len(self.engines) \
+        self._candidates = _concurrent_streams(engine, max(len(self.engines), 4), allow_sharing=False)
+        self.streams = _concurrent_streams(engine, len(self.engines)) if len(self._candidates) < len(self.engines) \
             else self._candidates[: len(self.engines)]
         self.calibration = None
         self._next = 0
