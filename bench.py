@@ -543,6 +543,9 @@ def main():
                 }
                 for s in stats
             }
+            result["kernels_note"] = ("HIP-event times of a separate pass on ONE stream (profiled_ms_per_step is that pass's wall time per clip); "
+                                      "the timed region runs two lanes, whose kernels overlap across clips, so the families' sum may exceed ms_per_step"
+                                      if lanes is not None else "HIP-event times of a separate pass on one stream")
             pre = by.get("preprocess_crops")
             if pre and pre["total_ms"] > 0:
                 gbs = pre["bytes"] / (pre["total_ms"] * 1e-3) / 1e9
