@@ -40,20 +40,20 @@ def extract_numbers(text: str) -> str:
 
 def parse_damage(results):
     """The part of ``damage_crop_to_percent`` behind the recogniser (``ai_runner.py:117-133``): ``results`` =
-    ``(boxes, detected_text, extra)`` -> ``(ok, (damage, original_string, confidence, results))``."""
-    boxes, detected_text, extra = results
-    if len(detected_text) == 2:
-        whole_number, decimal = (
-            (detected_text[0][0], detected_text[1][0]) if boxes[0][0][0] < boxes[1][0][0] else (detected_text[1][0], detected_text[0][0])
-        )
-        if whole_number != "" and decimal != "":
-            return True, (
-                float(extract_numbers(whole_number) + "." + extract_numbers(decimal)),
-                whole_number + "." + decimal,
-                detected_text[0][1],
-                (boxes, detected_text, extra),
-            )
-    return False, (-1, "_".join([r[0] for r in detected_text]), 0.0, results)
+    ``(boxes, detected_text, extra)`` -> ``(ok, (damage, original_string, confidence, results))``.
+
+    Exactly two text boxes are a reading: the one whose first corner lies further left is the whole part, the
+    other the decimal; both must be non-empty. The percent keeps only the digits of each part; the reported
+    confidence is the FIRST list entry's (a reference quirk: not the whole part's when the boxes arrive swapped).
+    Anything else is a miss: -1, the texts joined by "_", confidence 0."""
+    boxes, texts, _extra = results
+    if len(texts) == 2:
+        left_first = boxes[0][0][0] < boxes[1][0][0]
+        whole, decimal = (texts[0][0], texts[1][0]) if left_first else (texts[1][0], texts[0][0])
+        if whole and decimal:
+            value = float(f"{extract_numbers(whole)}.{extract_numbers(decimal)}")
+            return True, (value, f"{whole}.{decimal}", texts[0][1], results)
+    return False, (-1, "_".join(t[0] for t in texts), 0.0, results)
 
 
 def damage_crops(frames, engine) -> List[np.ndarray]:
