@@ -254,6 +254,7 @@ def clip_batch_side(eng, n_clip, kb, height, width, S, delta, lanes_n, clips=160
         for _ in range(4):
             lanes.submit(frames, boxes, n, kb)
         torch.cuda.synchronize(eng.device)
+        lanes.idle()
         t0 = time.perf_counter()
         for _ in range(calls):
             lanes.submit(frames, boxes, n, kb)
@@ -387,6 +388,8 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(device)
+        if lanes is not None:
+            lanes.idle()   # the device has drained: the next clips of the lanes start aligned (ClipLanes._aligned_start)
 
     for _ in range(args.warmup * repeat):
         step()
@@ -471,6 +474,8 @@ def main():
                 else ("crop stage of batch k+1 overlaps the backbone of batch k (2 streams, 2 input slots)" if not args.no_pipeline else "none"),
                 "lanes": args.lanes if lanes is not None else 1,
                 "lane_stream_calibration": lanes.calibration if lanes is not None else None,
+                "lane_start": ("after every device synchronisation the lanes' first clips are held behind a 1.5 ms spin kernel until both are "
+                               "enqueued and then start together (inside the timed region: once, at its start)") if lanes is not None else None,
             },
         }
         if world > 1:

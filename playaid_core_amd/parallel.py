@@ -329,7 +329,7 @@ class ClipLanes:
     ``submit`` only enqueues; results of a lane are valid once that lane's stream (or the device) is synchronised
     and are overwritten by the lane's next clip."""
 
-    def __init__(self, engine, sequence_length: int, frame_delta: int, lanes: int = 2):
+    def __init__(self, engine, sequence_length: int, frame_delta: int, lanes: int = 2, start_hold_us: int = 1500):
         self.engines = [engine] + [engine.clone() for _ in range(max(lanes, 1) - 1)]
         self.runners = [FrameParallelClip(e, sequence_length, frame_delta) for e in self.engines]
         # a few more mutually concurrent streams than lanes: calibrate() picks among them
@@ -338,12 +338,17 @@ class ClipLanes:
             else self._candidates[: len(self.engines)]
         self.calibration = None
         self._next = 0
+        self.start_hold_us = start_hold_us
+        self._helper = torch.cuda.Stream(engine.device)
+        self._go = torch.cuda.Event()
+        self._cold = True
 
     def calibrate(self, frames, boxes, n_total: int, clips: int = 12, batch_of: int = 0):
-        """Pick the lanes' streams by measurement on the caller's own clip shape. Streams that overlap on the
-        spin-kernel probe can still sit on hardware queues that share a dispatch pipe: such a pair ran real clips at
-        45.2 k frames/s where the other pairs of the same process ran at 47.9 k. Every combination of the
-        candidate streams is timed over ``clips`` clips; the fastest one is kept. -> {combination: frames/s}."""
+        """Pick the lanes' streams by measurement on the caller's own clip shape: every combination of the candidate
+        streams (they passed the spin-kernel probe, i.e. sit on distinct hardware queues at that moment; the runtime
+        may re-draw the mapping later) is timed over ``clips`` clips from an aligned start, the fastest is kept.
+        A pair that lands on ONE queue after all shows up here at the one-lane rate (43-45 k frames/s against 47 k).
+        -> {combination: frames/s}."""
         import itertools
 
         n = len(self.engines)
@@ -352,22 +357,45 @@ class ClipLanes:
         rates = {}
         for combo in itertools.combinations(range(len(self._candidates)), n):
             self.streams = [self._candidates[i] for i in combo]
+            self._cold = True
             for k in range(2 * n):
                 self.submit(frames, boxes, n_total, batch_of)
             torch.cuda.synchronize(self.engines[0].device)
+            self._cold = True
             t0 = time.perf_counter()
             for k in range(clips):
                 self.submit(frames, boxes, n_total, batch_of)
             torch.cuda.synchronize(self.engines[0].device)
-            rates[combo] = n_total * clips / (time.perf_counter() - t0)
+            rates[combo] = n_total * clips / (time.perf_counter() - t0 - 1e-6 * self.start_hold_us)
         best = max(rates, key=rates.get)
         self.streams = [self._candidates[i] for i in best]
+        self._cold = True
         self.calibration = {"picked": list(best), "rates": {",".join(map(str, c)): round(v, 1) for c, v in rates.items()}}
         return rates
+
+    def _aligned_start(self):
+        """Hold every lane behind a ~1.5 ms spin kernel on a helper stream while the caller enqueues the first clip of
+        each lane, so that the lanes then START TOGETHER. The offset between the lanes decides the rate and, once
+        running, stays what the start gave it: measured on the headline shape with the start offset set on the GPU,
+        47.7-47.9 k frames/s for offsets within +-0.3 ms of aligned (also one whole clip period later), 45.0-45.1 k
+        for anything between 0.35 and 1.2 ms -- one lane's crop / stem kernels (80 KB of LDS per workgroup) then fall
+        into the other lane's convolution layers for good. Left to the host, the offset is the time it takes to
+        enqueue one clip (~0.3-0.4 ms): right on the edge, which made identical runs land on either rate."""
+        self.engines[0].stream_spin(self.start_hold_us, self._helper)
+        self._go.record(self._helper)
+        for st in self.streams:
+            st.wait_event(self._go)
+
+    def idle(self):
+        """Tell the lanes that the device has drained (the caller synchronised it): the next clips start aligned."""
+        self._cold = True
 
     def submit(self, frames, boxes, n_total: int, batch_of: int = 0):
         """Enqueue one clip (``batch_of`` = k: k independent clips concatenated, see ``FrameParallelClip.run``) on the
         next lane -> (lane index, records view, logp view)."""
+        if self._cold and len(self.engines) > 1:
+            self._aligned_start()
+        self._cold = False
         lane = self._next
         self._next = (self._next + 1) % len(self.engines)
         with torch.cuda.stream(self.streams[lane]):
@@ -378,6 +406,7 @@ class ClipLanes:
     def synchronize(self):
         for st in self.streams:
             st.synchronize()
+        self._cold = True
 
     def close(self):
         for e in self.engines[1:]:
