@@ -55,7 +55,8 @@ def _pmc_traffic(kernel_name, dtype, frames, height, width):
     command -- counters cannot be read from inside this process, so the figure is REPLAYED from the
     file named in `traffic_source`, not measured in this run). (None, None) when no measurement of
     that kernel on that workload shape is on file."""
-    for name in (TRAFFIC_FILES[dtype], TRAFFIC_FALLBACK[dtype]):
+    extra = ("r02_clipbatch4_traffic.json",) if dtype == "f32" else ()   # 256-frame backbone batches (clip batches, long clip)
+    for name in (TRAFFIC_FILES[dtype],) + extra + (TRAFFIC_FALLBACK[dtype],):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 t = json.load(f)

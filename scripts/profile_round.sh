@@ -24,7 +24,7 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BA
 echo "sq done"
 cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/kernel_stats.csv
 python3 $R/scripts/rocprof_families.py $(ls $O/stats/*/*kernel_trace.csv | head -1) $O/rocprof_family_summary.json $DT > $O/families.txt
-python3 $R/scripts/pmc_traffic.py $O $O/traffic.json $DT
+python3 $R/scripts/pmc_traffic.py $O $O/traffic.json $DT $WORKLOAD   # WORKLOAD="frames height width" of a backbone batch when not a default shape
 python3 $R/scripts/pmc_sq.py $O/pmc_sq $O/pmc_sq_conv3x3.json $DT
 # raw traces are large: keep the summaries only
 rm -rf $O/stats $O/pmc_fetch $O/pmc_write $O/pmc_sq
