@@ -414,6 +414,14 @@ int pa_encoder_forward(pa_encoder* h, const float* feats, int32_t ld, int32_t se
 int pa_profile_enable(pa_engine* e, int32_t on);
 int pa_profile_read(pa_engine* e, pa_kernel_stat* stats, int32_t max_stats, int32_t* n_stats);
 
+/* quality 1..100: every 128 x 128 crop the engine cuts (pa_square_crops, pa_backbone_frames*, pa_infer_clip,
+ * pa_preprocess_*) additionally goes through the pixel arithmetic of a baseline JPEG write + read at that quality
+ * (4:2:0, integer DCT), as the reference's cv2.imwrite / cv2.imread of every crop does (ai_runner.py:420,446; OpenCV's
+ * default quality is 95) -- the returned crops and the model input then carry the codec's loss. 0 (the default)
+ * switches it off: crops are the exact resampler output. Crop IMAGES handed to pa_runner_inputs /
+ * pa_backbone_crop_images are taken as already decoded. */
+int pa_set_crop_jpeg_quality(pa_engine* e, int32_t quality);
+
 /* Keeps `stream` busy for about `microseconds` (one spinning thread; 0..100000). A probe, not a workload: two
  * HIP streams that the runtime multiplexed onto one hardware queue run such kernels strictly in turn, two that sit
  * on different queues side by side (playaid_core_amd/parallel.py picks the streams of its lanes with it). */

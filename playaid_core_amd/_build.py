@@ -30,6 +30,7 @@ SOURCES = [
     ("lstm.hip", []),
     ("convnet.hip", []),
     ("transformer.hip", []),
+    ("jpeg.hip", ["-ffp-contract=off"]),
     ("pa_api.hip", []),
 ]
 

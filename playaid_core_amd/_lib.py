@@ -128,6 +128,7 @@ SYMBOLS = [
     ("pa_features_import", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
     ("pa_profile_enable", C.c_int, [_P, C.c_int32]),
     ("pa_profile_read", C.c_int, [_P, C.POINTER(pa_kernel_stat), C.c_int32, C.POINTER(C.c_int32)]),
+    ("pa_set_crop_jpeg_quality", C.c_int, [_P, C.c_int32]),
     ("pa_stream_spin", C.c_int, [_P, C.c_int32, _P]),
     ("pa_stream_sync", C.c_int, [_P, _P]),
     ("pa_backbone_windows", C.c_int, [_P, _P, C.c_int32, _P, _P]),

@@ -126,7 +126,11 @@ class AIRunner:
     """Runs action recognition end to end (tracking boxes come with the clip)."""
 
     def __init__(self, input_video_path, debug: bool = False, model: CNNActionDetector = None,
-                 checkpoint_path: str = None, output_dir: str = None, **dataset_args):
+                 checkpoint_path: str = None, output_dir: str = None, crop_jpeg_quality: int = 0, **dataset_args):
+        """``crop_jpeg_quality``: the reference never shows the CNN a crop as cut -- every crop is written as a JPEG
+        (YOLOv5 ``--save-crop``, ``cv2.imwrite`` at ``ai_runner.py:420``) and read back (``:446``). 95 (OpenCV's
+        default) makes the crops this runner cuts from frames take the same write + read on the device
+        (``pa_set_crop_jpeg_quality``); 0, the default, feeds the exact resampler output."""
         self.clip = input_video_path if isinstance(input_video_path, ClipSource) else ClipSource.load(input_video_path)
         self.input_video_path = getattr(input_video_path, "name", input_video_path)
         self.video_name = self.clip.name
@@ -139,6 +143,8 @@ class AIRunner:
             model = CNNActionDetector.load_from_checkpoint(path, actions=list(MOVE_TO_CLASS_ID.keys()))
         self.model = model
         self.model.eval()
+        self.crop_jpeg_quality = int(crop_jpeg_quality)
+        self.model.engine.set_crop_jpeg_quality(self.crop_jpeg_quality)
         class_ids = sorted({int(l.split(" ")[0]) for t in self.clip.labels for l in t.splitlines() if l})
         if len(class_ids) != 2:
             # ai_runner.py:240-242 prints and exit()s here

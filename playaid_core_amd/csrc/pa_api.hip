@@ -61,6 +61,9 @@ struct pa_engine {
     // clip state
     int clip_frames = 0;
     int sub_frames = 0;  // > 0: the clip is a batch of independent clips of this many frames (pa_clip_begin_batch)
+    int jpeg_quality = 0;        // > 0: every crop goes through a baseline-JPEG write + read (pa_set_crop_jpeg_quality)
+    int32_t* jpeg_qtab = nullptr; // [2][64] device
+    uint8_t* crops_tmp = nullptr; // [max_crops][128][128][3]: the crops when the caller did not ask for them
     std::vector<char> ready;
     // device memory (all freed in pa_destroy)
     std::vector<void*> allocs;
@@ -613,7 +616,19 @@ int run_preprocess(pa_engine* e, const uint8_t* frames, int n, int height, int w
     p.fallback_list = e->fallback + 4;
     const double ncrops = (double)n * e->cfg.num_fighters;
     ProfScope ps(e, s, "preprocess_crops", 0.0, ncrops * (375.0 * 375 * 3 + 49152.0 * 5));
+    if (e->jpeg_quality > 0 && !p.crops_u8) p.crops_u8 = e->crops_tmp;   // the round trip works on the u8 crops
     HIPCHK(e, launch_preprocess(p, s));
+    if (e->jpeg_quality > 0) {
+        JpegParams j;
+        memset(&j, 0, sizeof(j));
+        j.crops_u8 = p.crops_u8;
+        j.qtab = e->jpeg_qtab;
+        j.x0 = crops_f32;
+        j.x0_bf16 = e->bf16 ? 1 : 0;
+        j.bgr = swap_rb ? 0 : 1;   // frames are B, G, R; swap_rb turns the crops into R, G, B
+        ProfScope pj(e, s, "jpeg_roundtrip", 0.0, ncrops * 49152.0 * 2);
+        HIPCHK(e, launch_jpeg_roundtrip(j, (int)ncrops, s));
+    }
     return PA_OK;
 }
 
@@ -700,6 +715,8 @@ int create_impl(const pa_config* cfg, const void* blob, size_t src_bytes, const 
     ALLOC(e->p1, (size_t)NC * 34 * 34 * 64, true);
     ALLOC(e->pooled, (size_t)NC * 512, true);
     ALLOC(e->feats_tmp, (size_t)NC * PA_FEATURE_STRIDE, true);
+    ALLOC(e->jpeg_qtab, 128, true);
+    ALLOC(e->crops_tmp, (size_t)NC * PA_CROP * PA_CROP * 3, true);
     ALLOC(e->cache, (size_t)e->cache_rows * PA_FEATURE_STRIDE, true);
     ALLOC(e->cache_status, (size_t)e->cache_rows, true);
     ALLOC(e->h1, (size_t)NC * 512, true);
@@ -1438,6 +1455,29 @@ int pa_profile_read(pa_engine* e, pa_kernel_stat* stats, int32_t max_stats, int3
     for (size_t i = 0; i < acc.size() && n < max_stats; ++i)
         if (acc[i].launches > 0) stats[n++] = acc[i];
     *n_stats = n;
+    return PA_OK;
+}
+
+int pa_set_crop_jpeg_quality(pa_engine* e, int32_t quality) {
+    if (!e || quality < 0 || quality > 100) return fail(e, PA_ERR_INVALID_ARG, "pa_set_crop_jpeg_quality: 0 (off) .. 100");
+    if (quality > 0) {
+        // jpeg_set_quality(quality, force_baseline = TRUE) on the standard tables (jcparam.c), natural order
+        static const int lum[64] = {16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56,
+                                    14, 17, 22, 29, 51, 87, 80, 62, 18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92,
+                                    49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
+        static const int chr[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99, 99, 99,
+                                    47, 66, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99,
+                                    99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
+        const int scale = quality < 50 ? 5000 / quality : 200 - quality * 2;
+        int32_t tab[128];
+        for (int i = 0; i < 64; ++i) {
+            const int a = (lum[i] * scale + 50) / 100, b = (chr[i] * scale + 50) / 100;
+            tab[i] = a < 1 ? 1 : (a > 255 ? 255 : a);
+            tab[64 + i] = b < 1 ? 1 : (b > 255 ? 255 : b);
+        }
+        HIPCHK(e, hipMemcpy(e->jpeg_qtab, tab, sizeof(tab), hipMemcpyHostToDevice));
+    }
+    e->jpeg_quality = quality;
     return PA_OK;
 }
 

@@ -178,6 +178,16 @@ struct RunnerInParams {
 };
 hipError_t launch_runner_inputs(const RunnerInParams& q, hipStream_t s);
 
+// baseline-JPEG write + read of the 128 x 128 crops, in place (jpeg.hip)
+struct JpegParams {
+    uint8_t* crops_u8;   // [ncrops][128][128][3]
+    const int32_t* qtab; // [2][64] quantisation tables (luminance, chrominance) in natural order, device
+    void* x0;            // model input [ncrops][134][134][4] (fp32 or bf16) rewritten from the new pixels, or nullptr
+    int32_t x0_bf16;
+    int32_t bgr;         // memory order of the crops: 1 = B, G, R (cv2), 0 = R, G, B
+};
+hipError_t launch_jpeg_roundtrip(const JpegParams& p, int ncrops, hipStream_t s);
+
 // crop_img + imutils.resize(width) of up to four pixel rectangles per frame (the damage HUD crops), see rect_resize_kernel
 struct RectResizeParams {
     const uint8_t* frames;       // [n][height][width][3]

@@ -144,6 +144,12 @@ class Engine:
         except Exception:
             pass
 
+    def set_crop_jpeg_quality(self, quality: int):
+        """``quality`` 1..100: every crop the engine cuts also goes through a baseline-JPEG write + read at that quality
+        (the reference writes every crop with ``cv2.imwrite`` and reads it back, ``ai_runner.py:420,446``; OpenCV's
+        default is 95); 0 switches it off (default: crops are the exact resampler output)."""
+        self._check(self._lib.pa_set_crop_jpeg_quality(self._h, int(quality)))
+
     def stream_spin(self, microseconds: int, stream: "torch.cuda.Stream"):
         """Keep ``stream`` busy for that long with one spinning thread (``pa_stream_spin``): the concurrency probe of
         ``parallel.ClipLanes``."""

@@ -613,3 +613,35 @@ def test_clip_batch_equals_separate_clips(engine):
         assert np.abs(lp1.cpu().numpy()[L - 4: L - 1] - want[0]["logp"][L - 4: L - 1]).max() > 1e-3
     with pytest.raises(ValueError):
         engine.clip_begin(50, batch_of=3)
+
+
+def test_runner_with_the_references_jpeg_round_trip(tmp_path, state_dict):
+    """AIRunner(crop_jpeg_quality=95): the crops cut from frames take the reference's cv2.imwrite / cv2.imread round trip
+    (ai_runner.py:420,446) before the CNN; labels equal the oracle pipeline fed with libjpeg-exact crops, and differ
+    from the run without it somewhere on the log-probabilities (the codec's loss is real)."""
+    from oracle import jpeg, pipeline
+    from playaid_core_amd.ai_runner import AIRunner, ClipSource
+    from playaid_core_amd.cnn_action_detector import CNNActionDetector
+
+    n, h, w = 30, 720, 1280
+    clip = ClipSource.synthetic(n, h, w)
+    ckpt = str(tmp_path / "seeded.ckpt")
+    synth.save_checkpoint(ckpt, seed=1234)
+    model = CNNActionDetector.load_from_checkpoint(ckpt, actions=list(MOVE_TO_CLASS_ID.keys()), max_batch_frames=32,
+                                                   max_clip_frames=64, max_frame_height=h, max_frame_width=w)
+    plain = AIRunner(clip, model=model, output_dir=str(tmp_path / "plain"))
+    plain.run_action_recognition()
+    lp_plain = plain._results["logp"].copy()
+    runner = AIRunner(clip, model=model, output_dir=str(tmp_path / "jpeg"), crop_jpeg_quality=95)
+    runner.run_action_recognition()
+    boxes = synth.make_boxes(n, h, w)
+    crops, ok = pipeline.crops_for_clip(clip.frames, boxes)
+    assert ok.all()
+    crops_jpeg = np.stack([[jpeg.roundtrip(crops[i, f], 95) for f in range(2)] for i in range(n)])
+    want = pipeline.run_action_recognition(clip.frames, boxes, state_dict, mode="cached", crops_rgb=crops_jpeg)
+    res = runner._results
+    assert np.array_equal(res["crops_rgb"], crops_jpeg)
+    assert np.abs(res["logp"] - want["logp"]).max() <= 1e-4
+    assert np.array_equal(res["action_id"], want["action_id"])
+    assert np.abs(res["logp"] - lp_plain).max() > 1e-3
+    model.engine.set_crop_jpeg_quality(0)

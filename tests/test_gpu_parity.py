@@ -153,3 +153,40 @@ def test_other_geometry_matches_oracle():
     assert got["logp"].shape == (n - 1, 2, 10)
     assert np.abs(got["logp"].astype(np.float64) - ref["logp"]).max() <= LOGP_TOL
     assert np.array_equal(got["action_id"], ref["action_id"])
+
+
+def test_crop_jpeg_roundtrip_matches_libjpeg_arithmetic(state_dict):
+    """pa_set_crop_jpeg_quality: the crops the engine cuts additionally take the reference's cv2.imwrite / cv2.imread
+    round trip (ai_runner.py:420,446). Bit-exact against oracle/jpeg.py (pinned against the live libjpeg-turbo) on the
+    returned crops, and the clip's labels equal the oracle pipeline fed with those crops."""
+    from oracle import jpeg, pipeline
+    from playaid_core_amd.engine import Engine
+
+    n, h, w = 12, 720, 1280
+    frames, boxes = synth.make_frames(n, h, w, seed=21), synth.make_boxes(n, h, w)
+    eng = Engine(state_dict, max_batch_frames=16, max_clip_frames=64, max_frame_height=h, max_frame_width=w)
+    try:
+        plain, st = eng.square_crops(frames, boxes)                         # B, G, R like the frames
+        for q in (95, 60):
+            eng.set_crop_jpeg_quality(q)
+            got, st2 = eng.square_crops(frames, boxes)
+            assert np.array_equal(st, st2)
+            for i in range(n):
+                for f in range(2):
+                    assert np.array_equal(got[i, f], jpeg.roundtrip_bgr(plain[i, f], q)), (q, i, f)
+        # whole clip at OpenCV's default quality: crops come back R, G, B; the CNN sees the round-tripped pixels
+        eng.set_crop_jpeg_quality(95)
+        res = eng.infer_clip(frames, boxes, want_crops=True)
+        crops_plain, ok = pipeline.crops_for_clip(frames, boxes)
+        assert ok.all()
+        crops_jpeg = np.stack([[jpeg.roundtrip(crops_plain[i, f], 95) for f in range(2)] for i in range(n)])
+        assert np.array_equal(res["crops_rgb"], crops_jpeg)
+        want = pipeline.run_action_recognition(frames, boxes, state_dict, mode="cached", crops_rgb=crops_jpeg)
+        assert np.abs(res["logp"] - want["logp"]).max() <= 1e-4
+        assert np.array_equal(res["action_id"], want["action_id"])
+        # and off again: the exact resampler output
+        eng.set_crop_jpeg_quality(0)
+        again, _ = eng.square_crops(frames, boxes)
+        assert np.array_equal(again, plain)
+    finally:
+        eng.close()
