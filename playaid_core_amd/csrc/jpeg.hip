@@ -8,8 +8,8 @@
 // Bit-exact against oracle/jpeg.py, which is pinned byte for byte against the live libjpeg-turbo behind Pillow.
 //
 // One workgroup = one crop: the Y plane (16 KB) and the two down-sampled chroma planes (4 KB each) live in LDS as
-// bytes; phase A one thread per 2x2 pixel quad (colour conversion + down-sampling), phase B one thread per 8x8 block
-// with the block in registers (384 blocks per crop), phase C one thread per 2x2 quad again (up-sampling + colour
+// bytes; 512 threads; phase A one thread per 2x2 pixel quad (colour conversion + down-sampling), phase B one thread per
+// 8x8 block with the block in registers (384 blocks per crop, one round), phase C one thread per 2x2 quad again (up-sampling + colour
 // conversion + the crop / model-input stores). Off unless pa_set_crop_jpeg_quality was called.
 #include "pa_kernels.h"
 
@@ -134,7 +134,7 @@ __device__ __forceinline__ int fancy(const uint8_t* c, int y, int x) {
     return (col * 3 + last + 8) >> 4;
 }
 
-__global__ __launch_bounds__(256) void jpeg_roundtrip_kernel(const JpegParams p) {
+__global__ __launch_bounds__(512) void jpeg_roundtrip_kernel(const JpegParams p) {
     __shared__ __attribute__((aligned(16))) uint8_t yp[128 * 128];
     __shared__ __attribute__((aligned(16))) uint8_t cbp[64 * 64];
     __shared__ __attribute__((aligned(16))) uint8_t crp[64 * 64];
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void jpeg_roundtrip_kernel(const JpegParams p)
     if (tid < 128) qt[tid >> 6][tid & 63] = p.qtab[tid];
     const int ri = p.bgr ? 2 : 0, bi = p.bgr ? 0 : 2;
     // ---- A: RGB -> YCbCr (jccolor.c), chroma 2x2 down-sampling with the bias 1, 2, 1, 2 along a row (jcsample.c)
-    for (int qd = tid; qd < 64 * 64; qd += 256) {
+    for (int qd = tid; qd < 64 * 64; qd += 512) {
         const int cy = qd >> 6, cx = qd & 63;
         int sb = 0, sr = 0;
 #pragma unroll
@@ -164,17 +164,16 @@ __global__ __launch_bounds__(256) void jpeg_roundtrip_kernel(const JpegParams p)
     }
     __syncthreads();
     // ---- B: every 8x8 block through the DCT pair: 256 luminance blocks, then 64 + 64 chrominance blocks
-    {
+    if (tid < 256) {
         const int by = tid >> 4, bx = tid & 15;
         block_roundtrip(yp + (by * 8) * 128 + bx * 8, 128, qt[0]);
-    }
-    if (tid < 128) {
+    } else if (tid < 384) {
         const int b = tid & 63, by = b >> 3, bx = b & 7;
-        block_roundtrip((tid < 64 ? cbp : crp) + (by * 8) * 64 + bx * 8, 64, qt[1]);
+        block_roundtrip((tid < 320 ? cbp : crp) + (by * 8) * 64 + bx * 8, 64, qt[1]);
     }
     __syncthreads();
     // ---- C: fancy up-sampling (jdsample.c), YCbCr -> RGB (jdcolor.c), stores
-    for (int i = tid; i < 128 * 128; i += 256) {
+    for (int i = tid; i < 128 * 128; i += 512) {
         const int y = i >> 7, x = i & 127;
         const int yy = yp[i], xb = fancy(cbp, y, x) - 128, xr = fancy(crp, y, x) - 128;
         const int r = clamp255(yy + ((91881 * xr + 32768) >> 16));
@@ -202,7 +201,7 @@ __global__ __launch_bounds__(256) void jpeg_roundtrip_kernel(const JpegParams p)
 
 hipError_t launch_jpeg_roundtrip(const JpegParams& p, int ncrops, hipStream_t s) {
     if (ncrops <= 0) return hipSuccess;
-    hipLaunchKernelGGL(jpeg_roundtrip_kernel, dim3(ncrops), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(jpeg_roundtrip_kernel, dim3(ncrops), dim3(512), 0, s, p);
     return hipGetLastError();
 }
 
