@@ -144,7 +144,6 @@ class AIRunner:
         self.model = model
         self.model.eval()
         self.crop_jpeg_quality = int(crop_jpeg_quality)
-        self.model.engine.set_crop_jpeg_quality(self.crop_jpeg_quality)
         class_ids = sorted({int(l.split(" ")[0]) for t in self.clip.labels for l in t.splitlines() if l})
         if len(class_ids) != 2:
             # ai_runner.py:240-242 prints and exit()s here
@@ -217,13 +216,17 @@ class AIRunner:
             bad = np.nonzero(missing[: n - 1, p])[0]
             assert len(bad) == 0, f"Failed to get frame crops/{fighter}/{self.video_name}_{bad[0] + 1}.jpg"
         own = np.arange(n, dtype=np.int32)
-        if all(np.array_equal(src[:, p], own) for p in range(src.shape[1])):
-            out = eng.infer_clip(self.clip.frames[:n], boxes, want_crops=True)
-        else:
-            # repaired gaps are cut from VideoCapture position j, not j-1 (ai_runner.py:405-406), so a crop
-            # may come from another decoded frame than its own, differently per fighter: the crop stage
-            # takes a per-crop source index and the clip still runs once
-            out = eng.infer_clip(self.clip.frames, boxes, want_crops=True, src=src)
+        eng.set_crop_jpeg_quality(self.crop_jpeg_quality)   # for this clip only: the engine is the model's, others use it
+        try:
+            if all(np.array_equal(src[:, p], own) for p in range(src.shape[1])):
+                out = eng.infer_clip(self.clip.frames[:n], boxes, want_crops=True)
+            else:
+                # repaired gaps are cut from VideoCapture position j, not j-1 (ai_runner.py:405-406), so a crop
+                # may come from another decoded frame than its own, differently per fighter: the crop stage
+                # takes a per-crop source index and the clip still runs once
+                out = eng.infer_clip(self.clip.frames, boxes, want_crops=True, src=src)
+        finally:
+            eng.set_crop_jpeg_quality(0)
         st = out["crop_status"].copy()
         st[missing] = 0
         bad = np.argwhere(st != 0)

@@ -644,4 +644,6 @@ def test_runner_with_the_references_jpeg_round_trip(tmp_path, state_dict):
     assert np.abs(res["logp"] - want["logp"]).max() <= 1e-4
     assert np.array_equal(res["action_id"], want["action_id"])
     assert np.abs(res["logp"] - lp_plain).max() > 1e-3
-    model.engine.set_crop_jpeg_quality(0)
+    # the option belongs to the runner's clip, not to the shared engine
+    again, _ = model.engine.square_crops(clip.frames[:2], boxes[:2])
+    assert np.array_equal(again[..., ::-1], crops[:2])
