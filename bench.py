@@ -475,7 +475,7 @@ def main():
                 else ("crop stage of batch k+1 overlaps the backbone of batch k (2 streams, 2 input slots)" if not args.no_pipeline else "none"),
                 "lanes": args.lanes if lanes is not None else 1,
                 "lane_stream_calibration": lanes.calibration if lanes is not None else None,
-                "lane_start": ("after every device synchronisation the lanes' first clips are held behind a 1.5 ms spin kernel until both are "
+                "lane_start": ("after every device synchronisation the lanes' first clips are held behind a 1-4 ms spin kernel until both are "
                                "enqueued and then start together (inside the timed region: once, at its start)") if lanes is not None else None,
             },
         }

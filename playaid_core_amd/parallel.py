@@ -342,6 +342,8 @@ class ClipLanes:
         self._helper = torch.cuda.Stream(engine.device)
         self._go = torch.cuda.Event()
         self._cold = True
+        self._submit_s = []        # host time of the last few submit() calls
+        self.last_hold_us = 0
 
     def calibrate(self, frames, boxes, n_total: int, clips: int = 12, batch_of: int = 0):
         """Pick the lanes' streams by measurement on the caller's own clip shape: every combination of the candidate
@@ -366,7 +368,7 @@ class ClipLanes:
             for k in range(clips):
                 self.submit(frames, boxes, n_total, batch_of)
             torch.cuda.synchronize(self.engines[0].device)
-            rates[combo] = n_total * clips / (time.perf_counter() - t0 - 1e-6 * self.start_hold_us)
+            rates[combo] = n_total * clips / (time.perf_counter() - t0 - 1e-6 * self.last_hold_us)
         best = max(rates, key=rates.get)
         self.streams = [self._candidates[i] for i in best]
         self._cold = True
@@ -381,7 +383,13 @@ class ClipLanes:
         for anything between 0.35 and 1.2 ms -- one lane's crop / stem kernels (80 KB of LDS per workgroup) then fall
         into the other lane's convolution layers for good. Left to the host, the offset is the time it takes to
         enqueue one clip (~0.3-0.4 ms): right on the edge, which made identical runs land on either rate."""
-        self.engines[0].stream_spin(self.start_hold_us, self._helper)
+        # long enough for the host to enqueue one clip per lane: three times what an unblocked submit() took lately
+        # (1.5 ms before anything was measured), within 1 .. 4 ms
+        hold = self.start_hold_us
+        if self._submit_s:
+            hold = int(min(max(3e6 * min(self._submit_s) * len(self.engines), 1000.0), 4000.0))
+        self.last_hold_us = hold
+        self.engines[0].stream_spin(hold, self._helper)
         self._go.record(self._helper)
         for st in self.streams:
             st.wait_event(self._go)
@@ -398,9 +406,13 @@ class ClipLanes:
         self._cold = False
         lane = self._next
         self._next = (self._next + 1) % len(self.engines)
+        t0 = time.perf_counter()
         with torch.cuda.stream(self.streams[lane]):
             rec, lp = self.runners[lane].run(frames, boxes, n_total, gather=False, pipeline=False, reuse_buffers=True,
                                              batch_of=batch_of)
+        # host time to enqueue one clip (the launches are asynchronous; a submit that had to wait for queue space
+        # is longer, which is why the start uses the smallest of the last few)
+        self._submit_s = (self._submit_s + [time.perf_counter() - t0])[-8:]
         return lane, rec, lp
 
     def synchronize(self):
