@@ -563,7 +563,10 @@ def main():
             result["pcie_inclusive"] = pcie_inclusive(eng, frames[:n_clip], boxes[:n_clip])
             result["pcie_inclusive_windows"] = pcie_inclusive_windows(eng, frames[:n_clip], boxes[:n_clip])
         if world == 1 and not long_clip and kb == 1 and not args.no_pcie and not args.no_pipeline and args.clip_batch_side > 1:
-            result["clip_batches"] = clip_batch_side(eng, n_clip, args.clip_batch_side, args.height, args.width, S, DELTA, max(args.lanes, 1))
+            try:
+                result["clip_batches"] = clip_batch_side(eng, n_clip, args.clip_batch_side, args.height, args.width, S, DELTA, max(args.lanes, 1))
+            except Exception as exc:  # a side measurement must never cost the line its headline
+                result["clip_batches"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(sd, args.height, args.width, args.cpu_sample_frames)
         print(json.dumps(result), flush=True)
