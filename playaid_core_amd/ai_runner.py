@@ -126,11 +126,13 @@ class AIRunner:
     """Runs action recognition end to end (tracking boxes come with the clip)."""
 
     def __init__(self, input_video_path, debug: bool = False, model: CNNActionDetector = None,
-                 checkpoint_path: str = None, output_dir: str = None, crop_jpeg_quality: int = 0, **dataset_args):
+                 checkpoint_path: str = None, output_dir: str = None, crop_jpeg_quality: int = 95, **dataset_args):
         """``crop_jpeg_quality``: the reference never shows the CNN a crop as cut -- every crop is written as a JPEG
         (YOLOv5 ``--save-crop``, ``cv2.imwrite`` at ``ai_runner.py:420``) and read back (``:446``). 95 (OpenCV's
-        default) makes the crops this runner cuts from frames take the same write + read on the device
-        (``pa_set_crop_jpeg_quality``); 0, the default, feeds the exact resampler output."""
+        default quality, and the default here) makes the crops this runner cuts from frames take the same write +
+        read on the device (``pa_set_crop_jpeg_quality``); 0 opts out and feeds the exact resampler output, which
+        differs from what the reference's CNN sees by more than 1e-3 on the log-probabilities. Crop IMAGES handed in
+        through ``ClipSource.crop_images`` are decoded JPEGs already and are never re-coded."""
         self.clip = input_video_path if isinstance(input_video_path, ClipSource) else ClipSource.load(input_video_path)
         self.input_video_path = getattr(input_video_path, "name", input_video_path)
         self.video_name = self.clip.name
