@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PA_ABI_VERSION 4
+#define PA_ABI_VERSION 5
 #define PA_WEIGHT_MAGIC 0x31574150 /* "PAW1" */
 #define PA_LSTM_MAGIC 0x314c4150   /* "PAL1" */
 #define PA_ENCODER_MAGIC 0x31454150 /* "PAE1" */
@@ -277,6 +277,34 @@ int pa_upload_crop_windows(pa_engine* e, const uint8_t* frames_host, int32_t n, 
                            pa_crop_window* desc_host, pa_crop_window* desc_dev, size_t* bytes_used, void* stream);
 int pa_preprocess_windows(pa_engine* e, const uint8_t* windows_dev, const pa_crop_window* desc_dev, int32_t n, int32_t height,
                           int32_t width, const double* boxes, int32_t slot, uint8_t* crops_rgb, int32_t* status, void* stream);
+
+/* ---- a1 / f2: Motion-JPEG decode on the device ------------------------------ */
+
+/* Replaces the per-frame decode of cv2.VideoCapture.read / cv2.imread (ai_runner.py:153,404-405,446;
+ * manuscript.py:154-155) for Motion-JPEG streams and JPEG image sequences: n baseline JPEG files (SOF0 / 8-bit SOF1,
+ * Huffman, one interleaved scan; 4:2:0, 4:2:2, 4:4:4 or grey; with or without restart markers) -> uint8 [n][height][width][3]
+ * frames in HBM, BGR like OpenCV (rgb = 0) or RGB (rgb = 1). The arithmetic is libjpeg(-turbo)'s defaults, which OpenCV's
+ * JPEG reader runs: integer IDCT (JDCT_ISLOW), fancy chroma up-sampling, jdcolor.c; oracle/jpeg.py::decode restates it and is
+ * pinned byte for byte against the live libjpeg-turbo. (OpenCV's FFmpeg backend for .avi containers runs FFmpeg's own
+ * decoder, which differs from libjpeg in the last bit; that arithmetic is not restated.)
+ *
+ * A handle owns the scratch for up to max_frames frames of max_height x max_width and max_bytes compressed bytes per
+ * call. pa_mjpeg_decode parses the marker segments on the host, then ENQUEUES on `stream`: one host -> device copy of the
+ * compressed bytes (the range of data_host that covers all n frames; pinned memory makes it asynchronous), the restart-marker
+ * scan, Huffman decoding (one lane per restart interval; a stream without DRI decodes one lane per frame), IDCT,
+ * up-sampling + colour conversion. spans_host: int64[n][2], frame f = bytes [spans[f][0], spans[f][1]) of data_host, in
+ * any order (container chunk headers between frames are never looked at); every frame of a call has the same size and
+ * sampling (tables and restart interval may change per frame).
+ * status_dev (optional): int32[n] device, 0 or a bit set: 1 invalid Huffman code, 2 restart markers do not match the
+ * header's interval, 4 coefficient index overflow -- such a frame's pixels are undefined, nothing is written out of
+ * bounds. Malformed or unsupported HEADERS fail the call with PA_ERR_INVALID_ARG and name the frame in
+ * pa_mjpeg_last_error; nothing is enqueued then. */
+typedef struct pa_mjpeg pa_mjpeg;
+int pa_mjpeg_create(int32_t device, int32_t max_frames, int32_t max_height, int32_t max_width, size_t max_bytes, pa_mjpeg** out);
+void pa_mjpeg_destroy(pa_mjpeg* h);
+const char* pa_mjpeg_last_error(const pa_mjpeg* h);
+int pa_mjpeg_decode(pa_mjpeg* h, const uint8_t* data_host, const int64_t* spans_host, int32_t n, int32_t height, int32_t width,
+                    int32_t rgb, uint8_t* frames_dev, int32_t* status_dev, void* stream);
 
 /* pa_backbone_frames for frames that are NOT consecutive in the clip (a resolution bucket of a
  * mixed-resolution stream, BASELINE.json configs[4]): frame_ids[n] (device, int32, 0-based)

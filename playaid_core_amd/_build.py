@@ -31,6 +31,7 @@ SOURCES = [
     ("convnet.hip", []),
     ("transformer.hip", []),
     ("jpeg.hip", ["-ffp-contract=off"]),
+    ("mjpeg.hip", []),
     ("pa_api.hip", []),
 ]
 
@@ -44,7 +45,7 @@ def _newer(target: str, deps) -> bool:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "hipcc")
-    headers = [os.path.join(CSRC, "pa_kernels.h"), os.path.join(HERE, "..", "include", "playaid_hip.h")]
+    headers = [os.path.join(CSRC, "pa_kernels.h"), os.path.join(CSRC, "jpeg_dct.h"), os.path.join(HERE, "..", "include", "playaid_hip.h")]
     objs = []
     rebuilt = False
     for src, extra in SOURCES:

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # PA_LIB_PATH: load a differently built library (e.g. the ablation build used by scripts/)
 LIB_PATH = os.environ.get("PA_LIB_PATH") or os.path.join(HERE, "libplayaid_hip.so")
 
-PA_ABI_VERSION = 4
+PA_ABI_VERSION = 5
 PA_DTYPE_F32 = 0
 PA_DTYPE_BF16 = 1
 PA_WEIGHT_MAGIC = 0x31574150
@@ -149,6 +149,10 @@ SYMBOLS = [
     ("pa_encoder_destroy", None, [_P]),
     ("pa_encoder_last_error", C.c_char_p, [_P]),
     ("pa_encoder_forward", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    ("pa_mjpeg_create", C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_size_t, C.POINTER(_P)]),
+    ("pa_mjpeg_destroy", None, [_P]),
+    ("pa_mjpeg_last_error", C.c_char_p, [_P]),
+    ("pa_mjpeg_decode", C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
 ]
 
 _lib = None

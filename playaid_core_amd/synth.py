@@ -429,3 +429,34 @@ def make_resformer_state_dict(seed: int = 2468, num_actions: int = 63, sequence_
     dense("model.classifier.weight", (num_actions, D_MODEL), gain=4.0)
     small("model.classifier.bias", (num_actions,), 0.5)
     return sd
+
+
+# ----------------------------------------------------------------------------
+# compressed clips (Motion-JPEG) for the decode path
+# ----------------------------------------------------------------------------
+
+def encode_jpeg_frames(frames_bgr, quality: int = 95, subsampling: int = 2, restart_marker_blocks: int = 0,
+                       restart_marker_rows: int = 0, optimize: bool = False) -> List[bytes]:
+    """uint8[n,H,W,3] BGR frames (or a list of them; uint8[H,W] = grey) -> one baseline JPEG file per frame, written by
+    the libjpeg-turbo behind Pillow with the settings ``cv2.imwrite`` / ``cv2.VideoWriter("MJPG")`` use (quality 95,
+    4:2:0 = ``subsampling`` 2). Synthetic-data helper for tests and ``bench.py`` only: encoding is not part of the
+    accelerated path (the reference only ever DECODES video, ``ai_runner.py:153``)."""
+    import io
+
+    from PIL import Image
+
+    out = []
+    for f in frames_bgr:
+        f = np.asarray(f)
+        im = Image.fromarray(f if f.ndim == 2 else np.ascontiguousarray(f[..., ::-1]))
+        kw = {}
+        if restart_marker_blocks:
+            kw["restart_marker_blocks"] = restart_marker_blocks
+        if restart_marker_rows:
+            kw["restart_marker_rows"] = restart_marker_rows
+        if f.ndim == 3:
+            kw["subsampling"] = subsampling
+        b = io.BytesIO()
+        im.save(b, "JPEG", quality=quality, optimize=optimize, **kw)
+        out.append(b.getvalue())
+    return out

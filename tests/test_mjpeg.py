@@ -1,0 +1,220 @@
+"""Row a1 / f2: Motion-JPEG decode. CPU part: the oracle's decoder is pinned byte for byte against the live
+libjpeg-turbo behind Pillow, container helpers. GPU part (through the C ABI): pa_mjpeg_decode == the oracle, bit for bit."""
+import io
+import os
+
+import numpy as np
+import pytest
+
+from playaid_core_amd import synth, video
+
+SIZES = [(1080, 1920), (720, 1280), (133, 77), (17, 31), (8, 8), (16, 16), (250, 333)]
+
+
+def _pil_decode(blob: bytes) -> np.ndarray:
+    from PIL import Image
+
+    return np.asarray(Image.open(io.BytesIO(blob)).convert("RGB"))
+
+
+def _cases():
+    """(name, frames_bgr, encoder kwargs) covering sampling, quality, restart markers, optimised tables, odd sizes."""
+    out = []
+    base = synth.make_frame(5, 1080, 1920)
+    for h, w in SIZES:
+        fr = base[:h, :w]
+        for q in (95, 75, 30):
+            for kw in ({}, {"restart_marker_rows": 1}, {"restart_marker_blocks": 5}, {"optimize": True}):
+                for ss in (2, 1, 0):
+                    if (h, w) in ((1080, 1920), (720, 1280)) and (ss != 2 or q == 30):
+                        continue  # the big frames: the path's own configuration only (4:2:0)
+                    out.append((f"{h}x{w}-q{q}-ss{ss}-{sorted(kw)}", fr, dict(quality=q, subsampling=ss, **kw)))
+    return out
+
+
+def test_oracle_decoder_is_pinned_to_live_libjpeg_turbo():
+    """oracle.jpeg.decode (own marker parser, own bit-serial Huffman decoder in C, own IDCT / up-sampling / colour
+    arithmetic) == PIL.Image.open of the same bytes, byte for byte."""
+    from oracle import jpeg
+
+    n = 0
+    for name, fr, kw in _cases():
+        blob = synth.encode_jpeg_frames([fr], **kw)[0]
+        assert np.array_equal(jpeg.decode(blob), _pil_decode(blob)), name
+        n += 1
+    assert n > 150
+    grey = synth.encode_jpeg_frames([synth.make_frame(1, 200, 300)[..., 0]], quality=90)[0]
+    assert np.array_equal(jpeg.decode(grey), _pil_decode(grey))
+    # cv2's channel order
+    blob = synth.encode_jpeg_frames([synth.make_frame(2, 64, 96)])[0]
+    assert np.array_equal(jpeg.decode_bgr(blob)[..., ::-1], _pil_decode(blob))
+
+
+def test_oracle_rejects_what_is_not_baseline():
+    from PIL import Image
+
+    from oracle import jpeg
+
+    b = io.BytesIO()
+    Image.fromarray(synth.make_frame(0, 64, 64)).save(b, "JPEG", progressive=True)
+    with pytest.raises(jpeg.JpegError):
+        jpeg.decode(b.getvalue())
+    with pytest.raises(jpeg.JpegError):
+        jpeg.decode(b"\x00\x01\x02\x03")
+    good = synth.encode_jpeg_frames([synth.make_frame(0, 64, 64)])[0]
+    with pytest.raises(jpeg.JpegError):
+        jpeg.decode(good[:100])
+
+
+def test_containers(tmp_path):
+    frames = synth.make_frames(5, 72, 128)
+    blobs = synth.encode_jpeg_frames(frames, quality=90)
+    raw = np.frombuffer(b"".join(blobs), np.uint8)
+    sp = video.split_jpeg_stream(raw)
+    assert sp.shape == (5, 2) and all(bytes(raw[a:b]) == blobs[i] for i, (a, b) in enumerate(sp))
+    path = str(tmp_path / "clip.avi")
+    video.write_avi_mjpeg(path, blobs, 30.0, 128, 72)
+    data, off, meta = video.read_avi_mjpeg(path)
+    assert meta["fps"] == 30.0 and (meta["height"], meta["width"]) == (72, 128) and meta["handler"] == b"MJPG"
+    assert all(bytes(data[a:b]) == blobs[i] for i, (a, b) in enumerate(off))
+    assert video.jpeg_frame_size(np.frombuffer(blobs[0], np.uint8)) == (72, 128)
+    with pytest.raises(video.VideoError):
+        video.read_avi_mjpeg(__file__)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+
+
+@pytest.fixture(scope="module")
+def decoder():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    d = video.MjpegDecoder(max_frames=16, max_height=1080, max_width=1920, max_bytes=32 << 20)
+    yield d
+    d.close()
+
+
+def _decode(decoder, blobs, h, w, rgb=False):
+    import torch
+
+    data = np.frombuffer(b"".join(blobs), np.uint8)
+    ends = np.cumsum([len(b) for b in blobs])
+    spans = np.stack([ends - [len(b) for b in blobs], ends], axis=1)
+    st = torch.zeros(len(blobs), dtype=torch.int32, device="cuda")
+    out = decoder.decode(data, spans, h, w, status=st, rgb=rgb)
+    torch.cuda.synchronize()
+    return out.cpu().numpy(), st.cpu().numpy()
+
+
+@pytest.mark.gpu
+def test_mjpeg_decode_is_bit_exact(decoder):
+    """Every sampling / quality / restart-marker / table variant and odd frame sizes: device frames == oracle (BGR)."""
+    from oracle import jpeg
+
+    for name, fr, kw in _cases():
+        blob = synth.encode_jpeg_frames([fr], **kw)[0]
+        got, st = _decode(decoder, [blob], fr.shape[0], fr.shape[1])
+        assert st[0] == 0, name
+        assert np.array_equal(got[0], jpeg.decode_bgr(blob)), name
+    grey = synth.encode_jpeg_frames([synth.make_frame(1, 200, 300)[..., 0]], quality=90)[0]
+    got, st = _decode(decoder, [grey], 200, 300, rgb=True)
+    assert st[0] == 0 and np.array_equal(got[0], jpeg.decode(grey))
+
+
+@pytest.mark.gpu
+def test_mjpeg_clip_with_changing_tables(decoder):
+    """One call, 12 frames of a 720p clip whose quantisation / Huffman tables and restart interval change from frame to
+    frame (a stream is allowed to): every frame equals the oracle; the frames also equal live Pillow."""
+    from oracle import jpeg
+
+    h, w = 720, 1280
+    frames = synth.make_frames(12, h, w)
+    blobs = []
+    for i, f in enumerate(frames):
+        kw = [dict(quality=95, restart_marker_rows=1), dict(quality=60, optimize=True), dict(quality=85, restart_marker_blocks=7),
+              dict(quality=95)][i % 4]
+        blobs += synth.encode_jpeg_frames([f], **kw)
+    got, st = _decode(decoder, blobs, h, w)
+    assert (st == 0).all()
+    for i, b in enumerate(blobs):
+        assert np.array_equal(got[i], jpeg.decode_bgr(b)), i
+        assert np.array_equal(got[i][..., ::-1], _pil_decode(b)), i
+
+
+@pytest.mark.gpu
+def test_mjpeg_errors_are_reported(decoder):
+    from PIL import Image
+
+    from playaid_core_amd import _lib
+    from playaid_core_amd.engine import EngineError
+
+    h, w = 64, 96
+    good = synth.encode_jpeg_frames([synth.make_frame(0, h, w)], quality=90, restart_marker_blocks=2)[0]
+    b = io.BytesIO()
+    Image.fromarray(synth.make_frame(0, h, w)).save(b, "JPEG", progressive=True)
+    with pytest.raises(EngineError) as ei:  # header the decoder does not take: nothing is enqueued
+        _decode(decoder, [good, b.getvalue()], h, w)
+    assert ei.value.code == _lib.PA_ERR_INVALID_ARG and "frame 1" in str(ei.value) and "progressive" in str(ei.value)
+    with pytest.raises(EngineError) as ei:  # size differs from what the caller said
+        _decode(decoder, [good], h, w + 16)
+    assert ei.value.code == _lib.PA_ERR_INVALID_ARG
+    with pytest.raises(EngineError) as ei:
+        _decode(decoder, [good] * 17, h, w)
+    assert ei.value.code == _lib.PA_ERR_CAPACITY
+    # a scan cut short: restart markers are missing -> status bit 2, no fault, the intact frame beside it is fine
+    cut = good[: len(good) // 2]
+    got, st = _decode(decoder, [cut, good], h, w)
+    assert st[0] & 2 and st[1] == 0
+    from oracle import jpeg
+
+    assert np.array_equal(got[1], jpeg.decode_bgr(good))
+    # a corrupted entropy segment decodes to garbage or raises a status bit, but stays inside its buffers
+    bad = bytearray(good)
+    for k in range(len(bad) - 200, len(bad) - 2, 7):
+        bad[k] = 0x5A
+    got, st = _decode(decoder, [bytes(bad), good], h, w)
+    assert st[1] == 0 and np.array_equal(got[1], jpeg.decode_bgr(good))
+
+
+@pytest.mark.gpu
+def test_videocapture_mirror_over_an_avi(tmp_path, decoder):
+    """cv2.VideoCapture's call shape (ai_runner.py:153,404-405; manuscript.py:70-86,154-155) over an MJPG .avi."""
+    from oracle import jpeg
+
+    n, h, w = 9, 360, 640
+    frames = synth.make_frames(n, h, w)
+    blobs = synth.encode_jpeg_frames(frames, quality=95)
+    path = str(tmp_path / "clip.avi")
+    video.write_avi_mjpeg(path, blobs, 60.0, w, h)
+    cap = video.VideoCapture(path)
+    assert cap.isOpened()
+    assert cap.get(video.CAP_PROP_FPS) == 60.0 and int(cap.get(video.CAP_PROP_FRAME_COUNT)) == n
+    assert (int(cap.get(video.CAP_PROP_FRAME_HEIGHT)), int(cap.get(video.CAP_PROP_FRAME_WIDTH))) == (h, w)
+    cap.set(video.CAP_PROP_POS_FRAMES, 4)
+    ok, fr = cap.read()
+    assert ok and fr.dtype == np.uint8 and np.array_equal(fr, jpeg.decode_bgr(blobs[4]))
+    ok, fr = cap.read()  # the position advanced
+    assert ok and np.array_equal(fr, jpeg.decode_bgr(blobs[5]))
+    cap.set(video.CAP_PROP_POS_FRAMES, n)
+    assert cap.read() == (False, None)
+    batch = cap.read_frames(2, 5).cpu().numpy()
+    for i in range(5):
+        assert np.array_equal(batch[i], jpeg.decode_bgr(blobs[2 + i]))
+    cap.release()
+    assert not cap.isOpened()
+    assert not video.VideoCapture(str(tmp_path / "missing.avi")).isOpened()
+    # raw concatenation and image-sequence directory
+    raw = str(tmp_path / "clip.mjpeg")
+    open(raw, "wb").write(b"".join(blobs))
+    cap = video.VideoCapture(raw)
+    assert cap.frame_count() == n and np.array_equal(cap.read_frames(8, 1).cpu().numpy()[0], jpeg.decode_bgr(blobs[8]))
+    cap.release()
+    d = tmp_path / "seq"
+    os.makedirs(d)
+    for i, b in enumerate(blobs[:3]):
+        open(d / f"frame_{i:04d}.jpg", "wb").write(b)
+    cap = video.VideoCapture(str(d))
+    assert cap.frame_count() == 3 and cap.read()[0]
+    cap.release()
