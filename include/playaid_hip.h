@@ -291,18 +291,27 @@ int pa_preprocess_windows(pa_engine* e, const uint8_t* windows_dev, const pa_cro
  * A handle owns the scratch for up to max_frames frames of max_height x max_width and max_bytes compressed bytes per
  * call. pa_mjpeg_decode parses the marker segments on the host, then ENQUEUES on `stream`: one host -> device copy of the
  * compressed bytes (the range of data_host that covers all n frames; pinned memory makes it asynchronous), the restart-marker
- * scan, Huffman decoding (one lane per restart interval; a stream without DRI decodes one lane per frame), IDCT,
- * up-sampling + colour conversion. spans_host: int64[n][2], frame f = bytes [spans[f][0], spans[f][1]) of data_host, in
+ * scan + byte un-stuffing, Huffman decoding (one lane per 128-byte subsequence of the stream, wherever it falls: the
+ * decoder states at the subsequence borders are found by self-synchronisation -- a speculative pass, then verify passes
+ * until nothing changes -- so a stream needs no restart markers to decode in parallel; restart markers, where present,
+ * are exact entry points), IDCT, up-sampling + colour conversion. spans_host: int64[n][2], frame f = bytes [spans[f][0], spans[f][1]) of data_host, in
  * any order (container chunk headers between frames are never looked at); every frame of a call has the same size and
  * sampling (tables and restart interval may change per frame).
  * status_dev (optional): int32[n] device, 0 or a bit set: 1 invalid Huffman code, 2 restart markers do not match the
- * header's interval, 4 coefficient index overflow -- such a frame's pixels are undefined, nothing is written out of
- * bounds. Malformed or unsupported HEADERS fail the call with PA_ERR_INVALID_ARG and name the frame in
+ * header's interval, 4 coefficient index overflow, 8 the decoder states had not settled after the enqueued verify
+ * passes (decode again after pa_mjpeg_set_sync_rounds(h, 0)) -- such a frame's pixels are undefined, nothing is written
+ * out of bounds. Malformed or unsupported HEADERS fail the call with PA_ERR_INVALID_ARG and name the frame in
  * pa_mjpeg_last_error; nothing is enqueued then. */
 typedef struct pa_mjpeg pa_mjpeg;
 int pa_mjpeg_create(int32_t device, int32_t max_frames, int32_t max_height, int32_t max_width, size_t max_bytes, pa_mjpeg** out);
 void pa_mjpeg_destroy(pa_mjpeg* h);
 const char* pa_mjpeg_last_error(const pa_mjpeg* h);
+/* Verify passes per call: 1..8 are enqueued without looking at their outcome (default 3; ordinary pictures settle in one
+ * or two, a frame that has not is flagged with status bit 8); 0 = exact mode: passes are repeated until one changes
+ * nothing, which synchronises the stream once per pass (long runs of identical blocks -- black bars -- re-synchronise
+ * slowly and can need many). pa_mjpeg_last_sync_rounds: how many the last call ran. */
+int pa_mjpeg_set_sync_rounds(pa_mjpeg* h, int32_t rounds);
+int pa_mjpeg_last_sync_rounds(const pa_mjpeg* h);
 int pa_mjpeg_decode(pa_mjpeg* h, const uint8_t* data_host, const int64_t* spans_host, int32_t n, int32_t height, int32_t width,
                     int32_t rgb, uint8_t* frames_dev, int32_t* status_dev, void* stream);
 

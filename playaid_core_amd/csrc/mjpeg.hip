@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -35,24 +36,36 @@ namespace mj {
 constexpr int LB = 10;           // bits of the direct Huffman lookup
 constexpr int CHUNK = 4096;      // bytes per workgroup of the marker scan (256 threads x 16 bytes)
 constexpr int MAX_BLOCKS_MCU = 10;
+constexpr int SUB_MIN = 128;     // bytes per subsequence (one lane) of the entropy decoder: a power of two >= this, per call
+constexpr int RING_DW = 32;      // dwords of a lane's LDS ring (128 bytes of its stream)
+constexpr int TOPUP = 16;        // symbols between two ring top-ups
+constexpr int WG_SUBS = 256;     // subsequences per workgroup
 
-enum { ERR_HUFF = 1, ERR_RST = 2, ERR_COEF = 4 };
+enum { ERR_HUFF = 1, ERR_RST = 2, ERR_COEF = 4, ERR_SYNC = 8 };
 
-struct HuffTab {
-    uint16_t lut[1 << LB];  // len << 8 | symbol for codes of <= LB bits, 0 = longer
-    int32_t maxcode[18];    // largest code of length l (-1: none); [17] = sentinel
-    int32_t valoff[17];     // valptr[l] - mincode[l]
-    uint8_t vals[256];
+// Huffman tables as the decoder's lanes read them (LDS image = global layout). A 16-bit entry holds everything a symbol
+// needs: code length (bits 0-4), number of extra bits s (5-8), zero run r (9-12; 0 in the DC tables). Codes of up to LB
+// bits are found in lut1 directly; a longer code's first LB bits lead to a link entry (bit 15 + the index of a 64-entry
+// second-level table, indexed by the next 6 bits). Should the 64 second-level tables of the pool not suffice (a table
+// with hundreds of 11-bit codes) the entry stays 0 and the lane walks the canonical MAXCODE list instead.
+struct HuffTables {
+    uint16_t lut1[4][1 << LB];  // DC0, DC1, AC0, AC1
+    uint16_t lut2[64][64];
+    int32_t maxcode[4][18];     // largest code of length l (-1: none); [17] = sentinel
+    int32_t valoff[4][17];      // valptr[l] - mincode[l]
+    uint8_t vals[4][256];
 };
 struct TableSet {
-    HuffTab h[4];       // DC0, DC1, AC0, AC1
+    HuffTables h;
     uint16_t q[4][64];  // quantisation tables, natural order
 };
-static_assert(sizeof(HuffTab) % 4 == 0, "copied to LDS as dwords");
+static_assert(sizeof(HuffTables) % 4 == 0, "copied to LDS as dwords");
 
 struct FrameDesc {
-    uint32_t scan_off, scan_len;  // entropy-coded segment inside the device byte buffer
-    int32_t ri, n_int, int_base, tabset;
+    uint32_t scan_off, scan_len;  // entropy-coded segment inside the device byte buffer (EOI excluded)
+    uint32_t clean_off;           // where the frame's un-stuffed stream starts in the clean buffer (16-byte aligned)
+    int32_t ri, n_int, seg_base, tabset;
+    int32_t sub_base, n_sub_cap;  // the frame's slice of the per-subsequence arrays
     uint8_t td[4], ta[4], tq[4];
 };
 
@@ -64,6 +77,7 @@ struct Geom {
     int32_t blocks_per_frame;
     int32_t height, width;
     int32_t fh, fv;         // chroma up-sampling factors (1 | 2)
+    int32_t sub_shift;      // log2 of the subsequence size in bytes
     uint8_t b_comp[MAX_BLOCKS_MCU], b_dy[MAX_BLOCKS_MCU], b_dx[MAX_BLOCKS_MCU];
 };
 
@@ -77,259 +91,435 @@ __constant__ uint8_t k_zigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32,
                                      41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
                                      30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
-// ---- restart markers ---------------------------------------------------------------------------------------------------------
+// ---- byte un-stuffing + restart markers --------------------------------------------------------------------------------------
+//
+// The entropy-coded segment of every frame is rewritten once into a CLEAN stream: stuffed zeros (FF 00 -> FF) and the
+// RSTm markers are removed, and the clean offset at which every restart interval starts is recorded (seg_start). Bit
+// positions in the clean stream are plain arithmetic, which is what lets the decoder below start anywhere.
 
-// markers whose 0xFF byte lies in this thread's 16 bytes [a, a + 16) and inside the scan [lo, hi)
-__device__ __forceinline__ uint32_t rst_mask(const uint8_t* bits, uint32_t a, uint32_t lo, uint32_t hi) {
+// per 16 raw bytes [a, a + 16) of the scan [lo, hi): bit j of `keep` = byte a + j survives, of `mark` = byte a + j is the
+// 0xFF of an RSTm marker
+__device__ __forceinline__ void classify16(const uint8_t* bits, uint32_t a, uint32_t lo, uint32_t hi, uint32_t& keep, uint32_t& mark,
+                                           uint32_t (&w)[4]) {
     const uint4 v = *reinterpret_cast<const uint4*>(bits + a);
-    const uint32_t w[5] = {v.x, v.y, v.z, v.w, bits[a + 16]};
-    uint32_t m = 0;
+    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    const uint32_t prev = a > lo ? bits[a - 1] : 0, next = bits[a + 16];
+    keep = 0;
+    mark = 0;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const uint32_t b0 = (w[j >> 2] >> (8 * (j & 3))) & 0xff, b1 = (w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 0xff;
+        const uint32_t b = (w[j >> 2] >> (8 * (j & 3))) & 0xff;
+        const uint32_t bp = j ? (w[(j - 1) >> 2] >> (8 * ((j - 1) & 3))) & 0xff : prev;
+        const uint32_t bn = j < 15 ? (w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 0xff : next;
         const uint32_t p = a + j;
-        if (b0 == 0xff && (b1 & 0xf8) == 0xd0 && p >= lo && p + 1 < hi) m |= 1u << j;
+        const bool in = p >= lo && p < hi;
+        const bool is_mark = b == 0xff && (bn & 0xf8) == 0xd0 && p + 1 < hi;
+        const bool drop = (bp == 0xff && p > lo && (b == 0 || (b & 0xf8) == 0xd0)) || is_mark;
+        if (in && !drop) keep |= 1u << j;
+        if (in && is_mark) mark |= 1u << j;
     }
-    return m;
 }
 
-__global__ __launch_bounds__(256) void rst_count_kernel(const uint8_t* __restrict__ bits, const FrameDesc* __restrict__ fd,
-                                                        int32_t* __restrict__ chunk_cnt, int max_chunks) {
-    __shared__ int red[4];
+// chunk_cnt[f][c] = (markers, kept bytes) of chunk c of frame f
+__global__ __launch_bounds__(256) void unstuff_count_kernel(const uint8_t* __restrict__ bits, const FrameDesc* __restrict__ fd,
+                                                            int2* __restrict__ chunk_cnt, int max_chunks) {
+    __shared__ int red[8];
     const int f = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
     const FrameDesc d = fd[f];
     const uint32_t lo = d.scan_off, hi = d.scan_off + d.scan_len;
     const uint32_t a = (lo & ~15u) + (uint32_t)c * CHUNK + tid * 16;
-    int cnt = 0;
-    if (d.ri && a < hi) cnt = __popc(rst_mask(bits, a, lo, hi));
-    for (int o = 32; o; o >>= 1) cnt += __shfl_down(cnt, o, 64);
-    if ((tid & 63) == 0) red[tid >> 6] = cnt;
-    __syncthreads();
-    if (tid == 0) chunk_cnt[f * max_chunks + c] = red[0] + red[1] + red[2] + red[3];
-}
-
-__global__ __launch_bounds__(256) void rst_write_kernel(const uint8_t* __restrict__ bits, const FrameDesc* __restrict__ fd,
-                                                        const int32_t* __restrict__ chunk_cnt, int max_chunks,
-                                                        uint32_t* __restrict__ rst_pos, int32_t* __restrict__ status) {
-    __shared__ int red[8];
-    __shared__ int scan[256];
-    const int f = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
-    const FrameDesc d = fd[f];
-    if (!d.ri) return;
-    // markers in the chunks before this one, and in the whole frame
-    int before = 0, total = 0;
-    for (int i = tid; i < max_chunks; i += 256) {
-        const int v = chunk_cnt[f * max_chunks + i];
-        total += v;
-        if (i < c) before += v;
+    int nm = 0, nk = 0;
+    if (a < hi) {
+        uint32_t keep, mark, w[4];
+        classify16(bits, a, lo, hi, keep, mark, w);
+        nm = __popc(mark);
+        nk = __popc(keep);
     }
     for (int o = 32; o; o >>= 1) {
-        before += __shfl_down(before, o, 64);
-        total += __shfl_down(total, o, 64);
+        nm += __shfl_down(nm, o, 64);
+        nk += __shfl_down(nk, o, 64);
     }
     if ((tid & 63) == 0) {
-        red[tid >> 6] = before;
-        red[4 + (tid >> 6)] = total;
+        red[tid >> 6] = nm;
+        red[4 + (tid >> 6)] = nk;
     }
     __syncthreads();
-    before = red[0] + red[1] + red[2] + red[3];
-    total = red[4] + red[5] + red[6] + red[7];
-    if (c == 0 && tid == 0 && total != d.n_int - 1) atomicOr(&status[f], ERR_RST);
+    if (tid == 0) chunk_cnt[f * max_chunks + c] = make_int2(red[0] + red[1] + red[2] + red[3], red[4] + red[5] + red[6] + red[7]);
+}
+
+__global__ __launch_bounds__(256) void unstuff_write_kernel(const uint8_t* __restrict__ bits, const FrameDesc* __restrict__ fd,
+                                                            const int2* __restrict__ chunk_cnt, int max_chunks,
+                                                            uint8_t* __restrict__ clean, uint32_t* __restrict__ seg_start,
+                                                            uint32_t* __restrict__ clean_len, int32_t* __restrict__ status) {
+    __shared__ int red[16];
+    __shared__ int2 scan[256];
+    const int f = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
+    const FrameDesc d = fd[f];
     const uint32_t lo = d.scan_off, hi = d.scan_off + d.scan_len;
+    if ((lo & ~15u) + (uint32_t)c * CHUNK >= hi && c != 0) return;
+    // markers / kept bytes in the chunks before this one, and in the whole frame
+    int bm = 0, bk = 0, tm = 0, tk = 0;
+    for (int i = tid; i < max_chunks; i += 256) {
+        const int2 v = chunk_cnt[f * max_chunks + i];
+        tm += v.x;
+        tk += v.y;
+        if (i < c) {
+            bm += v.x;
+            bk += v.y;
+        }
+    }
+    for (int o = 32; o; o >>= 1) {
+        bm += __shfl_down(bm, o, 64);
+        bk += __shfl_down(bk, o, 64);
+        tm += __shfl_down(tm, o, 64);
+        tk += __shfl_down(tk, o, 64);
+    }
+    if ((tid & 63) == 0) {
+        red[tid >> 6] = bm;
+        red[4 + (tid >> 6)] = bk;
+        red[8 + (tid >> 6)] = tm;
+        red[12 + (tid >> 6)] = tk;
+    }
+    __syncthreads();
+    bm = red[0] + red[1] + red[2] + red[3];
+    bk = red[4] + red[5] + red[6] + red[7];
+    tm = red[8] + red[9] + red[10] + red[11];
+    tk = red[12] + red[13] + red[14] + red[15];
+    if (c == 0 && tid == 0) {
+        clean_len[f] = (uint32_t)tk;
+        seg_start[d.seg_base] = 0;
+        if (tm != d.n_int - 1) atomicOr(&status[f], ERR_RST);
+    }
     const uint32_t a = (lo & ~15u) + (uint32_t)c * CHUNK + tid * 16;
-    const uint32_t m = a < hi ? rst_mask(bits, a, lo, hi) : 0;
-    scan[tid] = __popc(m);
+    uint32_t keep = 0, mark = 0, w[4] = {0, 0, 0, 0};
+    if (a < hi) classify16(bits, a, lo, hi, keep, mark, w);
+    scan[tid] = make_int2(__popc(mark), __popc(keep));
     __syncthreads();
     for (int o = 1; o < 256; o <<= 1) {  // inclusive scan of the per-thread counts
-        const int v = tid >= o ? scan[tid - o] : 0;
+        int2 v = make_int2(0, 0);
+        if (tid >= o) v = scan[tid - o];
         __syncthreads();
-        scan[tid] += v;
+        scan[tid].x += v.x;
+        scan[tid].y += v.y;
         __syncthreads();
     }
-    int k = before + scan[tid] - __popc(m);
-    for (uint32_t mm = m; mm; mm &= mm - 1, ++k)
-        if (k < d.n_int - 1) rst_pos[d.int_base + k] = a + (uint32_t)__ffs(mm) - 1 + 2;  // first byte after the marker
+    int km = bm + scan[tid].x - __popc(mark);    // markers before this thread's bytes
+    uint32_t kk = (uint32_t)(bk + scan[tid].y - __popc(keep));  // clean offset of this thread's first kept byte
+    uint8_t* out = clean + d.clean_off;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (mark & (1u << j)) {
+            // the interval after this marker starts at the clean offset reached so far
+            ++km;
+            if (km < d.n_int) seg_start[d.seg_base + km] = kk;
+        }
+        if (keep & (1u << j)) out[kk++] = (uint8_t)((w[j >> 2] >> (8 * (j & 3))) & 0xff);
+    }
 }
 
 // ---- entropy decoding --------------------------------------------------------------------------------------------------------
+//
+// One lane per subsequence (128 bytes or more, see below) of a frame's clean stream, wherever it falls (Weissenberger & Schmidt's
+// self-synchronising scheme, restated for this layout). A lane's decoding state at a bit position is (block of the MCU,
+// zig-zag index); given the right state at its entry a lane decodes exactly the codewords that START inside its
+// subsequence and hands (overshoot bits, block, index) to the next lane.
+//   pass A (MODE 0): every lane assumes the state of a block start at its first bit. Huffman streams re-synchronise by
+//                    themselves, so most exit states are already right;
+//   verify (MODE 1): every lane whose entry (= the predecessor's exit) differs from what it last decoded with decodes
+//                    again; repeated until no exit state changes = the exact sequential states. Lanes that follow a
+//                    restart marker are exact from the start: at a marker the state is known.
+//   scan           : per frame, exclusive scan of (blocks completed, DC sums) with resets at restart markers -> every
+//                    lane's absolute block index and DC predictions at entry;
+//   final (MODE 2) : decode once more and scatter the non-zero coefficients (int16, natural order) into the
+//                    per-component block rasters (cleared beforehand).
+// The subsequence size is chosen per call (a power of two, about four MCUs of the stream: states settle within a
+// couple of MCUs, so most lanes are right after pass A and one verify pass). Every lane keeps the next 128 bytes of its
+// stream in an LDS ring (33-dword pitch: the 64 lanes' window reads fall on distinct banks) that all lanes top up
+// together every 16 symbols with 16-byte loads; the 64-bit window is re-read from the ring at every symbol, so there is
+// no refill branch inside the symbol loop.
 
-struct BitReader {
-    const uint8_t* bits;
-    uint32_t pos, end;
-    uint64_t buf;   // valid bits at the top
-    int nbits;
-    bool marker;    // a marker (or the end of the data) was reached: zeros from here on (T.81 F.2.2.5)
-
-    __device__ __forceinline__ void refill() {
-        if (nbits > 32) return;
-        // bytes pos .. pos + 3 from two aligned dwords
-        const uint32_t* w = reinterpret_cast<const uint32_t*>(bits) + (pos >> 2);
-        const uint32_t x = __builtin_amdgcn_alignbyte(w[1], w[0], pos & 3);
-        uint32_t v;
-        if (!marker && pos + 4 <= end && (((~x) - 0x01010101u) & x & 0x80808080u) == 0) {
-            v = __builtin_bswap32(x);
-            pos += 4;
-        } else {
-            v = 0;
-            for (int k = 0; k < 4; ++k) {
-                uint32_t b = 0;
-                if (!marker) {
-                    if (pos >= end) {
-                        marker = true;
-                    } else {
-                        b = bits[pos];
-                        if (b == 0xff) {
-                            if (bits[pos + 1] == 0) {
-                                pos += 2;  // stuffed zero
-                            } else {
-                                marker = true;
-                                b = 0;
-                            }
-                        } else {
-                            ++pos;
-                        }
-                    }
-                }
-                v = (v << 8) | b;
-            }
-        }
-        buf |= (uint64_t)v << (32 - nbits);
-        nbits += 32;
-    }
-    __device__ __forceinline__ uint32_t peek16() const { return (uint32_t)(buf >> 48); }
-    __device__ __forceinline__ void skip(int n) {
-        buf <<= n;
-        nbits -= n;
-    }
-    // the next s bits (0 <= s <= 16)
-    __device__ __forceinline__ uint32_t take(int s) {
-        const uint32_t v = (uint32_t)((buf >> 1) >> (63 - s));
-        skip(s);
-        return v;
-    }
+struct SubCnt {     // what a subsequence contributes to the scan
+    int32_t blk;    // blocks completed; bit 31: a restart marker lies inside, blk then counts from the frame start
+    int32_t dc[3];  // sums of the DC differences decoded (since that marker, if any)
 };
 
-__global__ __launch_bounds__(64) void huff_kernel(const uint8_t* __restrict__ bits, const FrameDesc* __restrict__ fd,
-                                                  const TableSet* __restrict__ ts, const uint32_t* __restrict__ rst_pos, const Geom g,
-                                                  int16_t* __restrict__ coef, int32_t* __restrict__ status) {
-    __shared__ HuffTab tab[4];
+
+template <int MODE>
+__global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restrict__ clean, const FrameDesc* __restrict__ fd,
+                                                         const TableSet* __restrict__ ts, const uint32_t* __restrict__ seg_start,
+                                                         const uint32_t* __restrict__ clean_len, const Geom g,
+                                                         const uint32_t* __restrict__ g_in, uint32_t* __restrict__ g_out,
+                                                         uint32_t* __restrict__ used, SubCnt* __restrict__ cnt,
+                                                         const SubCnt* __restrict__ entry, int16_t* __restrict__ coef,
+                                                         int32_t* __restrict__ status, int32_t* __restrict__ changed,
+                                                         const int32_t* __restrict__ changed_last) {
+    // verify pass: a frame whose previous verify pass changed nothing has settled (changed_last = that pass's flags)
+    if (MODE == 1 && changed_last && changed_last[blockIdx.y] == 0) return;
+    __shared__ HuffTables T;
     __shared__ uint8_t zz[64];
     __shared__ BlkInfo binfo[MAX_BLOCKS_MCU];
-    const int f = blockIdx.y, lane = threadIdx.x;
+    __shared__ uint32_t ring[WG_SUBS * (RING_DW + 1)];
+    const int f = blockIdx.y, tid = threadIdx.x;
     const FrameDesc d = fd[f];
-    {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(ts[d.tabset].h);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(tab);
-        for (int i = lane; i < (int)(sizeof(HuffTab) * 4 / 4); i += 64) dst[i] = src[i];
-        zz[lane] = k_zigzag[lane];
-        if (lane < g.blocks_per_mcu) {
-            // everything a lane needs when it moves on to block `lane` of an MCU, as one 16-byte LDS read
-            const int c = g.b_comp[lane];
+    const uint32_t clen = clean_len[f];
+    const int sh = g.sub_shift;
+    const int nsub = (int)((clen + (1u << sh) - 1) >> sh);
+    const int j0 = blockIdx.x * WG_SUBS, j = j0 + tid;
+    if (j0 >= nsub) return;
+    if (MODE == 2 && blockIdx.x == 0 && tid == 0 && changed_last[f]) atomicOr(&status[f], ERR_SYNC);
+    bool active = j < nsub && j < d.n_sub_cap;
+    const size_t sj = (size_t)d.sub_base + j;
+    const uint32_t entry_st = (MODE == 0 || j == 0 || !active) ? 0u : g_in[sj - 1];
+    bool mine = active;  // this lane decodes in this pass and records what it found
+    if (MODE == 1) {
+        mine = active && entry_st != used[sj];
+        if (active && !mine) g_out[sj] = g_in[sj];
+        if (!__syncthreads_or(mine)) return;
+        active = mine;
+    }
+    {   // tables, block layout of an MCU
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&ts[d.tabset].h);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&T);
+        for (int i = tid; i < (int)(sizeof(HuffTables) / 4); i += 256) dst[i] = src[i];
+        if (tid < 64) zz[tid] = k_zigzag[tid];
+        if (tid < g.blocks_per_mcu) {
+            const int c = g.b_comp[tid];
             BlkInfo bi;
             bi.base = c == 0 ? g.blk_off[0] : (c == 1 ? g.blk_off[1] : g.blk_off[2]);
             bi.bx = c == 0 ? g.bx[0] : (c == 1 ? g.bx[1] : g.bx[2]);
             bi.vs = (uint8_t)(c == 0 ? g.vs[0] : (c == 1 ? g.vs[1] : g.vs[2]));
             bi.hs = (uint8_t)(c == 0 ? g.hs[0] : (c == 1 ? g.hs[1] : g.hs[2]));
-            bi.dy = g.b_dy[lane];
-            bi.dx = g.b_dx[lane];
+            bi.dy = g.b_dy[tid];
+            bi.dx = g.b_dx[tid];
             bi.tdc = fd[f].td[c];
             bi.tac = (uint8_t)(2 + fd[f].ta[c]);
             bi.comp = (uint8_t)c;
             bi.pad = 0;
-            binfo[lane] = bi;
+            binfo[tid] = bi;
         }
     }
     __syncthreads();
-    const int iv = blockIdx.x * 64 + lane;
-    bool active = iv < d.n_int;
-    const int mcus = g.mcus_x * g.mcus_y;
-    const int mcu0 = active ? iv * d.ri : 0;
-    int mleft = d.ri ? min(d.ri, mcus - mcu0) : mcus;
-    int my = mcu0 / g.mcus_x, mx = mcu0 - my * g.mcus_x;
-    BitReader br;
-    br.bits = bits;
-    br.end = d.scan_off + d.scan_len;
-    br.pos = d.scan_off;
-    if (active && iv > 0) br.pos = rst_pos[d.int_base + iv - 1];
-    if (br.pos < d.scan_off || br.pos > br.end) active = false;  // marker list shorter than the header promised
-    br.buf = 0;
-    br.nbits = 0;
-    br.marker = false;
+    // positions are bits from the start of the frame's clean stream
+    const uint32_t s_byte = (uint32_t)j << sh;
+    const uint32_t end_bits = min((uint32_t)(j + 1) << sh, clen) * 8;
+    uint32_t bitpos = s_byte * 8 + (entry_st & 31);
+    int b = (entry_st >> 5) & 15, z = (entry_st >> 9) & 63;
+    // this lane's ring: bytes [fill - 128, fill) of the stream, dword X at ring[(X & 31)]
+    uint32_t* const my_ring = ring + tid * (RING_DW + 1);
+    const uint8_t* const stream = clean + d.clean_off;
+    uint32_t fill = s_byte;  // multiple of 16
+    auto top_up = [&]() {
+        // keep the dwords (bitpos >> 5) and the one after it, fill the rest of the ring
+        while (fill + 16 <= ((bitpos >> 5) << 2) + 4 * RING_DW) {
+            const uint4 v = *reinterpret_cast<const uint4*>(stream + fill);
+            uint32_t* q = my_ring + ((fill >> 2) & (RING_DW - 1));
+            q[0] = __builtin_bswap32(v.x); q[1] = __builtin_bswap32(v.y);  // most significant bit first, as the codes read
+            q[2] = __builtin_bswap32(v.z); q[3] = __builtin_bswap32(v.w);
+            fill += 16;
+        }
+    };
+    // first restart boundary at or after this subsequence's first byte
+    int nbk = d.n_int;  // index of the next boundary's interval; n_int = none
+    uint32_t nb_bits = 0xffffffffu;
+    if (active && d.n_int > 1) {
+        int lo = 1, hi = d.n_int;  // lower_bound over seg_start[1 .. n_int)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (seg_start[d.seg_base + mid] < s_byte) lo = mid + 1; else hi = mid;
+        }
+        nbk = lo;
+        if (nbk < d.n_int) nb_bits = seg_start[d.seg_base + nbk] * 8;
+    }
+    int nblk = 0, reset = 0, dc0 = 0, dc1 = 0, dc2 = 0, err = 0;
+    int absblk = 0;  // index of the current block in scan order (MODE 2; from the last restart marker otherwise)
+    if (MODE == 2 && active) {
+        const SubCnt e = entry[sj];
+        absblk = e.blk & 0x7fffffff;
+        dc0 = e.dc[0]; dc1 = e.dc[1]; dc2 = e.dc[2];
+    }
+    const int bpm = g.blocks_per_mcu;
     int16_t* const frame_coef = coef + (size_t)f * g.blocks_per_frame * 64;
-    int pred0 = 0, pred1 = 0, pred2 = 0;
-    int b = 0, z = 0, err = 0;
-    BlkInfo bi = binfo[0];
-    int16_t* blk = frame_coef + ((size_t)bi.base + (size_t)(my * bi.vs + bi.dy) * bi.bx + mx * bi.hs + bi.dx) * 64;
-    if (mleft <= 0) active = false;
-    while (__ballot(active)) {
+    BlkInfo bi = binfo[b < bpm ? b : 0];
+    int16_t* blk = frame_coef;
+    int mx = 0, my = 0;
+    const int total_blocks = g.mcus_x * g.mcus_y * bpm;
+    auto place = [&]() {  // MODE 2: raster address of block `absblk`
+        const int mcu = absblk / bpm;
+        my = mcu / g.mcus_x;
+        mx = mcu - my * g.mcus_x;
+        blk = frame_coef + ((size_t)bi.base + (size_t)(my * bi.vs + bi.dy) * bi.bx + mx * bi.hs + bi.dx) * 64;
+    };
+    if (MODE == 2 && active) {
+        if (absblk % bpm != b) {  // the scan and the synchronised state disagree: corrupt stream
+            err |= ERR_SYNC;
+            active = false;
+        } else if (absblk >= total_blocks) {
+            active = false;  // padding after the last MCU
+        } else {
+            place();
+        }
+    }
+    uint32_t lim = min(nb_bits, end_bits);
+    for (int it = 0; __ballot(active); ++it) {
         if (active) {
-            br.refill();
+            if ((it & (TOPUP - 1)) == 0) top_up();
+            if (bitpos >= lim) {
+                if (bitpos >= nb_bits) {
+                    // restart marker: byte aligned, block 0 of MCU nbk * ri, predictions zero (T.81 F.2.2.4 / E.2.4)
+                    bitpos = nb_bits;
+                    b = 0; z = 0;
+                    bi = binfo[0];
+                    reset = 1;
+                    nblk = 0;
+                    dc0 = dc1 = dc2 = 0;
+                    absblk = nbk * d.ri * bpm;
+                    if (MODE == 2) {
+                        if (absblk >= total_blocks) active = false; else place();
+                    }
+                    ++nbk;
+                    nb_bits = nbk < d.n_int ? seg_start[d.seg_base + nbk] * 8 : 0xffffffffu;
+                    lim = min(nb_bits, end_bits);
+                }
+                if (bitpos >= end_bits) active = false;
+            }
+        }
+        if (active) {
+            const uint32_t dw = bitpos >> 5, sh = bitpos & 31;
+            const uint32_t w0 = my_ring[dw & (RING_DW - 1)], w1 = my_ring[(dw + 1) & (RING_DW - 1)];
+            const uint32_t win = sh ? __builtin_amdgcn_alignbit(w0, w1, 32 - sh) : w0;  // the next 32 bits of the stream
             const bool dc = z == 0;
-            const HuffTab& T = tab[dc ? bi.tdc : bi.tac];
-            const uint32_t pk = br.peek16();
-            const uint32_t e = T.lut[pk >> (16 - LB)];
-            int len = e >> 8, sym = e & 0xff;
-            if (e == 0) {
+            const int t = dc ? bi.tdc : bi.tac;
+            uint32_t e = T.lut1[t][win >> (32 - LB)];
+            if (e & 0x8000u) e = T.lut2[e & 63][(win >> (32 - LB - 6)) & 63];
+            int len = e & 31, s = (e >> 5) & 15, r = (e >> 9) & 15;
+            bool invalid = false;
+            if (e == 0) {  // a code the tables above do not hold: canonical search (T.81 F.2.2.3)
+                const uint32_t pk = win >> 16;
                 len = 17;
+                int sym = 0;
                 for (int l = LB + 1; l <= 16; ++l) {
                     const int code = (int)(pk >> (16 - l));
-                    if (code <= T.maxcode[l]) {
-                        sym = T.vals[(T.valoff[l] + code) & 255];
+                    if (code <= T.maxcode[t][l]) {
+                        sym = T.vals[t][(T.valoff[t][l] + code) & 255];
                         len = l;
                         break;
                     }
                 }
                 if (len == 17) {
-                    err |= ERR_HUFF;
-                    active = false;
-                    len = 0;
+                    // no such code: the 1-bits that pad the byte in front of a restart marker (caught below), a lane
+                    // that is out of step (A / verify: move on by one bit), or a corrupt stream (final)
+                    invalid = true;
+                    len = 1;
+                    sym = 0;
                 }
+                s = dc ? sym : sym & 15;
+                r = dc ? 0 : sym >> 4;
             }
-            br.skip(len);
-            const int r = dc ? 0 : sym >> 4, s = dc ? sym : sym & 15;
-            int v = 0;
-            if (s) {
-                const int raw = (int)br.take(s);
-                v = raw < (1 << (s - 1)) ? raw - (1 << s) + 1 : raw;
-            }
-            if (dc) {
-                if (s > 11) {
-                    err |= ERR_HUFF;
-                    active = false;
-                }
-                int p = bi.comp == 0 ? pred0 : (bi.comp == 1 ? pred1 : pred2);
-                p += v;
-                if (bi.comp == 0) pred0 = p; else if (bi.comp == 1) pred1 = p; else pred2 = p;
-                if (p) blk[0] = (int16_t)p;
-                z = 1;
-            } else if (s) {
-                z += r;
-                if (z > 63) {
-                    err |= ERR_COEF;
-                    active = false;
-                    z = 63;
-                }
-                blk[zz[z]] = (int16_t)v;
-                ++z;
+            const uint32_t np = bitpos + len + s;
+            if (np > nb_bits || (invalid && nb_bits - bitpos < 8)) {
+                bitpos = nb_bits;  // the padding bits in front of a restart marker, not a symbol
+            } else if (invalid && MODE == 2) {
+                err |= ERR_HUFF;
+                active = false;
             } else {
-                z = r == 15 ? z + 16 : 64;  // ZRL | EOB
-            }
-            if (z >= 64) {
-                z = 0;
-                if (++b == g.blocks_per_mcu) {
-                    b = 0;
-                    if (++mx == g.mcus_x) {
-                        mx = 0;
-                        ++my;
-                    }
-                    if (--mleft == 0) active = false;
+                bitpos = np;
+                int v = 0;
+                if (s && (dc || MODE == 2)) {  // the value: only the DC differences matter before the final pass
+                    const int raw = (int)((win << len) >> (32 - s));
+                    v = raw < (1 << (s - 1)) ? raw - (1 << s) + 1 : raw;
                 }
-                bi = binfo[b];
-                blk = frame_coef + ((size_t)bi.base + (size_t)(my * bi.vs + bi.dy) * bi.bx + mx * bi.hs + bi.dx) * 64;
+                if (dc) {
+                    if (bi.comp == 0) dc0 += v; else if (bi.comp == 1) dc1 += v; else dc2 += v;
+                    if (MODE == 2) {
+                        const int p = bi.comp == 0 ? dc0 : (bi.comp == 1 ? dc1 : dc2);
+                        if (p) blk[0] = (int16_t)p;
+                    }
+                    z = 1;
+                } else if (s) {
+                    z += r;
+                    if (z > 63) {
+                        if (MODE == 2) {
+                            err |= ERR_COEF;
+                            active = false;
+                        }
+                        z = 64;
+                    } else {
+                        if (MODE == 2) blk[zz[z]] = (int16_t)v;
+                        ++z;
+                    }
+                } else {
+                    z = r == 15 ? z + 16 : 64;  // ZRL | EOB
+                }
+                if (z >= 64) {
+                    z = 0;
+                    ++nblk;
+                    ++absblk;
+                    if (++b >= bpm) b = 0;
+                    bi = binfo[b];
+                    if (MODE == 2) {
+                        if (absblk >= total_blocks) {
+                            active = false;
+                        } else if (b == 0) {
+                            if (++mx == g.mcus_x) {
+                                mx = 0;
+                                ++my;
+                            }
+                        }
+                        blk = frame_coef + ((size_t)bi.base + (size_t)(my * bi.vs + bi.dy) * bi.bx + mx * bi.hs + bi.dx) * 64;
+                    }
+                }
             }
         }
     }
     if (err) atomicOr(&status[f], err);
+    if (MODE != 2 && mine) {
+        const uint32_t over = bitpos >= end_bits ? bitpos - end_bits : 0;
+        const uint32_t st = (over & 31) | ((uint32_t)b << 5) | ((uint32_t)z << 9);
+        if (MODE == 1 && st != g_in[sj]) atomicOr(&changed[f], 1);
+        g_out[sj] = st;
+        used[sj] = entry_st;
+        SubCnt c;
+        c.blk = reset ? (int32_t)(((uint32_t)absblk & 0x7fffffffu) | 0x80000000u) : nblk;
+        c.dc[0] = dc0; c.dc[1] = dc1; c.dc[2] = dc2;
+        cnt[sj] = c;
+    }
+}
+
+// entry[j] = what lanes 0 .. j-1 of the frame accumulated: absolute block index and DC predictions at lane j's entry
+__global__ __launch_bounds__(1024) void sub_scan_kernel(const FrameDesc* __restrict__ fd, const uint32_t* __restrict__ clean_len,
+                                                        const SubCnt* __restrict__ cnt, SubCnt* __restrict__ entry, int sub_shift) {
+    __shared__ SubCnt sh[1024];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const FrameDesc d = fd[f];
+    int nsub = (int)((clean_len[f] + (1u << sub_shift) - 1) >> sub_shift);
+    nsub = nsub < d.n_sub_cap ? nsub : d.n_sub_cap;
+    const int per = (nsub + 1023) / 1024;
+    const int lo = tid * per, hi = min(lo + per, nsub);
+    auto combine = [](const SubCnt& a, const SubCnt& b) {  // a then b
+        if (b.blk < 0) return b;
+        SubCnt r;
+        r.blk = a.blk + b.blk;  // keeps a's marker bit: b.blk < 2^30
+        r.dc[0] = a.dc[0] + b.dc[0]; r.dc[1] = a.dc[1] + b.dc[1]; r.dc[2] = a.dc[2] + b.dc[2];
+        return r;
+    };
+    SubCnt acc = {0, {0, 0, 0}};
+    for (int i = lo; i < hi; ++i) acc = combine(acc, cnt[(size_t)d.sub_base + i]);
+    sh[tid] = acc;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        SubCnt v = {0, {0, 0, 0}};
+        const bool has = tid >= o;
+        if (has) v = sh[tid - o];
+        __syncthreads();
+        if (has) sh[tid] = combine(v, sh[tid]);
+        __syncthreads();
+    }
+    SubCnt run = {0, {0, 0, 0}};
+    if (tid > 0) run = sh[tid - 1];
+    for (int i = lo; i < hi; ++i) {
+        entry[(size_t)d.sub_base + i] = run;
+        run = combine(run, cnt[(size_t)d.sub_base + i]);
+    }
 }
 
 // ---- de-quantisation + inverse DCT -------------------------------------------------------------------------------------------
@@ -584,22 +774,43 @@ const char* parse_header(const uint8_t* d, size_t n, Parsed& P) {
     }
 }
 
-void build_hufftab(HuffTab& T, const uint8_t* counts, const uint8_t* syms) {
-    memset(&T, 0, sizeof T);
-    memcpy(T.vals, syms, 256);
+// Table t (0 DC0, 1 DC1, 2 AC0, 3 AC1) of a set from a DHT segment's counts / symbols; `pool` = second-level tables taken so far.
+void build_hufftab(HuffTables& T, int t, const uint8_t* counts, const uint8_t* syms, int& pool) {
+    const bool dc = t < 2;
+    auto entry = [&](int len, int sym) -> uint16_t {
+        const int s = dc ? (sym & 15) : (sym & 15), r = dc ? 0 : (sym >> 4);
+        return (uint16_t)(len | (s << 5) | (r << 9));
+    };
+    memset(T.lut1[t], 0, sizeof T.lut1[t]);
+    memcpy(T.vals[t], syms, 256);
     int code = 0, k = 0;
     for (int l = 1; l <= 16; ++l) {
-        T.valoff[l] = k - code;
+        T.valoff[t][l] = k - code;
         for (int i = 0; i < counts[l - 1]; ++i, ++k, ++code) {
             if (l <= LB) {
                 const int lo = code << (LB - l), hi = (code + 1) << (LB - l);
-                for (int e = lo; e < hi && e < (1 << LB); ++e) T.lut[e] = (uint16_t)((l << 8) | syms[k]);
+                for (int e = lo; e < hi && e < (1 << LB); ++e) T.lut1[t][e] = entry(l, syms[k]);
+            } else {
+                const int prefix = code >> (l - LB);
+                if (prefix >= (1 << LB)) continue;  // over-subscribed table: left to the canonical search (and its error)
+                uint16_t& link = T.lut1[t][prefix];
+                if (!(link & 0x8000)) {
+                    if (link != 0 || pool >= 64) continue;  // pool exhausted: the canonical search finds this code
+                    memset(T.lut2[pool], 0, sizeof T.lut2[pool]);
+                    link = (uint16_t)(0x8000 | pool++);
+                }
+                uint16_t* sub = T.lut2[link & 63];
+                const int rest = l - LB;  // 1..6 more bits
+                const int lo = (code & ((1 << rest) - 1)) << (6 - rest), hi = lo + (1 << (6 - rest));
+                for (int e = lo; e < hi; ++e) sub[e] = entry(l, syms[k]);
             }
         }
-        T.maxcode[l] = counts[l - 1] ? code - 1 : -1;
+        T.maxcode[t][l] = counts[l - 1] ? code - 1 : -1;
         code <<= 1;
     }
-    T.maxcode[17] = 0x7fffffff;
+    T.maxcode[t][17] = 0x7fffffff;
+    T.maxcode[t][0] = -1;
+    T.valoff[t][0] = 0;
 }
 
 }  // namespace mj
@@ -611,24 +822,39 @@ struct pa_mjpeg {
     int device = 0, max_frames = 0, max_h = 0, max_w = 0;
     size_t max_bytes = 0;
     size_t max_blocks = 0;      // per frame
+    size_t max_subs = 0, max_segs = 0;
     int max_chunks_cap = 0;
+    int sync_rounds = 8;
+    int sub_shift_override = 0;  // tuning: log2 of the subsequence size, 0 = chosen from the stream
     uint8_t* d_bits = nullptr;
+    uint8_t* d_clean = nullptr;
     FrameDesc* d_fd = nullptr;
     TableSet* d_ts = nullptr;
-    int32_t* d_chunk = nullptr;
-    uint32_t* d_rst = nullptr;
+    int2* d_chunk = nullptr;
+    uint32_t* d_seg = nullptr;
+    uint32_t* d_clean_len = nullptr;
+    uint32_t* d_g[2] = {nullptr, nullptr};
+    uint32_t* d_used = nullptr;
+    SubCnt* d_cnt = nullptr;
+    SubCnt* d_entry = nullptr;
+    int32_t* d_changed = nullptr;  // [MAX_ROUNDS + 1][max_frames]
     int16_t* d_coef = nullptr;
     uint8_t* d_planes = nullptr;
     int32_t* d_status = nullptr;
     // pinned host staging, two sets used in turn
     FrameDesc* h_fd[2] = {nullptr, nullptr};
     TableSet* h_ts[2] = {nullptr, nullptr};
+    int32_t* h_flag = nullptr;
     hipEvent_t staged[2] = {nullptr, nullptr};
     bool staged_used[2] = {false, false};
     int turn = 0;
-    int last_height = 0, last_width = 0;
+    int last_rounds = 0;
     std::string last_error;
 };
+
+namespace {
+constexpr int MAX_ROUNDS = 16;  // verify passes enqueued without looking at the result (pa_mjpeg_set_sync_rounds)
+}
 
 extern "C" {
 
@@ -636,19 +862,15 @@ const char* pa_mjpeg_last_error(const pa_mjpeg* h) { return h ? h->last_error.c_
 
 void pa_mjpeg_destroy(pa_mjpeg* h) {
     if (!h) return;
-    (void)hipFree(h->d_bits);
-    (void)hipFree(h->d_fd);
-    (void)hipFree(h->d_ts);
-    (void)hipFree(h->d_chunk);
-    (void)hipFree(h->d_rst);
-    (void)hipFree(h->d_coef);
-    (void)hipFree(h->d_planes);
-    (void)hipFree(h->d_status);
+    void* dev[] = {h->d_bits, h->d_clean, h->d_fd, h->d_ts, h->d_chunk, h->d_seg, h->d_clean_len, h->d_g[0], h->d_g[1], h->d_used,
+                   h->d_cnt, h->d_entry, h->d_changed, h->d_coef, h->d_planes, h->d_status};
+    for (void* p : dev) (void)hipFree(p);
     for (int i = 0; i < 2; ++i) {
         if (h->h_fd[i]) (void)hipHostFree(h->h_fd[i]);
         if (h->h_ts[i]) (void)hipHostFree(h->h_ts[i]);
         if (h->staged[i]) (void)hipEventDestroy(h->staged[i]);
     }
+    if (h->h_flag) (void)hipHostFree(h->h_flag);
     delete h;
 }
 
@@ -656,11 +878,12 @@ int pa_mjpeg_create(int32_t device, int32_t max_frames, int32_t max_height, int3
     if (!out) return PA_ERR_INVALID_ARG;
     *out = nullptr;
     if (max_frames < 1 || max_height < 1 || max_width < 1 || max_height > 65535 || max_width > 65535 || max_bytes < 1024 ||
-        max_bytes > 0xf0000000ull)
+        max_bytes > 0xe0000000ull)
         return PA_ERR_INVALID_ARG;
     pa_mjpeg* h = new pa_mjpeg();
     *out = h;  // handed back on failure too (pa_mjpeg_last_error, then pa_mjpeg_destroy)
     h->device = device; h->max_frames = max_frames; h->max_h = max_height; h->max_w = max_width; h->max_bytes = max_bytes;
+    if (const char* e = getenv("PA_MJPEG_SUB_SHIFT")) h->sub_shift_override = atoi(e);  // tuning knob (scripts/mjpeg_rate.py)
     auto chk = [&](hipError_t e, const char* what) -> bool {
         if (e == hipSuccess) return true;
         h->last_error = std::string(what) + ": " + hipGetErrorString(e);
@@ -669,25 +892,46 @@ int pa_mjpeg_create(int32_t device, int32_t max_frames, int32_t max_height, int3
     if (!chk(hipSetDevice(device), "hipSetDevice")) return PA_ERR_NO_DEVICE;
     // worst case: three full-resolution components, padded to 16-pixel MCUs
     const size_t bw = ((size_t)max_width + 15) / 16 * 2, bh = ((size_t)max_height + 15) / 16 * 2;
+    const size_t n = (size_t)max_frames;
     h->max_blocks = 3 * bw * bh;
     h->max_chunks_cap = (int)(max_bytes / CHUNK) + 3;
-    const size_t n = (size_t)max_frames;
+    h->max_subs = max_bytes / SUB_MIN + 2 * n + 2;
+    h->max_segs = n * bw * bh + n;
+    const size_t clean_bytes = max_bytes + 32 * n + 4096;
     if (!chk(hipMalloc(&h->d_bits, max_bytes + 64), "hipMalloc bitstream")) return PA_ERR_HIP;
+    if (!chk(hipMalloc(&h->d_clean, clean_bytes), "hipMalloc clean stream")) return PA_ERR_HIP;
     if (!chk(hipMalloc(&h->d_fd, n * sizeof(FrameDesc)), "hipMalloc descriptors")) return PA_ERR_HIP;
     if (!chk(hipMalloc(&h->d_ts, n * sizeof(TableSet)), "hipMalloc tables")) return PA_ERR_HIP;
-    if (!chk(hipMalloc(&h->d_chunk, (n * h->max_chunks_cap) * sizeof(int32_t)), "hipMalloc chunk counts")) return PA_ERR_HIP;
-    if (!chk(hipMalloc(&h->d_rst, n * bw * bh * sizeof(uint32_t)), "hipMalloc restart positions")) return PA_ERR_HIP;
+    if (!chk(hipMalloc(&h->d_chunk, (n * h->max_chunks_cap) * sizeof(int2)), "hipMalloc chunk counts")) return PA_ERR_HIP;
+    if (!chk(hipMalloc(&h->d_seg, h->max_segs * sizeof(uint32_t)), "hipMalloc restart positions")) return PA_ERR_HIP;
+    if (!chk(hipMalloc(&h->d_clean_len, n * sizeof(uint32_t)), "hipMalloc clean lengths")) return PA_ERR_HIP;
+    for (int i = 0; i < 2; ++i)
+        if (!chk(hipMalloc(&h->d_g[i], h->max_subs * sizeof(uint32_t)), "hipMalloc states")) return PA_ERR_HIP;
+    if (!chk(hipMalloc(&h->d_used, h->max_subs * sizeof(uint32_t)), "hipMalloc states")) return PA_ERR_HIP;
+    if (!chk(hipMalloc(&h->d_cnt, h->max_subs * sizeof(SubCnt)), "hipMalloc counts")) return PA_ERR_HIP;
+    if (!chk(hipMalloc(&h->d_entry, h->max_subs * sizeof(SubCnt)), "hipMalloc entries")) return PA_ERR_HIP;
+    if (!chk(hipMalloc(&h->d_changed, (MAX_ROUNDS + 1) * n * sizeof(int32_t)), "hipMalloc flags")) return PA_ERR_HIP;
     if (!chk(hipMalloc(&h->d_coef, n * h->max_blocks * 64 * sizeof(int16_t)), "hipMalloc coefficients")) return PA_ERR_HIP;
     if (!chk(hipMalloc(&h->d_planes, n * h->max_blocks * 64), "hipMalloc sample planes")) return PA_ERR_HIP;
     if (!chk(hipMalloc(&h->d_status, n * sizeof(int32_t)), "hipMalloc status")) return PA_ERR_HIP;
     if (!chk(hipMemset(h->d_bits, 0, max_bytes + 64), "hipMemset")) return PA_ERR_HIP;
+    if (!chk(hipMemset(h->d_clean, 0, clean_bytes), "hipMemset")) return PA_ERR_HIP;
     for (int i = 0; i < 2; ++i) {
         if (!chk(hipHostMalloc(&h->h_fd[i], n * sizeof(FrameDesc)), "hipHostMalloc")) return PA_ERR_HIP;
         if (!chk(hipHostMalloc(&h->h_ts[i], n * sizeof(TableSet)), "hipHostMalloc")) return PA_ERR_HIP;
         if (!chk(hipEventCreateWithFlags(&h->staged[i], hipEventDisableTiming), "hipEventCreate")) return PA_ERR_HIP;
     }
+    if (!chk(hipHostMalloc(&h->h_flag, n * sizeof(int32_t)), "hipHostMalloc")) return PA_ERR_HIP;
     return PA_OK;
 }
+
+int pa_mjpeg_set_sync_rounds(pa_mjpeg* h, int32_t rounds) {
+    if (!h || rounds < 0 || rounds > MAX_ROUNDS) return PA_ERR_INVALID_ARG;
+    h->sync_rounds = rounds;
+    return PA_OK;
+}
+
+int pa_mjpeg_last_sync_rounds(const pa_mjpeg* h) { return h ? h->last_rounds : 0; }
 
 int pa_mjpeg_decode(pa_mjpeg* h, const uint8_t* data_host, const int64_t* spans_host, int32_t n, int32_t height, int32_t width,
                     int32_t rgb, uint8_t* frames_dev, int32_t* status_dev, void* stream) {
@@ -722,8 +966,10 @@ int pa_mjpeg_decode(pa_mjpeg* h, const uint8_t* data_host, const int64_t* spans_
     Geom g;
     memset(&g, 0, sizeof g);
     Parsed first, prev, cur;
-    int n_sets = 0, int_total = 0;
+    int n_sets = 0;
+    size_t seg_total = 0, sub_total = 0, clean_total = 0;
     uint32_t max_scan = 0;
+    int max_sub = 1;
     for (int f = 0; f < n; ++f) {
         const int64_t o = spans_host[2 * f], e = spans_host[2 * f + 1];
         const char* msg = parse_header(data_host + o, (size_t)(e - o), cur);
@@ -777,32 +1023,57 @@ int pa_mjpeg_decode(pa_mjpeg* h, const uint8_t* data_host, const int64_t* spans_
                            memcmp(cur.syms, prev.syms, sizeof cur.syms) == 0 && memcmp(cur.hdef, prev.hdef, sizeof cur.hdef) == 0;
         if (!share) {
             TableSet& T = ts[n_sets++];
-            for (int t = 0; t < 4; ++t) {
-                if (cur.hdef[t]) build_hufftab(T.h[t], cur.counts[t], cur.syms[t]);
-                else memset(&T.h[t], 0, sizeof(HuffTab));
-            }
+            memset(&T.h, 0, sizeof T.h);
+            int pool = 0;
+            for (int t = 0; t < 4; ++t)
+                if (cur.hdef[t]) build_hufftab(T.h, t, cur.counts[t], cur.syms[t], pool);
             memcpy(T.q, cur.q, sizeof T.q);
         }
         prev = cur;
         FrameDesc& d = fd[f];
         memset(&d, 0, sizeof d);
+        // the entropy-coded segment ends in front of the EOI marker (fill bytes / container padding may follow it)
+        int64_t end = e;
+        while (end - o > (int64_t)cur.scan_off + 2 && !(data_host[end - 2] == 0xff && data_host[end - 1] == 0xd9) && e - end < 16) --end;
+        if (data_host[end - 2] == 0xff && data_host[end - 1] == 0xd9) end -= 2; else end = e;
         d.scan_off = (uint32_t)(o - base + (int64_t)cur.scan_off);
-        d.scan_len = (uint32_t)((e - o) - (int64_t)cur.scan_off);
+        d.scan_len = (uint32_t)((end - o) - (int64_t)cur.scan_off);
         d.ri = cur.ri;
         const int mcus = g.mcus_x * g.mcus_y;
         d.n_int = cur.ri ? (mcus + cur.ri - 1) / cur.ri : 1;
-        d.int_base = int_total;
-        int_total += d.n_int;
+        d.seg_base = (int32_t)seg_total;
+        seg_total += (size_t)d.n_int;
+        d.sub_base = (int32_t)sub_total;
+
+        d.clean_off = (uint32_t)clean_total;
+        clean_total += ((size_t)d.scan_len + 31) & ~(size_t)15;
         d.tabset = n_sets - 1;
         for (int c = 0; c < cur.ncomp; ++c) {
             d.td[c] = (uint8_t)cur.td[c]; d.ta[c] = (uint8_t)cur.ta[c]; d.tq[c] = (uint8_t)cur.tq[c];
         }
         max_scan = d.scan_len > max_scan ? d.scan_len : max_scan;
     }
+    // subsequence size: about eight MCUs of the stream, a power of two (measured: at 1080p / quality 95 the slowest lanes
+    // need about ten MCUs to fall into step; scripts/mjpeg_sync_probe.py)
+    {
+        size_t bytes = 0;
+        for (int f = 0; f < n; ++f) bytes += fd[f].scan_len;
+        const size_t per_mcu = bytes / ((size_t)n * g.mcus_x * g.mcus_y) + 1;
+        int sh = 7;
+        while ((1u << sh) < 8 * per_mcu && sh < 13) ++sh;
+        if (h->sub_shift_override >= 7 && h->sub_shift_override <= 13) sh = h->sub_shift_override;
+        g.sub_shift = sh;
+        for (int f = 0; f < n; ++f) {
+            FrameDesc& d = fd[f];
+            d.sub_base = (int32_t)sub_total;
+            d.n_sub_cap = (int32_t)(((d.scan_len + (1u << sh) - 1) >> sh) + 1);
+            sub_total += (size_t)d.n_sub_cap;
+            max_sub = d.n_sub_cap > max_sub ? d.n_sub_cap : max_sub;
+        }
+    }
     const int max_chunks = (int)(max_scan / CHUNK) + 2;
     if (max_chunks > h->max_chunks_cap) return bad(PA_ERR_CAPACITY, "pa_mjpeg_decode: scan longer than the handle's chunk table");
-    int max_int = 1;
-    for (int f = 0; f < n; ++f) max_int = fd[f].n_int > max_int ? fd[f].n_int : max_int;
+    if (seg_total > h->max_segs || sub_total > h->max_subs) return bad(PA_ERR_CAPACITY, "pa_mjpeg_decode: more restart intervals / subsequences than the handle holds");
     if (!chk(hipMemcpyAsync(h->d_bits, data_host + base, (size_t)total, hipMemcpyHostToDevice, s), "upload bitstream")) return PA_ERR_HIP;
     if (!chk(hipMemsetAsync(h->d_bits + total, 0, 64, s), "pad bitstream")) return PA_ERR_HIP;
     if (!chk(hipMemcpyAsync(h->d_fd, fd, (size_t)n * sizeof(FrameDesc), hipMemcpyHostToDevice, s), "upload descriptors")) return PA_ERR_HIP;
@@ -810,16 +1081,50 @@ int pa_mjpeg_decode(pa_mjpeg* h, const uint8_t* data_host, const int64_t* spans_
     if (!chk(hipEventRecord(h->staged[k], s), "hipEventRecord")) return PA_ERR_HIP;
     h->staged_used[k] = true;
     if (!chk(hipMemsetAsync(h->d_status, 0, (size_t)n * sizeof(int32_t), s), "clear status")) return PA_ERR_HIP;
+    if (!chk(hipMemsetAsync(h->d_changed, 0, (size_t)(MAX_ROUNDS + 1) * h->max_frames * sizeof(int32_t), s), "clear flags")) return PA_ERR_HIP;
     if (!chk(hipMemsetAsync(h->d_coef, 0, (size_t)n * g.blocks_per_frame * 64 * sizeof(int16_t), s), "clear coefficients")) return PA_ERR_HIP;
-    bool any_ri = false;
-    for (int f = 0; f < n; ++f) any_ri = any_ri || fd[f].ri != 0;
-    if (any_ri) {
-        hipLaunchKernelGGL(rst_count_kernel, dim3(max_chunks, n), dim3(256), 0, s, h->d_bits, h->d_fd, h->d_chunk, max_chunks);
-        hipLaunchKernelGGL(rst_write_kernel, dim3(max_chunks, n), dim3(256), 0, s, h->d_bits, h->d_fd, h->d_chunk, max_chunks, h->d_rst,
-                           h->d_status);
+    hipLaunchKernelGGL(unstuff_count_kernel, dim3(max_chunks, n), dim3(256), 0, s, h->d_bits, h->d_fd, h->d_chunk, max_chunks);
+    hipLaunchKernelGGL(unstuff_write_kernel, dim3(max_chunks, n), dim3(256), 0, s, h->d_bits, h->d_fd, h->d_chunk, max_chunks, h->d_clean,
+                       h->d_seg, h->d_clean_len, h->d_status);
+    const dim3 sgrid((max_sub + WG_SUBS - 1) / WG_SUBS, n);
+    int cur_g = 0;
+    hipLaunchKernelGGL((sub_decode_kernel<0>), sgrid, dim3(256), 0, s, h->d_clean, h->d_fd, h->d_ts, h->d_seg, h->d_clean_len, g,
+                       (const uint32_t*)nullptr, h->d_g[0], h->d_used, h->d_cnt, (const SubCnt*)nullptr, (int16_t*)nullptr, h->d_status,
+                       (int32_t*)nullptr, (const int32_t*)nullptr);
+    auto verify = [&](int slot, int prev_slot) {
+        int32_t* flag = h->d_changed + (size_t)slot * h->max_frames;
+        const int32_t* prev = prev_slot >= 0 ? h->d_changed + (size_t)prev_slot * h->max_frames : nullptr;
+        hipLaunchKernelGGL((sub_decode_kernel<1>), sgrid, dim3(256), 0, s, h->d_clean, h->d_fd, h->d_ts, h->d_seg, h->d_clean_len, g,
+                           h->d_g[cur_g], h->d_g[cur_g ^ 1], h->d_used, h->d_cnt, (const SubCnt*)nullptr, (int16_t*)nullptr, h->d_status, flag,
+                           prev);
+        cur_g ^= 1;
+    };
+    int last_slot = MAX_ROUNDS;  // an all-zero row unless a verify pass wrote it
+    if (h->sync_rounds > 0) {
+        for (int r = 0; r < h->sync_rounds; ++r) verify(r, r - 1);
+        last_slot = h->sync_rounds - 1;
+        h->last_rounds = h->sync_rounds;
+    } else {
+        // exact mode: verify until a pass changes nothing, looking at the flags on the host (synchronises the stream)
+        int rounds = 0;
+        for (;;) {
+            if (!chk(hipMemsetAsync(h->d_changed, 0, (size_t)h->max_frames * sizeof(int32_t), s), "clear flags")) return PA_ERR_HIP;
+            verify(0, -1);
+            ++rounds;
+            if (!chk(hipMemcpyAsync(h->h_flag, h->d_changed, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s), "read flags")) return PA_ERR_HIP;
+            if (!chk(hipStreamSynchronize(s), "hipStreamSynchronize")) return PA_ERR_HIP;
+            bool any = false;
+            for (int f = 0; f < n; ++f) any = any || h->h_flag[f] != 0;
+            if (!any) break;
+            if (rounds > max_sub + 2) return bad(PA_ERR_HIP, "pa_mjpeg_decode: synchronisation did not settle");
+        }
+        last_slot = 0;
+        h->last_rounds = rounds;
     }
-    hipLaunchKernelGGL(huff_kernel, dim3((max_int + 63) / 64, n), dim3(64), 0, s, h->d_bits, h->d_fd, h->d_ts, h->d_rst, g, h->d_coef,
-                       h->d_status);
+    hipLaunchKernelGGL(sub_scan_kernel, dim3(n), dim3(1024), 0, s, h->d_fd, h->d_clean_len, h->d_cnt, h->d_entry, g.sub_shift);
+    hipLaunchKernelGGL((sub_decode_kernel<2>), sgrid, dim3(256), 0, s, h->d_clean, h->d_fd, h->d_ts, h->d_seg, h->d_clean_len, g,
+                       h->d_g[cur_g], (uint32_t*)nullptr, h->d_used, h->d_cnt, h->d_entry, h->d_coef, h->d_status, (int32_t*)nullptr,
+                       h->d_changed + (size_t)last_slot * h->max_frames);
     const long long nblk = (long long)n * g.blocks_per_frame;
     hipLaunchKernelGGL(idct_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, s, h->d_coef, h->d_fd, h->d_ts, g, h->d_planes, n);
     const int fv = g.ncomp == 3 ? g.fv : 1, fhh = g.ncomp == 3 ? g.fh : 1;
@@ -830,7 +1135,6 @@ int pa_mjpeg_decode(pa_mjpeg* h, const uint8_t* data_host, const int64_t* spans_
     if (status_dev && !chk(hipMemcpyAsync(status_dev, h->d_status, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, s), "copy status"))
         return PA_ERR_HIP;
     if (!chk(hipGetLastError(), "kernel launch")) return PA_ERR_HIP;
-    h->last_height = height; h->last_width = width;
     return PA_OK;
 }
 

@@ -209,6 +209,19 @@ class MjpegDecoder:
         except Exception:
             pass
 
+    def set_sync_rounds(self, rounds: int):
+        """Verify passes of the self-synchronising entropy decoder: 1..8 enqueued blindly (default 3; a frame that has
+        not settled gets status bit 8), 0 = repeat until settled (one stream synchronisation per pass)."""
+        from . import _lib
+        from .engine import EngineError
+
+        rc = self._lib.pa_mjpeg_set_sync_rounds(self._h, int(rounds))
+        if rc != _lib.PA_OK:
+            raise EngineError(rc, "sync rounds must be 0..8")
+
+    def last_sync_rounds(self) -> int:
+        return int(self._lib.pa_mjpeg_last_sync_rounds(self._h))
+
     def decode(self, data, spans, height: int, width: int, out=None, status=None, rgb: bool = False):
         """``data``: the compressed bytes, a uint8 numpy array or CPU torch tensor (pin it for an asynchronous copy);
         ``spans`` int64[n, 2] = (start, end) of every frame's JPEG file in ``data``, or int64[n + 1] offsets of

@@ -1,0 +1,52 @@
+"""Decode rate of pa_mjpeg_decode on one GPU: 64-frame 1080p clips, compressed bytes in pinned host memory.
+usage: python scripts/mjpeg_rate.py [--frames 64] [--quality 95] [--height 1080 --width 1920] [--variants none,rows1,blk8]"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from playaid_core_amd import synth, video  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--frames", type=int, default=64)
+ap.add_argument("--quality", type=int, default=95)
+ap.add_argument("--height", type=int, default=1080)
+ap.add_argument("--width", type=int, default=1920)
+ap.add_argument("--variants", default="none,rows1,blk30,blk8,blk2")
+ap.add_argument("--reps", type=int, default=10)
+args = ap.parse_args()
+n, h, w = args.frames, args.height, args.width
+frames = synth.make_frames_torch(n, h, w, device="cuda").cpu().numpy()
+for var in args.variants.split(","):
+    kw = {}
+    if var.startswith("rows"):
+        kw["restart_marker_rows"] = int(var[4:])
+    elif var.startswith("blk"):
+        kw["restart_marker_blocks"] = int(var[3:])
+    t0 = time.time()
+    blobs = synth.encode_jpeg_frames(frames, quality=args.quality, **kw)
+    enc_s = time.time() - t0
+    sizes = np.array([len(b) for b in blobs])
+    ends = np.cumsum(sizes)
+    spans = np.stack([ends - sizes, ends], axis=1)
+    data = torch.from_numpy(np.frombuffer(b"".join(blobs), np.uint8).copy()).pin_memory()
+    dec = video.MjpegDecoder(n, h, w, int(ends[-1]) + 4096)
+    out = torch.empty((n, h, w, 3), dtype=torch.uint8, device="cuda")
+    st = torch.zeros(n, dtype=torch.int32, device="cuda")
+    dec.decode(data, spans, h, w, out=out, status=st)
+    torch.cuda.synchronize()
+    assert int(st.abs().sum()) == 0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.reps):
+        dec.decode(data, spans, h, w, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / args.reps
+    print(f"{var:8s} q{args.quality} {sizes.mean() / 1e6:.3f} MB/frame  {ms:.3f} ms per {n} frames = {n / ms * 1e3:.0f} frames/s "
+          f"({ends[-1] / ms / 1e6:.2f} GB/s compressed; host encode {enc_s / n * 1e3:.1f} ms/frame)", flush=True)
+    dec.close()
