@@ -140,6 +140,81 @@ def pcie_inclusive(eng, frames_dev, boxes_dev, steps=8):
     }
 
 
+def decode_inclusive(eng, frames_dev, boxes_dev, steps=8, quality=95, restart_blocks=0):
+    """decode -> labels: the clip as a Motion-JPEG stream (one baseline JPEG per frame, written by libjpeg-turbo at
+    OpenCV's defaults: quality 95, 4:2:0) in pinned HOST memory; per clip the compressed bytes cross PCIe and are decoded
+    on the device (pa_mjpeg_decode: un-stuffing, self-synchronising Huffman decoding, IDCT, up-sampling, colour
+    conversion) on a side stream into one of two frame buffers while the previous clip runs crops + CNN + head. Replaces
+    cv2.VideoCapture.read (ai_runner.py:153,404-405). Reported beside `value`, never as it."""
+    from playaid_core_amd import video
+
+    dev = eng.device
+    n, h, w, _ = frames_dev.shape
+    t0 = time.perf_counter()
+    kw = {"restart_marker_blocks": restart_blocks} if restart_blocks else {}
+    blobs = synth.encode_jpeg_frames(frames_dev.cpu().numpy(), quality=quality, **kw)
+    enc_s = time.perf_counter() - t0
+    sizes = np.array([len(b) for b in blobs], dtype=np.int64)
+    ends = np.cumsum(sizes)
+    spans = np.stack([ends - sizes, ends], axis=1)
+    data = torch.from_numpy(np.frombuffer(b"".join(blobs), np.uint8).copy()).pin_memory()
+    decs = [video.MjpegDecoder(n, h, w, int(ends[-1]) + 4096, device=str(dev)) for _ in range(2)]
+    bufs = [torch.empty_like(frames_dev), torch.empty_like(frames_dev)]
+    st = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(2)]
+    rec = eng.alloc_records(n - 1)
+    side, main = torch.cuda.Stream(dev), torch.cuda.current_stream(dev)
+    ready = [torch.cuda.Event(), torch.cuda.Event()]
+    free = [torch.cuda.Event(), torch.cuda.Event()]
+
+    def run(k_steps, compute=True):
+        for e in free:
+            e.record(main)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for k in range(k_steps + 1):
+            if k < k_steps:
+                with torch.cuda.stream(side):
+                    side.wait_event(free[k & 1])
+                    decs[k & 1].decode(data, spans, h, w, out=bufs[k & 1], status=st[k & 1])
+                    ready[k & 1].record(side)
+            if k > 0:
+                j = (k - 1) & 1
+                main.wait_event(ready[j])
+                if compute:
+                    eng.infer_clip_device(bufs[j], boxes_dev, rec)
+                free[j].record(main)
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / k_steps
+
+    try:
+        run(2)
+        bad = int(sum(int((s != 0).sum()) for s in st))
+        dt = run(steps)
+        dt_dec = run(steps, compute=False)
+        psnr = None
+        if bad == 0:
+            d = (bufs[0][:4].float() - frames_dev[:4].float())
+            psnr = round(float(10 * torch.log10(255.0 ** 2 / (d * d).mean())), 2)
+    finally:
+        for d_ in decs:
+            d_.close()
+    return {
+        "value": round(n / dt, 1),
+        "unit": "frames/s",
+        "ms_per_clip": round(dt * 1e3, 3),
+        "decode_only_frames_per_s": round(n / dt_dec, 1),
+        "decode_only_ms_per_clip": round(dt_dec * 1e3, 3),
+        "compressed_MB_per_clip": round(float(ends[-1]) / 1e6, 2),
+        "compressed_MB_per_frame": round(float(sizes.mean()) / 1e6, 3),
+        "jpeg": {"quality": quality, "subsampling": "4:2:0", "restart_interval_mcus": restart_blocks or None,
+                 "encoder": "libjpeg-turbo via Pillow (host, outside the timed region)", "host_encode_ms_per_frame": round(enc_s / n * 1e3, 1),
+                 "psnr_vs_raw_dB": psnr},
+        "frames_with_decode_errors": bad,
+        "method": f"{steps} clips; compressed frames in pinned host memory; H2D copy + device Motion-JPEG decode of clip k+1 on a "
+        "side stream (two frame buffers) under crops + CNN + head of clip k on the decoded frames",
+    }
+
+
 def pcie_inclusive_windows(eng, frames_dev, boxes_dev, steps=8):
     """PCIe-inclusive again, but only the crops' source slices cross the link (pa_upload_crop_windows: ~0.42 MB per
     1080p crop instead of 6.2 MB per frame), double buffered like above."""
@@ -321,6 +396,9 @@ def main():
     ap.add_argument("--cpu-sample-frames", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive side measurement")
+    ap.add_argument("--no-decode", action="store_true", help="skip the decode-inclusive (Motion-JPEG) side measurement")
+    ap.add_argument("--jpeg-quality", type=int, default=95, help="decode_inclusive: quality of the synthetic Motion-JPEG clip (OpenCV's default)")
+    ap.add_argument("--jpeg-restart-blocks", type=int, default=0, help="decode_inclusive: restart interval in MCUs (0 = none, like OpenCV / FFmpeg writers)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse ranks > GPUs)")
     ap.add_argument("--no-pipeline", action="store_true", help="crop stage and backbone on one stream (no overlap across steps)")
@@ -562,6 +640,12 @@ def main():
         if world == 1 and not long_clip and not args.no_pcie:
             result["pcie_inclusive"] = pcie_inclusive(eng, frames[:n_clip], boxes[:n_clip])
             result["pcie_inclusive_windows"] = pcie_inclusive_windows(eng, frames[:n_clip], boxes[:n_clip])
+            if not args.no_decode:
+                try:
+                    result["decode_inclusive"] = decode_inclusive(eng, frames[:n_clip], boxes[:n_clip], quality=args.jpeg_quality,
+                                                                  restart_blocks=args.jpeg_restart_blocks)
+                except Exception as exc:  # a side measurement must never cost the line its headline
+                    result["decode_inclusive"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not long_clip and kb == 1 and not args.no_pcie and not args.no_pipeline and args.clip_batch_side > 1:
             try:
                 result["clip_batches"] = clip_batch_side(eng, n_clip, args.clip_batch_side, args.height, args.width, S, DELTA, max(args.lanes, 1))

@@ -9,11 +9,14 @@ argument meaning, 1-indexed frame numbers and result layout.
 What differs, and why:
 
 * Input. The reference opens a video with OpenCV and shells out to a YOLOv5
-  checkout (``:153,191-224``); neither exists in this build (SURVEY.md section
-  8c). ``input_video_path`` here names a clip archive (``.npz`` with ``frames``
+  checkout (``:153,191-224``). ``input_video_path`` here names a Motion-JPEG
+  video (``.avi`` / ``.mjpeg`` / a directory of ``.jpg`` frames), which is decoded on
+  the device (``video.py``, ``pa_mjpeg_decode``; the detector's label files are
+  read from ``<output_dir>/labels/<video>_<n>.txt`` where ``detect.py --save-txt
+  --save-conf`` leaves them), or a clip archive (``.npz`` with ``frames``
   uint8[N,H,W,3] BGR and ``labels``: one YOLO text block per frame, lines
-  ``"cls cx cy w h conf"`` exactly as ``detect.py --save-txt --save-conf``
-  writes them) or is a ``ClipSource`` already in memory.
+  ``"cls cx cy w h conf"``), or is a ``ClipSource`` already in memory. Other
+  codecs (H.264 ...) need a decoder this stack does not have.
 * Work. Crops, backbone, head and argmax run on the MI355X for the whole clip
   at once (each crop through ResNet-18 once, not once per window);
   ``action_recognition`` then serves single (frame, fighter) queries from
@@ -68,7 +71,8 @@ class ClipSource:
         ``cv2.imread``), any size, or None where the detector saved none. With them the runner takes the
         reference's own input branch (``ai_runner.py:446-459``) from the images instead of cutting crops from
         ``frames``; ``frames`` may then be an empty ``uint8[n, 0, 0, 3]`` array."""
-        assert frames.ndim == 4 and frames.shape[3] == 3 and frames.dtype == np.uint8
+        # frames: uint8[n, H, W, 3] BGR, a numpy array or a tensor already in HBM (a decoded video stays where it was decoded)
+        assert frames.ndim == 4 and frames.shape[3] == 3 and str(frames.dtype).endswith("uint8")
         assert len(labels) == frames.shape[0]
         assert crop_images is None or len(crop_images) == len(labels)
         self.frames = frames
@@ -76,14 +80,59 @@ class ClipSource:
         self.name = name
         self.crop_images = crop_images
 
+    VIDEO_EXTENSIONS = (".avi", ".mjpeg", ".mjpg")
+
     @classmethod
-    def load(cls, path: str) -> "ClipSource":
+    def load(cls, path: str, labels_dir: str = None) -> "ClipSource":
+        """``.npz`` clip archive, or a video the device can decode (Motion-JPEG ``.avi`` / ``.mjpeg`` or a directory of
+        ``.jpg`` frames, ``playaid_core_amd/video.py``) plus the detector's label files."""
+        if os.path.isdir(path) or path.lower().endswith(cls.VIDEO_EXTENSIONS):
+            return cls.from_video(path, labels_dir)
         z = np.load(path, allow_pickle=False)
         name = os.path.splitext(os.path.basename(path))[0]
         return cls(z["frames"], [str(s) for s in z["labels"]], name)
 
+    @classmethod
+    def from_video(cls, path: str, labels_dir: str = None, labels: List[str] = None, batch_frames: int = 64) -> "ClipSource":
+        """What the reference does with ``cv2.VideoCapture(input_video_path)`` + the YOLOv5 output directory
+        (``ai_runner.py:153,156-159``): every frame decoded ON THE DEVICE (``video.VideoCapture.read_frames``; the
+        frames stay in HBM), the label text of frame n (1-indexed) read from ``<labels_dir>/<video>_<n>.txt``
+        (default ``<AI_CACHE>/<video>/labels``, where ``detect.py --save-txt`` puts it; a frame without detections
+        has no file, ``:255-262``)."""
+        import torch
+
+        from . import video
+
+        name = os.path.splitext(os.path.basename(os.path.normpath(path)))[0]
+        cap = video.VideoCapture(path, batch_frames=batch_frames)
+        if not cap.isOpened():
+            raise FileNotFoundError(f"cannot open {path} as a Motion-JPEG stream")
+        n = cap.frame_count()
+        frames = torch.empty((n, cap.height, cap.width, 3), dtype=torch.uint8, device=cap._device)
+        status = torch.zeros(n, dtype=torch.int32, device=cap._device)
+        for j0 in range(0, n, batch_frames):
+            cnt = min(batch_frames, n - j0)
+            cap.read_frames(j0, cnt, out=frames[j0:j0 + cnt], status=status[j0:j0 + cnt])
+        torch.cuda.synchronize()
+        bad = torch.nonzero(status).flatten().tolist()
+        for j in bad:  # a frame whose decoder states had not settled in the enqueued passes: decode it again, exactly
+            cap.read_frames(j, 1, out=frames[j:j + 1], status=status[j:j + 1], exact=True)
+        torch.cuda.synchronize()
+        still = torch.nonzero(status).flatten().tolist()
+        cap.release()
+        if still:
+            raise ValueError(f"{path}: frame {still[0] + 1} does not decode (status {int(status[still[0]])})")
+        if labels is None:
+            labels_dir = labels_dir or os.path.join(constants.AI_CACHE, name, "labels")
+            labels = []
+            for i in range(n):
+                fp = os.path.join(labels_dir, f"{name}_{i + 1}.txt")
+                labels.append(open(fp).read() if os.path.exists(fp) else "")
+        return cls(frames, labels, name)
+
     def save(self, path: str):
-        np.savez(path, frames=self.frames, labels=np.array(self.labels))
+        frames = self.frames if isinstance(self.frames, np.ndarray) else self.frames.cpu().numpy()
+        np.savez(path, frames=frames, labels=np.array(self.labels))
 
     @classmethod
     def synthetic(cls, n: int, height: int, width: int, seed: int = 7, name: str = "synthetic") -> "ClipSource":
@@ -133,7 +182,14 @@ class AIRunner:
         read on the device (``pa_set_crop_jpeg_quality``); 0 opts out and feeds the exact resampler output, which
         differs from what the reference's CNN sees by more than 1e-3 on the log-probabilities. Crop IMAGES handed in
         through ``ClipSource.crop_images`` are decoded JPEGs already and are never re-coded."""
-        self.clip = input_video_path if isinstance(input_video_path, ClipSource) else ClipSource.load(input_video_path)
+        if isinstance(input_video_path, ClipSource):
+            self.clip = input_video_path
+        else:
+            # a video (decoded on the device) finds its detector output where the reference's run_yolo leaves it:
+            # <yolo_output_dir>/labels/<video>_<n>.txt (ai_runner.py:156-159, 191-224)
+            name = os.path.splitext(os.path.basename(os.path.normpath(input_video_path)))[0]
+            ydir = output_dir or os.path.join(constants.AI_CACHE, name)
+            self.clip = ClipSource.load(input_video_path, labels_dir=os.path.join(ydir, "labels"))
         self.input_video_path = getattr(input_video_path, "name", input_video_path)
         self.video_name = self.clip.name
         self.dataset_args = dataset_args

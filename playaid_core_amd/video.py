@@ -178,6 +178,8 @@ def jpeg_frame_size(buf: np.ndarray) -> Tuple[int, int]:
 class MjpegDecoder:
     """``pa_mjpeg_create`` / ``pa_mjpeg_decode``: compressed frames in (pinned) host memory -> uint8[n,H,W,3] in HBM."""
 
+    DEFAULT_SYNC_ROUNDS = 8
+
     def __init__(self, max_frames: int, max_height: int, max_width: int, max_bytes: int, device: str = "cuda:0"):
         import torch
 
@@ -336,9 +338,14 @@ class VideoCapture:
         None)`` past the end (``ai_runner.py:405-415`` handles exactly that)."""
         if not self._opened or not 0 <= self._pos < len(self._spans):
             return False, None
-        fr = self.read_frames(self._pos, 1)
+        st = self._torch.zeros(1, dtype=self._torch.int32, device=self._device)
+        fr = self.read_frames(self._pos, 1, status=st)
+        if int(st[0]) & 8:  # decoder states not settled in the enqueued passes (long flat areas): decode exactly
+            fr = self.read_frames(self._pos, 1, status=st, exact=True)
         self._torch.cuda.synchronize(fr.device)
         self._pos += 1
+        if int(st[0]):
+            return False, None  # a frame that does not decode reads as a failed read (ai_runner.py:405-415 copes with it)
         return True, fr[0].cpu().numpy()
 
     def release(self):
@@ -362,12 +369,20 @@ class VideoCapture:
             self._dec = MjpegDecoder(cap_n, self.height, self.width, max(nbytes, cap_n * per_frame) + 4096, self._device)
         return self._dec
 
-    def read_frames(self, j0: int, n: int, out=None, status=None, rgb: bool = False):
-        """Frames ``j0 .. j0 + n - 1`` -> device tensor uint8[n, H, W, 3] (BGR), enqueued on the current stream."""
+    def read_frames(self, j0: int, n: int, out=None, status=None, rgb: bool = False, exact: bool = False):
+        """Frames ``j0 .. j0 + n - 1`` -> device tensor uint8[n, H, W, 3] (BGR), enqueued on the current stream.
+        ``exact``: run the entropy decoder's verify passes until nothing changes (synchronises the stream; for frames that
+        came back with status bit 8)."""
         if not self._opened:
             raise VideoError("capture is not open")
         if not (0 <= j0 and j0 + n <= len(self._spans) and n >= 1):
             raise IndexError(f"frames {j0}..{j0 + n - 1} outside the stream's {len(self._spans)}")
         sp = self._spans[j0:j0 + n]
         dec = self._decoder(n, int(sp[:, 1].max() - sp[:, 0].min()))
-        return dec.decode(self._data, sp, self.height, self.width, out=out, status=status, rgb=rgb)
+        if exact:
+            dec.set_sync_rounds(0)
+        try:
+            return dec.decode(self._data, sp, self.height, self.width, out=out, status=status, rgb=rgb)
+        finally:
+            if exact:
+                dec.set_sync_rounds(MjpegDecoder.DEFAULT_SYNC_ROUNDS)

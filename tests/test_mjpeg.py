@@ -218,3 +218,77 @@ def test_videocapture_mirror_over_an_avi(tmp_path, decoder):
     cap = video.VideoCapture(str(d))
     assert cap.frame_count() == 3 and cap.read()[0]
     cap.release()
+
+
+@pytest.mark.gpu
+def test_airunner_from_a_video_file(tmp_path, state_dict):
+    """Rows a1 + b2 together: AIRunner(<video>.avi) -- frames decoded on the device, label files where run_yolo leaves them --
+    writes the same ai_output.yaml as the runner fed with the ORACLE's decode of the same JPEG files."""
+    import yaml
+
+    from oracle import jpeg
+    from playaid_core_amd.ai_runner import AIRunner, ClipSource
+    from playaid_core_amd.anim_ontology import MOVE_TO_CLASS_ID
+    from playaid_core_amd.cnn_action_detector import CNNActionDetector
+
+    n, h, w = 20, 720, 1280
+    synth_clip = ClipSource.synthetic(n, h, w)
+    blobs = synth.encode_jpeg_frames(synth_clip.frames, quality=95)
+    out_dir = tmp_path / "ai_cache" / "match"
+    os.makedirs(out_dir / "labels")
+    for i, text in enumerate(synth_clip.labels):
+        open(out_dir / "labels" / f"match_{i + 1}.txt", "w").write(text)
+    path = str(tmp_path / "match.avi")
+    video.write_avi_mjpeg(path, blobs, 60.0, w, h)
+    ckpt = str(tmp_path / "seeded.ckpt")
+    synth.save_checkpoint(ckpt, seed=1234)
+    model = CNNActionDetector.load_from_checkpoint(ckpt, actions=list(MOVE_TO_CLASS_ID.keys()), max_batch_frames=32,
+                                                   max_clip_frames=64, max_frame_height=h, max_frame_width=w)
+    runner = AIRunner(path, model=model, output_dir=str(out_dir))
+    assert runner.video_name == "match" and runner.max_frames == n and runner.clip.frames.is_cuda
+    runner.run_action_recognition()
+    runner.write_output()
+    decoded = np.stack([jpeg.decode_bgr(b) for b in blobs])
+    assert np.array_equal(runner.clip.frames.cpu().numpy(), decoded)
+    ref = AIRunner(ClipSource(decoded, synth_clip.labels, name="ref"), model=model, output_dir=str(tmp_path / "ref"))
+    ref.run_action_recognition()
+    ref.write_output()
+    a, b = yaml.safe_load(open(runner.ai_output_file)), yaml.safe_load(open(ref.ai_output_file))
+    assert a == b and len(a["Joker"]) == n - 1
+    # the codec's loss is real: the raw frames give other log-probabilities
+    raw = AIRunner(synth_clip, model=model, output_dir=str(tmp_path / "raw"))
+    raw.run_action_recognition()
+    assert np.abs(raw._results["logp"] - runner._results["logp"]).max() > 1e-4
+
+
+@pytest.mark.gpu
+def test_flat_frames_need_the_exact_mode(decoder):
+    """Long runs of identical blocks (black bars) re-synchronise slowly: the enqueued verify passes may not settle, which the
+    status word says (bit 8), and the exact mode (verify until nothing changes) decodes the frame bit-exactly."""
+    import torch
+
+    from oracle import jpeg
+
+    h, w = 1080, 1920
+    flat = np.zeros((h, w, 3), np.uint8)
+    flat[: h // 2] = 40
+    flat[100:200, 300:900] = synth.make_frame(3, 100, 600)
+    blob = synth.encode_jpeg_frames([flat], quality=95)[0]
+    want = jpeg.decode_bgr(blob)
+    got, st = _decode(decoder, [blob], h, w)
+    if st[0] == 0:
+        assert np.array_equal(got[0], want)
+    else:
+        assert st[0] & 8
+    decoder.set_sync_rounds(0)
+    try:
+        got, st = _decode(decoder, [blob], h, w)
+        assert st[0] == 0 and np.array_equal(got[0], want) and decoder.last_sync_rounds() >= 1
+    finally:
+        decoder.set_sync_rounds(video.MjpegDecoder.DEFAULT_SYNC_ROUNDS)
+    # the capture mirror does that by itself
+    cap = video.VideoCapture([blob])
+    ok, fr = cap.read()
+    assert ok and np.array_equal(fr, want)
+    cap.release()
+    del torch
