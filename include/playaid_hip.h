@@ -312,6 +312,12 @@ const char* pa_mjpeg_last_error(const pa_mjpeg* h);
  * slowly and can need many). pa_mjpeg_last_sync_rounds: how many the last call ran. */
 int pa_mjpeg_set_sync_rounds(pa_mjpeg* h, int32_t rounds);
 int pa_mjpeg_last_sync_rounds(const pa_mjpeg* h);
+/* Diagnostics of the entropy decoder (scripts/mjpeg_rate.py): for pass kind m = 0 speculative, 1 verify, 2 final of the most
+ * recent call, out8_host[2m] = shader-clock cycles the first wave of the first frame spent in its symbol loop,
+ * out8_host[2m + 1] = (100 MHz wall ticks << 32) | symbols it walked; out8_host[8 + 2m] = cycles of those spent outside
+ * the straight-line symbol loop (ring top-ups, restart markers, general symbols), out8_host[9 + 2m] = how often it
+ * left that loop. out8_host holds 16 values. Synchronises the device. */
+int pa_mjpeg_debug_counters(unsigned long long* out8_host);
 int pa_mjpeg_decode(pa_mjpeg* h, const uint8_t* data_host, const int64_t* spans_host, int32_t n, int32_t height, int32_t width,
                     int32_t rgb, uint8_t* frames_dev, int32_t* status_dev, void* stream);
 

@@ -154,6 +154,7 @@ SYMBOLS = [
     ("pa_mjpeg_last_error", C.c_char_p, [_P]),
     ("pa_mjpeg_set_sync_rounds", C.c_int, [_P, C.c_int32]),
     ("pa_mjpeg_last_sync_rounds", C.c_int, [_P]),
+    ("pa_mjpeg_debug_counters", C.c_int, [_P]),
     ("pa_mjpeg_decode", C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
 ]
 

@@ -44,13 +44,15 @@ constexpr int WG_SUBS = 256;     // subsequences per workgroup
 enum { ERR_HUFF = 1, ERR_RST = 2, ERR_COEF = 4, ERR_SYNC = 8 };
 
 // Huffman tables as the decoder's lanes read them (LDS image = global layout). A 16-bit entry holds everything a symbol
-// needs: code length (bits 0-4), number of extra bits s (5-8), zero run r (9-12; 0 in the DC tables). Codes of up to LB
-// bits are found in lut1 directly; a longer code's first LB bits lead to a link entry (bit 15 + the index of a 64-entry
-// second-level table, indexed by the next 6 bits). Should the 64 second-level tables of the pool not suffice (a table
-// with hundreds of 11-bit codes) the entry stays 0 and the lane walks the canonical MAXCODE list instead.
+// needs: code length (bits 0-4), number of extra bits s (5-8), zero run r (9-12; 0 in the DC tables); 0 = no entry.
+// Codes of up to LB bits are found in lut1 under their first LB bits. Longer codes sit at the top of a canonical code
+// space: whenever they all start with six 1-bits (every table whose long codes fill less than 1/64 of the code space --
+// the standard tables, and what libjpeg's optimiser produces) they are found in lutB under bits 6..15, so both tables
+// are read at once and neither look-up waits for the other. A code in neither table leaves both entries 0 and the lane
+// walks the canonical MAXCODE list instead.
 struct HuffTables {
     uint16_t lut1[4][1 << LB];  // DC0, DC1, AC0, AC1
-    uint16_t lut2[64][64];
+    uint16_t lutB[4][1 << LB];
     int32_t maxcode[4][18];     // largest code of length l (-1: none); [17] = sentinel
     int32_t valoff[4][17];      // valptr[l] - mincode[l]
     uint8_t vals[4][256];
@@ -86,6 +88,9 @@ struct BlkInfo {  // huff_kernel: one block position of an MCU
     uint8_t vs, hs, dy, dx, tdc, tac, comp, pad;
 };
 static_assert(sizeof(BlkInfo) == 16, "one ds_read_b128");
+
+// diagnostics (pa_mjpeg_debug_counters): shader-clock cycles, 100 MHz wall ticks and symbols of one wave's symbol loop
+__device__ unsigned long long g_dbg[16];
 
 __constant__ uint8_t k_zigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
                                      41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
@@ -304,7 +309,9 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
     const uint32_t end_bits = min((uint32_t)(j + 1) << sh, clen) * 8;
     uint32_t bitpos = s_byte * 8 + (entry_st & 31);
     int b = (entry_st >> 5) & 15, z = (entry_st >> 9) & 63;
-    // this lane's ring: bytes [fill - 128, fill) of the stream, dword X at ring[(X & 31)]
+    const int bpm = g.blocks_per_mcu;
+    if (b >= bpm) b = 0;
+    // this lane's ring: bytes [fill - 128, fill) of the stream, most significant bit first; dword X at ring[X & 31]
     uint32_t* const my_ring = ring + tid * (RING_DW + 1);
     const uint8_t* const stream = clean + d.clean_off;
     uint32_t fill = s_byte;  // multiple of 16
@@ -313,7 +320,7 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
         while (fill + 16 <= ((bitpos >> 5) << 2) + 4 * RING_DW) {
             const uint4 v = *reinterpret_cast<const uint4*>(stream + fill);
             uint32_t* q = my_ring + ((fill >> 2) & (RING_DW - 1));
-            q[0] = __builtin_bswap32(v.x); q[1] = __builtin_bswap32(v.y);  // most significant bit first, as the codes read
+            q[0] = __builtin_bswap32(v.x); q[1] = __builtin_bswap32(v.y);
             q[2] = __builtin_bswap32(v.z); q[3] = __builtin_bswap32(v.w);
             fill += 16;
         }
@@ -337,150 +344,271 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
         absblk = e.blk & 0x7fffffff;
         dc0 = e.dc[0]; dc1 = e.dc[1]; dc2 = e.dc[2];
     }
-    const int bpm = g.blocks_per_mcu;
     int16_t* const frame_coef = coef + (size_t)f * g.blocks_per_frame * 64;
-    BlkInfo bi = binfo[b < bpm ? b : 0];
-    int16_t* blk = frame_coef;
-    int mx = 0, my = 0;
     const int total_blocks = g.mcus_x * g.mcus_y * bpm;
-    auto place = [&]() {  // MODE 2: raster address of block `absblk`
-        const int mcu = absblk / bpm;
-        my = mcu / g.mcus_x;
-        mx = mcu - my * g.mcus_x;
-        blk = frame_coef + ((size_t)bi.base + (size_t)(my * bi.vs + bi.dy) * bi.bx + mx * bi.hs + bi.dx) * 64;
+    // the current block of the MCU: Huffman tables (offsets of their lut1 rows), component, raster geometry
+    uint32_t tdc = 0, tac = 0;
+    int comp = 0, mx = 0, my = 0;
+    int bbase = 0, bbx = 0, bvs = 0, bhs = 0, bdy = 0, bdx = 0;
+    auto take_block = [&](const BlkInfo& bi) {
+        tdc = (uint32_t)bi.tdc << LB;
+        tac = (uint32_t)bi.tac << LB;
+        comp = bi.comp;
+        if (MODE == 2) {
+            bbase = bi.base; bbx = bi.bx; bvs = bi.vs; bhs = bi.hs; bdy = bi.dy; bdx = bi.dx;
+        }
     };
+    take_block(binfo[b]);
     if (MODE == 2 && active) {
         if (absblk % bpm != b) {  // the scan and the synchronised state disagree: corrupt stream
             err |= ERR_SYNC;
             active = false;
-        } else if (absblk >= total_blocks) {
-            active = false;  // padding after the last MCU
         } else {
-            place();
+            const int mcu = absblk / bpm;
+            my = mcu / g.mcus_x;
+            mx = mcu - my * g.mcus_x;
         }
     }
     uint32_t lim = min(nb_bits, end_bits);
-    for (int it = 0; __ballot(active); ++it) {
+    // bit buffer: the next nb bits of the stream at the top of buf (bitpos = 32 * dwi - nb), refilled a dword at a time
+    uint64_t buf = 0;
+    int nb = 0;
+    uint32_t dwi = 0;
+    auto reload = [&]() {
+        dwi = bitpos >> 5;
+        const uint32_t w0 = my_ring[dwi & (RING_DW - 1)], w1 = my_ring[(dwi + 1) & (RING_DW - 1)];
+        buf = (((uint64_t)w0 << 32) | w1) << (bitpos & 31);
+        nb = 64 - (int)(bitpos & 31);
+        dwi += 2;
+    };
+    const uint16_t* const lut1 = &T.lut1[0][0];
+    const uint16_t* const lutB = &T.lutB[0][0];
+    // what the lane hands on, captured when it reaches the end of its subsequence (it free-runs after that)
+    uint32_t x_state = 0;
+    int x_blk = 0, x_dc0 = 0, x_dc1 = 0, x_dc2 = 0;
+    bool gen = false, first = true;
+    const bool stamp = blockIdx.x == 0 && blockIdx.y == 0 && tid < 64;
+    const unsigned long long c0 = clock64(), w0t = wall_clock64();
+    int it = 0;
+    unsigned long long slow_cyc = 0;
+    int outer = 0;
+    while (__ballot(active)) {
+        const unsigned long long cs = clock64();
+        ++outer;
+        // ---- the slow step: ring top-up, restart markers, end of the subsequence, symbols the fast loop does not take
+        if (MODE == 2 && absblk >= total_blocks) active = false;  // what follows the last block is padding
         if (active) {
-            if ((it & (TOPUP - 1)) == 0) top_up();
+            top_up();
+            if (first) reload();
+            first = false;
             if (bitpos >= lim) {
+                gen = false;
                 if (bitpos >= nb_bits) {
                     // restart marker: byte aligned, block 0 of MCU nbk * ri, predictions zero (T.81 F.2.2.4 / E.2.4)
                     bitpos = nb_bits;
+                    reload();
                     b = 0; z = 0;
-                    bi = binfo[0];
+                    take_block(binfo[0]);
                     reset = 1;
                     nblk = 0;
                     dc0 = dc1 = dc2 = 0;
                     absblk = nbk * d.ri * bpm;
                     if (MODE == 2) {
-                        if (absblk >= total_blocks) active = false; else place();
+                        const int mcu = nbk * d.ri;
+                        my = mcu / g.mcus_x;
+                        mx = mcu - my * g.mcus_x;
                     }
                     ++nbk;
                     nb_bits = nbk < d.n_int ? seg_start[d.seg_base + nbk] * 8 : 0xffffffffu;
                     lim = min(nb_bits, end_bits);
                 }
-                if (bitpos >= end_bits) active = false;
-            }
-        }
-        if (active) {
-            const uint32_t dw = bitpos >> 5, sh = bitpos & 31;
-            const uint32_t w0 = my_ring[dw & (RING_DW - 1)], w1 = my_ring[(dw + 1) & (RING_DW - 1)];
-            const uint32_t win = sh ? __builtin_amdgcn_alignbit(w0, w1, 32 - sh) : w0;  // the next 32 bits of the stream
-            const bool dc = z == 0;
-            const int t = dc ? bi.tdc : bi.tac;
-            uint32_t e = T.lut1[t][win >> (32 - LB)];
-            if (e & 0x8000u) e = T.lut2[e & 63][(win >> (32 - LB - 6)) & 63];
-            int len = e & 31, s = (e >> 5) & 15, r = (e >> 9) & 15;
-            bool invalid = false;
-            if (e == 0) {  // a code the tables above do not hold: canonical search (T.81 F.2.2.3)
-                const uint32_t pk = win >> 16;
-                len = 17;
-                int sym = 0;
-                for (int l = LB + 1; l <= 16; ++l) {
-                    const int code = (int)(pk >> (16 - l));
-                    if (code <= T.maxcode[t][l]) {
-                        sym = T.vals[t][(T.valoff[t][l] + code) & 255];
-                        len = l;
-                        break;
+                if (bitpos >= end_bits) {
+                    active = false;
+                    x_state = ((bitpos - end_bits) & 31) | ((uint32_t)b << 5) | ((uint32_t)z << 9);
+                    x_blk = reset ? (int32_t)(((uint32_t)absblk & 0x7fffffffu) | 0x80000000u) : nblk;
+                    x_dc0 = dc0; x_dc1 = dc1; x_dc2 = dc2;
+                }
+            } else if (gen) {
+                // one symbol the general way: codes outside the look-up tables, padding in front of a marker, errors
+                gen = false;
+                {
+                    const uint32_t wn = my_ring[dwi & (RING_DW - 1)];
+                    if (nb <= 32) {
+                        buf |= (uint64_t)wn << (32 - nb);
+                        nb += 32;
+                        ++dwi;
                     }
                 }
-                if (len == 17) {
-                    // no such code: the 1-bits that pad the byte in front of a restart marker (caught below), a lane
-                    // that is out of step (A / verify: move on by one bit), or a corrupt stream (final)
-                    invalid = true;
-                    len = 1;
-                    sym = 0;
+                const uint32_t win = (uint32_t)(buf >> 32);
+                const bool dc = z == 0;
+                const uint32_t t = (dc ? tdc : tac) >> LB;
+                uint32_t e = T.lut1[t][win >> (32 - LB)];
+                if (e == 0 && (win >> 26) == 63) e = T.lutB[t][(win >> (26 - LB)) & ((1 << LB) - 1)];
+                int len = e & 31, s = (e >> 5) & 15, r = (e >> 9) & 15;
+                bool invalid = false;
+                if (e == 0) {  // canonical search (T.81 F.2.2.3)
+                    const uint32_t pk = win >> 16;
+                    len = 17;
+                    int sym = 0;
+                    for (int l = LB + 1; l <= 16; ++l) {
+                        const int code = (int)(pk >> (16 - l));
+                        if (code <= T.maxcode[t][l]) {
+                            sym = T.vals[t][(T.valoff[t][l] + code) & 255];
+                            len = l;
+                            break;
+                        }
+                    }
+                    if (len == 17) {
+                        // no such code: the 1-bits that pad the byte in front of a restart marker (caught below), a lane
+                        // that is out of step (A / verify: move on by one bit), or a corrupt stream (final)
+                        invalid = true;
+                        len = 1;
+                        sym = 0;
+                    }
+                    s = dc ? sym : sym & 15;
+                    r = dc ? 0 : sym >> 4;
                 }
-                s = dc ? sym : sym & 15;
-                r = dc ? 0 : sym >> 4;
-            }
-            const uint32_t np = bitpos + len + s;
-            if (np > nb_bits || (invalid && nb_bits - bitpos < 8)) {
-                bitpos = nb_bits;  // the padding bits in front of a restart marker, not a symbol
-            } else if (invalid && MODE == 2) {
-                err |= ERR_HUFF;
-                active = false;
-            } else {
-                bitpos = np;
-                int v = 0;
-                if (s && (dc || MODE == 2)) {  // the value: only the DC differences matter before the final pass
-                    const int raw = (int)((win << len) >> (32 - s));
-                    v = raw < (1 << (s - 1)) ? raw - (1 << s) + 1 : raw;
-                }
-                if (dc) {
-                    if (bi.comp == 0) dc0 += v; else if (bi.comp == 1) dc1 += v; else dc2 += v;
+                const int use = len + s;
+                const uint32_t np = bitpos + use;
+                if (np > nb_bits || (invalid && nb_bits - bitpos < 8)) {
+                    bitpos = nb_bits;  // the padding bits in front of a restart marker, not a symbol
+                    reload();
+                } else if (invalid && MODE == 2) {
+                    err |= ERR_HUFF;
+                    active = false;
+                } else {
+                    bitpos = np;
+                    buf <<= use;
+                    nb -= use;
+                    const uint32_t raw = s ? (uint32_t)(win << len) >> (32 - s) : 0u;
+                    const int v = (int)raw - ((int)raw < ((1 << s) >> 1) ? (1 << s) - 1 : 0);
+                    if (dc) {
+                        if (comp == 0) dc0 += v; else if (comp == 1) dc1 += v; else dc2 += v;
+                    }
+                    const int zc = dc ? 0 : z + r;
+                    const bool over = !dc && s && zc > 63;
+                    int zn = dc ? 1 : (s ? zc + 1 : (r == 15 ? z + 16 : 64));
                     if (MODE == 2) {
-                        const int p = bi.comp == 0 ? dc0 : (bi.comp == 1 ? dc1 : dc2);
-                        if (p) blk[0] = (int16_t)p;
-                    }
-                    z = 1;
-                } else if (s) {
-                    z += r;
-                    if (z > 63) {
-                        if (MODE == 2) {
+                        const int p = comp == 0 ? dc0 : (comp == 1 ? dc1 : dc2);
+                        if (over) {
                             err |= ERR_COEF;
                             active = false;
+                        } else if ((dc ? p != 0 : s != 0) && absblk < total_blocks) {
+                            int16_t* blk = frame_coef + ((size_t)bbase + (size_t)(my * bvs + bdy) * bbx + mx * bhs + bdx) * 64;
+                            blk[dc ? 0 : zz[zc]] = (int16_t)(dc ? p : v);
                         }
-                        z = 64;
-                    } else {
-                        if (MODE == 2) blk[zz[z]] = (int16_t)v;
-                        ++z;
                     }
-                } else {
-                    z = r == 15 ? z + 16 : 64;  // ZRL | EOB
-                }
-                if (z >= 64) {
-                    z = 0;
-                    ++nblk;
-                    ++absblk;
-                    if (++b >= bpm) b = 0;
-                    bi = binfo[b];
-                    if (MODE == 2) {
-                        if (absblk >= total_blocks) {
-                            active = false;
-                        } else if (b == 0) {
-                            if (++mx == g.mcus_x) {
+                    if (over) zn = 64;
+                    if (zn >= 64) {
+                        zn = 0;
+                        ++nblk;
+                        ++absblk;
+                        if (++b >= bpm) {
+                            b = 0;
+                            if (MODE == 2 && ++mx == g.mcus_x) {
                                 mx = 0;
                                 ++my;
                             }
                         }
-                        blk = frame_coef + ((size_t)bi.base + (size_t)(my * bi.vs + bi.dy) * bi.bx + mx * bi.hs + bi.dx) * 64;
+                        take_block(binfo[b]);
                     }
+                    z = zn;
                 }
             }
         }
+        // ---- the fast loop: straight-line code, every lane; left as soon as one active lane meets anything else.
+        // The LDS reads whose addresses do not depend on the symbol in hand (the ring dword of the next refill, the
+        // next block's tables) are issued one symbol ahead, so a symbol waits for one LDS round trip: its two table
+        // look-ups, made side by side.
+        slow_cyc += clock64() - cs;
+        uint32_t wn = my_ring[dwi & (RING_DW - 1)];
+        int bn = b + 1 == bpm ? 0 : b + 1;
+        BlkInfo nxt = binfo[bn];
+        for (int k = 0; k < TOPUP; ++k, ++it) {
+            uint64_t fbuf = buf;
+            int fnb = nb;
+            uint32_t fdwi = dwi;
+            {
+                const bool need = fnb <= 32;
+                fbuf |= need ? (uint64_t)wn << ((32 - fnb) & 31) : 0ull;
+                fnb += need ? 32 : 0;
+                fdwi += need ? 1u : 0u;
+            }
+            const uint32_t wn_next = my_ring[fdwi & (RING_DW - 1)];
+            const uint32_t win = (uint32_t)(fbuf >> 32);
+            const bool dc = z == 0;
+            const uint32_t tb = dc ? tdc : tac;
+            const uint32_t eA = lut1[tb + (win >> (32 - LB))];
+            const uint32_t eB = lutB[tb + ((win >> (26 - LB)) & ((1 << LB) - 1))];
+            const uint32_t e = eA ? eA : ((win >> 26) == 63 ? eB : 0u);
+            const int len = e & 31, s = (e >> 5) & 15, r = (e >> 9) & 15;
+            const int use = len + s;
+            const uint32_t np = bitpos + use;
+            const int zc = dc ? 0 : z + r;
+            const bool rare = bitpos >= lim || e == 0 || np > nb_bits || zc > 63;
+            if (__ballot(active && rare)) {
+                gen = rare && bitpos < lim;
+                break;
+            }
+            // commit
+            bitpos = np;
+            buf = fbuf << use;
+            nb = fnb - use;
+            dwi = fdwi;
+            wn = wn_next;
+            const uint32_t raw = s ? (uint32_t)(win << len) >> ((32 - s) & 31) : 0u;
+            const int v = (int)raw - ((int)raw < ((1 << s) >> 1) ? (1 << s) - 1 : 0);
+            const int dv = dc ? v : 0;
+            dc0 += comp == 0 ? dv : 0;
+            dc1 += comp == 1 ? dv : 0;
+            dc2 += comp == 2 ? dv : 0;
+            const int zn = dc ? 1 : (s ? zc + 1 : (r == 15 ? z + 16 : 64));  // ... ZRL | EOB
+            if (MODE == 2) {
+                const int p = comp == 0 ? dc0 : (comp == 1 ? dc1 : dc2);
+                const uint32_t zi = zz[zc];
+                if (active && (dc ? p != 0 : s != 0) && absblk < total_blocks) {
+                    int16_t* blk = frame_coef + ((size_t)bbase + (size_t)(my * bvs + bdy) * bbx + mx * bhs + bdx) * 64;
+                    blk[dc ? 0u : zi] = (int16_t)(dc ? p : v);
+                }
+            }
+            const bool bend = zn >= 64;
+            z = bend ? 0 : zn;
+            nblk += bend ? 1 : 0;
+            absblk += bend ? 1 : 0;
+            if (MODE == 2) {
+                const bool wrap = bend && bn == 0;
+                const bool roww = wrap && mx + 1 == g.mcus_x;
+                mx = roww ? 0 : (wrap ? mx + 1 : mx);
+                my += roww ? 1 : 0;
+                bbase = bend ? nxt.base : bbase;
+                bbx = bend ? nxt.bx : bbx;
+                bvs = bend ? (int)nxt.vs : bvs;
+                bhs = bend ? (int)nxt.hs : bhs;
+                bdy = bend ? (int)nxt.dy : bdy;
+                bdx = bend ? (int)nxt.dx : bdx;
+            }
+            b = bend ? bn : b;
+            tdc = bend ? (uint32_t)nxt.tdc << LB : tdc;
+            tac = bend ? (uint32_t)nxt.tac << LB : tac;
+            comp = bend ? (int)nxt.comp : comp;
+            bn = b + 1 == bpm ? 0 : b + 1;
+            nxt = binfo[bn];
+        }
+    }
+    if (stamp && tid == 0) {
+        g_dbg[MODE * 2] = clock64() - c0;
+        g_dbg[MODE * 2 + 1] = ((wall_clock64() - w0t) << 32) | (unsigned)it;
+        g_dbg[8 + MODE * 2] = slow_cyc;
+        g_dbg[8 + MODE * 2 + 1] = (unsigned)outer;
     }
     if (err) atomicOr(&status[f], err);
     if (MODE != 2 && mine) {
-        const uint32_t over = bitpos >= end_bits ? bitpos - end_bits : 0;
-        const uint32_t st = (over & 31) | ((uint32_t)b << 5) | ((uint32_t)z << 9);
-        if (MODE == 1 && st != g_in[sj]) atomicOr(&changed[f], 1);
-        g_out[sj] = st;
+        if (MODE == 1 && x_state != g_in[sj]) atomicOr(&changed[f], 1);
+        g_out[sj] = x_state;
         used[sj] = entry_st;
         SubCnt c;
-        c.blk = reset ? (int32_t)(((uint32_t)absblk & 0x7fffffffu) | 0x80000000u) : nblk;
-        c.dc[0] = dc0; c.dc[1] = dc1; c.dc[2] = dc2;
+        c.blk = x_blk;
+        c.dc[0] = x_dc0; c.dc[1] = x_dc1; c.dc[2] = x_dc2;
         cnt[sj] = c;
     }
 }
@@ -774,35 +902,29 @@ const char* parse_header(const uint8_t* d, size_t n, Parsed& P) {
     }
 }
 
-// Table t (0 DC0, 1 DC1, 2 AC0, 3 AC1) of a set from a DHT segment's counts / symbols; `pool` = second-level tables taken so far.
-void build_hufftab(HuffTables& T, int t, const uint8_t* counts, const uint8_t* syms, int& pool) {
+// Table t (0 DC0, 1 DC1, 2 AC0, 3 AC1) of a set from a DHT segment's counts / symbols.
+void build_hufftab(HuffTables& T, int t, const uint8_t* counts, const uint8_t* syms) {
     const bool dc = t < 2;
     auto entry = [&](int len, int sym) -> uint16_t {
-        const int s = dc ? (sym & 15) : (sym & 15), r = dc ? 0 : (sym >> 4);
+        const int s = sym & 15, r = dc ? 0 : (sym >> 4);
         return (uint16_t)(len | (s << 5) | (r << 9));
     };
     memset(T.lut1[t], 0, sizeof T.lut1[t]);
+    memset(T.lutB[t], 0, sizeof T.lutB[t]);
     memcpy(T.vals[t], syms, 256);
     int code = 0, k = 0;
     for (int l = 1; l <= 16; ++l) {
         T.valoff[t][l] = k - code;
         for (int i = 0; i < counts[l - 1]; ++i, ++k, ++code) {
+            if (code >= (1 << l)) continue;  // over-subscribed table: left to the canonical search (and its error)
             if (l <= LB) {
                 const int lo = code << (LB - l), hi = (code + 1) << (LB - l);
-                for (int e = lo; e < hi && e < (1 << LB); ++e) T.lut1[t][e] = entry(l, syms[k]);
-            } else {
-                const int prefix = code >> (l - LB);
-                if (prefix >= (1 << LB)) continue;  // over-subscribed table: left to the canonical search (and its error)
-                uint16_t& link = T.lut1[t][prefix];
-                if (!(link & 0x8000)) {
-                    if (link != 0 || pool >= 64) continue;  // pool exhausted: the canonical search finds this code
-                    memset(T.lut2[pool], 0, sizeof T.lut2[pool]);
-                    link = (uint16_t)(0x8000 | pool++);
-                }
-                uint16_t* sub = T.lut2[link & 63];
-                const int rest = l - LB;  // 1..6 more bits
-                const int lo = (code & ((1 << rest) - 1)) << (6 - rest), hi = lo + (1 << (6 - rest));
-                for (int e = lo; e < hi; ++e) sub[e] = entry(l, syms[k]);
+                for (int e = lo; e < hi; ++e) T.lut1[t][e] = entry(l, syms[k]);
+            } else if ((code >> (l - 6)) == 63) {
+                // six leading 1-bits: found under bits 6 .. 6 + LB - 1 of the window
+                const int rest = l - 6;  // <= 10 bits after them
+                const int lo = (code & ((1 << rest) - 1)) << (LB - rest), hi = lo + (1 << (LB - rest));
+                for (int e = lo; e < hi; ++e) T.lutB[t][e] = entry(l, syms[k]);
             }
         }
         T.maxcode[t][l] = counts[l - 1] ? code - 1 : -1;
@@ -933,6 +1055,11 @@ int pa_mjpeg_set_sync_rounds(pa_mjpeg* h, int32_t rounds) {
 
 int pa_mjpeg_last_sync_rounds(const pa_mjpeg* h) { return h ? h->last_rounds : 0; }
 
+int pa_mjpeg_debug_counters(unsigned long long* out8_host) {
+    if (!out8_host) return PA_ERR_INVALID_ARG;
+    return hipMemcpyFromSymbol(out8_host, HIP_SYMBOL(g_dbg), 16 * sizeof(unsigned long long)) == hipSuccess ? PA_OK : PA_ERR_HIP;
+}
+
 int pa_mjpeg_decode(pa_mjpeg* h, const uint8_t* data_host, const int64_t* spans_host, int32_t n, int32_t height, int32_t width,
                     int32_t rgb, uint8_t* frames_dev, int32_t* status_dev, void* stream) {
     if (!h) return PA_ERR_INVALID_ARG;
@@ -1024,9 +1151,8 @@ int pa_mjpeg_decode(pa_mjpeg* h, const uint8_t* data_host, const int64_t* spans_
         if (!share) {
             TableSet& T = ts[n_sets++];
             memset(&T.h, 0, sizeof T.h);
-            int pool = 0;
             for (int t = 0; t < 4; ++t)
-                if (cur.hdef[t]) build_hufftab(T.h, t, cur.counts[t], cur.syms[t], pool);
+                if (cur.hdef[t]) build_hufftab(T.h, t, cur.counts[t], cur.syms[t]);
             memcpy(T.q, cur.q, sizeof T.q);
         }
         prev = cur;
@@ -1053,14 +1179,17 @@ int pa_mjpeg_decode(pa_mjpeg* h, const uint8_t* data_host, const int64_t* spans_
         }
         max_scan = d.scan_len > max_scan ? d.scan_len : max_scan;
     }
-    // subsequence size: about eight MCUs of the stream, a power of two (measured: at 1080p / quality 95 the slowest lanes
-    // need about ten MCUs to fall into step; scripts/mjpeg_sync_probe.py)
+    // subsequence size: about four MCUs of the stream, a power of two. Measured at 1080p / quality 95 (1 MB per frame,
+    // scripts/mjpeg_sync_probe.py, scripts/mjpeg_rate.py): the slowest lanes need about ten MCUs to fall into step, i.e.
+    // two verify passes at 1024 bytes, three at 512, eleven at 128; a lane's symbol takes ~1000 cycles whether one or two
+    // waves share its SIMD (~115 instructions, one LDS round trip), so 512-byte lanes (two waves per SIMD) finish a
+    // pass in half the time of 1024-byte lanes and win although they need one more pass: 5.0 vs 5.8 ms per 64 frames.
     {
         size_t bytes = 0;
         for (int f = 0; f < n; ++f) bytes += fd[f].scan_len;
         const size_t per_mcu = bytes / ((size_t)n * g.mcus_x * g.mcus_y) + 1;
         int sh = 7;
-        while ((1u << sh) < 8 * per_mcu && sh < 13) ++sh;
+        while ((1u << sh) < 7 * per_mcu / 2 && sh < 13) ++sh;
         if (h->sub_shift_override >= 7 && h->sub_shift_override <= 13) sh = h->sub_shift_override;
         g.sub_shift = sh;
         for (int f = 0; f < n; ++f) {

@@ -49,4 +49,13 @@ for var in args.variants.split(","):
     ms = e0.elapsed_time(e1) / args.reps
     print(f"{var:8s} q{args.quality} {sizes.mean() / 1e6:.3f} MB/frame  {ms:.3f} ms per {n} frames = {n / ms * 1e3:.0f} frames/s "
           f"({ends[-1] / ms / 1e6:.2f} GB/s compressed; host encode {enc_s / n * 1e3:.1f} ms/frame)", flush=True)
+    import ctypes as C
+    from playaid_core_amd import _lib
+    c = (C.c_ulonglong * 16)()
+    _lib.load().pa_mjpeg_debug_counters(c)
+    for m, nm in enumerate(("spec", "verify", "final")):
+        cyc, ticks, syms = c[2 * m], c[2 * m + 1] >> 32, c[2 * m + 1] & 0xffffffff
+        if syms:
+            print(f"   {nm}: wave 0 walked {syms} symbols in {cyc} shader cycles = {cyc / syms:.0f} cycles/symbol, {ticks / 100:.1f} us "
+                  f"-> {cyc / max(ticks, 1) * 100 / 1e3:.2f} GHz; slow steps {c[9 + 2 * m]} taking {c[8 + 2 * m]} cycles", flush=True)
     dec.close()
