@@ -1188,8 +1188,8 @@ int pa_mjpeg_decode(pa_mjpeg* h, const uint8_t* data_host, const int64_t* spans_
         size_t bytes = 0;
         for (int f = 0; f < n; ++f) bytes += fd[f].scan_len;
         const size_t per_mcu = bytes / ((size_t)n * g.mcus_x * g.mcus_y) + 1;
-        int sh = 7;
-        while ((1u << sh) < 7 * per_mcu / 2 && sh < 13) ++sh;
+        int sh = 8;  // the power of two nearest to four MCUs, 256 bytes .. 8 KB
+        while ((3u << sh) / 2 < 4 * per_mcu && sh < 13) ++sh;
         if (h->sub_shift_override >= 7 && h->sub_shift_override <= 13) sh = h->sub_shift_override;
         g.sub_shift = sh;
         for (int f = 0; f < n; ++f) {
