@@ -306,8 +306,14 @@ typedef struct pa_mjpeg pa_mjpeg;
 int pa_mjpeg_create(int32_t device, int32_t max_frames, int32_t max_height, int32_t max_width, size_t max_bytes, pa_mjpeg** out);
 void pa_mjpeg_destroy(pa_mjpeg* h);
 const char* pa_mjpeg_last_error(const pa_mjpeg* h);
-/* Verify passes per call: 1..8 are enqueued without looking at their outcome (default 3; ordinary pictures settle in one
- * or two, a frame that has not is flagged with status bit 8); 0 = exact mode: passes are repeated until one changes
+/* Host only, no device: the marker segments of one JPEG file as pa_mjpeg_decode reads them. info8 = height, width,
+ * components, max horizontal / vertical sampling factor (2,2 = 4:2:0), restart interval in MCUs (0 = none), byte offset
+ * of the entropy-coded data, 0. PA_ERR_INVALID_ARG with the reason in `why` for files the decoder does not take
+ * (progressive, arithmetic, 12-bit, multi-scan, truncated headers). */
+int pa_mjpeg_probe(const uint8_t* data_host, size_t nbytes, int32_t* info8, char* why, size_t why_bytes);
+/* Verify passes per call: 1..16 are enqueued without looking at their outcome (default 8; a pass over a frame whose
+ * previous pass changed nothing returns at once; 1080p frames at quality 95 settle in three, and a frame that has not
+ * settled is flagged with status bit 8); 0 = exact mode: passes are repeated until one changes
  * nothing, which synchronises the stream once per pass (long runs of identical blocks -- black bars -- re-synchronise
  * slowly and can need many). pa_mjpeg_last_sync_rounds: how many the last call ran. */
 int pa_mjpeg_set_sync_rounds(pa_mjpeg* h, int32_t rounds);

@@ -152,6 +152,7 @@ SYMBOLS = [
     ("pa_mjpeg_create", C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_size_t, C.POINTER(_P)]),
     ("pa_mjpeg_destroy", None, [_P]),
     ("pa_mjpeg_last_error", C.c_char_p, [_P]),
+    ("pa_mjpeg_probe", C.c_int, [_P, C.c_size_t, C.POINTER(C.c_int32), C.c_char_p, C.c_size_t]),
     ("pa_mjpeg_set_sync_rounds", C.c_int, [_P, C.c_int32]),
     ("pa_mjpeg_last_sync_rounds", C.c_int, [_P]),
     ("pa_mjpeg_debug_counters", C.c_int, [_P]),

@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -1044,6 +1045,22 @@ int pa_mjpeg_create(int32_t device, int32_t max_frames, int32_t max_height, int3
         if (!chk(hipEventCreateWithFlags(&h->staged[i], hipEventDisableTiming), "hipEventCreate")) return PA_ERR_HIP;
     }
     if (!chk(hipHostMalloc(&h->h_flag, n * sizeof(int32_t)), "hipHostMalloc")) return PA_ERR_HIP;
+    return PA_OK;
+}
+
+int pa_mjpeg_probe(const uint8_t* data_host, size_t nbytes, int32_t* info8, char* why, size_t why_bytes) {
+    if (!data_host || !info8) return PA_ERR_INVALID_ARG;
+    Parsed P;
+    const char* msg = parse_header(data_host, nbytes, P);
+    if (why && why_bytes) snprintf(why, why_bytes, "%s", msg ? msg : "");
+    if (msg) return PA_ERR_INVALID_ARG;
+    int hmax = 1, vmax = 1;
+    for (int c = 0; c < P.ncomp; ++c) {
+        hmax = P.h[c] > hmax ? P.h[c] : hmax;
+        vmax = P.v[c] > vmax ? P.v[c] : vmax;
+    }
+    info8[0] = P.height; info8[1] = P.width; info8[2] = P.ncomp; info8[3] = hmax; info8[4] = vmax; info8[5] = P.ri;
+    info8[6] = (int32_t)P.scan_off; info8[7] = 0;
     return PA_OK;
 }
 

@@ -141,3 +141,46 @@ def test_product_path_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+
+
+def test_jpeg_header_probe_on_the_host(lib):
+    """pa_mjpeg_probe is pure host code (the marker parser of pa_mjpeg_decode): sizes, sampling, restart interval of real
+    files; every truncation of a file and random corruptions are refused or parsed, never read out of bounds (this test is
+    what scripts/asan_host.sh runs against the sanitizer build)."""
+    import io
+
+    import numpy as np
+    from PIL import Image
+
+    from playaid_core_amd import _lib, synth
+
+    def probe(blob):
+        info = (ctypes.c_int32 * 8)()
+        why = ctypes.create_string_buffer(128)
+        # an exact-size heap buffer: under scripts/asan_host.sh any read past the file's last byte hits a red zone
+        buf = np.frombuffer(blob if blob else b"\0", np.uint8).copy()
+        rc = lib.pa_mjpeg_probe(buf.ctypes.data_as(ctypes.c_void_p), len(blob), info, why, 128)
+        return rc, list(info), why.value.decode()
+
+    fr = synth.make_frame(1, 90, 130)
+    blob = synth.encode_jpeg_frames([fr], quality=90, restart_marker_blocks=3)[0]
+    rc, info, why = probe(blob)
+    assert rc == 0 and info[:6] == [90, 130, 3, 2, 2, 3] and why == "" and blob[info[6] - 2 - 12:info[6] - 12][:1] != b""
+    rc, info, _ = probe(synth.encode_jpeg_frames([fr], subsampling=0)[0])
+    assert rc == 0 and info[3:6] == [1, 1, 0]
+    rc, info, _ = probe(synth.encode_jpeg_frames([fr[..., 0]])[0])
+    assert rc == 0 and info[2] == 1
+    b = io.BytesIO()
+    Image.fromarray(fr).save(b, "JPEG", progressive=True)
+    rc, _, why = probe(b.getvalue())
+    assert rc == _lib.PA_ERR_INVALID_ARG and "progressive" in why
+    for cut in range(0, info[6] + 40, 1):  # every truncation of the header
+        rc, _, why = probe(blob[:cut])
+        assert rc in (0, _lib.PA_ERR_INVALID_ARG) and (rc == 0 or why)
+    rng = np.random.default_rng(3)
+    for _ in range(300):  # corrupted headers
+        bad = bytearray(blob[:700])
+        for k in rng.integers(2, len(bad), 6):
+            bad[k] = int(rng.integers(0, 256))
+        rc, _, _ = probe(bytes(bad))
+        assert rc in (0, _lib.PA_ERR_INVALID_ARG)
