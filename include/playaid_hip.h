@@ -476,6 +476,14 @@ int pa_set_crop_jpeg_quality(pa_engine* e, int32_t quality);
  * on different queues side by side (playaid_core_amd/parallel.py picks the streams of its lanes with it). */
 int pa_stream_spin(pa_engine* e, int32_t microseconds, void* stream);
 
+/* A gate the HOST opens: pa_stream_gate enqueues a one-thread kernel that keeps `stream` busy until pa_stream_gate_open is
+ * called (a store to coherent pinned memory the kernel polls), or max_microseconds (1..100000) have passed -- the bound
+ * makes a gate nobody opens cost that long instead of hanging the queue. One gate per engine at a time.
+ * playaid_core_amd/parallel.py (ClipLanes) enqueues the first clip of every lane behind an event recorded after one gate
+ * and opens it when the last of them is enqueued, so the lanes start together whatever the host's submit times were. */
+int pa_stream_gate(pa_engine* e, int32_t max_microseconds, void* stream);
+int pa_stream_gate_open(pa_engine* e);
+
 /* Blocks until all work enqueued on `stream` is done (hipStreamSynchronize). */
 int pa_stream_sync(pa_engine* e, void* stream);
 

@@ -130,6 +130,8 @@ SYMBOLS = [
     ("pa_profile_read", C.c_int, [_P, C.POINTER(pa_kernel_stat), C.c_int32, C.POINTER(C.c_int32)]),
     ("pa_set_crop_jpeg_quality", C.c_int, [_P, C.c_int32]),
     ("pa_stream_spin", C.c_int, [_P, C.c_int32, _P]),
+    ("pa_stream_gate", C.c_int, [_P, C.c_int32, _P]),
+    ("pa_stream_gate_open", C.c_int, [_P]),
     ("pa_stream_sync", C.c_int, [_P, _P]),
     ("pa_backbone_windows", C.c_int, [_P, _P, C.c_int32, _P, _P]),
     ("pa_lstm_blob_bytes", C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

@@ -371,6 +371,25 @@ __global__ void spin_kernel(long long ticks, int* sink) {
     if (ticks < 0) *sink = n;  // (never true: keeps the loop observable)
 }
 
+// A gate: keeps its stream busy until the HOST stores a non-zero value to *flag (coherent pinned memory), or max_ticks
+// (100 MHz) have passed -- the bound is what makes it safe: a host that never opens the gate costs max_ticks, not a hang.
+// parallel.ClipLanes holds the first clip of every lane behind one such gate and opens it when all of them are enqueued.
+__global__ void gate_kernel(const int* flag, long long max_ticks, int* sink) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    int n = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0 &&
+           (long long)(__builtin_amdgcn_s_memrealtime() - t0) < max_ticks && n < (1 << 24)) {
+        __builtin_amdgcn_s_sleep(8);
+        ++n;
+    }
+    if (max_ticks < 0) *sink = n;
+}
+
+hipError_t launch_gate(const int* flag, int32_t max_microseconds, hipStream_t s) {
+    hipLaunchKernelGGL(gate_kernel, dim3(1), dim3(1), 0, s, flag, (long long)max_microseconds * 100, (int*)nullptr);
+    return hipGetLastError();
+}
+
 hipError_t launch_spin(int32_t microseconds, hipStream_t s) {
     hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(1), 0, s, (long long)microseconds * 100, (int*)nullptr);
     return hipGetLastError();

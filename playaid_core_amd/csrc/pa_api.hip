@@ -61,6 +61,7 @@ struct pa_engine {
     // clip state
     int clip_frames = 0;
     int sub_frames = 0;  // > 0: the clip is a batch of independent clips of this many frames (pa_clip_begin_batch)
+    int* gate_flag = nullptr;    // coherent pinned word the host opens pa_stream_gate's kernel with
     int jpeg_quality = 0;        // > 0: every crop goes through a baseline-JPEG write + read (pa_set_crop_jpeg_quality)
     int32_t* jpeg_qtab = nullptr; // [2][64] device
     uint8_t* crops_tmp = nullptr; // [max_crops][128][128][3]: the crops when the caller did not ask for them
@@ -990,6 +991,7 @@ void pa_destroy(pa_engine* e) {
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->side) (void)hipStreamDestroy(e->side);
+    if (e->gate_flag) (void)hipHostFree(e->gate_flag);
     for (void* p : e->allocs) (void)hipFree(p);
     delete e;
 }
@@ -1484,6 +1486,20 @@ int pa_set_crop_jpeg_quality(pa_engine* e, int32_t quality) {
 int pa_stream_spin(pa_engine* e, int32_t microseconds, void* stream) {
     if (!e || microseconds < 0 || microseconds > 100000) return fail(e, PA_ERR_INVALID_ARG, "pa_stream_spin: 0..100000 us");
     HIPCHK(e, launch_spin(microseconds, (hipStream_t)stream));
+    return PA_OK;
+}
+
+int pa_stream_gate(pa_engine* e, int32_t max_microseconds, void* stream) {
+    if (!e || max_microseconds < 1 || max_microseconds > 100000) return fail(e, PA_ERR_INVALID_ARG, "pa_stream_gate: 1..100000 us");
+    if (!e->gate_flag) HIPCHK(e, hipHostMalloc((void**)&e->gate_flag, 64, hipHostMallocCoherent | hipHostMallocMapped));
+    __atomic_store_n(e->gate_flag, 0, __ATOMIC_SEQ_CST);
+    HIPCHK(e, launch_gate(e->gate_flag, max_microseconds, (hipStream_t)stream));
+    return PA_OK;
+}
+
+int pa_stream_gate_open(pa_engine* e) {
+    if (!e) return PA_ERR_INVALID_ARG;
+    if (e->gate_flag) __atomic_store_n(e->gate_flag, 1, __ATOMIC_SEQ_CST);
     return PA_OK;
 }
 

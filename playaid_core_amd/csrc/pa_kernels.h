@@ -226,7 +226,8 @@ hipError_t launch_detect_nms(const DetectParams& q, hipStream_t s);
 // small dense layer on the vector units (side models: LSTM / transformer heads): C[m*ldc + n] = act(X[m*ld + :K] . W[n*K + :K] + bias[n])
 hipError_t launch_linear_f32(const float* X, int ld, const float* W, const float* bias, float* C, int ldc, int M, int N, int K, int relu,
                              hipStream_t s);
-hipError_t launch_spin(int32_t microseconds, hipStream_t s);  // one thread busy for that long (stream-concurrency probe)
+hipError_t launch_spin(int32_t microseconds, hipStream_t s);
+hipError_t launch_gate(const int* flag, int32_t max_microseconds, hipStream_t s);  // one thread busy for that long (stream-concurrency probe)
 hipError_t launch_nchw_to_padded(const float* x, float* out, int32_t n, int32_t out_bf16, hipStream_t s);
 // 3x3/2 max pool, padded [n][66][66][64] -> padded [n][34][34][64]
 hipError_t launch_maxpool(const float* in, float* out, int32_t n, hipStream_t s);

@@ -155,6 +155,13 @@ class Engine:
         ``parallel.ClipLanes``."""
         self._check(self._lib.pa_stream_spin(self._h, int(microseconds), C.c_void_p(stream.cuda_stream)))
 
+    def stream_gate(self, max_microseconds: int, stream: "torch.cuda.Stream"):
+        """Keep ``stream`` busy until ``stream_gate_open()`` (or ``max_microseconds``, the safety bound): ``pa_stream_gate``."""
+        self._check(self._lib.pa_stream_gate(self._h, int(max_microseconds), C.c_void_p(stream.cuda_stream)))
+
+    def stream_gate_open(self):
+        self._check(self._lib.pa_stream_gate_open(self._h))
+
     def _check(self, rc: int):
         if rc != _lib.PA_OK:
             raise EngineError(rc, self._lib.pa_last_error(self._h).decode())

@@ -329,7 +329,7 @@ class ClipLanes:
     ``submit`` only enqueues; results of a lane are valid once that lane's stream (or the device) is synchronised
     and are overwritten by the lane's next clip."""
 
-    def __init__(self, engine, sequence_length: int, frame_delta: int, lanes: int = 2, start_hold_us: int = 1500):
+    def __init__(self, engine, sequence_length: int, frame_delta: int, lanes: int = 2, gate_timeout_us: int = 20000):
         self.engines = [engine] + [engine.clone() for _ in range(max(lanes, 1) - 1)]
         self.runners = [FrameParallelClip(e, sequence_length, frame_delta) for e in self.engines]
         # a few more mutually concurrent streams than lanes: calibrate() picks among them
@@ -338,12 +338,11 @@ class ClipLanes:
             else self._candidates[: len(self.engines)]
         self.calibration = None
         self._next = 0
-        self.start_hold_us = start_hold_us
+        self.gate_timeout_us = gate_timeout_us
+        self._gate_pending = 0
         self._helper = torch.cuda.Stream(engine.device)
         self._go = torch.cuda.Event()
         self._cold = True
-        self._submit_s = []        # host time of the last few submit() calls
-        self.last_hold_us = 0
 
     def calibrate(self, frames, boxes, n_total: int, clips: int = 12, batch_of: int = 0):
         """Pick the lanes' streams by measurement on the caller's own clip shape: every combination of the candidate
@@ -368,7 +367,7 @@ class ClipLanes:
             for k in range(clips):
                 self.submit(frames, boxes, n_total, batch_of)
             torch.cuda.synchronize(self.engines[0].device)
-            rates[combo] = n_total * clips / (time.perf_counter() - t0 - 1e-6 * self.last_hold_us)
+            rates[combo] = n_total * clips / (time.perf_counter() - t0)
         best = max(rates, key=rates.get)
         self.streams = [self._candidates[i] for i in best]
         self._cold = True
@@ -376,26 +375,34 @@ class ClipLanes:
         return rates
 
     def _aligned_start(self):
-        """Hold every lane behind a ~1.5 ms spin kernel on a helper stream while the caller enqueues the first clip of
-        each lane, so that the lanes then START TOGETHER. The offset between the lanes decides the rate and, once
-        running, stays what the start gave it: measured on the headline shape with the start offset set on the GPU,
-        47.7-47.9 k frames/s for offsets within +-0.3 ms of aligned (also one whole clip period later), 45.0-45.1 k
-        for anything between 0.35 and 1.2 ms -- one lane's crop / stem kernels (80 KB of LDS per workgroup) then fall
-        into the other lane's convolution layers for good. Left to the host, the offset is the time it takes to
-        enqueue one clip (~0.3-0.4 ms): right on the edge, which made identical runs land on either rate."""
-        # long enough for the host to enqueue one clip per lane: three times what an unblocked submit() took lately
-        # (1.5 ms before anything was measured), within 1 .. 4 ms
-        hold = self.start_hold_us
-        if self._submit_s:
-            hold = int(min(max(3e6 * min(self._submit_s) * len(self.engines), 1000.0), 4000.0))
-        self.last_hold_us = hold
-        self.engines[0].stream_spin(hold, self._helper)
+        """Hold every lane behind ONE gate while the caller enqueues the first clip of each lane, so that the lanes then
+        START TOGETHER. The offset between the lanes decides the rate and, once running, stays what the start gave it:
+        measured on the headline shape with the start offset set on the GPU, 47.7-47.9 k frames/s for offsets within
+        +-0.3 ms of aligned (also one whole clip period later), 45.0-45.1 k for anything between 0.35 and 1.2 ms -- one
+        lane's crop / stem kernels (80 KB of LDS per workgroup) then fall into the other lane's convolution layers for
+        good. Left to the host, the offset is the time it takes to enqueue one clip (~0.3-0.4 ms): right on the edge,
+        which made identical runs land on either rate.
+
+        The gate is a one-thread kernel on a helper stream that polls a word of coherent pinned memory
+        (``pa_stream_gate``); ``submit`` opens it as soon as every lane has its first clip enqueued -- no guess of how
+        long the host will take (round 2 held the lanes behind a spin kernel of 1-4 ms sized from recent submit times).
+        Should the caller stop submitting before that, ``synchronize`` / ``idle`` open it, and the kernel gives up by
+        itself after ``gate_timeout_us``."""
+        self.engines[0].stream_gate(self.gate_timeout_us, self._helper)
         self._go.record(self._helper)
         for st in self.streams:
             st.wait_event(self._go)
+        self._gate_pending = len(self.engines)
+
+    def _gate_progress(self, force: bool = False):
+        if self._gate_pending > 0:
+            self._gate_pending = 0 if force else self._gate_pending - 1
+            if self._gate_pending == 0:
+                self.engines[0].stream_gate_open()
 
     def idle(self):
         """Tell the lanes that the device has drained (the caller synchronised it): the next clips start aligned."""
+        self._gate_progress(force=True)
         self._cold = True
 
     def submit(self, frames, boxes, n_total: int, batch_of: int = 0):
@@ -406,16 +413,14 @@ class ClipLanes:
         self._cold = False
         lane = self._next
         self._next = (self._next + 1) % len(self.engines)
-        t0 = time.perf_counter()
         with torch.cuda.stream(self.streams[lane]):
             rec, lp = self.runners[lane].run(frames, boxes, n_total, gather=False, pipeline=False, reuse_buffers=True,
                                              batch_of=batch_of)
-        # host time to enqueue one clip (the launches are asynchronous; a submit that had to wait for queue space
-        # is longer, which is why the start uses the smallest of the last few)
-        self._submit_s = (self._submit_s + [time.perf_counter() - t0])[-8:]
+        self._gate_progress()  # the last lane's first clip is enqueued: open the gate
         return lane, rec, lp
 
     def synchronize(self):
+        self._gate_progress(force=True)
         for st in self.streams:
             st.synchronize()
         self._cold = True
