@@ -204,6 +204,25 @@ int pa_detect_postprocess(pa_engine* e, const float* pred, int32_t n_frames, int
                           float conf_thres, float iou_thres, uint32_t class_mask, int32_t max_det, int32_t net_height,
                           int32_t net_width, int32_t img_height, int32_t img_width, float* dets, int32_t* counts, void* stream);
 
+/* Replaces the crop half of the same subprocess (`--save-crop`, ai_runner.py:208) and the cv2.imread that reads each
+ * crop back (:445-446): per (frame, fighter) YOLOv5 v7.0's utils/plots.py::save_one_box -- the label row's pixel box ->
+ * xyxy2xywh -> wh * 1.02 + 10 -> xywh2xyxy -> .long() -> clip_boxes -> im[y1:y2, x1:x2] (float32 like torch) -- and, for
+ * jpeg_quality 1..100, the pixel arithmetic of its Image.save(quality=95, subsampling=0) + a JPEG read (4:4:4 baseline
+ * JPEG of an image of ANY size, edge blocks filled by edge replication; jpeg_quality 0 leaves the raw cut).
+ * frames uint8[n_src,H,W,3] BGR; n clip frames; src_frame int32[n][num_fighters] (device; NULL = every crop from its own
+ * frame, n_src == n) says which frame a crop's pixels come from (the reference's tail repair copies the last crop FILE of a
+ * fighter to later frames, ai_runner.py:270-289); dets float32[n][max_det][6] / counts int32[n] as pa_detect_postprocess
+ * wrote them (label rows, label-file order);
+ * det_index int32[n][num_fighters] (device) = which detection of its frame each fighter's crop is cut from, -1 none, or
+ * NULL = the first detection of the fighter's class (cfg.fighter_class_ids) in label order, i.e. the crop file whose name
+ * carries no counter. The BGR images land back to back (16-byte aligned) in `images`, desc[n][num_fighters] describes them
+ * (height = width = 0: no detection / empty rectangle / no room left in `images`, the latter also counted for
+ * pa_device_errors): exactly what pa_runner_inputs / pa_backbone_crop_images take. Restated in oracle/detect.py
+ * (rectangle: parity unpinned, YOLOv5 is not vendored) + oracle/jpeg.py::roundtrip_any (pinned to live libjpeg-turbo). */
+int pa_save_one_box_crops(pa_engine* e, const uint8_t* frames, int32_t n_src, int32_t height, int32_t width, const float* dets,
+                          const int32_t* counts, int32_t max_det, const int32_t* det_index, const int32_t* src_frame, int32_t n,
+                          int32_t jpeg_quality, uint8_t* images, size_t images_capacity, pa_crop_image* desc, void* stream);
+
 /* Boxes from the game log instead of a detector. Replaces the
  * projection half of Fighter.set_from_json (fighter.py:494-539: calculate_lookat_matrix,
  * calculate_intrinsic_matrix, project_point_to_pixel on four corners, all for the

@@ -109,3 +109,37 @@ def detect_frame(pred: np.ndarray, net_hw: Tuple[int, int], img_hw: Tuple[int, i
                  iou_thres: float = 0.45, classes: Sequence[int] = (2, 3), max_det: int = 2) -> Tuple[np.ndarray, str]:
     rows = scale_and_normalise(non_max_suppression(pred, conf_thres, iou_thres, classes, max_det), net_hw, img_hw)
     return rows, label_text(rows)
+
+
+def save_one_box_rect(row: np.ndarray, img_hw: Tuple[int, int], gain: float = 1.02, pad: int = 10):
+    """The rectangle ``utils/plots.py::save_one_box`` cuts for one detection, as ``detect.py --save-crop`` calls it
+    (``ai_runner.py:208``; ``gain=1.02, pad=10, square=False``): from a LABEL row (cls, cx, cy, w, h, conf; normalised)
+    back to the rounded pixel box it was written from (``scale_boxes(...).round()``: whole numbers, so the centre is a
+    multiple of 0.5 and recovered exactly), then in float32 like torch: ``b = xyxy2xywh(xyxy)``, ``wh = wh * gain + pad``,
+    ``xywh2xyxy(b).long()`` (truncation), ``clip_boxes``. -> (x1, y1, x2, y2) ints; the crop is ``im[y1:y2, x1:x2]``."""
+    H, W = img_hw
+    cx, cy, w, h = (F(v) for v in row[1:5])
+    xc = F(np.rint(F(2) * (cx * F(W)))) / F(2)
+    yc = F(np.rint(F(2) * (cy * F(H)))) / F(2)
+    bw = F(np.rint(w * F(W))) * F(gain) + F(pad)
+    bh = F(np.rint(h * F(H))) * F(gain) + F(pad)
+    x1, y1 = F(xc - bw / F(2)), F(yc - bh / F(2))
+    x2, y2 = F(xc + bw / F(2)), F(yc + bh / F(2))
+    t = lambda v: int(np.trunc(v))  # noqa: E731  (.long())
+    x1, x2 = min(max(t(x1), 0), W), min(max(t(x2), 0), W)
+    y1, y2 = min(max(t(y1), 0), H), min(max(t(y2), 0), H)
+    return x1, y1, x2, y2
+
+
+def save_one_box(row: np.ndarray, im_bgr: np.ndarray, quality: int = 95):
+    """-> what ``cv2.imread(crops/<Fighter>/<video>_<n>.jpg)`` returns in the reference (``ai_runner.py:446``): the BGR
+    crop after YOLOv5 v7.0's ``Image.fromarray(crop[..., ::-1]).save(f, quality=95, subsampling=0)`` and a JPEG read, or
+    None for an empty rectangle. **Parity unpinned** for the rectangle (un-vendored YOLOv5); the JPEG step is the
+    libjpeg-pinned ``oracle.jpeg.roundtrip_any``."""
+    from . import jpeg
+
+    x1, y1, x2, y2 = save_one_box_rect(row, im_bgr.shape[:2])
+    if x2 <= x1 or y2 <= y1:
+        return None
+    crop = np.ascontiguousarray(im_bgr[y1:y2, x1:x2])
+    return np.ascontiguousarray(jpeg.roundtrip_any(crop[..., ::-1], quality, subsampling=0)[..., ::-1])

@@ -414,3 +414,37 @@ def decode(data: bytes) -> np.ndarray:
 def decode_bgr(data: bytes) -> np.ndarray:
     """``cv2.imread`` / ``VideoCapture.read`` channel order."""
     return np.ascontiguousarray(decode(data)[..., ::-1])
+
+
+def _expand(p: np.ndarray, mult: int) -> np.ndarray:
+    """The last real row / column repeated up to a whole number of ``mult``-pixel blocks (jcprepct.c / jcsample.c)."""
+    h, w = p.shape
+    ph, pw = -(-h // mult) * mult, -(-w // mult) * mult
+    return np.pad(p, ((0, ph - h), (0, pw - w)), mode="edge")
+
+
+def roundtrip_any(rgb: np.ndarray, quality: int = 95, subsampling: int = 0) -> np.ndarray:
+    """``roundtrip`` for ANY image size and 4:4:4 (``subsampling`` 0, what YOLOv5 v7.0's ``save_one_box`` writes) or 4:2:0
+    (2, OpenCV's ``imwrite``): uint8[h,w,3] R,G,B -> what the JPEG of that quality decodes to. Edge blocks as libjpeg
+    pads them on the way in and trims them on the way out. **Pinned**: equals ``Image.save(quality, subsampling)`` +
+    ``Image.open`` of live libjpeg-turbo (``tests/test_oracle_jpeg.py``)."""
+    h, w, _ = rgb.shape
+    ql, qc = quant_tables(quality)
+    y, cb, cr = rgb_to_ycc(rgb)
+    if subsampling == 0:
+        planes = [_plane_roundtrip(_expand(p, 8), q)[:h, :w] for p, q in ((y, ql), (cb, qc), (cr, qc))]
+        return ycc_to_rgb(*planes)
+    if subsampling != 2:
+        raise ValueError("subsampling 0 (4:4:4) or 2 (4:2:0)")
+    # libjpeg pads the INPUT to the right (jcsample.c expand_right_edge: columns replicated up to whole blocks of the
+    # down-sampled width) and to an even number of rows (jcprepct.c: the last row group), down-samples, and then fills the
+    # DOWN-SAMPLED component up to whole blocks by repeating its last row (jcprepct.c expand_bottom_edge on the output)
+    y_out = _plane_roundtrip(_expand(y, 8), ql)[:h, :w]
+    ch, cw = -(-h // 2), -(-w // 2)
+
+    def chroma(p):
+        pw = -(-w // 16) * 16
+        p = np.pad(p, ((0, h & 1), (0, pw - w)), mode="edge")
+        return h2v2_fancy_upsample(_plane_roundtrip(_expand(h2v2_downsample(p), 8), qc)[:ch, :cw])[:h, :w]
+
+    return ycc_to_rgb(y_out, chroma(cb), chroma(cr))

@@ -32,6 +32,7 @@ SOURCES = [
     ("transformer.hip", []),
     ("jpeg.hip", ["-ffp-contract=off"]),
     ("mjpeg.hip", []),
+    ("savebox.hip", ["-ffp-contract=off"]),
     ("pa_api.hip", []),
 ]
 

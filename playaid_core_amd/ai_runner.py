@@ -175,13 +175,26 @@ class AIRunner:
     """Runs action recognition end to end (tracking boxes come with the clip)."""
 
     def __init__(self, input_video_path, debug: bool = False, model: CNNActionDetector = None,
-                 checkpoint_path: str = None, output_dir: str = None, crop_jpeg_quality: int = 95, **dataset_args):
+                 checkpoint_path: str = None, output_dir: str = None, crop_jpeg_quality: int = 95, crop_mode: str = "yolo",
+                 **dataset_args):
         """``crop_jpeg_quality``: the reference never shows the CNN a crop as cut -- every crop is written as a JPEG
         (YOLOv5 ``--save-crop``, ``cv2.imwrite`` at ``ai_runner.py:420``) and read back (``:446``). 95 (OpenCV's
         default quality, and the default here) makes the crops this runner cuts from frames take the same write +
         read on the device (``pa_set_crop_jpeg_quality``); 0 opts out and feeds the exact resampler output, which
         differs from what the reference's CNN sees by more than 1e-3 on the log-probabilities. Crop IMAGES handed in
-        through ``ClipSource.crop_images`` are decoded JPEGs already and are never re-coded."""
+        through ``ClipSource.crop_images`` are decoded JPEGs already and are never re-coded.
+
+        ``crop_mode``: "yolo" (default) gives the CNN what the reference's gets -- for every (frame, fighter) the
+        detector reported, YOLOv5's own ``--save-crop`` image (``save_one_box``: the box x 1.02 + 10 px, not square, any
+        size, written as a 4:4:4 JPEG; ``ai_runner.py:208``) through the runner's resize / letterbox (``:446-459``), and only
+        for repaired gap frames the ``square_crop(128, padding=30)`` the reference cuts itself and writes with
+        ``cv2.imwrite`` (4:2:0; ``:417-420``); all of it on the device (``pa_save_one_box_crops``,
+        ``pa_square_crops``, ``pa_backbone_crop_images``). "square" cuts ``square_crop`` for every frame (one fused crop
+        stage, the bench's formulation; what the reference's ground-truth data generator does,
+        ``data_gen_scripts/gen_gt_action_detection.py:52-53``)."""
+        if crop_mode not in ("yolo", "square"):
+            raise ValueError("crop_mode is 'yolo' or 'square'")
+        self.crop_mode = crop_mode
         if isinstance(input_video_path, ClipSource):
             self.clip = input_video_path
         else:
@@ -273,6 +286,9 @@ class AIRunner:
             # every frame in [1, max_frames) is the middle of its own window (ai_runner.py:443-447)
             bad = np.nonzero(missing[: n - 1, p])[0]
             assert len(bad) == 0, f"Failed to get frame crops/{fighter}/{self.video_name}_{bad[0] + 1}.jpg"
+        if self.crop_mode == "yolo":
+            self._results = self._run_clip_yolo_crops(eng, boxes, src, missing)
+            return self._results
         own = np.arange(n, dtype=np.int32)
         eng.set_crop_jpeg_quality(self.crop_jpeg_quality)   # for this clip only: the engine is the model's, others use it
         try:
@@ -290,6 +306,60 @@ class AIRunner:
         bad = np.argwhere(st != 0)
         assert len(bad) == 0, f"Failed to get square crop from frame {bad[0][0] + 1}"  # ai_runner.py:418
         self._results = out
+        return out
+
+    def _run_clip_yolo_crops(self, eng, boxes, src, missing):
+        """The reference's own mix of crops, made on the device: ``save_one_box`` images (+ their 4:4:4 JPEG write /
+        read) where the detector reported the fighter, ``square_crop(128, 30)`` (+ ``cv2.imwrite``'s 4:2:0 JPEG) where the
+        label repair interpolated it, copies where the repair copied files -- then every image through the runner's
+        input branch and the backbone in one pass."""
+        cl = self.cleaned
+        n, F = self.max_frames, len(self.fighters)
+        dev = eng.device
+        frames = self.clip.frames
+        fd = frames if isinstance(frames, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(frames)).to(dev)
+        q = self.crop_jpeg_quality
+        kind = cl.crop_kind.copy()
+        kind[missing] = 0
+        rows = torch.from_numpy(np.ascontiguousarray(cl.crop_row)).to(dev)
+        counts = torch.full((n,), F, dtype=torch.int32, device=dev)
+        det_index = np.where(kind == 1, np.arange(F, dtype=np.int32)[None, :], -1).astype(np.int32)
+        srcf = np.where(kind == 1, src, 0).astype(np.int32)
+        step = eng.max_batch_frames
+        parts, descs, base = [], [], 0
+        for f0 in range(0, n, step):
+            cnt = min(step, n - f0)
+            images, desc = eng.save_one_box_crops(fd, rows[f0:f0 + cnt], counts[f0:f0 + cnt], det_index=det_index[f0:f0 + cnt],
+                                                  jpeg_quality=q, src_frame=srcf[f0:f0 + cnt])
+            used = int((desc[:, 0] + ((desc[:, 1] & 0xFFFFFFFF) * (desc[:, 1] >> 32) * 3 + 15) // 16 * 16).max().item()) if cnt else 0
+            desc = desc.clone()
+            desc[:, 0] += base
+            parts.append(images[:used])
+            descs.append(desc)
+            base += used
+        eng.check_device_errors()
+        desc = torch.cat(descs)
+        # the repaired gaps: square crops (BGR, as cv2.imwrite gets them) with the 4:2:0 write / read, as 128 x 128 images
+        rep = np.argwhere(kind == 2)
+        if len(rep):
+            eng.set_crop_jpeg_quality(q)
+            try:
+                sq, st = eng.square_crops(fd[torch.from_numpy(src[rep[:, 0], rep[:, 1]].astype(np.int64)).to(dev)],
+                                          np.repeat(boxes[rep[:, 0], rep[:, 1]][:, None, :], F, axis=1), padding=eng.cfg.crop_padding)
+            finally:
+                eng.set_crop_jpeg_quality(0)
+            assert (st[:, 0] == 0).all(), f"Failed to get square crop from frame {rep[np.nonzero(st[:, 0])[0][0], 0] + 1}"  # ai_runner.py:418
+            sqd = torch.from_numpy(np.ascontiguousarray(sq[:, 0])).to(dev).reshape(-1)
+            parts.append(sqd)
+            e = torch.from_numpy((rep[:, 0] * F + rep[:, 1]).astype(np.int64)).to(dev)
+            desc[e, 0] = base + torch.arange(len(rep), device=dev, dtype=torch.int64) * (128 * 128 * 3)
+            desc[e, 1] = (128 << 32) | 128
+        images = torch.cat(parts + [torch.zeros(64, dtype=torch.uint8, device=dev)])
+        out = eng.infer_clip_from_packed_crop_images(images, desc, n, want_crops=True)
+        st = out["crop_status"].copy()
+        st[missing | (kind == 0)] = 0
+        bad = np.argwhere(st != 0)
+        assert len(bad) == 0, f"Bad shape of crop image for frame {bad[0][0] + 1}"  # ai_runner.py:458
         return out
 
     def _run_clip_from_crop_images(self, eng, boxes, src, missing):

@@ -75,7 +75,8 @@ struct pa_engine {
     size_t arena_cap = 0, arena_used = 0;
     std::vector<uint8_t> arena_stage;  // host mirror while pa_create folds (empty in adopt mode and afterwards)
     bool adopt = false;
-    int32_t* dev_errors = nullptr;  // [4] device-side error counters ([0] = scatter ids outside the clip)
+    int32_t* dev_errors = nullptr;  // [4] device-side error counters ([0] = scatter ids outside the clip, [1] = crop images that did not fit)
+    int32_t* savebox_rects = nullptr;  // [max_crops][4] scratch of pa_save_one_box_crops
     float* x0 = nullptr;      // slot 0 of the model-input double buffer [max_crops][134][134][4]
     float* x0_slot[2] = {nullptr, nullptr};
     int32_t* pre_status[2] = {nullptr, nullptr};  // per-slot crop status written by the preprocess stage
@@ -710,6 +711,7 @@ int create_impl(const pa_config* cfg, const void* blob, size_t src_bytes, const 
     ALLOC(e->x0_slot[0], (size_t)NC * 134 * 134 * 4, true);
     ALLOC(e->x0_slot[1], (size_t)NC * 134 * 134 * 4, true);
     e->x0 = e->x0_slot[0];
+    ALLOC(e->savebox_rects, (size_t)NC * 4, true);
     ALLOC(e->pre_status[0], (size_t)NC, true);
     ALLOC(e->pre_status[1], (size_t)NC, true);
     ALLOC(e->c1, (size_t)NC * 66 * 66 * 64, true);
@@ -1316,6 +1318,46 @@ int pa_backbone_frames_indexed(pa_engine* e, const uint8_t* frames, int32_t n, i
     return PA_OK;
 }
 
+int pa_save_one_box_crops(pa_engine* e, const uint8_t* frames, int32_t n_src, int32_t height, int32_t width, const float* dets,
+                          const int32_t* counts, int32_t max_det, const int32_t* det_index, const int32_t* src_frame, int32_t n,
+                          int32_t jpeg_quality, uint8_t* images, size_t images_capacity, pa_crop_image* desc, void* stream) {
+    if (!e || !frames || !dets || !counts || !images || !desc || n < 1 || n_src < 1 || height < 1 || width < 1 || max_det < 1 ||
+        jpeg_quality < 0 || jpeg_quality > 100 || (!src_frame && n_src != n))
+        return fail(e, PA_ERR_INVALID_ARG, "pa_save_one_box_crops: bad argument");
+    const int F = e->cfg.num_fighters;
+    if (n * F > e->max_crops) return fail(e, PA_ERR_CAPACITY, "pa_save_one_box_crops: more frames than max_batch_frames");
+    pa::SaveBoxParams p;
+    memset(&p, 0, sizeof p);
+    p.frames = frames; p.height = height; p.width = width; p.fighters = F; p.n_entries = n * F;
+    p.dets = dets; p.counts = counts; p.max_det = max_det; p.det_index = det_index;
+    p.src_frame = src_frame; p.n_src = n_src;
+    for (int i = 0; i < 4; ++i) p.class_ids[i] = e->cfg.fighter_class_ids[i];
+    p.gain = 1.02f; p.pad = 10.0f;  // save_one_box's defaults, which detect.py does not override
+    p.images = images; p.capacity = images_capacity;
+    p.desc = reinterpret_cast<pa::CropImageDesc*>(desc);
+    p.rects = reinterpret_cast<pa::SaveBoxRect*>(e->savebox_rects);
+    p.overflow = e->dev_errors + 1;
+    p.quality = jpeg_quality;
+    if (jpeg_quality > 0) {
+        // jpeg_set_quality(quality, force_baseline = TRUE) on the standard tables (jcparam.c), natural order
+        static const int lum[64] = {16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56,
+                                    14, 17, 22, 29, 51, 87, 80, 62, 18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92,
+                                    49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
+        static const int chr[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99, 99, 99,
+                                    47, 66, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99,
+                                    99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
+        const int scale = jpeg_quality < 50 ? 5000 / jpeg_quality : 200 - jpeg_quality * 2;
+        for (int i = 0; i < 64; ++i) {
+            const int a = (lum[i] * scale + 50) / 100, b = (chr[i] * scale + 50) / 100;
+            p.qtab[i] = a < 1 ? 1 : (a > 255 ? 255 : a);
+            p.qtab[64 + i] = b < 1 ? 1 : (b > 255 ? 255 : b);
+        }
+    }
+    ProfScope ps(e, (hipStream_t)stream, "save_one_box_crops", 0.0, 0.0);
+    HIPCHK(e, pa::launch_save_one_box(p, (hipStream_t)stream));
+    return PA_OK;
+}
+
 int pa_device_errors(pa_engine* e, int32_t* bad_frame_ids_host, void* stream) {
     if (!e || !bad_frame_ids_host) return fail(e, PA_ERR_INVALID_ARG, "pa_device_errors: bad argument");
     hipStream_t s = (hipStream_t)stream;
@@ -1324,6 +1366,8 @@ int pa_device_errors(pa_engine* e, int32_t* bad_frame_ids_host, void* stream) {
     HIPCHK(e, hipMemsetAsync(e->dev_errors, 0, sizeof(h), s));
     HIPCHK(e, hipStreamSynchronize(s));
     *bad_frame_ids_host = h[0];
+    if (h[1] != 0)
+        return fail(e, PA_ERR_CAPACITY, "pa_save_one_box_crops: " + std::to_string(h[1]) + " crop image(s) did not fit the image buffer");
     if (h[0] != 0)
         return fail(e, PA_ERR_CAPACITY, "pa_backbone_frames_indexed: " + std::to_string(h[0]) +
                                             " frame id(s) outside the clip were skipped on the device");

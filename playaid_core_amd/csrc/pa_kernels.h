@@ -188,6 +188,29 @@ struct JpegParams {
 };
 hipError_t launch_jpeg_roundtrip(const JpegParams& p, int ncrops, hipStream_t s);
 
+// YOLOv5 save_one_box crops + their 4:4:4 JPEG write / read (savebox.hip)
+struct SaveBoxRect { int32_t x1, y1, w, h; };
+struct SaveBoxParams {
+    const uint8_t* frames;      // [n][height][width][3] BGR
+    int32_t height, width, fighters, n_entries;  // n_entries = frames * fighters
+    const float* dets;          // [n][max_det][6] label rows (cls cx cy w h conf, normalised), label-file order
+    const int32_t* counts;      // [n]
+    int32_t max_det;
+    const int32_t* det_index;   // [n_entries] detection of each (frame, fighter), -1 = none; nullptr = first of the class
+    const int32_t* src_frame;   // [n_entries] frame (of n_src) the pixels are cut from; nullptr = the entry's own frame
+    int32_t n_src;
+    int32_t class_ids[4];
+    float gain, pad;
+    uint8_t* images;            // packed output
+    unsigned long long capacity;
+    CropImageDesc* desc;        // [n_entries]
+    SaveBoxRect* rects;         // [n_entries] scratch
+    int32_t* overflow;          // device counter: entries that did not fit `capacity`
+    int32_t quality;            // 0 = no JPEG write / read
+    int32_t qtab[128];          // quantisation tables (luminance, chrominance), natural order
+};
+hipError_t launch_save_one_box(const SaveBoxParams& p, hipStream_t s);
+
 // crop_img + imutils.resize(width) of up to four pixel rectangles per frame (the damage HUD crops), see rect_resize_kernel
 struct RectResizeParams {
     const uint8_t* frames;       // [n][height][width][3]

@@ -303,6 +303,29 @@ class Engine:
             out["crops_rgb"] = crops.cpu().numpy()
         return out
 
+    def infer_clip_from_packed_crop_images(self, images: torch.Tensor, desc: torch.Tensor, n: int, want_crops: bool = False):
+        """``infer_clip_from_crop_images`` for crop images that are already on the device (``save_one_box_crops``):
+        packed bytes + descriptors int64[n * F, 2] in (frame, fighter) order."""
+        records = self.alloc_records(n - 1)
+        logp = torch.empty((n - 1, self.F, self.A), dtype=torch.float32, device=self.device)
+        status = torch.empty((n, self.F), dtype=torch.int32, device=self.device)
+        crops = torch.empty((n, self.F, 128, 128, 3), dtype=torch.uint8, device=self.device) if want_crops else None
+        self.clip_begin(n)
+        step = self.max_batch_frames
+        for f0 in range(0, n, step):
+            cnt = min(step, n - f0)
+            self._check(self._lib.pa_backbone_crop_images(self._h, _ptr(images), images.numel(), _ptr(desc[f0 * self.F:]), cnt, f0,
+                                                          _ptr(crops[f0 : f0 + cnt]) if want_crops else C.c_void_p(0),
+                                                          _ptr(status[f0 : f0 + cnt]), self._stream()))
+        self.head_frames(1, n, records, logp)
+        torch.cuda.synchronize(self.device)
+        out = self.decode_records(records)
+        out["logp"] = logp.cpu().numpy()
+        out["crop_status"] = status.cpu().numpy()
+        if want_crops:
+            out["crops_rgb"] = crops.cpu().numpy()
+        return out
+
     # -- f1: detection post-processing ------------------------------------------
     def detect_postprocess(self, pred, net_hw, img_hw, conf_thres: float = 0.25, iou_thres: float = 0.45,
                            classes=(2, 3), max_det: int = 2):
@@ -319,6 +342,37 @@ class Engine:
                                                     int(net_hw[0]), int(net_hw[1]), int(img_hw[0]), int(img_hw[1]), _ptr(dets),
                                                     _ptr(counts), self._stream()))
         return dets, counts
+
+    def save_one_box_crops(self, frames_dev: torch.Tensor, dets: torch.Tensor, counts: torch.Tensor, det_index=None,
+                           jpeg_quality: int = 95, images: torch.Tensor = None, desc: torch.Tensor = None, src_frame=None):
+        """``detect.py --save-crop`` + ``cv2.imread`` of every crop (``ai_runner.py:208,445-446``) on the device: frames
+        uint8[n,H,W,3] + the detections of ``detect_postprocess`` -> (packed BGR crop images uint8[...] device, descriptors
+        int64[n * F, 2] device = what ``pa_runner_inputs`` / ``pa_backbone_crop_images`` take). ``det_index`` int32[n, F]:
+        which detection each fighter's crop comes from (-1 none); None = the first of the fighter's class in label order.
+        ``src_frame`` int32[n, F]: the frame each crop's pixels are cut from when that is not its own (``n = dets.shape[0]``)."""
+        n_src, h, w, _ = frames_dev.shape
+        n = dets.shape[0]
+        sf = self._dev(src_frame, torch.int32) if src_frame is not None else None
+        if images is None:
+            images = torch.empty(n * self.F * min(h * w, 1 << 20) * 3 + 64, dtype=torch.uint8, device=self.device)
+        if desc is None:
+            desc = torch.zeros((n * self.F, 2), dtype=torch.int64, device=self.device)
+        di = self._dev(det_index, torch.int32) if det_index is not None else None
+        self._check(self._lib.pa_save_one_box_crops(self._h, _ptr(frames_dev), n_src, h, w, _ptr(dets), _ptr(counts), dets.shape[1],
+                                                    _ptr(di), _ptr(sf), n, int(jpeg_quality), _ptr(images), images.numel(), _ptr(desc),
+                                                    self._stream()))
+        return images, desc
+
+    @staticmethod
+    def unpack_crop_images(images: torch.Tensor, desc: torch.Tensor):
+        """(packed images, descriptors) -> list of uint8[h, w, 3] numpy arrays (None where height == 0), host side."""
+        d = desc.cpu().numpy()
+        buf = images.cpu().numpy()
+        out = []
+        for off, hw in d:
+            hh, ww = int(hw) & 0xFFFFFFFF, int(hw) >> 32
+            out.append(buf[off: off + hh * ww * 3].reshape(hh, ww, 3).copy() if hh and ww else None)
+        return out
 
     # -- boxes from the game log ----------------------------------------------
     def project_boxes(self, log_rows) -> torch.Tensor:

@@ -61,6 +61,10 @@ class CleanedLabels:
     label_crop: List[List[Optional[YoloCrop]]]       # [i][p]: what read_fighter_yolo_crop returns after repair
     pixel_frame: np.ndarray                          # int32 [max_frames, F]: decoded-frame index (0-based) the crop is cut from, -1 = no crop
     pixel_box: np.ndarray                            # float64 [max_frames, F, 4]: normalised cx cy w h used for the cut
+    crop_kind: np.ndarray = None                     # int32 [max_frames, F]: what crops/<Fighter>/<video>_<n>.jpg holds -- 0 nothing,
+                                                     # 1 the detector's save_one_box crop (ai_runner.py:208), 2 a square_crop repair (:417-420)
+    crop_row: np.ndarray = None                      # float32 [max_frames, F, 6]: kind 1: the label row (cls cx cy w h conf) whose box
+                                                     # save_one_box cut, from decoded frame pixel_frame
     log: List[str] = field(default_factory=list)     # the messages the reference prints
 
     def identity_source(self) -> bool:
@@ -83,6 +87,7 @@ def clean_yolo_labels(labels: List[str], fighters: List[str], n_decoded_frames: 
     max_frames = nonempty[-1] + 1
     log: List[str] = []
     frames: List[List[YoloCrop]] = [parse_label(labels[i], f"{name}_{i + 1}.txt") for i in range(max_frames)]
+    original = [list(fr) for fr in frames]  # as the detector wrote them (the crop files follow these, not the repair)
     class_ids = [constants.CHAR_LIST.index(f) for f in fighters]
 
     # crops the detector saved: one per (frame, class) it reported
@@ -116,10 +121,17 @@ def clean_yolo_labels(labels: List[str], fighters: List[str], n_decoded_frames: 
     F = len(fighters)
     pixel_frame = np.full((max_frames, F), -1, dtype=np.int32)
     pixel_box = np.zeros((max_frames, F, 4), dtype=np.float64)
+    crop_kind = np.zeros((max_frames, F), dtype=np.int32)
+    crop_row = np.zeros((max_frames, F, 6), dtype=np.float32)
     for p, cid in enumerate(class_ids):
         for f in has_crop[cid]:
             pixel_frame[f - 1, p] = f - 1
             pixel_box[f - 1, p] = _fighter_crop(frames[f - 1], cid).yolo_crop()
+            # the crop FILE without a counter in its name is the first detection of the class the detector wrote
+            # (detect.py saves in label order; later ones get <n>2.jpg, which the reference deletes, :247-258)
+            first = _fighter_crop(original[f - 1], cid)
+            crop_kind[f - 1, p] = 1
+            crop_row[f - 1, p] = [first.class_id, first.center_x, first.center_y, first.crop_width, first.crop_height, first.confidence]
 
     # -- gaps (:361-424)
     for p, (fighter, cid) in enumerate(zip(fighters, class_ids)):
@@ -140,10 +152,13 @@ def clean_yolo_labels(labels: List[str], fighters: List[str], n_decoded_frames: 
                     if j < n_decoded_frames:  # VideoCapture position j = decoded frame index j (:405-406)
                         pixel_frame[j - 1, p] = j
                         pixel_box[j - 1, p] = interp.yolo_crop()
+                        crop_kind[j - 1, p] = 2
                     else:  # read failed: the crop image of frame j-1 is copied (:407-416)
                         log.append(f"Failed to read from frame {j} during interpolation")
                         pixel_frame[j - 1, p] = pixel_frame[j - 2, p]
                         pixel_box[j - 1, p] = pixel_box[j - 2, p]
+                        crop_kind[j - 1, p] = crop_kind[j - 2, p]
+                        crop_row[j - 1, p] = crop_row[j - 2, p]
             latest = current
 
     # -- tail (:270-289): duplicate the shorter fighter's last crop image
@@ -157,7 +172,9 @@ def clean_yolo_labels(labels: List[str], fighters: List[str], n_decoded_frames: 
             for i in range(lf, mx):  # frames lf .. mx-1 (frame mx itself is left without a crop)
                 pixel_frame[i - 1, p] = pixel_frame[lf - 1, p]
                 pixel_box[i - 1, p] = pixel_box[lf - 1, p]
+                crop_kind[i - 1, p] = crop_kind[lf - 1, p]  # a copy of that image FILE, whatever made it
+                crop_row[i - 1, p] = crop_row[lf - 1, p]
 
     out_labels = ["".join(str(c) + "\n" for c in fr) for fr in frames]
     label_crop = [[_fighter_crop(fr, cid) for cid in class_ids] for fr in frames]
-    return CleanedLabels(max_frames, out_labels, label_crop, pixel_frame, pixel_box, log)
+    return CleanedLabels(max_frames, out_labels, label_crop, pixel_frame, pixel_box, crop_kind, crop_row, log)

@@ -101,7 +101,7 @@ def test_runner_repairs_label_gaps(tmp_path, state_dict):
         ckpt, actions=list(MOVE_TO_CLASS_ID.keys()), max_batch_frames=64, max_clip_frames=64,
         max_frame_height=h, max_frame_width=w,
     )
-    runner = AIRunner(clip, model=model, output_dir=str(tmp_path / "ai_cache"))
+    runner = AIRunner(clip, model=model, output_dir=str(tmp_path / "ai_cache"), crop_mode="square")
     assert runner.max_frames == n
     runner.run_action_recognition()
     # expected (frame index, box) per entry, written out independently of label_cleaning.py
@@ -630,10 +630,10 @@ def test_runner_with_the_references_jpeg_round_trip(tmp_path, state_dict):
     synth.save_checkpoint(ckpt, seed=1234)
     model = CNNActionDetector.load_from_checkpoint(ckpt, actions=list(MOVE_TO_CLASS_ID.keys()), max_batch_frames=32,
                                                    max_clip_frames=64, max_frame_height=h, max_frame_width=w)
-    plain = AIRunner(clip, model=model, output_dir=str(tmp_path / "plain"), crop_jpeg_quality=0)
+    plain = AIRunner(clip, model=model, output_dir=str(tmp_path / "plain"), crop_jpeg_quality=0, crop_mode="square")
     plain.run_action_recognition()
     lp_plain = plain._results["logp"].copy()
-    runner = AIRunner(clip, model=model, output_dir=str(tmp_path / "jpeg"))
+    runner = AIRunner(clip, model=model, output_dir=str(tmp_path / "jpeg"), crop_mode="square")
     assert runner.crop_jpeg_quality == 95
     runner.run_action_recognition()
     boxes = synth.make_boxes(n, h, w)

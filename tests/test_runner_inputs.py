@@ -102,7 +102,7 @@ def test_airunner_on_a_crop_image_clip(tmp_path, state_dict, engine):
                                                    max_clip_frames=64, max_frame_height=720, max_frame_width=1280)
     clip = ClipSource.synthetic(20, 720, 1280)
     # crop_jpeg_quality=0: clip2's images below stand for DECODED crop files, so the frame-cut crops must not be re-coded
-    by_frames = AIRunner(clip, model=model, output_dir=str(tmp_path / "a"), crop_jpeg_quality=0)
+    by_frames = AIRunner(clip, model=model, output_dir=str(tmp_path / "a"), crop_jpeg_quality=0, crop_mode="square")
     by_frames.run_action_recognition()
     by_frames.write_output()
     # what YOLOv5 --save-crop would have stored: here the 128 x 128 BGR square crops of the same boxes
