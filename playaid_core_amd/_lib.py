@@ -109,6 +109,7 @@ SYMBOLS = [
     ("pa_backbone_crop_images", C.c_int, [_P, _P, C.c_size_t, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     ("pa_detect_postprocess", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_uint32, C.c_int32,
                                         C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
+    ("pa_clean_detections", C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
     ("pa_save_one_box_crops", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int32, _P, _P, C.c_int32, C.c_int32, _P,
                                         C.c_size_t, _P, _P]),
     ("pa_project_boxes", C.c_int, [_P, _P, C.c_int32, _P, _P]),

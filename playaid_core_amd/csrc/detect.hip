@@ -144,3 +144,166 @@ hipError_t launch_detect_nms(const DetectParams& q, hipStream_t s) {
 }
 
 }  // namespace pa
+
+// ---- label repair on the device (rows a3 / f1) ---------------------------------------------------------------------------
+//
+// AIRunner.clean_yolo_crops / clean_yolo_crops_for_fighter (playaid/ai_runner.py:226-289, 306-424) on the detection table
+// pa_detect_postprocess wrote, without the label files in between: per fighter the reference resolves duplicate
+// detections of its class (nearest centre, L1, to the class's previous box), interpolates the boxes of frames it is
+// missing in (measured from the END frame, pixels from VideoCapture position j = one decoded frame late), and copies the
+// last crop file of the fighter whose detections end first. The host mirror (playaid_core_amd/label_cleaning.py) takes
+// the same decisions on the label TEXT; to agree with it bit for bit the rows are first taken through the label file's
+// '%g' formatting (six significant digits) as detect.py writes and float() reads them.
+namespace pa {
+namespace {
+
+__device__ double pow10i(int k) {  // 10^k, k in -22 .. 22 (exact in double from 0 up)
+    const double t[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                          1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+    k = k < -22 ? -22 : (k > 22 ? 22 : k);
+    return k >= 0 ? t[k] : 1.0 / t[-k];
+}
+
+// float(('%g' % v)): v rounded to six significant decimal digits, as a double
+__device__ double g6(float vf) {
+    const double v = (double)vf;
+    if (v == 0.0 || !(fabs(v) < 1e30)) return v;
+    const double a = fabs(v);
+    int e = (int)floor(log10(a));
+    double scaled = e <= 5 ? a * pow10i(5 - e) : a / pow10i(e - 5);
+    if (scaled < 99999.5) { --e; scaled = e <= 5 ? a * pow10i(5 - e) : a / pow10i(e - 5); }
+    if (scaled >= 999999.5) { ++e; scaled = e <= 5 ? a * pow10i(5 - e) : a / pow10i(e - 5); }
+    double r = rint(scaled);
+    if (r >= 1e6) { r /= 10.0; ++e; }
+    const double out = e <= 5 ? r / pow10i(5 - e) : r * pow10i(e - 5);
+    return v < 0 ? -out : out;
+}
+
+struct Lab { double v[6]; };  // cls cx cy w h conf
+
+__global__ void clean_labels_kernel(const CleanParams p) {
+    // one thread per fighter; the frames are walked in order (every step depends on the previous one)
+    __shared__ int last_sh[4];
+    __shared__ int maxf_sh;
+    const int f = threadIdx.x;
+    const int F = p.fighters, n = p.n_labels, md = p.max_det;
+    if (f < 4) last_sh[f] = 0;
+    if (f == 0) {
+        int mf = 0;
+        for (int i = 0; i < n; ++i)
+            if (p.counts[i] > 0) mf = i + 1;  // the last label file that is not empty (:244-245)
+        maxf_sh = mf;
+        p.info[0] = mf;
+        p.info[1] = 0; p.info[2] = 0; p.info[3] = 0;
+    }
+    __syncthreads();
+    const int maxf = maxf_sh;
+    if (f >= F) return;
+    const int cid = p.class_ids[f];
+    auto fail = [&](int code, int frame) {
+        if (atomicCAS(&p.info[1], 0, code) == 0) p.info[2] = frame;
+    };
+    auto LAB = [&](int i) -> double* { return p.lab + ((size_t)i * F + f) * 6; };
+    // -- duplicates (:314-359) and the detector's own crops
+    bool have_prev = false;
+    double pcx = 0, pcy = 0;
+    for (int i = 0; i < maxf; ++i) {
+        double* L = LAB(i);
+        p.pixel_frame[i * F + f] = -1;
+        p.crop_kind[i * F + f] = 0;
+        for (int k = 0; k < 4; ++k) p.pixel_box[((size_t)i * F + f) * 4 + k] = 0.0;
+        for (int k = 0; k < 6; ++k) p.crop_row[((size_t)i * F + f) * 6 + k] = 0.f;
+        L[0] = -1.0;
+        int cnt = 0, first = -1, best = -1;
+        double bestd = 10000.0;
+        const int c = p.counts[i] < md ? p.counts[i] : md;
+        for (int k = 0; k < c; ++k) {
+            const float* r = p.dets + ((size_t)i * md + k) * 6;
+            if ((int)g6(r[0]) != cid) continue;
+            ++cnt;
+            if (first < 0) first = k;
+            if (have_prev) {
+                const double d = fabs(g6(r[1]) - pcx) + fabs(g6(r[2]) - pcy);
+                if (d < bestd) { bestd = d; best = k; }
+            }
+        }
+        if (cnt == 0) continue;
+        int pick = first;
+        if (cnt > 1) {
+            if (!have_prev) { fail(1, i + 1); return; }  // "We should have cleaned out the duplicates at this point" (:343)
+            pick = best;
+            atomicAdd(&p.info[3], 1);
+        }
+        const float* r = p.dets + ((size_t)i * md + pick) * 6;
+        for (int k = 0; k < 6; ++k) L[k] = g6(r[k]);
+        L[0] = (double)(int)L[0];
+        have_prev = true;
+        pcx = L[1]; pcy = L[2];
+        p.pixel_frame[i * F + f] = i;
+        for (int k = 0; k < 4; ++k) p.pixel_box[((size_t)i * F + f) * 4 + k] = L[1 + k];
+        p.crop_kind[i * F + f] = 1;
+        // the crop file without a counter in its name is the class's first detection in label order (:247-258)
+        const float* r0 = p.dets + ((size_t)i * md + first) * 6;
+        for (int k = 0; k < 6; ++k) p.crop_row[((size_t)i * F + f) * 6 + k] = (float)g6(r0[k]);
+    }
+    // -- gaps (:361-424)
+    int latest = 1, last = 0;
+    for (int cur = 1; cur <= maxf; ++cur) {
+        if (p.crop_kind[(cur - 1) * F + f] != 1) continue;
+        last = cur;
+        if (cur - latest > 1) {
+            const double* S = LAB(latest - 1);
+            if (S[0] < 0) { fail(2, latest); return; }  // "missing start_yolo_crop" (:375-378)
+            const double* E = LAB(cur - 1);
+            Lab s, e;
+            for (int k = 0; k < 6; ++k) { s.v[k] = S[k]; e.v[k] = E[k]; }
+            for (int j = latest + 1; j < cur; ++j) {
+                const double pct = (double)(cur - j) / (double)(cur - latest);  // measured from the END frame (:389-390)
+                double* L = LAB(j - 1);
+                L[0] = s.v[0];
+                for (int k = 1; k < 6; ++k) L[k] = s.v[k] + (pct * (e.v[k] - s.v[k]));
+                const int o = (j - 1) * F + f;
+                if (j < p.n_decoded) {  // VideoCapture position j = decoded frame index j (:405-406)
+                    p.pixel_frame[o] = j;
+                    for (int k = 0; k < 4; ++k) p.pixel_box[(size_t)o * 4 + k] = L[1 + k];
+                    p.crop_kind[o] = 2;
+                } else {  // the read failed: the previous frame's crop image is copied (:407-416)
+                    const int q = (j - 2) * F + f;
+                    p.pixel_frame[o] = p.pixel_frame[q];
+                    for (int k = 0; k < 4; ++k) p.pixel_box[(size_t)o * 4 + k] = p.pixel_box[(size_t)q * 4 + k];
+                    p.crop_kind[o] = p.crop_kind[q];
+                    for (int k = 0; k < 6; ++k) p.crop_row[(size_t)o * 6 + k] = p.crop_row[(size_t)q * 6 + k];
+                }
+            }
+        }
+        latest = cur;
+    }
+    // -- tail (:270-289): the fighter whose crops end first gets its last crop file copied up to, not including, the
+    // other's last frame. "Last" = the last frame that holds a crop of any kind.
+    int lf = 0;
+    for (int i = 0; i < maxf; ++i)
+        if (p.pixel_frame[i * F + f] >= 0) lf = i + 1;
+    last_sh[f] = lf;
+    __syncthreads();
+    if (lf == 0) { fail(3, 0); return; }  // a fighter without any detection
+    int mx = 0;
+    for (int q = 0; q < F; ++q) mx = last_sh[q] > mx ? last_sh[q] : mx;
+    const int src = (lf - 1) * F + f;
+    for (int i = lf; i < mx; ++i) {
+        const int o = (i - 1) * F + f;
+        p.pixel_frame[o] = p.pixel_frame[src];
+        for (int k = 0; k < 4; ++k) p.pixel_box[(size_t)o * 4 + k] = p.pixel_box[(size_t)src * 4 + k];
+        p.crop_kind[o] = p.crop_kind[src];
+        for (int k = 0; k < 6; ++k) p.crop_row[(size_t)o * 6 + k] = p.crop_row[(size_t)src * 6 + k];
+    }
+    (void)last;
+}
+
+}  // namespace
+
+hipError_t launch_clean_labels(const CleanParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(clean_labels_kernel, dim3(1), dim3(64), 0, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace pa

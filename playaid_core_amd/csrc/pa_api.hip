@@ -1318,6 +1318,21 @@ int pa_backbone_frames_indexed(pa_engine* e, const uint8_t* frames, int32_t n, i
     return PA_OK;
 }
 
+int pa_clean_detections(pa_engine* e, const float* dets, const int32_t* counts, int32_t n_labels, int32_t max_det, int32_t n_decoded_frames,
+                        double* labels, int32_t* pixel_frame, double* pixel_box, int32_t* crop_kind, float* crop_row, int32_t* info4,
+                        void* stream) {
+    if (!e || !dets || !counts || !labels || !pixel_frame || !pixel_box || !crop_kind || !crop_row || !info4 || n_labels < 1 ||
+        max_det < 1 || n_decoded_frames < 1)
+        return fail(e, PA_ERR_INVALID_ARG, "pa_clean_detections: bad argument");
+    pa::CleanParams p;
+    p.dets = dets; p.counts = counts; p.n_labels = n_labels; p.max_det = max_det; p.n_decoded = n_decoded_frames;
+    p.fighters = e->cfg.num_fighters;
+    for (int i = 0; i < 4; ++i) p.class_ids[i] = e->cfg.fighter_class_ids[i];
+    p.lab = labels; p.pixel_frame = pixel_frame; p.pixel_box = pixel_box; p.crop_kind = crop_kind; p.crop_row = crop_row; p.info = info4;
+    HIPCHK(e, pa::launch_clean_labels(p, (hipStream_t)stream));
+    return PA_OK;
+}
+
 int pa_save_one_box_crops(pa_engine* e, const uint8_t* frames, int32_t n_src, int32_t height, int32_t width, const float* dets,
                           const int32_t* counts, int32_t max_det, const int32_t* det_index, const int32_t* src_frame, int32_t n,
                           int32_t jpeg_quality, uint8_t* images, size_t images_capacity, pa_crop_image* desc, void* stream) {

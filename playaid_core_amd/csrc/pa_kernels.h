@@ -188,6 +188,21 @@ struct JpegParams {
 };
 hipError_t launch_jpeg_roundtrip(const JpegParams& p, int ncrops, hipStream_t s);
 
+// label repair on the detection table (detect.hip::clean_labels_kernel)
+struct CleanParams {
+    const float* dets;      // [n_labels][max_det][6] label rows, label-file order
+    const int32_t* counts;  // [n_labels]
+    int32_t n_labels, max_det, n_decoded, fighters;
+    int32_t class_ids[4];
+    double* lab;            // [n_labels][F][6] repaired label row of each fighter (cls < 0: none)
+    int32_t* pixel_frame;   // [n_labels][F]
+    double* pixel_box;      // [n_labels][F][4]
+    int32_t* crop_kind;     // [n_labels][F]
+    float* crop_row;        // [n_labels][F][6]
+    int32_t* info;          // [4]: max_frames, error code, error frame, duplicates resolved
+};
+hipError_t launch_clean_labels(const CleanParams& p, hipStream_t s);
+
 // YOLOv5 save_one_box crops + their 4:4:4 JPEG write / read (savebox.hip)
 struct SaveBoxRect { int32_t x1, y1, w, h; };
 struct SaveBoxParams {

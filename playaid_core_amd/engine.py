@@ -343,6 +343,25 @@ class Engine:
                                                     _ptr(counts), self._stream()))
         return dets, counts
 
+    def clean_detections(self, dets: torch.Tensor, counts: torch.Tensor, n_decoded_frames: int):
+        """``clean_yolo_crops`` (``ai_runner.py:226-424``) on the detection table, on the device (``pa_clean_detections``)
+        -> dict of device tensors: labels float64[n,F,6], pixel_frame int32[n,F], pixel_box float64[n,F,4], crop_kind
+        int32[n,F], crop_row float32[n,F,6], info int32[4] (max_frames, error code, error frame, duplicates resolved)."""
+        n, md = dets.shape[0], dets.shape[1]
+        dev = self.device
+        out = {
+            "labels": torch.empty((n, self.F, 6), dtype=torch.float64, device=dev),
+            "pixel_frame": torch.empty((n, self.F), dtype=torch.int32, device=dev),
+            "pixel_box": torch.empty((n, self.F, 4), dtype=torch.float64, device=dev),
+            "crop_kind": torch.empty((n, self.F), dtype=torch.int32, device=dev),
+            "crop_row": torch.empty((n, self.F, 6), dtype=torch.float32, device=dev),
+            "info": torch.zeros(4, dtype=torch.int32, device=dev),
+        }
+        self._check(self._lib.pa_clean_detections(self._h, _ptr(dets), _ptr(counts), n, md, int(n_decoded_frames), _ptr(out["labels"]),
+                                                  _ptr(out["pixel_frame"]), _ptr(out["pixel_box"]), _ptr(out["crop_kind"]),
+                                                  _ptr(out["crop_row"]), _ptr(out["info"]), self._stream()))
+        return out
+
     def save_one_box_crops(self, frames_dev: torch.Tensor, dets: torch.Tensor, counts: torch.Tensor, det_index=None,
                            jpeg_quality: int = 95, images: torch.Tensor = None, desc: torch.Tensor = None, src_frame=None):
         """``detect.py --save-crop`` + ``cv2.imread`` of every crop (``ai_runner.py:208,445-446``) on the device: frames
