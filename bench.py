@@ -263,6 +263,50 @@ def pcie_inclusive_windows(eng, frames_dev, boxes_dev, steps=8):
     }
 
 
+def bench_f4(args):
+    """the reference's alternative temporal models on the same conv kernels, timed per call
+    (windows in, log-probabilities out, input resident in HBM). rnn = RNNActionDetector (ResNet-18 -> 3-layer LSTM,
+    models/rnn_action_detector.py:74-95), resformer = ResnetTransformerDetector (timm ResNet-50 -> 3-layer transformer
+    encoder, models/resnet_transformer_detector.py:65-93). Single GPU, own metric (never the headline)."""
+    from playaid_core_amd.anim_ontology import ACTIONS
+
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(device)
+    b, s_len = args.f4_windows, 7
+    if args.workload == "rnn":
+        from playaid_core_amd.rnn_action_detector import RNNActionDetector
+        model = RNNActionDetector("Joker", ACTIONS, state_dict=synth.make_rnn_state_dict(), max_rows=b * s_len)
+        backbone_gflop_per_crop = 1.1843  # ResNet-18 at 128 x 128 with fc -> 300 (SURVEY 8a7 minus the unused fc rows)
+        name = "RNNActionDetector: ResNet-18 (fc 300) -> LSTM(300, 512, 3 layers) -> 512-128-A"
+    else:
+        from playaid_core_amd.resnet_transformer_detector import ResnetTransformerDetector
+        model = ResnetTransformerDetector(ACTIONS, sequence_length=s_len, state_dict=synth.make_resformer_state_dict(sequence_length=s_len),
+                                          max_rows=b * s_len)
+        backbone_gflop_per_crop = 2.0 * 1.339  # timm resnet50 at 128 x 128: 1.339 GMAC
+        name = "ResnetTransformerDetector: ResNet-50 -> Linear(2048, 247) + time encoding -> 3 encoder layers (d 256, 8 heads, ff 2048) -> A"
+    x = (torch.rand((b, s_len, 3, 128, 128), device=device) * 255).round() / 255
+    for _ in range(args.warmup):
+        out = model(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = model(x)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    tf = backbone_gflop_per_crop * b * s_len / dt / 1e3
+    print(json.dumps({
+        "metric": f"windows/sec, {args.workload} temporal model (7 x 128 x 128 windows resident in HBM -> per-frame log-probabilities)",
+        "value": round(b / dt, 1), "unit": "windows/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic (seeded random-init weights, random windows)",
+        "config": {"workload": f"{args.workload}: {name}; {b} windows ({b * s_len} crops) per call", "windows_per_call": b},
+        "backbone_tflops_if_all_time_were_backbone": round(tf, 2),
+        "backbone_frac_of_fp32_matrix_peak_lower_bound": round(tf / PEAK_FP32_MATRIX_TFLOPS, 4),
+        "finite": bool(torch.isfinite(out).all()),
+    }), flush=True)
+    model.close()
+
+
 def bench_mixed(args):
     """BASELINE.json configs[4]: a 1080p/720p interleaved clip, frames resident in HBM per resolution bucket, fixed-size
     batches through hipGraph-captured "crop + backbone + scatter into the feature cache" sequences, one head pass per
@@ -377,7 +421,8 @@ def main():
                     "--gpus > 1, off (configs[1]: a 64-frame clip per step) when --gpus 1; 0 = a --frames clip per rank (weak scaling)")
     ap.add_argument("--inner-repeat", type=int, default=20,
                     help="configs[1]/[2] only: clips per timed step (ms_per_step stays per clip)")
-    ap.add_argument("--workload", default="clip", choices=["clip", "mixed"],
+    ap.add_argument("--f4-windows", type=int, default=64, help="--workload rnn | resformer: windows per call")
+    ap.add_argument("--workload", default="clip", choices=["clip", "mixed", "rnn", "resformer"],
                     help="clip = the headline / configs[1-3] workloads; mixed = BASELINE.json configs[4] (mixed-resolution stream, "
                     "bucketing + hipGraph replay; single GPU, reported under its own metric)")
     ap.add_argument("--lanes", type=int, default=2,
@@ -408,6 +453,8 @@ def main():
 
     if args.workload == "mixed":
         return bench_mixed(args)
+    if args.workload in ("rnn", "resformer"):
+        return bench_f4(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -14,6 +14,7 @@
 // the hot loop: no MFMA tiling here on purpose.
 #include "pa_kernels.h"
 #include "../../include/playaid_hip.h"
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -122,6 +123,111 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict_
     }
 }
 
+
+// One LAYER in one launch (round 3): the H / 8 workgroups of lstm_step_kernel stay resident for all time steps. Each
+// keeps its 32 rows of W_hh (8 hidden units x 4 gates, 64 KB at H = 512) in LDS and its c state in registers, so a step
+// moves only h(t-1) (N x H floats) in and 8 x N values out; the steps are separated by a grid barrier (one atomic counter,
+// agent-scope release / acquire fences: the XCDs' L2s are not coherent for plain stores). The barrier gives up after
+// 20 ms (*err = 1) so that a grid that is not fully resident cannot hang the queue (pa_lstm_last_status reports it, the
+// handle then falls back to one launch per step).
+// The recurrent product of a step, [32 rows] x [N] dots of length H, is spread as thread = (row, eighth of k): 16-byte
+// LDS reads of the weights (row pitch H + 32 floats: the 16 lanes of a read phase fall on distinct banks) and of h
+// (broadcast across rows), H / 8 x N FMAs per thread, three shuffle steps to add the eighths. Measured per step (us):
+// barrier wait 3.5, h load 3.0, product 46.7 with lstm_step_kernel's wave-per-gate loop -> see profiles/README.md.
+constexpr int LSTM_WPITCH_PAD = 32;
+__global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict__ pre_all, const float* __restrict__ w_hh,
+                                                         const float* __restrict__ b_hh, float* __restrict__ hseq, int L, int N, int H,
+                                                         int* __restrict__ counter, int* __restrict__ err) {
+    extern __shared__ float sm[];
+    const int WP = H + LSTM_WPITCH_PAD;
+    float* ws = sm;                              // [32][WP]: rows (gate * 8 + u) of this workgroup's units
+    float* hs = ws + (size_t)32 * WP;            // [N][H]
+    float* gs = hs + (size_t)N * H;              // [32][LSTM_NMAX]
+    __shared__ int go;
+    const int j0 = blockIdx.x * 8, nwg = gridDim.x;
+    const int row = threadIdx.x >> 3, part = threadIdx.x & 7;
+    for (int i = threadIdx.x; i < 32 * H; i += 256) {
+        const int r = i / H, k = i - r * H;
+        ws[(size_t)r * WP + k] = w_hh[(size_t)((r >> 3) * H + j0 + (r & 7)) * H + k];
+    }
+    float c_reg = 0.f;  // thread (u, n) = threadIdx.x < 8 * LSTM_NMAX owns c[n][j0 + u]
+    __syncthreads();
+    for (int t = 0; t < L; ++t) {
+        const float* pre = pre_all + (size_t)t * N * 4 * H;
+        if (t > 0) {
+            // every workgroup has published h(t-1)
+            if (threadIdx.x == 0) {
+                const unsigned long long t0 = wall_clock64();
+                int ok = 1;
+                while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < t * nwg) {
+                    if (wall_clock64() - t0 > 2000000ull || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = 0;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                go = ok;
+            }
+            __syncthreads();
+            if (!go) return;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const float4* h_prev = reinterpret_cast<const float4*>(hseq + (size_t)(t - 1) * N * H);
+            for (int i = threadIdx.x; i < N * H / 4; i += 256) reinterpret_cast<float4*>(hs)[i] = h_prev[i];
+            __syncthreads();
+            float acc[LSTM_NMAX];
+#pragma unroll
+            for (int n = 0; n < LSTM_NMAX; ++n) acc[n] = 0.f;
+            const float4* wr = reinterpret_cast<const float4*>(ws + (size_t)row * WP);
+            for (int i = 0; i < H / 32; ++i) {
+                const int q = i * 8 + part;  // float4 index along k
+                const float4 w = wr[q];
+#pragma unroll
+                for (int n = 0; n < LSTM_NMAX; ++n)
+                    if (n < N) {
+                        const float4 hv = reinterpret_cast<const float4*>(hs + (size_t)n * H)[q];
+                        acc[n] = fmaf(w.x, hv.x, acc[n]);
+                        acc[n] = fmaf(w.y, hv.y, acc[n]);
+                        acc[n] = fmaf(w.z, hv.z, acc[n]);
+                        acc[n] = fmaf(w.w, hv.w, acc[n]);
+                    }
+            }
+#pragma unroll
+            for (int n = 0; n < LSTM_NMAX; ++n)
+                if (n < N) {
+                    float v = acc[n];
+                    v += __shfl_xor(v, 1, 64);
+                    v += __shfl_xor(v, 2, 64);
+                    v += __shfl_xor(v, 4, 64);
+                    if (part == 0) gs[row * LSTM_NMAX + n] = v;
+                }
+            __syncthreads();
+        }
+        if (threadIdx.x < 8 * LSTM_NMAX) {
+            const int u = threadIdx.x / LSTM_NMAX, n = threadIdx.x % LSTM_NMAX;
+            if (n < N) {
+                const int j = j0 + u;
+                float g4[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float rec = (t > 0 ? gs[(g * 8 + u) * LSTM_NMAX + n] : 0.f) + b_hh[g * H + j];
+                    g4[g] = pre[(size_t)n * 4 * H + g * H + j] + rec;
+                }
+                const float ig = sigmoidf(g4[0]), fg = sigmoidf(g4[1]), gg = tanhf(g4[2]), og = sigmoidf(g4[3]);
+                const float cn = fg * (t > 0 ? c_reg : 0.f) + ig * gg;
+                c_reg = cn;
+                hseq[(size_t)t * N * H + n * H + j] = og * tanhf(cn);
+            }
+        }
+        // publish h(t): stores first, then the arrival
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // action_decoder + log_softmax for one row: Linear(H,128) + ReLU -> Linear(128,A) -> log_softmax
 __global__ __launch_bounds__(128) void lstm_decode_kernel(const float* __restrict__ h, const float* __restrict__ w1,
                                                           const float* __restrict__ b1, const float* __restrict__ w2,
@@ -170,6 +276,9 @@ struct pa_lstm {
     float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
     float *weights = nullptr;            // one allocation behind all of the above
     float *pre = nullptr, *hseq[2] = {nullptr, nullptr}, *c = nullptr;
+    int* sync_words = nullptr;            // [2 * layers]: per layer the grid barrier's counter and its error word
+    int* sync_host = nullptr;             // pinned copy of the error words
+    bool persistent = true;               // one launch per layer (lstm_layer_kernel); false after a barrier timeout
     std::string last_error;
 };
 
@@ -231,6 +340,27 @@ int pa_lstm_create(int32_t device, int32_t input_dim, int32_t hidden_dim, int32_
     for (int i = 0; i < 2; ++i)
         if (!chk(hipMalloc(&h->hseq[i], (size_t)max_rows * H * sizeof(float)), "hipMalloc h")) return PA_ERR_HIP;
     if (!chk(hipMalloc(&h->c, (size_t)pa::LSTM_NMAX * H * sizeof(float)), "hipMalloc c")) return PA_ERR_HIP;
+    if (!chk(hipMalloc(&h->sync_words, 2 * 8 * sizeof(int)), "hipMalloc barrier words")) return PA_ERR_HIP;
+    if (!chk(hipHostMalloc(&h->sync_host, 2 * 8 * sizeof(int)), "hipHostMalloc")) return PA_ERR_HIP;
+    memset(h->sync_host, 0, 2 * 8 * sizeof(int));
+    {
+        // W_hh rows + h(t-1) + gate scratch in LDS: beyond the 64 KB default
+        const size_t lds = ((size_t)32 * (H + pa::LSTM_WPITCH_PAD) + (size_t)pa::LSTM_NMAX * H + 4 * 8 * pa::LSTM_NMAX) * sizeof(float);
+        if (lds > 160 * 1024 || H % 32 != 0 || getenv("PA_LSTM_STEPS")) h->persistent = false;
+        else if (!chk(hipFuncSetAttribute(reinterpret_cast<const void*>(&pa::lstm_layer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)lds), "hipFuncSetAttribute")) return PA_ERR_HIP;
+    }
+    return PA_OK;
+}
+
+int pa_lstm_last_status(pa_lstm* h) {
+    if (!h) return PA_ERR_INVALID_ARG;
+    for (int l = 0; l < h->layers; ++l)
+        if (h->sync_host && h->sync_host[2 * l + 1]) {
+            h->last_error = "pa_lstm_forward: the grid barrier of the per-layer kernel timed out (its workgroups were not all resident); "
+                            "the results of that call are invalid, later calls launch one kernel per time step";
+            return PA_ERR_HIP;
+        }
     return PA_OK;
 }
 
@@ -241,6 +371,8 @@ void pa_lstm_destroy(pa_lstm* h) {
     (void)hipFree(h->hseq[0]);
     (void)hipFree(h->hseq[1]);
     (void)hipFree(h->c);
+    (void)hipFree(h->sync_words);
+    if (h->sync_host) (void)hipHostFree(h->sync_host);
     delete h;
 }
 
@@ -259,6 +391,19 @@ int pa_lstm_forward(pa_lstm* h, const float* x, int32_t ld, int32_t seq_len, int
         const int in_ld = l == 0 ? ld : H, K = l == 0 ? h->in_dim : H;
         (void)pa::launch_linear_f32(in, in_ld, h->w_ih[l], h->b_ih[l], h->pre, 4 * H, M, 4 * H, K, 0, s);
         float* hs = h->hseq[l & 1];
+        if (h->persistent) {
+            // all time steps of the layer in one launch; a barrier that timed out in an earlier call (grid not resident)
+            // switches this handle to one launch per step for good
+            if (h->sync_host[2 * l + 1]) h->persistent = false;
+        }
+        if (h->persistent) {
+            const size_t lds = ((size_t)32 * (H + pa::LSTM_WPITCH_PAD) + (size_t)batch * H + 4 * 8 * pa::LSTM_NMAX) * sizeof(float);
+            (void)hipMemsetAsync(h->sync_words + 2 * l, 0, 2 * sizeof(int), s);
+            hipLaunchKernelGGL(pa::lstm_layer_kernel, dim3(H / 8), dim3(256), lds, s, h->pre, h->w_hh[l], h->b_hh[l], hs, seq_len, batch, H,
+                               h->sync_words + 2 * l, h->sync_words + 2 * l + 1);
+            (void)hipMemcpyAsync(h->sync_host + 2 * l, h->sync_words + 2 * l, 2 * sizeof(int), hipMemcpyDeviceToHost, s);
+            continue;
+        }
         for (int t = 0; t < seq_len; ++t)
             hipLaunchKernelGGL(pa::lstm_step_kernel, dim3(H / 8), dim3(256), step_lds, s, h->pre + (size_t)t * batch * 4 * H, h->w_hh[l],
                                h->b_hh[l], t ? hs + (size_t)(t - 1) * batch * H : nullptr, h->c, hs + (size_t)t * batch * H, batch, H);

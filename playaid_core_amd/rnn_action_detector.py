@@ -169,6 +169,17 @@ class RNNActionDetector:
         rc = self._lib.pa_lstm_forward(self._h, _ptr(self._feats), _lib.PA_FEATURE_STRIDE, b, s, _ptr(out), eng._stream())
         if rc != 0:
             raise EngineError(rc, self._lib.pa_lstm_last_error(self._h).decode())
-        return out if x.is_cuda else out.cpu()
+        if x.is_cuda:
+            return out
+        res = out.cpu()  # synchronises
+        self.check()
+        return res
+
+    def check(self):
+        """After the stream of a ``forward`` has been synchronised: raises if the per-layer LSTM kernel's grid barrier
+        timed out in that call (``pa_lstm_last_status``)."""
+        rc = self._lib.pa_lstm_last_status(self._h)
+        if rc != 0:
+            raise EngineError(rc, self._lib.pa_lstm_last_error(self._h).decode())
 
     __call__ = forward
