@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PA_ABI_VERSION 5
+#define PA_ABI_VERSION 6
 #define PA_WEIGHT_MAGIC 0x31574150 /* "PAW1" */
 #define PA_LSTM_MAGIC 0x314c4150   /* "PAL1" */
 #define PA_ENCODER_MAGIC 0x31454150 /* "PAE1" */
@@ -203,6 +203,41 @@ int pa_backbone_crop_images(pa_engine* e, const uint8_t* images, size_t images_b
 int pa_detect_postprocess(pa_engine* e, const float* pred, int32_t n_frames, int32_t rows, int32_t num_classes,
                           float conf_thres, float iou_thres, uint32_t class_mask, int32_t max_det, int32_t net_height,
                           int32_t net_width, int32_t img_height, int32_t img_width, float* dets, int32_t* counts, void* stream);
+
+/* ---- f1: the detection network ---------------------------------------------
+ *
+ * Replaces the network half of the YOLOv5 subprocess (ai_runner.py:191-224: `detect.py --weights <yolov5s checkpoint>
+ * --source <video>`): frames -> letterbox (cv2.resize INTER_LINEAR to the un-padded size, 114-grey border, BGR -> RGB,
+ * / 255) -> a fully convolutional network given as a LAYER TABLE -> Detect decode -> pred float32[n][rows][5 + nc] in
+ * network-input pixels, i.e. the input of pa_detect_postprocess. The table (playaid_core_amd/yolov5.py builds YOLOv5s
+ * v7.0 from an ultralytics state dict) arrives BatchNorm-folded: per convolution [cout][ky][kx][cin] at w_off and the bias
+ * [cout] at b_off (float offsets into one blob); the 6x6 stem as [cout][6][6][4] (channel 3 zero). Activations are
+ * zero-bordered NHWC device buffers of buf_floats_per_image[b] floats per image; a layer addresses a CHANNEL SLICE of a
+ * buffer (coff = first channel, cstride = channels per pixel of the buffer), so concatenations are free. */
+typedef struct pa_net_layer {
+    int32_t kind;      /* 0 convolution, 3 stem 6x6/2 + SiLU on the letter-boxed image, 4 max-pool 5x5/1, 5 nearest 2x up-sampling,
+                          6 Detect decode of one scale (3 anchors) */
+    int32_t cin, cout; /* kind 0: cin % 32 == 0, cout % 64 == 0 (pad with zero weights); kinds 4 / 5: cin = channels moved */
+    int32_t ksize, stride;           /* kind 0: 1 | 3, 1 | 2 */
+    int32_t in_h, in_w;              /* interior of the input */
+    int32_t in_buf, in_coff, in_cstride, in_pad;
+    int32_t out_buf, out_coff, out_cstride, out_pad;
+    int32_t res_buf, res_coff;       /* residual slice (-1: none): the output's geometry and cstride */
+    int32_t act;                     /* 0 none, 1 ReLU, 2 SiLU */
+    int32_t res_after;               /* 1: residual added after the activation (YOLOv5 Bottleneck), 0: before (ResNet) */
+    int32_t reserved;
+    int64_t w_off, b_off;
+    float aux[8];                    /* kind 6: stride of the scale, then 3 anchors (w, h) in network-input pixels */
+} pa_net_layer;
+typedef struct pa_detector pa_detector;
+int pa_detector_create(int32_t device, const pa_net_layer* layers, int32_t n_layers, const int64_t* buf_floats_per_image, int32_t n_bufs,
+                       const float* weights_host, size_t n_weights, int32_t max_images, int32_t net_h, int32_t net_w, int32_t num_classes,
+                       pa_detector** out);
+void pa_detector_destroy(pa_detector* h);
+const char* pa_detector_last_error(const pa_detector* h);
+int pa_detector_rows(const pa_detector* h); /* rows of pred per image: 3 x sum over the decode layers of in_h x in_w */
+/* frames uint8[n,H,W,3] BGR (device) -> pred float32[n][rows][5 + nc] (device). */
+int pa_detector_forward(pa_detector* h, const uint8_t* frames, int32_t n, int32_t height, int32_t width, float* pred, void* stream);
 
 /* Replaces AIRunner.clean_yolo_crops / clean_yolo_crops_for_fighter (ai_runner.py:226-289, 306-424) on the table
  * pa_detect_postprocess wrote (dets float32[n_labels][max_det][6], counts int32[n_labels]; label n = index n - 1), with no

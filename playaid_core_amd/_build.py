@@ -33,6 +33,7 @@ SOURCES = [
     ("jpeg.hip", ["-ffp-contract=off"]),
     ("mjpeg.hip", []),
     ("savebox.hip", ["-ffp-contract=off"]),
+    ("yolo.hip", ["-ffp-contract=off"]),
     ("pa_api.hip", []),
 ]
 

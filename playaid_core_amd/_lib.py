@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # PA_LIB_PATH: load a differently built library (e.g. the ablation build used by scripts/)
 LIB_PATH = os.environ.get("PA_LIB_PATH") or os.path.join(HERE, "libplayaid_hip.so")
 
-PA_ABI_VERSION = 5
+PA_ABI_VERSION = 6
 PA_DTYPE_F32 = 0
 PA_DTYPE_BF16 = 1
 PA_WEIGHT_MAGIC = 0x31574150
@@ -81,6 +81,12 @@ class pa_conv_desc(C.Structure):
                                         "res_buf", "relu")] + [("w_off", C.c_int64), ("b_off", C.c_int64)]
 
 
+class pa_net_layer(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("kind", "cin", "cout", "ksize", "stride", "in_h", "in_w", "in_buf", "in_coff", "in_cstride", "in_pad",
+                                        "out_buf", "out_coff", "out_cstride", "out_pad", "res_buf", "res_coff", "act", "res_after",
+                                        "reserved")] + [("w_off", C.c_int64), ("b_off", C.c_int64), ("aux", C.c_float * 8)]
+
+
 class pa_kernel_stat(C.Structure):
     _fields_ = [
         ("name", C.c_char * 48),
@@ -109,6 +115,12 @@ SYMBOLS = [
     ("pa_backbone_crop_images", C.c_int, [_P, _P, C.c_size_t, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     ("pa_detect_postprocess", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_uint32, C.c_int32,
                                         C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
+    ("pa_detector_create", C.c_int, [C.c_int32, C.POINTER(pa_net_layer), C.c_int32, C.POINTER(C.c_int64), C.c_int32, _P, C.c_size_t,
+                                     C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P)]),
+    ("pa_detector_destroy", None, [_P]),
+    ("pa_detector_last_error", C.c_char_p, [_P]),
+    ("pa_detector_rows", C.c_int, [_P]),
+    ("pa_detector_forward", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     ("pa_clean_detections", C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
     ("pa_save_one_box_crops", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int32, _P, _P, C.c_int32, C.c_int32, _P,
                                         C.c_size_t, _P, _P]),

@@ -368,11 +368,15 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const GemmParams p) {
         if (!direct_out) {
             *reinterpret_cast<f32x4*>(p.slab + ((size_t)z * p.M + m) * p.N + tile_n * BN + c4) = v;
         } else {
-            v += bias4 + res_t[i];
-            if (p.relu) {
+            v += p.res_after ? bias4 : bias4 + res_t[i];
+            if (p.relu == 1) {
                 v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
                 v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+            } else if (p.relu == 2) {
+                v.x = v.x / (1.f + expf(-v.x)); v.y = v.y / (1.f + expf(-v.y));
+                v.z = v.z / (1.f + expf(-v.z)); v.w = v.w / (1.f + expf(-v.w));
             }
+            if (p.res_after) v += res_t[i];
             *reinterpret_cast<f32x4*>(p.out + o_t[i]) = v;
         }
     }
@@ -398,14 +402,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
             const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
             s.x += bv.x; s.y += bv.y; s.z += bv.z; s.w += bv.w;
         }
-        if (p.residual) {
-            const float4 rv = *reinterpret_cast<const float4*>(p.residual + o);
-            s.x += rv.x; s.y += rv.y; s.z += rv.z; s.w += rv.w;
-        }
-        if (p.relu) {
+        float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.residual) rv = *reinterpret_cast<const float4*>(p.residual + o);
+        if (!p.res_after) { s.x += rv.x; s.y += rv.y; s.z += rv.z; s.w += rv.w; }
+        if (p.relu == 1) {
             s.x = s.x > 0.f ? s.x : 0.f; s.y = s.y > 0.f ? s.y : 0.f;
             s.z = s.z > 0.f ? s.z : 0.f; s.w = s.w > 0.f ? s.w : 0.f;
+        } else if (p.relu == 2) {
+            s.x = s.x / (1.f + expf(-s.x)); s.y = s.y / (1.f + expf(-s.y));
+            s.z = s.z / (1.f + expf(-s.z)); s.w = s.w / (1.f + expf(-s.w));
         }
+        if (p.res_after) { s.x += rv.x; s.y += rv.y; s.z += rv.z; s.w += rv.w; }
         *reinterpret_cast<float4*>(p.out + o) = s;
     }
 }

@@ -32,7 +32,8 @@ struct GemmParams {
     int32_t howo_shift, wo_shift;  // log2 of the above when both are powers of two, else -1 (set by the launcher)
     int32_t in_img_stride, in_row_stride, in_px_stride, stride, off_y, off_x;
     int32_t out_img_stride, out_row_stride, out_px_stride, out_pad;
-    int32_t relu;
+    int32_t relu;           // activation of the epilogue: 0 none, 1 ReLU, 2 SiLU (x * sigmoid(x))
+    int32_t res_after;      // 1: the residual is added AFTER the activation (YOLOv5's Bottleneck), 0: before (ResNet)
     // optional second im2col source appended to K (k2_steps * 32 values, 1x1 taps): act2 addressed as
     //   act2 + img*in2_img_stride + (oy*stride2 + off2)*in2_row_stride + (ox*stride2 + off2)*in2_px_stride + kc
     const float* act2;

@@ -460,3 +460,66 @@ def encode_jpeg_frames(frames_bgr, quality: int = 95, subsampling: int = 2, rest
         im.save(b, "JPEG", quality=quality, optimize=optimize, **kw)
         out.append(b.getvalue())
     return out
+
+
+# ----------------------------------------------------------------------------
+# a YOLOv5s checkpoint's state dict (the detector the reference shells out to)
+# ----------------------------------------------------------------------------
+
+def make_yolov5s_state_dict(seed: int = 1357, nc: int = 6) -> Dict[str, np.ndarray]:
+    """Seeded fp32 weights in the key layout of an ultralytics/yolov5 v7.0 ``yolov5s`` checkpoint (``models/yolov5s.yaml``:
+    ``model.<i>.conv.weight``, ``model.<i>.bn.{weight,bias,running_mean,running_var}``, C3's ``cv1 / cv2 / cv3 / m.<j>.cv1|cv2``,
+    SPPF's ``cv1 / cv2``, ``model.24.m.<k>.{weight,bias}``, ``model.24.anchors`` in stride units). ``nc`` = 6: the
+    reference's ``CHAR_LIST`` (``constants.py:51``; ``--classes 2 3`` picks two of them). Same distributions as
+    ``make_state_dict``; the Detect biases as ``Model._initialize_biases`` leaves them (objectness ~ 8 / (640 / s)^2)."""
+    sd: Dict[str, np.ndarray] = {}
+    c = (32, 64, 128, 256, 512)
+
+    def conv(prefix, c1, c2, k):
+        fan = c1 * k * k
+        a = math.sqrt(3.0 / fan) * 1.5   # SiLU shrinks the signal: this gain keeps 60 layers alive without saturating the head
+        sd[prefix + ".conv.weight"] = uniform((c2, c1, k, k), _name_seed(prefix + ".conv.weight", seed), -a, a)
+        sd[prefix + ".bn.weight"] = uniform((c2,), _name_seed(prefix + ".bn.weight", seed), 0.5, 1.5)
+        sd[prefix + ".bn.bias"] = uniform((c2,), _name_seed(prefix + ".bn.bias", seed), -0.1, 0.1)
+        sd[prefix + ".bn.running_mean"] = uniform((c2,), _name_seed(prefix + ".bn.running_mean", seed), -0.1, 0.1)
+        sd[prefix + ".bn.running_var"] = uniform((c2,), _name_seed(prefix + ".bn.running_var", seed), 0.5, 1.5)
+
+    def c3(prefix, c1, c2, n):
+        c_ = c2 // 2
+        conv(prefix + ".cv1", c1, c_, 1)
+        conv(prefix + ".cv2", c1, c_, 1)
+        conv(prefix + ".cv3", 2 * c_, c2, 1)
+        for j in range(n):
+            conv(f"{prefix}.m.{j}.cv1", c_, c_, 1)
+            conv(f"{prefix}.m.{j}.cv2", c_, c_, 3)
+
+    conv("model.0", 3, c[0], 6)
+    conv("model.1", c[0], c[1], 3)
+    c3("model.2", c[1], c[1], 1)
+    conv("model.3", c[1], c[2], 3)
+    c3("model.4", c[2], c[2], 2)
+    conv("model.5", c[2], c[3], 3)
+    c3("model.6", c[3], c[3], 3)
+    conv("model.7", c[3], c[4], 3)
+    c3("model.8", c[4], c[4], 1)
+    conv("model.9.cv1", c[4], c[3], 1)
+    conv("model.9.cv2", 4 * c[3], c[4], 1)
+    conv("model.10", c[4], c[3], 1)
+    c3("model.13", 2 * c[3], c[3], 1)
+    conv("model.14", c[3], c[2], 1)
+    c3("model.17", 2 * c[2], c[2], 1)
+    conv("model.18", c[2], c[2], 3)
+    c3("model.20", 2 * c[2], c[3], 1)
+    conv("model.21", c[3], c[3], 3)
+    c3("model.23", 2 * c[3], c[4], 1)
+    no = 5 + nc
+    for i, (ch, s) in enumerate(((c[2], 8), (c[3], 16), (c[4], 32))):
+        a = math.sqrt(3.0 / ch)
+        sd[f"model.24.m.{i}.weight"] = uniform((3 * no, ch, 1, 1), _name_seed(f"model.24.m.{i}.weight", seed), -a, a)
+        b = uniform((3, no), _name_seed(f"model.24.m.{i}.bias", seed), -0.05, 0.05)
+        b[:, 4] += math.log(8 / (640 / s) ** 2)
+        b[:, 5:] += math.log(0.6 / (nc - 0.99999))
+        sd[f"model.24.m.{i}.bias"] = b.reshape(-1)
+    anchors = np.array([[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]], np.float32).reshape(3, 3, 2)
+    sd["model.24.anchors"] = anchors / np.array([8, 16, 32], np.float32)[:, None, None]
+    return sd

@@ -10,10 +10,10 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 LOG=${1:-$R/profiles/r03_asan_host.log}
 B=$R/build/asan
 mkdir -p $B
-SRC="igemm igemm_bf16 patchconv patchconv_bf16 stem stem_pool misc preprocess detect lstm convnet transformer jpeg mjpeg savebox pa_api"
+SRC="igemm igemm_bf16 patchconv patchconv_bf16 stem stem_pool misc preprocess detect lstm convnet transformer jpeg mjpeg savebox yolo pa_api"
 for s in $SRC; do
   extra=""
-  case $s in preprocess|detect|jpeg|savebox) extra="-ffp-contract=off";; esac
+  case $s in preprocess|detect|jpeg|savebox|yolo) extra="-ffp-contract=off";; esac
   if [ ! -f $B/$s.o ] || [ $R/playaid_core_amd/csrc/$s.hip -nt $B/$s.o ]; then
     hipcc --offload-arch=gfx950 -O1 -g -fPIC -std=c++17 -fsanitize=address,undefined -fno-gpu-sanitize -fno-omit-frame-pointer $extra \
       -c $R/playaid_core_amd/csrc/$s.hip -o $B/$s.o

@@ -1,0 +1,108 @@
+"""Row f1: the detection network (YOLOv5s as a layer table on the implicit-GEMM kernel) against oracle/yolov5.py."""
+import numpy as np
+import pytest
+
+from playaid_core_amd import synth
+
+NC = 6
+NET = (384, 640)
+
+
+def test_table_covers_the_published_graph():
+    from playaid_core_amd.yolov5 import build_yolov5s_table
+
+    sd = synth.make_yolov5s_state_dict()
+    layers, bufs, weights, rows = build_yolov5s_table(sd, NET, NC)
+    kinds = [l.kind for l in layers]
+    # the 6x6 stem + 55 GEMM convolutions of the graph (56 Conv modules besides the stem, model.2's cv1 / cv2 merged
+    # into one) + the 3 Detect convolutions, 3 SPPF max-pools, 2 up-samplings, 3 decodes
+    assert kinds.count(3) == 1 and kinds.count(0) == 55 + 3 and kinds.count(4) == 3 and kinds.count(5) == 2 and kinds.count(6) == 3
+    assert rows == 3 * (48 * 80 + 24 * 40 + 12 * 20)
+    n_params = sum(int(np.prod(v.shape)) for k, v in sd.items() if k.endswith("conv.weight") or k.startswith("model.24.m"))
+    assert 7.0e6 < n_params < 7.3e6  # yolov5s: 7.0 M weights (7.2 M parameters with the BatchNorm vectors)
+    assert all(l.cin % 32 == 0 and l.cout % 64 == 0 for l in layers if l.kind == 0)
+
+
+def test_oracle_front_end():
+    from oracle import yolov5 as oy
+
+    f = synth.make_frame(3, 720, 1280)
+    x = oy.letterbox(f, NET)
+    assert x.shape == (3, 384, 640) and x.dtype == np.float32
+    assert np.all(x[:, :12] == np.float32(114) / np.float32(255)) and np.all(x[:, 372:] == np.float32(114) / np.float32(255))
+    # 720p -> 360 x 640 is an exact 2x reduction: (a + b + c + d + 2) >> 2 of every 2 x 2 block, BGR -> RGB
+    blk = f.astype(np.int64).reshape(360, 2, 640, 2, 3).sum(axis=(1, 3))
+    want = ((blk + 2) >> 2)[..., ::-1].transpose(2, 0, 1).astype(np.float32) / np.float32(255)
+    assert np.array_equal(x[:, 12:372], want)
+    # 1080p -> 360 x 640 samples pixel (3y + 1, 3x + 1) exactly
+    g = synth.make_frame(4, 1080, 1920)
+    y = oy.letterbox(g, NET)
+    assert np.array_equal(y[:, 12:372], g[1::3, 1::3, ::-1].transpose(2, 0, 1).astype(np.float32) / np.float32(255))
+    # a size that really interpolates stays within the pixel range and close to the area mean
+    r = oy.resize_linear_u8(f[:100, :150], 97, 61)
+    assert r.shape == (61, 97, 3) and abs(float(r.mean()) - float(f[:100, :150].mean())) < 2.0
+
+
+@pytest.mark.gpu
+def test_detection_network_against_the_oracle(engine):
+    """frames -> letterbox -> YOLOv5s -> Detect decode on the device == the torch CPU oracle on the same state dict."""
+    import torch
+
+    from oracle import detect as odet
+    from oracle import yolov5 as oy
+    from playaid_core_amd import detect as pdet
+    from playaid_core_amd.yolov5 import YoloV5Detector
+
+    sd = synth.make_yolov5s_state_dict()
+    det = YoloV5Detector(sd, NC, NET, max_images=4)
+    try:
+        for h, w, n in ((720, 1280, 3), (1080, 1920, 2)):
+            frames = synth.make_frames(n, h, w, seed=5)
+            got = det(frames)
+            torch.cuda.synchronize()
+            got = got.cpu().numpy()
+            x = torch.from_numpy(np.stack([oy.letterbox(f, NET) for f in frames]))
+            want = oy.forward(x, sd, NC).numpy()
+            assert got.shape == want.shape == (n, det.rows, 5 + NC)
+            # boxes in network pixels, scores in 0..1: fp32 through 60 layers whose synthetic weights amplify on purpose
+            assert np.abs(got[..., :4] - want[..., :4]).max() <= 2e-2, np.abs(got[..., :4] - want[..., :4]).max()
+            assert np.abs(got[..., 4:] - want[..., 4:]).max() <= 2e-4, np.abs(got[..., 4:] - want[..., 4:]).max()
+            assert want[..., 4].max() > 0.05 and want[..., 5:].std() > 0.05  # a live network, not a bias echo
+        # through the post-processing the reference's subprocess runs (thresholds lowered so that the seeded network
+        # "detects" something): same label text as the oracle's NMS on the oracle's rows wherever the scores are apart
+        frames = synth.make_frames(2, 720, 1280, seed=5)
+        labels = det.labels(engine, frames, conf_thres=0.02, max_det=4, classes=(0, 1, 2, 3, 4, 5))
+        x = torch.from_numpy(np.stack([oy.letterbox(f, NET) for f in frames]))
+        want = oy.forward(x, sd, NC).numpy()
+        for i in range(2):
+            rows, text = odet.detect_frame(want[i], NET, (720, 1280), conf_thres=0.02, classes=(0, 1, 2, 3, 4, 5), max_det=4)
+            got_rows = np.array([[float(v) for v in l.split(" ")] for l in labels[i].splitlines()])
+            assert got_rows.shape == rows.shape and len(rows) >= 1
+            assert np.array_equal(got_rows[:, 0], rows[:, 0])
+            assert np.abs(got_rows[:, 1:5] - rows[:, 1:5]).max() <= 2e-3 and np.abs(got_rows[:, 5] - rows[:, 5]).max() <= 2e-4
+        assert pdet.label_lines(np.zeros((0, 6), np.float32)) == ""
+    finally:
+        det.close()
+
+
+@pytest.mark.gpu
+def test_detection_network_batches_and_small_frames():
+    """More frames than the handle's max_images are run in chunks; a frame smaller than the network input is enlarged
+    (letterbox scales up as well) -- both equal the oracle."""
+    import torch
+
+    from oracle import yolov5 as oy
+    from playaid_core_amd.yolov5 import YoloV5Detector
+
+    sd = synth.make_yolov5s_state_dict()
+    det = YoloV5Detector(sd, NC, NET, max_images=2)
+    try:
+        frames = synth.make_frames(5, 270, 480, seed=9)  # 16:9, enlarged by 4 / 3 to 360 x 640
+        got = det(frames)
+        torch.cuda.synchronize()
+        x = torch.from_numpy(np.stack([oy.letterbox(f, NET) for f in frames]))
+        want = oy.forward(x, sd, NC).numpy()
+        assert np.abs(got.cpu().numpy()[..., 4:] - want[..., 4:]).max() <= 2e-4
+        assert np.abs(got.cpu().numpy()[..., :4] - want[..., :4]).max() <= 2e-2
+    finally:
+        det.close()
