@@ -307,6 +307,44 @@ def bench_f4(args):
     model.close()
 
 
+def bench_detect(args):
+    """the detection stage the reference runs as a YOLOv5 subprocess (ai_runner.py:191-224) --
+    frames resident in HBM -> letterbox -> YOLOv5s (seeded random-init weights, 6 classes) -> Detect decode -> confidence gates
+    + class-aware NMS (--max-det 2 --classes 2 3) -> label rows. Single GPU, own metric (never the headline)."""
+    from playaid_core_amd.yolov5 import YoloV5Detector
+
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(device)
+    n = args.frames
+    frames = synth.make_frames_torch(n, args.height, args.width, device=device)
+    eng = Engine(synth.make_state_dict(seed=1234), device=str(device), max_batch_frames=8, max_clip_frames=64, max_frame_height=args.height,
+                 max_frame_width=args.width)
+    det = YoloV5Detector(synth.make_yolov5s_state_dict(), 6, (384, 640), max_images=n, device=str(device))
+    for _ in range(args.warmup):
+        dets, counts = det.detections(eng, frames)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dets, counts = det.detections(eng, frames)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    tf = det.flops_per_image * n / dt / 1e12
+    print(json.dumps({
+        "metric": f"{args.height}p frames/sec, detection stage (frames resident in HBM -> YOLOv5s -> NMS -> label rows)",
+        "value": round(n / dt, 1), "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic (seeded random-init weights, synthetic frames)",
+        "config": {"workload": f"detect: {n} x {args.height}x{args.width} frames per step, YOLOv5s v7.0 at 384 x 640, 6 classes",
+                   "layers": det.n_layers, "rows_per_image": det.rows},
+        "gflop_per_image_executed": round(det.flops_per_image / 1e9, 3),
+        "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(tf / PEAK_FP32_MATRIX_TFLOPS, 4), "traffic": None,
+                     "note": "whole stage (letterbox, stem, 58 GEMM convolutions, pools, decode, NMS) against the fp32 matrix peak"},
+    }), flush=True)
+    det.close()
+    eng.close()
+
+
 def bench_mixed(args):
     """BASELINE.json configs[4]: a 1080p/720p interleaved clip, frames resident in HBM per resolution bucket, fixed-size
     batches through hipGraph-captured "crop + backbone + scatter into the feature cache" sequences, one head pass per
@@ -422,7 +460,7 @@ def main():
     ap.add_argument("--inner-repeat", type=int, default=20,
                     help="configs[1]/[2] only: clips per timed step (ms_per_step stays per clip)")
     ap.add_argument("--f4-windows", type=int, default=64, help="--workload rnn | resformer: windows per call")
-    ap.add_argument("--workload", default="clip", choices=["clip", "mixed", "rnn", "resformer"],
+    ap.add_argument("--workload", default="clip", choices=["clip", "mixed", "rnn", "resformer", "detect"],
                     help="clip = the headline / configs[1-3] workloads; mixed = BASELINE.json configs[4] (mixed-resolution stream, "
                     "bucketing + hipGraph replay; single GPU, reported under its own metric)")
     ap.add_argument("--lanes", type=int, default=2,
@@ -455,6 +493,8 @@ def main():
         return bench_mixed(args)
     if args.workload in ("rnn", "resformer"):
         return bench_f4(args)
+    if args.workload == "detect":
+        return bench_detect(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -211,7 +211,7 @@ int pa_detect_postprocess(pa_engine* e, const float* pred, int32_t n_frames, int
  * / 255) -> a fully convolutional network given as a LAYER TABLE -> Detect decode -> pred float32[n][rows][5 + nc] in
  * network-input pixels, i.e. the input of pa_detect_postprocess. The table (playaid_core_amd/yolov5.py builds YOLOv5s
  * v7.0 from an ultralytics state dict) arrives BatchNorm-folded: per convolution [cout][ky][kx][cin] at w_off and the bias
- * [cout] at b_off (float offsets into one blob); the 6x6 stem as [cout][6][6][4] (channel 3 zero). Activations are
+ * [cout] at b_off (float offsets into one blob); the 6x6 stem as [cout][6 ky][8 px][4 ch] (kx >= 6 and channel 3 zero, cout % 64 == 0). Activations are
  * zero-bordered NHWC device buffers of buf_floats_per_image[b] floats per image; a layer addresses a CHANNEL SLICE of a
  * buffer (coff = first channel, cstride = channels per pixel of the buffer), so concatenations are free. */
 typedef struct pa_net_layer {

@@ -8,7 +8,8 @@
 // into their slice of the consumer's input. Kinds:
 //   0  convolution 1x1 | 3x3, stride 1 | 2, + bias, activation (none / ReLU / SiLU), residual before or after it
 //      (implicit GEMM on the matrix cores, igemm.hip; cin % 32 == 0, cout % 64 == 0: the table pads with zero weights)
-//   3  the 6x6 / 2 stem on the letter-boxed RGB image + bias + SiLU (direct, vector units: 3 input channels)
+//   3  the 6x6 / 2 stem on the letter-boxed RGB image + bias + SiLU: the same GEMM kernel, one tap per kernel row whose K
+//      chunk is 8 consecutive NHWC4 pixels (weights [cout][6][8 px][4 ch], kx >= 6 and channel 3 zero)
 //   4  max-pool 5x5 / 1 (SPPF), slice to slice
 //   5  nearest-neighbour 2x up-sampling, slice to slice
 //   6  Detect decode of one scale: sigmoid, grid / anchor arithmetic -> rows (cx, cy, w, h, obj, classes) in net pixels
@@ -69,47 +70,6 @@ __global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restric
     }
     float4 o = make_float4((float)rgb[0] / 255.0f, (float)rgb[1] / 255.0f, (float)rgb[2] / 255.0f, 0.f);
     reinterpret_cast<float4*>(out)[((size_t)img * (net_h + 4) + y + 2) * (net_w + 4) + x + 2] = o;
-}
-
-// 6x6 / 2 convolution (padding 2) of the letter-boxed image, 3 -> cout (32) channels, + bias + SiLU.
-// thread = one output pixel x 8 channels; weights [cout][6][6][4] in LDS.
-__global__ __launch_bounds__(256) void stem6_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                    float* __restrict__ out, int n, int net_h, int net_w, int cout, int out_pad,
-                                                    int out_cstride, int out_coff) {
-    extern __shared__ float ws[];  // [cout][144]
-    for (int i = threadIdx.x; i < cout * 144; i += 256) ws[i] = w[i];
-    __syncthreads();
-    const int oh = net_h / 2, ow = net_w / 2, groups = cout / 8;
-    const long long total = (long long)n * oh * ow * groups;
-    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
-        const int gq = (int)(t % groups);
-        long long pix = t / groups;
-        const int ox = (int)(pix % ow);
-        pix /= ow;
-        const int oy = (int)(pix % oh), img = (int)(pix / oh);
-        float acc[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-        // input pixel (2 oy - 2 + ky, 2 ox - 2 + kx) sits at bordered coordinates (2 oy + ky, 2 ox + kx)
-        const float4* xin = reinterpret_cast<const float4*>(x) + ((size_t)img * (net_h + 4) + 2 * oy) * (net_w + 4) + 2 * ox;
-        for (int ky = 0; ky < 6; ++ky)
-            for (int kx = 0; kx < 6; ++kx) {
-                const float4 v = xin[(size_t)ky * (net_w + 4) + kx];
-                const float* wk = ws + (gq * 8) * 144 + (ky * 6 + kx) * 4;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    acc[k] = fmaf(v.x, wk[k * 144], acc[k]);
-                    acc[k] = fmaf(v.y, wk[k * 144 + 1], acc[k]);
-                    acc[k] = fmaf(v.z, wk[k * 144 + 2], acc[k]);
-                }
-            }
-        float* o = out + (((size_t)img * (oh + 2 * out_pad) + oy + out_pad) * (ow + 2 * out_pad) + ox + out_pad) * out_cstride + out_coff + gq * 8;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float v = acc[k] + bias[gq * 8 + k];
-            o[k] = v / (1.f + expf(-v));
-        }
-    }
 }
 
 struct SliceGeom {
@@ -263,7 +223,7 @@ int pa_detector_create(int32_t device, const pa_net_layer* layers, int32_t n_lay
                 (size_t)L.b_off + L.cout > n_weights)
                 return bad(i, "weights outside the blob");
         } else if (L.kind == 3) {
-            if (L.in_h != net_h || L.in_w != net_w || L.cout % 8 || L.cout > 64 || L.w_off < 0 || (size_t)L.w_off + (size_t)L.cout * 144 > n_weights ||
+            if (L.in_h != net_h || L.in_w != net_w || L.cout % 64 || L.w_off < 0 || (size_t)L.w_off + (size_t)L.cout * 192 > n_weights ||
                 L.b_off < 0 || (size_t)L.b_off + L.cout > n_weights || !slice_ok(L.out_buf, net_h / 2, net_w / 2, L.out_pad, L.out_cstride, L.out_coff, L.cout))
                 return bad(i, "bad stem");
         } else if (L.kind == 4 || L.kind == 5) {
@@ -297,7 +257,8 @@ int pa_detector_create(int32_t device, const pa_net_layer* layers, int32_t n_lay
         if (!chk(hipMalloc(&h->bufs[b], bytes), "hipMalloc activations")) return PA_ERR_HIP;
         if (!chk(hipMemset(h->bufs[b], 0, bytes), "hipMemset activations")) return PA_ERR_HIP;  // the zero borders stay zero
     }
-    const size_t x0_bytes = (size_t)max_images * (net_h + 4) * (net_w + 4) * 4 * sizeof(float);
+    // (+ slack: the stem's 8-pixel K chunks of the last row run two pixels past it, a partial last GEMM tile further)
+    const size_t x0_bytes = ((size_t)max_images * (net_h + 4) * (net_w + 4) * 4 + 128 * 2048) * sizeof(float);
     if (!chk(hipMalloc(&h->x0, x0_bytes), "hipMalloc input")) return PA_ERR_HIP;
     if (!chk(hipMemset(h->x0, 0, x0_bytes), "hipMemset input")) return PA_ERR_HIP;
     std::vector<float> anc((size_t)n_decode * 8, 0.f);
@@ -338,11 +299,31 @@ int pa_detector_forward(pa_detector* h, const uint8_t* frames, int32_t n, int32_
     for (size_t li = 0; li < h->layers.size(); ++li) {
         const pa_net_layer& L = h->layers[li];
         if (L.kind == 3) {
-            const long long total = (long long)n * (h->net_h / 2) * (h->net_w / 2) * (L.cout / 8);
-            hipLaunchKernelGGL(pa::stem6_kernel, dim3(pa::grid_for(total)), dim3(256), (size_t)L.cout * 144 * sizeof(float), s, h->x0,
-                               h->weights + L.w_off, h->weights + L.b_off, h->bufs[L.out_buf], n, h->net_h, h->net_w, L.cout, L.out_pad,
-                               L.out_cstride, L.out_coff);
-            DT_HIP(hipGetLastError());
+            // the 6x6 / 2 stem as an implicit GEMM: one tap per kernel row, its K chunk = 8 consecutive NHWC4 pixels of
+            // the letter-boxed image (kx 6, 7 and channel 3 meet zero weights), K = 6 x 32
+            const int oh = h->net_h / 2, ow = h->net_w / 2;
+            pa::GemmParams p;
+            memset(&p, 0, sizeof(p));
+            p.act = h->x0;
+            p.wgt = h->weights + L.w_off;
+            p.bias = h->weights + L.b_off;
+            p.out = h->bufs[L.out_buf] + L.out_coff;
+            p.M = n * oh * ow;
+            p.N = L.cout;
+            p.taps = 6; p.kw_taps = 1; p.chunk = 32; p.ktot = 192;
+            p.howo = oh * ow; p.wo = ow;
+            p.in_px_stride = 4;
+            p.in_row_stride = (h->net_w + 4) * 4;
+            p.in_img_stride = (h->net_h + 4) * (h->net_w + 4) * 4;
+            p.stride = 2;
+            p.out_px_stride = L.out_cstride;
+            p.out_row_stride = (ow + 2 * L.out_pad) * L.out_cstride;
+            p.out_img_stride = (oh + 2 * L.out_pad) * (ow + 2 * L.out_pad) * L.out_cstride;
+            p.out_pad = L.out_pad;
+            p.relu = 2;
+            p.splitk = 1;
+            const hipError_t pe = pa::launch_igemm(p, pa::TILE_128x64, s);
+            if (pe != hipSuccess) return fail(PA_ERR_HIP, "stem: " + std::string(hipGetErrorString(pe)));
             continue;
         }
         if (L.kind == 4 || L.kind == 5) {
