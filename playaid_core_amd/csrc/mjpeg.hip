@@ -258,7 +258,8 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
                                                          uint32_t* __restrict__ used, SubCnt* __restrict__ cnt,
                                                          const SubCnt* __restrict__ entry, int16_t* __restrict__ coef,
                                                          int32_t* __restrict__ status, int32_t* __restrict__ changed,
-                                                         const int32_t* __restrict__ changed_last) {
+                                                         const int32_t* __restrict__ changed_last, const int32_t* __restrict__ todo,
+                                                         const int32_t* __restrict__ todo_cnt) {
     // verify pass: a frame whose previous verify pass changed nothing has settled (changed_last = that pass's flags)
     if (MODE == 1 && changed_last && changed_last[blockIdx.y] == 0) return;
     __shared__ HuffTables T;
@@ -270,19 +271,24 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
     const uint32_t clen = clean_len[f];
     const int sh = g.sub_shift;
     const int nsub = (int)((clen + (1u << sh) - 1) >> sh);
-    const int j0 = blockIdx.x * WG_SUBS, j = j0 + tid;
-    if (j0 >= nsub) return;
+    const int j0 = blockIdx.x * WG_SUBS;
+    int j = j0 + tid;
+    bool active;
+    if (MODE == 1) {
+        // a verify pass walks the COMPACT list of the frame's lanes whose entry changed (sub_verify_plan_kernel): the few
+        // lanes that still move in a late pass fill whole waves instead of keeping one lane busy in every wave
+        const int cnt = todo_cnt[f];
+        if (j0 >= cnt) return;
+        active = j < cnt;
+        j = active ? todo[(size_t)d.sub_base + j] : 0;
+    } else {
+        if (j0 >= nsub) return;
+        active = j < nsub && j < d.n_sub_cap;
+    }
     if (MODE == 2 && blockIdx.x == 0 && tid == 0 && changed_last[f]) atomicOr(&status[f], ERR_SYNC);
-    bool active = j < nsub && j < d.n_sub_cap;
     const size_t sj = (size_t)d.sub_base + j;
     const uint32_t entry_st = (MODE == 0 || j == 0 || !active) ? 0u : g_in[sj - 1];
-    bool mine = active;  // this lane decodes in this pass and records what it found
-    if (MODE == 1) {
-        mine = active && entry_st != used[sj];
-        if (active && !mine) g_out[sj] = g_in[sj];
-        if (!__syncthreads_or(mine)) return;
-        active = mine;
-    }
+    const bool mine = active;  // this lane decodes in this pass and records what it found
     {   // tables, block layout of an MCU
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&ts[d.tabset].h);
         uint32_t* dst = reinterpret_cast<uint32_t*>(&T);
@@ -612,6 +618,47 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
         c.dc[0] = x_dc0; c.dc[1] = x_dc1; c.dc[2] = x_dc2;
         cnt[sj] = c;
     }
+}
+
+// Which lanes of a frame decode again in the next verify pass: those whose entry state (the predecessor's exit) is not the
+// one they last decoded with. Their indices are compacted into todo[] (frame order), the others keep their exit state.
+__global__ __launch_bounds__(1024) void sub_verify_plan_kernel(const FrameDesc* __restrict__ fd, const uint32_t* __restrict__ clean_len,
+                                                               int sub_shift, const uint32_t* __restrict__ g_in, uint32_t* __restrict__ g_out,
+                                                               const uint32_t* __restrict__ used, int32_t* __restrict__ todo,
+                                                               int32_t* __restrict__ todo_cnt, const int32_t* __restrict__ changed_last) {
+    __shared__ int sh[1024];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    if (changed_last && changed_last[f] == 0) {  // settled: nothing to do (both state buffers already agree)
+        if (tid == 0) todo_cnt[f] = 0;
+        return;
+    }
+    const FrameDesc d = fd[f];
+    int nsub = (int)((clean_len[f] + (1u << sub_shift) - 1) >> sub_shift);
+    nsub = nsub < d.n_sub_cap ? nsub : d.n_sub_cap;
+    const int per = (nsub + 1023) / 1024;
+    const int lo = tid * per, hi = min(lo + per, nsub);
+    int cnt = 0;
+    for (int j = lo; j < hi; ++j) {
+        const size_t sj = (size_t)d.sub_base + j;
+        const uint32_t entry_st = j == 0 ? 0u : g_in[sj - 1];
+        cnt += entry_st != used[sj] ? 1 : 0;
+    }
+    sh[tid] = cnt;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = tid >= o ? sh[tid - o] : 0;
+        __syncthreads();
+        sh[tid] += v;
+        __syncthreads();
+    }
+    int k = sh[tid] - cnt;
+    for (int j = lo; j < hi; ++j) {
+        const size_t sj = (size_t)d.sub_base + j;
+        const uint32_t entry_st = j == 0 ? 0u : g_in[sj - 1];
+        if (entry_st != used[sj]) todo[(size_t)d.sub_base + k++] = j;
+        else g_out[sj] = g_in[sj];
+    }
+    if (tid == 1023) todo_cnt[f] = sh[1023];
 }
 
 // entry[j] = what lanes 0 .. j-1 of the frame accumulated: absolute block index and DC predictions at lane j's entry
@@ -961,6 +1008,8 @@ struct pa_mjpeg {
     SubCnt* d_cnt = nullptr;
     SubCnt* d_entry = nullptr;
     int32_t* d_changed = nullptr;  // [MAX_ROUNDS + 1][max_frames]
+    int32_t* d_todo = nullptr;     // [max_subs] compact lane lists of a verify pass
+    int32_t* d_todo_cnt = nullptr; // [max_frames]
     int16_t* d_coef = nullptr;
     uint8_t* d_planes = nullptr;
     int32_t* d_status = nullptr;
@@ -986,7 +1035,7 @@ const char* pa_mjpeg_last_error(const pa_mjpeg* h) { return h ? h->last_error.c_
 void pa_mjpeg_destroy(pa_mjpeg* h) {
     if (!h) return;
     void* dev[] = {h->d_bits, h->d_clean, h->d_fd, h->d_ts, h->d_chunk, h->d_seg, h->d_clean_len, h->d_g[0], h->d_g[1], h->d_used,
-                   h->d_cnt, h->d_entry, h->d_changed, h->d_coef, h->d_planes, h->d_status};
+                   h->d_cnt, h->d_entry, h->d_changed, h->d_todo, h->d_todo_cnt, h->d_coef, h->d_planes, h->d_status};
     for (void* p : dev) (void)hipFree(p);
     for (int i = 0; i < 2; ++i) {
         if (h->h_fd[i]) (void)hipHostFree(h->h_fd[i]);
@@ -1034,6 +1083,8 @@ int pa_mjpeg_create(int32_t device, int32_t max_frames, int32_t max_height, int3
     if (!chk(hipMalloc(&h->d_cnt, h->max_subs * sizeof(SubCnt)), "hipMalloc counts")) return PA_ERR_HIP;
     if (!chk(hipMalloc(&h->d_entry, h->max_subs * sizeof(SubCnt)), "hipMalloc entries")) return PA_ERR_HIP;
     if (!chk(hipMalloc(&h->d_changed, (MAX_ROUNDS + 1) * n * sizeof(int32_t)), "hipMalloc flags")) return PA_ERR_HIP;
+    if (!chk(hipMalloc(&h->d_todo, h->max_subs * sizeof(int32_t)), "hipMalloc lane lists")) return PA_ERR_HIP;
+    if (!chk(hipMalloc(&h->d_todo_cnt, n * sizeof(int32_t)), "hipMalloc lane counts")) return PA_ERR_HIP;
     if (!chk(hipMalloc(&h->d_coef, n * h->max_blocks * 64 * sizeof(int16_t)), "hipMalloc coefficients")) return PA_ERR_HIP;
     if (!chk(hipMalloc(&h->d_planes, n * h->max_blocks * 64), "hipMalloc sample planes")) return PA_ERR_HIP;
     if (!chk(hipMalloc(&h->d_status, n * sizeof(int32_t)), "hipMalloc status")) return PA_ERR_HIP;
@@ -1236,13 +1287,15 @@ int pa_mjpeg_decode(pa_mjpeg* h, const uint8_t* data_host, const int64_t* spans_
     int cur_g = 0;
     hipLaunchKernelGGL((sub_decode_kernel<0>), sgrid, dim3(256), 0, s, h->d_clean, h->d_fd, h->d_ts, h->d_seg, h->d_clean_len, g,
                        (const uint32_t*)nullptr, h->d_g[0], h->d_used, h->d_cnt, (const SubCnt*)nullptr, (int16_t*)nullptr, h->d_status,
-                       (int32_t*)nullptr, (const int32_t*)nullptr);
+                       (int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr);
     auto verify = [&](int slot, int prev_slot) {
         int32_t* flag = h->d_changed + (size_t)slot * h->max_frames;
         const int32_t* prev = prev_slot >= 0 ? h->d_changed + (size_t)prev_slot * h->max_frames : nullptr;
+        hipLaunchKernelGGL(sub_verify_plan_kernel, dim3(n), dim3(1024), 0, s, h->d_fd, h->d_clean_len, g.sub_shift, h->d_g[cur_g],
+                           h->d_g[cur_g ^ 1], h->d_used, h->d_todo, h->d_todo_cnt, prev);
         hipLaunchKernelGGL((sub_decode_kernel<1>), sgrid, dim3(256), 0, s, h->d_clean, h->d_fd, h->d_ts, h->d_seg, h->d_clean_len, g,
                            h->d_g[cur_g], h->d_g[cur_g ^ 1], h->d_used, h->d_cnt, (const SubCnt*)nullptr, (int16_t*)nullptr, h->d_status, flag,
-                           prev);
+                           prev, h->d_todo, h->d_todo_cnt);
         cur_g ^= 1;
     };
     int last_slot = MAX_ROUNDS;  // an all-zero row unless a verify pass wrote it
@@ -1270,7 +1323,7 @@ int pa_mjpeg_decode(pa_mjpeg* h, const uint8_t* data_host, const int64_t* spans_
     hipLaunchKernelGGL(sub_scan_kernel, dim3(n), dim3(1024), 0, s, h->d_fd, h->d_clean_len, h->d_cnt, h->d_entry, g.sub_shift);
     hipLaunchKernelGGL((sub_decode_kernel<2>), sgrid, dim3(256), 0, s, h->d_clean, h->d_fd, h->d_ts, h->d_seg, h->d_clean_len, g,
                        h->d_g[cur_g], (uint32_t*)nullptr, h->d_used, h->d_cnt, h->d_entry, h->d_coef, h->d_status, (int32_t*)nullptr,
-                       h->d_changed + (size_t)last_slot * h->max_frames);
+                       h->d_changed + (size_t)last_slot * h->max_frames, (const int32_t*)nullptr, (const int32_t*)nullptr);
     const long long nblk = (long long)n * g.blocks_per_frame;
     hipLaunchKernelGGL(idct_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, s, h->d_coef, h->d_fd, h->d_ts, g, h->d_planes, n);
     const int fv = g.ncomp == 3 ? g.fv : 1, fhh = g.ncomp == 3 ? g.fh : 1;

@@ -18,6 +18,7 @@ ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--variants", default="none,rows1,blk30,blk8,blk2")
 ap.add_argument("--reps", type=int, default=10)
+ap.add_argument("--rounds", type=int, default=-1, help="verify passes enqueued per call (default: the library's)")
 args = ap.parse_args()
 n, h, w = args.frames, args.height, args.width
 frames = synth.make_frames_torch(n, h, w, device="cuda").cpu().numpy()
@@ -35,6 +36,8 @@ for var in args.variants.split(","):
     spans = np.stack([ends - sizes, ends], axis=1)
     data = torch.from_numpy(np.frombuffer(b"".join(blobs), np.uint8).copy()).pin_memory()
     dec = video.MjpegDecoder(n, h, w, int(ends[-1]) + 4096)
+    if args.rounds >= 0:
+        dec.set_sync_rounds(args.rounds)
     out = torch.empty((n, h, w, 3), dtype=torch.uint8, device="cuda")
     st = torch.zeros(n, dtype=torch.int32, device="cuda")
     dec.decode(data, spans, h, w, out=out, status=st)
