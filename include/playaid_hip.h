@@ -361,9 +361,11 @@ int pa_preprocess_windows(pa_engine* e, const uint8_t* windows_dev, const pa_cro
  * decoder, which differs from libjpeg in the last bit; that arithmetic is not restated.)
  *
  * A handle owns the scratch for up to max_frames frames of max_height x max_width and max_bytes compressed bytes per
- * call. pa_mjpeg_decode parses the marker segments on the host, then ENQUEUES on `stream`: one host -> device copy of the
- * compressed bytes (the range of data_host that covers all n frames; pinned memory makes it asynchronous), the restart-marker
- * scan + byte un-stuffing, Huffman decoding (one lane per 128-byte subsequence of the stream, wherever it falls: the
+ * call. pa_mjpeg_decode parses the marker segments on the host, then ENQUEUES: one host -> device copy of the compressed
+ * bytes (the range of data_host that covers all n frames; pinned memory makes it asynchronous) on a copy stream of the
+ * handle's own, which `stream` waits for -- so the upload of one call runs under the decode passes of the call before it;
+ * data_host must stay untouched until `stream` has passed this call -- and, on `stream`, the restart-marker
+ * scan + byte un-stuffing, Huffman decoding (one lane per subsequence of the stream, wherever it falls: the
  * decoder states at the subsequence borders are found by self-synchronisation -- a speculative pass, then verify passes
  * until nothing changes -- so a stream needs no restart markers to decode in parallel; restart markers, where present,
  * are exact entry points), IDCT, up-sampling + colour conversion. spans_host: int64[n][2], frame f = bytes [spans[f][0], spans[f][1]) of data_host, in

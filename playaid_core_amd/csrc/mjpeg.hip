@@ -11,13 +11,16 @@
 //   host : marker segments of every frame (SOF0/SOF1, DQT, DHT, DRI, SOS) -> frame descriptors + Huffman / quantisation
 //          table sets (consecutive frames with identical tables share one set)
 //   copy : the compressed bytes, the descriptors and the table sets, host -> HBM
-//   rst_count_kernel / rst_write_kernel : positions of the RSTm markers of every frame, in stream order
-//   huff_kernel  : ONE LANE PER RESTART INTERVAL walks its interval's bit stream (byte-stuffing handled in the reader,
-//                  10-bit direct lookup + canonical fallback for longer codes, tables in LDS) and scatters the non-zero
-//                  quantised coefficients (int16, natural order) into per-component block rasters; DC prediction is
-//                  local to an interval by definition of the restart marker. A stream without DRI is one interval per
-//                  frame -- correct, but one lane per frame.
-//   idct_kernel  : one thread per 8x8 block, block in registers -> uint8 sample planes (padded to whole MCUs)
+//   unstuff_count_kernel / unstuff_write_kernel : the CLEAN stream of every frame (stuffed zeros and RSTm markers taken
+//                  out, restart positions recorded)
+//   sub_decode_kernel<0|1> + sub_verify_plan_kernel : one lane per subsequence of the clean stream finds the decoder
+//                  state at its first bit (self-synchronisation, see below); nothing is stored but states and counts
+//   sub_scan_kernel : block index at every subsequence's entry
+//   sub_decode_kernel<2> : the final pass stores the non-zero quantised AC coefficients (int16) where the scan puts them
+//                  -- block number in scan order, zig-zag index -- and every block's DC DIFFERENCE in an array apart
+//   dc_scan_kernel : DC differences -> DC coefficients (running sums per component, from zero at every restart interval)
+//   idct_kernel  : one thread per 8x8 block of the component rasters gathers its block from the scan-order buffer
+//                  (de-zig-zag by constant indices), block in registers -> uint8 sample planes (padded to whole MCUs)
 //   ycc_kernel   : up-sampling + colour conversion, 8 pixels x FV rows per thread, 8-byte stores
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -84,18 +87,8 @@ struct Geom {
     uint8_t b_comp[MAX_BLOCKS_MCU], b_dy[MAX_BLOCKS_MCU], b_dx[MAX_BLOCKS_MCU];
 };
 
-struct BlkInfo {  // huff_kernel: one block position of an MCU
-    int32_t base, bx;
-    uint8_t vs, hs, dy, dx, tdc, tac, comp, pad;
-};
-static_assert(sizeof(BlkInfo) == 16, "one ds_read_b128");
-
 // diagnostics (pa_mjpeg_debug_counters): shader-clock cycles, 100 MHz wall ticks and symbols of one wave's symbol loop
 __device__ unsigned long long g_dbg[16];
-
-__constant__ uint8_t k_zigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
-                                     41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
-                                     30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
 // ---- byte un-stuffing + restart markers --------------------------------------------------------------------------------------
 //
@@ -234,10 +227,11 @@ __global__ __launch_bounds__(256) void unstuff_write_kernel(const uint8_t* __res
 //   verify (MODE 1): every lane whose entry (= the predecessor's exit) differs from what it last decoded with decodes
 //                    again; repeated until no exit state changes = the exact sequential states. Lanes that follow a
 //                    restart marker are exact from the start: at a marker the state is known.
-//   scan           : per frame, exclusive scan of (blocks completed, DC sums) with resets at restart markers -> every
-//                    lane's absolute block index and DC predictions at entry;
-//   final (MODE 2) : decode once more and scatter the non-zero coefficients (int16, natural order) into the
-//                    per-component block rasters (cleared beforehand).
+//   scan           : per frame, exclusive scan of the blocks completed, with resets at restart markers -> every lane's
+//                    absolute block index at entry;
+//   final (MODE 2) : decode once more and store the non-zero AC coefficients and the DC differences (int16) by block
+//                    number in scan order (buffers cleared beforehand). Only this pass extracts values; the passes
+//                    before it need code lengths, run lengths and sizes alone.
 // The subsequence size is chosen per call (a power of two, about four MCUs of the stream: states settle within a
 // couple of MCUs, so most lanes are right after pass A and one verify pass). Every lane keeps the next 128 bytes of its
 // stream in an LDS ring (33-dword pitch: the 64 lanes' window reads fall on distinct banks) that all lanes top up
@@ -246,7 +240,6 @@ __global__ __launch_bounds__(256) void unstuff_write_kernel(const uint8_t* __res
 
 struct SubCnt {     // what a subsequence contributes to the scan
     int32_t blk;    // blocks completed; bit 31: a restart marker lies inside, blk then counts from the frame start
-    int32_t dc[3];  // sums of the DC differences decoded (since that marker, if any)
 };
 
 
@@ -259,12 +252,10 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
                                                          const SubCnt* __restrict__ entry, int16_t* __restrict__ coef,
                                                          int32_t* __restrict__ status, int32_t* __restrict__ changed,
                                                          const int32_t* __restrict__ changed_last, const int32_t* __restrict__ todo,
-                                                         const int32_t* __restrict__ todo_cnt) {
+                                                         const int32_t* __restrict__ todo_cnt, int16_t* __restrict__ dcdiff) {
     // verify pass: a frame whose previous verify pass changed nothing has settled (changed_last = that pass's flags)
     if (MODE == 1 && changed_last && changed_last[blockIdx.y] == 0) return;
     __shared__ HuffTables T;
-    __shared__ uint8_t zz[64];
-    __shared__ BlkInfo binfo[MAX_BLOCKS_MCU];
     __shared__ uint32_t ring[WG_SUBS * (RING_DW + 1)];
     const int f = blockIdx.y, tid = threadIdx.x;
     const FrameDesc d = fd[f];
@@ -293,22 +284,14 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&ts[d.tabset].h);
         uint32_t* dst = reinterpret_cast<uint32_t*>(&T);
         for (int i = tid; i < (int)(sizeof(HuffTables) / 4); i += 256) dst[i] = src[i];
-        if (tid < 64) zz[tid] = k_zigzag[tid];
-        if (tid < g.blocks_per_mcu) {
-            const int c = g.b_comp[tid];
-            BlkInfo bi;
-            bi.base = c == 0 ? g.blk_off[0] : (c == 1 ? g.blk_off[1] : g.blk_off[2]);
-            bi.bx = c == 0 ? g.bx[0] : (c == 1 ? g.bx[1] : g.bx[2]);
-            bi.vs = (uint8_t)(c == 0 ? g.vs[0] : (c == 1 ? g.vs[1] : g.vs[2]));
-            bi.hs = (uint8_t)(c == 0 ? g.hs[0] : (c == 1 ? g.hs[1] : g.hs[2]));
-            bi.dy = g.b_dy[tid];
-            bi.dx = g.b_dx[tid];
-            bi.tdc = fd[f].td[c];
-            bi.tac = (uint8_t)(2 + fd[f].ta[c]);
-            bi.comp = (uint8_t)c;
-            bi.pad = 0;
-            binfo[tid] = bi;
-        }
+    }
+    // Huffman table of every block position of an MCU (baseline: two DC, two AC tables), one bit each, wave-uniform:
+    // bit b = the DC table of block b, bit 16 + b = its AC table
+    uint32_t tabsel = 0;
+    for (int bb = 0; bb < g.blocks_per_mcu; ++bb) {
+        const int c = g.b_comp[bb];
+        tabsel |= (uint32_t)(d.td[c] & 1) << bb;
+        tabsel |= (uint32_t)(d.ta[c] & 1) << (16 + bb);
     }
     __syncthreads();
     // positions are bits from the start of the frame's clean stream
@@ -344,37 +327,21 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
         nbk = lo;
         if (nbk < d.n_int) nb_bits = seg_start[d.seg_base + nbk] * 8;
     }
-    int nblk = 0, reset = 0, dc0 = 0, dc1 = 0, dc2 = 0, err = 0;
+    int nblk = 0, reset = 0, err = 0;
     int absblk = 0;  // index of the current block in scan order (MODE 2; from the last restart marker otherwise)
     if (MODE == 2 && active) {
         const SubCnt e = entry[sj];
         absblk = e.blk & 0x7fffffff;
-        dc0 = e.dc[0]; dc1 = e.dc[1]; dc2 = e.dc[2];
     }
-    int16_t* const frame_coef = coef + (size_t)f * g.blocks_per_frame * 64;
+    // final pass: coefficients in SCAN order (block absblk of the frame, zig-zag index inside the block), DC differences apart
     const int total_blocks = g.mcus_x * g.mcus_y * bpm;
-    // the current block of the MCU: Huffman tables (offsets of their lut1 rows), component, raster geometry
-    uint32_t tdc = 0, tac = 0;
-    int comp = 0, mx = 0, my = 0;
-    int bbase = 0, bbx = 0, bvs = 0, bhs = 0, bdy = 0, bdx = 0;
-    auto take_block = [&](const BlkInfo& bi) {
-        tdc = (uint32_t)bi.tdc << LB;
-        tac = (uint32_t)bi.tac << LB;
-        comp = bi.comp;
-        if (MODE == 2) {
-            bbase = bi.base; bbx = bi.bx; bvs = bi.vs; bhs = bi.hs; bdy = bi.dy; bdx = bi.dx;
-        }
-    };
-    take_block(binfo[b]);
-    if (MODE == 2 && active) {
-        if (absblk % bpm != b) {  // the scan and the synchronised state disagree: corrupt stream
-            err |= ERR_SYNC;
-            active = false;
-        } else {
-            const int mcu = absblk / bpm;
-            my = mcu / g.mcus_x;
-            mx = mcu - my * g.mcus_x;
-        }
+    int16_t* const frame_coef = MODE == 2 ? coef + (size_t)f * total_blocks * 64 : nullptr;
+    int16_t* const frame_dc = MODE == 2 ? dcdiff + (size_t)f * total_blocks : nullptr;
+    // row of T.lut1 / T.lutB for the symbol in hand: DC tables 0-1, AC tables 2-3
+    auto table_row = [&](bool dc, int blk) -> uint32_t { return ((tabsel >> (blk + (dc ? 0 : 16))) & 1u) | (dc ? 0u : 2u); };
+    if (MODE == 2 && active && absblk % bpm != b) {  // the scan and the synchronised state disagree: corrupt stream
+        err |= ERR_SYNC;
+        active = false;
     }
     uint32_t lim = min(nb_bits, end_bits);
     // bit buffer: the next nb bits of the stream at the top of buf (bitpos = 32 * dwi - nb), refilled a dword at a time
@@ -392,7 +359,7 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
     const uint16_t* const lutB = &T.lutB[0][0];
     // what the lane hands on, captured when it reaches the end of its subsequence (it free-runs after that)
     uint32_t x_state = 0;
-    int x_blk = 0, x_dc0 = 0, x_dc1 = 0, x_dc2 = 0;
+    int x_blk = 0;
     bool gen = false, first = true;
     const bool stamp = blockIdx.x == 0 && blockIdx.y == 0 && tid < 64;
     const unsigned long long c0 = clock64(), w0t = wall_clock64();
@@ -415,16 +382,9 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
                     bitpos = nb_bits;
                     reload();
                     b = 0; z = 0;
-                    take_block(binfo[0]);
                     reset = 1;
                     nblk = 0;
-                    dc0 = dc1 = dc2 = 0;
                     absblk = nbk * d.ri * bpm;
-                    if (MODE == 2) {
-                        const int mcu = nbk * d.ri;
-                        my = mcu / g.mcus_x;
-                        mx = mcu - my * g.mcus_x;
-                    }
                     ++nbk;
                     nb_bits = nbk < d.n_int ? seg_start[d.seg_base + nbk] * 8 : 0xffffffffu;
                     lim = min(nb_bits, end_bits);
@@ -433,7 +393,6 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
                     active = false;
                     x_state = ((bitpos - end_bits) & 31) | ((uint32_t)b << 5) | ((uint32_t)z << 9);
                     x_blk = reset ? (int32_t)(((uint32_t)absblk & 0x7fffffffu) | 0x80000000u) : nblk;
-                    x_dc0 = dc0; x_dc1 = dc1; x_dc2 = dc2;
                 }
             } else if (gen) {
                 // one symbol the general way: codes outside the look-up tables, padding in front of a marker, errors
@@ -448,7 +407,7 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
                 }
                 const uint32_t win = (uint32_t)(buf >> 32);
                 const bool dc = z == 0;
-                const uint32_t t = (dc ? tdc : tac) >> LB;
+                const uint32_t t = table_row(dc, b);
                 uint32_t e = T.lut1[t][win >> (32 - LB)];
                 if (e == 0 && (win >> 26) == 63) e = T.lutB[t][(win >> (26 - LB)) & ((1 << LB) - 1)];
                 int len = e & 31, s = (e >> 5) & 15, r = (e >> 9) & 15;
@@ -489,20 +448,19 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
                     nb -= use;
                     const uint32_t raw = s ? (uint32_t)(win << len) >> (32 - s) : 0u;
                     const int v = (int)raw - ((int)raw < ((1 << s) >> 1) ? (1 << s) - 1 : 0);
-                    if (dc) {
-                        if (comp == 0) dc0 += v; else if (comp == 1) dc1 += v; else dc2 += v;
-                    }
                     const int zc = dc ? 0 : z + r;
                     const bool over = !dc && s && zc > 63;
                     int zn = dc ? 1 : (s ? zc + 1 : (r == 15 ? z + 16 : 64));
                     if (MODE == 2) {
-                        const int p = comp == 0 ? dc0 : (comp == 1 ? dc1 : dc2);
                         if (over) {
                             err |= ERR_COEF;
                             active = false;
-                        } else if ((dc ? p != 0 : s != 0) && absblk < total_blocks) {
-                            int16_t* blk = frame_coef + ((size_t)bbase + (size_t)(my * bvs + bdy) * bbx + mx * bhs + bdx) * 64;
-                            blk[dc ? 0 : zz[zc]] = (int16_t)(dc ? p : v);
+                        } else if (absblk < total_blocks) {
+                            if (dc) {
+                                frame_dc[absblk] = (int16_t)v;  // the difference; dc_scan_kernel adds the predictions up
+                            } else if (s) {
+                                frame_coef[(size_t)absblk * 64 + zc] = (int16_t)v;
+                            }
                         }
                     }
                     if (over) zn = 64;
@@ -510,14 +468,7 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
                         zn = 0;
                         ++nblk;
                         ++absblk;
-                        if (++b >= bpm) {
-                            b = 0;
-                            if (MODE == 2 && ++mx == g.mcus_x) {
-                                mx = 0;
-                                ++my;
-                            }
-                        }
-                        take_block(binfo[b]);
+                        if (++b >= bpm) b = 0;
                     }
                     z = zn;
                 }
@@ -529,8 +480,6 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
         // look-ups, made side by side.
         slow_cyc += clock64() - cs;
         uint32_t wn = my_ring[dwi & (RING_DW - 1)];
-        int bn = b + 1 == bpm ? 0 : b + 1;
-        BlkInfo nxt = binfo[bn];
         for (int k = 0; k < TOPUP; ++k, ++it) {
             uint64_t fbuf = buf;
             int fnb = nb;
@@ -544,9 +493,10 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
             const uint32_t wn_next = my_ring[fdwi & (RING_DW - 1)];
             const uint32_t win = (uint32_t)(fbuf >> 32);
             const bool dc = z == 0;
-            const uint32_t tb = dc ? tdc : tac;
-            const uint32_t eA = lut1[tb + (win >> (32 - LB))];
-            const uint32_t eB = lutB[tb + ((win >> (26 - LB)) & ((1 << LB) - 1))];
+            const uint32_t tb = table_row(dc, b) << LB;
+            uint32_t eA = lut1[tb + (win >> (32 - LB))];
+            uint32_t eB = lutB[tb + ((win >> (26 - LB)) & ((1 << LB) - 1))];
+            asm volatile("" : "+v"(eA), "+v"(eB));  // both look-ups in flight together, not the second behind a branch
             const uint32_t e = eA ? eA : ((win >> 26) == 63 ? eB : 0u);
             const int len = e & 31, s = (e >> 5) & 15, r = (e >> 9) & 15;
             const int use = len + s;
@@ -563,43 +513,22 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
             nb = fnb - use;
             dwi = fdwi;
             wn = wn_next;
-            const uint32_t raw = s ? (uint32_t)(win << len) >> ((32 - s) & 31) : 0u;
-            const int v = (int)raw - ((int)raw < ((1 << s) >> 1) ? (1 << s) - 1 : 0);
-            const int dv = dc ? v : 0;
-            dc0 += comp == 0 ? dv : 0;
-            dc1 += comp == 1 ? dv : 0;
-            dc2 += comp == 2 ? dv : 0;
-            const int zn = dc ? 1 : (s ? zc + 1 : (r == 15 ? z + 16 : 64));  // ... ZRL | EOB
+            const int zn = dc ? 1 : (s ? zc + 1 : (r == 15 ? z + 16 : 64));  // DC | coefficient | ZRL | EOB
             if (MODE == 2) {
-                const int p = comp == 0 ? dc0 : (comp == 1 ? dc1 : dc2);
-                const uint32_t zi = zz[zc];
-                if (active && (dc ? p != 0 : s != 0) && absblk < total_blocks) {
-                    int16_t* blk = frame_coef + ((size_t)bbase + (size_t)(my * bvs + bdy) * bbx + mx * bhs + bdx) * 64;
-                    blk[dc ? 0u : zi] = (int16_t)(dc ? p : v);
-                }
+                // the value (extra bits, T.81 F.2.2.1 EXTEND): nothing before the final pass needs it
+                const uint32_t raw = s ? (uint32_t)(win << len) >> ((32 - s) & 31) : 0u;
+                const int v = (int)raw - ((int)raw < ((1 << s) >> 1) ? (1 << s) - 1 : 0);
+                // one store: the DC difference (dc_scan_kernel adds the predictions up) or a non-zero AC coefficient
+                int16_t* const base = dc ? frame_dc : frame_coef;
+                const uint32_t off = dc ? (uint32_t)absblk : (uint32_t)absblk * 64u + (uint32_t)zc;
+                if (active && absblk < total_blocks && (dc || s)) base[off] = (int16_t)v;
             }
             const bool bend = zn >= 64;
             z = bend ? 0 : zn;
             nblk += bend ? 1 : 0;
             absblk += bend ? 1 : 0;
-            if (MODE == 2) {
-                const bool wrap = bend && bn == 0;
-                const bool roww = wrap && mx + 1 == g.mcus_x;
-                mx = roww ? 0 : (wrap ? mx + 1 : mx);
-                my += roww ? 1 : 0;
-                bbase = bend ? nxt.base : bbase;
-                bbx = bend ? nxt.bx : bbx;
-                bvs = bend ? (int)nxt.vs : bvs;
-                bhs = bend ? (int)nxt.hs : bhs;
-                bdy = bend ? (int)nxt.dy : bdy;
-                bdx = bend ? (int)nxt.dx : bdx;
-            }
+            const int bn = b + 1 == bpm ? 0 : b + 1;
             b = bend ? bn : b;
-            tdc = bend ? (uint32_t)nxt.tdc << LB : tdc;
-            tac = bend ? (uint32_t)nxt.tac << LB : tac;
-            comp = bend ? (int)nxt.comp : comp;
-            bn = b + 1 == bpm ? 0 : b + 1;
-            nxt = binfo[bn];
         }
     }
     if (stamp && tid == 0) {
@@ -615,7 +544,6 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
         used[sj] = entry_st;
         SubCnt c;
         c.blk = x_blk;
-        c.dc[0] = x_dc0; c.dc[1] = x_dc1; c.dc[2] = x_dc2;
         cnt[sj] = c;
     }
 }
@@ -661,7 +589,7 @@ __global__ __launch_bounds__(1024) void sub_verify_plan_kernel(const FrameDesc* 
     if (tid == 1023) todo_cnt[f] = sh[1023];
 }
 
-// entry[j] = what lanes 0 .. j-1 of the frame accumulated: absolute block index and DC predictions at lane j's entry
+// entry[j] = what lanes 0 .. j-1 of the frame accumulated: the absolute block index at lane j's entry
 __global__ __launch_bounds__(1024) void sub_scan_kernel(const FrameDesc* __restrict__ fd, const uint32_t* __restrict__ clean_len,
                                                         const SubCnt* __restrict__ cnt, SubCnt* __restrict__ entry, int sub_shift) {
     __shared__ SubCnt sh[1024];
@@ -675,22 +603,21 @@ __global__ __launch_bounds__(1024) void sub_scan_kernel(const FrameDesc* __restr
         if (b.blk < 0) return b;
         SubCnt r;
         r.blk = a.blk + b.blk;  // keeps a's marker bit: b.blk < 2^30
-        r.dc[0] = a.dc[0] + b.dc[0]; r.dc[1] = a.dc[1] + b.dc[1]; r.dc[2] = a.dc[2] + b.dc[2];
         return r;
     };
-    SubCnt acc = {0, {0, 0, 0}};
+    SubCnt acc = {0};
     for (int i = lo; i < hi; ++i) acc = combine(acc, cnt[(size_t)d.sub_base + i]);
     sh[tid] = acc;
     __syncthreads();
     for (int o = 1; o < 1024; o <<= 1) {
-        SubCnt v = {0, {0, 0, 0}};
+        SubCnt v = {0};
         const bool has = tid >= o;
         if (has) v = sh[tid - o];
         __syncthreads();
         if (has) sh[tid] = combine(v, sh[tid]);
         __syncthreads();
     }
-    SubCnt run = {0, {0, 0, 0}};
+    SubCnt run = {0};
     if (tid > 0) run = sh[tid - 1];
     for (int i = lo; i < hi; ++i) {
         entry[(size_t)d.sub_base + i] = run;
@@ -698,22 +625,99 @@ __global__ __launch_bounds__(1024) void sub_scan_kernel(const FrameDesc* __restr
     }
 }
 
+// DC differences (scan order, as the final pass left them) -> DC coefficients, in place: per component a running sum over
+// the component's blocks in scan order, starting again from zero at every restart interval (T.81 F.2.1.3.1 / F.2.2.4).
+// One workgroup per (frame, component); every thread owns a run of consecutive blocks of the component.
+__global__ __launch_bounds__(1024) void dc_scan_kernel(int16_t* __restrict__ dc, const FrameDesc* __restrict__ fd, const Geom g) {
+    __shared__ int sh_sum[1024];
+    __shared__ int sh_flag[1024];
+    const int f = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
+    if (c >= g.ncomp) return;
+    const int bpm = g.blocks_per_mcu;
+    int b0 = 0, nbc = 0;  // the component's blocks inside an MCU: b0 .. b0 + nbc
+    for (int b = 0; b < bpm; ++b) {
+        if (g.b_comp[b] == c) {
+            if (nbc == 0) b0 = b;
+            ++nbc;
+        }
+    }
+    const int ri = fd[f].ri;
+    const int mcus = g.mcus_x * g.mcus_y, n = mcus * nbc;
+    int16_t* __restrict__ p = dc + (size_t)f * mcus * bpm + b0;
+    const int per = (n + 1023) / 1024;
+    const int lo = min(tid * per, n), hi = min(lo + per, n);
+    int run = 0, flag = 0;
+    {
+        int mcu = lo / nbc, t = lo - mcu * nbc;
+        for (int k = lo; k < hi; ++k) {
+            if (t == 0 && ri > 0 && mcu % ri == 0) {
+                run = 0;
+                flag = 1;
+            }
+            run += p[(size_t)mcu * bpm + t];
+            if (++t == nbc) {
+                t = 0;
+                ++mcu;
+            }
+        }
+    }
+    sh_sum[tid] = run;
+    sh_flag[tid] = flag;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {  // segmented inclusive scan: a run with a restart inside forgets what precedes it
+        int vs = 0, vf = 0;
+        const bool has = tid >= o;
+        if (has) {
+            vs = sh_sum[tid - o];
+            vf = sh_flag[tid - o];
+        }
+        __syncthreads();
+        if (has && !sh_flag[tid]) {
+            sh_sum[tid] += vs;
+            sh_flag[tid] = vf;
+        }
+        __syncthreads();
+    }
+    run = tid > 0 ? sh_sum[tid - 1] : 0;
+    int mcu = lo / nbc, t = lo - mcu * nbc;
+    for (int k = lo; k < hi; ++k) {
+        if (t == 0 && ri > 0 && mcu % ri == 0) run = 0;
+        run += p[(size_t)mcu * bpm + t];
+        p[(size_t)mcu * bpm + t] = (int16_t)run;
+        if (++t == nbc) {
+            t = 0;
+            ++mcu;
+        }
+    }
+}
+
 // ---- de-quantisation + inverse DCT -------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void idct_kernel(const int16_t* __restrict__ coef, const FrameDesc* __restrict__ fd,
-                                                   const TableSet* __restrict__ ts, const Geom g, uint8_t* __restrict__ planes,
-                                                   int n_frames) {
+// One thread per block of the component rasters. Its coefficients lie where the scan put them: block
+// mcu * blocks_per_mcu + (position inside the MCU) of the frame, zig-zag order, the DC coefficient in dc[] (dc_scan_kernel).
+__global__ __launch_bounds__(256) void idct_kernel(const int16_t* __restrict__ coef, const int16_t* __restrict__ dc,
+                                                   const FrameDesc* __restrict__ fd, const TableSet* __restrict__ ts, const Geom g,
+                                                   uint8_t* __restrict__ planes, int n_frames) {
     using namespace dct;
+    constexpr int ZZ[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                            41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                            30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= (long long)n_frames * g.blocks_per_frame) return;
     const int f = (int)(t / g.blocks_per_frame), r = (int)(t - (long long)f * g.blocks_per_frame);
     const int c = (g.ncomp > 2 && r >= g.blk_off[2]) ? 2 : ((g.ncomp > 1 && r >= g.blk_off[1]) ? 1 : 0);
     const int off_c = c == 0 ? g.blk_off[0] : (c == 1 ? g.blk_off[1] : g.blk_off[2]);
     const int bx_c = c == 0 ? g.bx[0] : (c == 1 ? g.bx[1] : g.bx[2]);
+    const int hs_c = c == 0 ? g.hs[0] : (c == 1 ? g.hs[1] : g.hs[2]);
+    const int vs_c = c == 0 ? g.vs[0] : (c == 1 ? g.vs[1] : g.vs[2]);
+    const int b0_c = c == 0 ? 0 : (c == 1 ? g.hs[0] * g.vs[0] : g.hs[0] * g.vs[0] + g.hs[1] * g.vs[1]);
     const int rb = r - off_c;
     const int by = rb / bx_c, bx = rb - by * bx_c;
+    const int my = by / vs_c, mx = bx / hs_c;
+    const size_t sblk = (size_t)f * g.blocks_per_frame + (size_t)(my * g.mcus_x + mx) * g.blocks_per_mcu + b0_c + (by - my * vs_c) * hs_c +
+                        (bx - mx * hs_c);  // blocks_per_frame = mcus * blocks_per_mcu: the rasters are padded to whole MCUs
     const uint16_t* __restrict__ q = ts[fd[f].tabset].q[fd[f].tq[c]];
-    const uint4* src = reinterpret_cast<const uint4*>(coef + (size_t)t * 64);
+    const uint4* src = reinterpret_cast<const uint4*>(coef + sblk * 64);
     int d[64];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -721,10 +725,11 @@ __global__ __launch_bounds__(256) void idct_kernel(const int16_t* __restrict__ c
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            d[i * 8 + 2 * j] = (int)(int16_t)(w[j] & 0xffff) * (int)q[i * 8 + 2 * j];
-            d[i * 8 + 2 * j + 1] = (int)(int16_t)(w[j] >> 16) * (int)q[i * 8 + 2 * j + 1];
+            d[ZZ[i * 8 + 2 * j]] = (int)(int16_t)(w[j] & 0xffff) * (int)q[ZZ[i * 8 + 2 * j]];
+            d[ZZ[i * 8 + 2 * j + 1]] = (int)(int16_t)(w[j] >> 16) * (int)q[ZZ[i * 8 + 2 * j + 1]];
         }
     }
+    d[0] = (int)dc[sblk] * (int)q[0];
 #pragma unroll
     for (int x = 0; x < 8; ++x) idct8<true>(d + x, 8);
 #pragma unroll
@@ -1011,6 +1016,7 @@ struct pa_mjpeg {
     int32_t* d_todo = nullptr;     // [max_subs] compact lane lists of a verify pass
     int32_t* d_todo_cnt = nullptr; // [max_frames]
     int16_t* d_coef = nullptr;
+    int16_t* d_dc = nullptr;       // [max_frames][blocks of a frame in scan order] DC differences
     uint8_t* d_planes = nullptr;
     int32_t* d_status = nullptr;
     // pinned host staging, two sets used in turn
@@ -1018,6 +1024,11 @@ struct pa_mjpeg {
     TableSet* h_ts[2] = {nullptr, nullptr};
     int32_t* h_flag = nullptr;
     hipEvent_t staged[2] = {nullptr, nullptr};
+    // the compressed bytes travel on a stream of the handle's own, so that the upload of one call overlaps the decode
+    // passes of the call before it (the raw bytes are dead once the clean stream is written)
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t bits_ready = nullptr, bits_free = nullptr;
+    bool bits_free_recorded = false;
     bool staged_used[2] = {false, false};
     int turn = 0;
     int last_rounds = 0;
@@ -1035,7 +1046,7 @@ const char* pa_mjpeg_last_error(const pa_mjpeg* h) { return h ? h->last_error.c_
 void pa_mjpeg_destroy(pa_mjpeg* h) {
     if (!h) return;
     void* dev[] = {h->d_bits, h->d_clean, h->d_fd, h->d_ts, h->d_chunk, h->d_seg, h->d_clean_len, h->d_g[0], h->d_g[1], h->d_used,
-                   h->d_cnt, h->d_entry, h->d_changed, h->d_todo, h->d_todo_cnt, h->d_coef, h->d_planes, h->d_status};
+                   h->d_cnt, h->d_entry, h->d_changed, h->d_todo, h->d_todo_cnt, h->d_coef, h->d_dc, h->d_planes, h->d_status};
     for (void* p : dev) (void)hipFree(p);
     for (int i = 0; i < 2; ++i) {
         if (h->h_fd[i]) (void)hipHostFree(h->h_fd[i]);
@@ -1043,6 +1054,12 @@ void pa_mjpeg_destroy(pa_mjpeg* h) {
         if (h->staged[i]) (void)hipEventDestroy(h->staged[i]);
     }
     if (h->h_flag) (void)hipHostFree(h->h_flag);
+    if (h->copy_stream) {
+        (void)hipStreamSynchronize(h->copy_stream);
+        (void)hipStreamDestroy(h->copy_stream);
+    }
+    if (h->bits_ready) (void)hipEventDestroy(h->bits_ready);
+    if (h->bits_free) (void)hipEventDestroy(h->bits_free);
     delete h;
 }
 
@@ -1086,6 +1103,7 @@ int pa_mjpeg_create(int32_t device, int32_t max_frames, int32_t max_height, int3
     if (!chk(hipMalloc(&h->d_todo, h->max_subs * sizeof(int32_t)), "hipMalloc lane lists")) return PA_ERR_HIP;
     if (!chk(hipMalloc(&h->d_todo_cnt, n * sizeof(int32_t)), "hipMalloc lane counts")) return PA_ERR_HIP;
     if (!chk(hipMalloc(&h->d_coef, n * h->max_blocks * 64 * sizeof(int16_t)), "hipMalloc coefficients")) return PA_ERR_HIP;
+    if (!chk(hipMalloc(&h->d_dc, n * h->max_blocks * sizeof(int16_t)), "hipMalloc DC differences")) return PA_ERR_HIP;
     if (!chk(hipMalloc(&h->d_planes, n * h->max_blocks * 64), "hipMalloc sample planes")) return PA_ERR_HIP;
     if (!chk(hipMalloc(&h->d_status, n * sizeof(int32_t)), "hipMalloc status")) return PA_ERR_HIP;
     if (!chk(hipMemset(h->d_bits, 0, max_bytes + 64), "hipMemset")) return PA_ERR_HIP;
@@ -1095,6 +1113,9 @@ int pa_mjpeg_create(int32_t device, int32_t max_frames, int32_t max_height, int3
         if (!chk(hipHostMalloc(&h->h_ts[i], n * sizeof(TableSet)), "hipHostMalloc")) return PA_ERR_HIP;
         if (!chk(hipEventCreateWithFlags(&h->staged[i], hipEventDisableTiming), "hipEventCreate")) return PA_ERR_HIP;
     }
+    if (!chk(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking), "hipStreamCreate")) return PA_ERR_HIP;
+    if (!chk(hipEventCreateWithFlags(&h->bits_ready, hipEventDisableTiming), "hipEventCreate")) return PA_ERR_HIP;
+    if (!chk(hipEventCreateWithFlags(&h->bits_free, hipEventDisableTiming), "hipEventCreate")) return PA_ERR_HIP;
     if (!chk(hipHostMalloc(&h->h_flag, n * sizeof(int32_t)), "hipHostMalloc")) return PA_ERR_HIP;
     return PA_OK;
 }
@@ -1271,8 +1292,12 @@ int pa_mjpeg_decode(pa_mjpeg* h, const uint8_t* data_host, const int64_t* spans_
     const int max_chunks = (int)(max_scan / CHUNK) + 2;
     if (max_chunks > h->max_chunks_cap) return bad(PA_ERR_CAPACITY, "pa_mjpeg_decode: scan longer than the handle's chunk table");
     if (seg_total > h->max_segs || sub_total > h->max_subs) return bad(PA_ERR_CAPACITY, "pa_mjpeg_decode: more restart intervals / subsequences than the handle holds");
-    if (!chk(hipMemcpyAsync(h->d_bits, data_host + base, (size_t)total, hipMemcpyHostToDevice, s), "upload bitstream")) return PA_ERR_HIP;
-    if (!chk(hipMemsetAsync(h->d_bits + total, 0, 64, s), "pad bitstream")) return PA_ERR_HIP;
+    // compressed bytes: on the handle's copy stream, as soon as the call before this one has written its clean stream
+    if (h->bits_free_recorded && !chk(hipStreamWaitEvent(h->copy_stream, h->bits_free, 0), "hipStreamWaitEvent")) return PA_ERR_HIP;
+    if (!chk(hipMemcpyAsync(h->d_bits, data_host + base, (size_t)total, hipMemcpyHostToDevice, h->copy_stream), "upload bitstream")) return PA_ERR_HIP;
+    if (!chk(hipMemsetAsync(h->d_bits + total, 0, 64, h->copy_stream), "pad bitstream")) return PA_ERR_HIP;
+    if (!chk(hipEventRecord(h->bits_ready, h->copy_stream), "hipEventRecord")) return PA_ERR_HIP;
+    if (!chk(hipStreamWaitEvent(s, h->bits_ready, 0), "hipStreamWaitEvent")) return PA_ERR_HIP;
     if (!chk(hipMemcpyAsync(h->d_fd, fd, (size_t)n * sizeof(FrameDesc), hipMemcpyHostToDevice, s), "upload descriptors")) return PA_ERR_HIP;
     if (!chk(hipMemcpyAsync(h->d_ts, ts, (size_t)n_sets * sizeof(TableSet), hipMemcpyHostToDevice, s), "upload tables")) return PA_ERR_HIP;
     if (!chk(hipEventRecord(h->staged[k], s), "hipEventRecord")) return PA_ERR_HIP;
@@ -1280,14 +1305,17 @@ int pa_mjpeg_decode(pa_mjpeg* h, const uint8_t* data_host, const int64_t* spans_
     if (!chk(hipMemsetAsync(h->d_status, 0, (size_t)n * sizeof(int32_t), s), "clear status")) return PA_ERR_HIP;
     if (!chk(hipMemsetAsync(h->d_changed, 0, (size_t)(MAX_ROUNDS + 1) * h->max_frames * sizeof(int32_t), s), "clear flags")) return PA_ERR_HIP;
     if (!chk(hipMemsetAsync(h->d_coef, 0, (size_t)n * g.blocks_per_frame * 64 * sizeof(int16_t), s), "clear coefficients")) return PA_ERR_HIP;
+    if (!chk(hipMemsetAsync(h->d_dc, 0, (size_t)n * g.mcus_x * g.mcus_y * g.blocks_per_mcu * sizeof(int16_t), s), "clear DC differences")) return PA_ERR_HIP;
     hipLaunchKernelGGL(unstuff_count_kernel, dim3(max_chunks, n), dim3(256), 0, s, h->d_bits, h->d_fd, h->d_chunk, max_chunks);
     hipLaunchKernelGGL(unstuff_write_kernel, dim3(max_chunks, n), dim3(256), 0, s, h->d_bits, h->d_fd, h->d_chunk, max_chunks, h->d_clean,
                        h->d_seg, h->d_clean_len, h->d_status);
+    if (!chk(hipEventRecord(h->bits_free, s), "hipEventRecord")) return PA_ERR_HIP;
+    h->bits_free_recorded = true;
     const dim3 sgrid((max_sub + WG_SUBS - 1) / WG_SUBS, n);
     int cur_g = 0;
     hipLaunchKernelGGL((sub_decode_kernel<0>), sgrid, dim3(256), 0, s, h->d_clean, h->d_fd, h->d_ts, h->d_seg, h->d_clean_len, g,
                        (const uint32_t*)nullptr, h->d_g[0], h->d_used, h->d_cnt, (const SubCnt*)nullptr, (int16_t*)nullptr, h->d_status,
-                       (int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr);
+                       (int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, (int16_t*)nullptr);
     auto verify = [&](int slot, int prev_slot) {
         int32_t* flag = h->d_changed + (size_t)slot * h->max_frames;
         const int32_t* prev = prev_slot >= 0 ? h->d_changed + (size_t)prev_slot * h->max_frames : nullptr;
@@ -1295,7 +1323,7 @@ int pa_mjpeg_decode(pa_mjpeg* h, const uint8_t* data_host, const int64_t* spans_
                            h->d_g[cur_g ^ 1], h->d_used, h->d_todo, h->d_todo_cnt, prev);
         hipLaunchKernelGGL((sub_decode_kernel<1>), sgrid, dim3(256), 0, s, h->d_clean, h->d_fd, h->d_ts, h->d_seg, h->d_clean_len, g,
                            h->d_g[cur_g], h->d_g[cur_g ^ 1], h->d_used, h->d_cnt, (const SubCnt*)nullptr, (int16_t*)nullptr, h->d_status, flag,
-                           prev, h->d_todo, h->d_todo_cnt);
+                           prev, h->d_todo, h->d_todo_cnt, (int16_t*)nullptr);
         cur_g ^= 1;
     };
     int last_slot = MAX_ROUNDS;  // an all-zero row unless a verify pass wrote it
@@ -1323,9 +1351,10 @@ int pa_mjpeg_decode(pa_mjpeg* h, const uint8_t* data_host, const int64_t* spans_
     hipLaunchKernelGGL(sub_scan_kernel, dim3(n), dim3(1024), 0, s, h->d_fd, h->d_clean_len, h->d_cnt, h->d_entry, g.sub_shift);
     hipLaunchKernelGGL((sub_decode_kernel<2>), sgrid, dim3(256), 0, s, h->d_clean, h->d_fd, h->d_ts, h->d_seg, h->d_clean_len, g,
                        h->d_g[cur_g], (uint32_t*)nullptr, h->d_used, h->d_cnt, h->d_entry, h->d_coef, h->d_status, (int32_t*)nullptr,
-                       h->d_changed + (size_t)last_slot * h->max_frames, (const int32_t*)nullptr, (const int32_t*)nullptr);
+                       h->d_changed + (size_t)last_slot * h->max_frames, (const int32_t*)nullptr, (const int32_t*)nullptr, h->d_dc);
+    hipLaunchKernelGGL(dc_scan_kernel, dim3(n, g.ncomp), dim3(1024), 0, s, h->d_dc, h->d_fd, g);
     const long long nblk = (long long)n * g.blocks_per_frame;
-    hipLaunchKernelGGL(idct_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, s, h->d_coef, h->d_fd, h->d_ts, g, h->d_planes, n);
+    hipLaunchKernelGGL(idct_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, s, h->d_coef, h->d_dc, h->d_fd, h->d_ts, g, h->d_planes, n);
     const int fv = g.ncomp == 3 ? g.fv : 1, fhh = g.ncomp == 3 ? g.fh : 1;
     const dim3 grid((width + 511) / 512, (height + 4 * fv - 1) / (4 * fv), n);
     if (fhh == 2 && fv == 2) hipLaunchKernelGGL((ycc_kernel<2, 2>), grid, dim3(256), 0, s, h->d_planes, g, frames_dev, rgb);
