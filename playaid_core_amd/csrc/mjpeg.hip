@@ -47,8 +47,16 @@ constexpr int WG_SUBS = 256;     // subsequences per workgroup
 
 enum { ERR_HUFF = 1, ERR_RST = 2, ERR_COEF = 4, ERR_SYNC = 8 };
 
+// How far a symbol moves the zig-zag index (T.81 F.2.2.2): the DC symbol to 1; a coefficient RRRRSSSS past its run of
+// zeros and itself; ZRL 16; EOB (libjpeg: any other symbol of size 0) beyond the end of the block from wherever it stands.
+__host__ __device__ inline int symbol_advance(bool dc, int sym) {
+    if (dc) return 1;
+    const int s = sym & 15, r = sym >> 4;
+    return s ? r + 1 : (r == 15 ? 16 : 64);
+}
+
 // Huffman tables as the decoder's lanes read them (LDS image = global layout). A 16-bit entry holds everything a symbol
-// needs: code length (bits 0-4), number of extra bits s (5-8), zero run r (9-12; 0 in the DC tables); 0 = no entry.
+// needs: code length (bits 0-4), number of extra bits s (5-8), advance of the zig-zag index (9-15); 0 = no entry.
 // Codes of up to LB bits are found in lut1 under their first LB bits. Longer codes sit at the top of a canonical code
 // space: whenever they all start with six 1-bits (every table whose long codes fill less than 1/64 of the code space --
 // the standard tables, and what libjpeg's optimiser produces) they are found in lutB under bits 6..15, so both tables
@@ -301,7 +309,8 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
     int b = (entry_st >> 5) & 15, z = (entry_st >> 9) & 63;
     const int bpm = g.blocks_per_mcu;
     if (b >= bpm) b = 0;
-    // this lane's ring: bytes [fill - 128, fill) of the stream, most significant bit first; dword X at ring[X & 31]
+    // this lane's ring: bytes [fill - 128, fill) of the stream, most significant bit first; dword X at ring[X & 31], and
+    // ring[32] repeats ring[0] so that a window's two dwords are always neighbours
     uint32_t* const my_ring = ring + tid * (RING_DW + 1);
     const uint8_t* const stream = clean + d.clean_off;
     uint32_t fill = s_byte;  // multiple of 16
@@ -312,6 +321,7 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
             uint32_t* q = my_ring + ((fill >> 2) & (RING_DW - 1));
             q[0] = __builtin_bswap32(v.x); q[1] = __builtin_bswap32(v.y);
             q[2] = __builtin_bswap32(v.z); q[3] = __builtin_bswap32(v.w);
+            if (q == my_ring) my_ring[RING_DW] = q[0];
             fill += 16;
         }
     };
@@ -328,7 +338,7 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
         if (nbk < d.n_int) nb_bits = seg_start[d.seg_base + nbk] * 8;
     }
     int nblk = 0, reset = 0, err = 0;
-    int absblk = 0;  // index of the current block in scan order (MODE 2; from the last restart marker otherwise)
+    int absblk = 0;  // MODE 2: index of the current block in scan order; else: first block of the last restart interval entered
     if (MODE == 2 && active) {
         const SubCnt e = entry[sj];
         absblk = e.blk & 0x7fffffff;
@@ -344,23 +354,17 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
         active = false;
     }
     uint32_t lim = min(nb_bits, end_bits);
-    // bit buffer: the next nb bits of the stream at the top of buf (bitpos = 32 * dwi - nb), refilled a dword at a time
-    uint64_t buf = 0;
-    int nb = 0;
-    uint32_t dwi = 0;
-    auto reload = [&]() {
-        dwi = bitpos >> 5;
-        const uint32_t w0 = my_ring[dwi & (RING_DW - 1)], w1 = my_ring[(dwi + 1) & (RING_DW - 1)];
-        buf = (((uint64_t)w0 << 32) | w1) << (bitpos & 31);
-        nb = 64 - (int)(bitpos & 31);
-        dwi += 2;
+    // the next 32 bits of the stream, straight from the ring
+    auto window = [&]() -> uint32_t {
+        const uint32_t* q = my_ring + ((bitpos >> 5) & (RING_DW - 1));
+        return (uint32_t)(((((uint64_t)q[0]) << 32) | q[1]) << (bitpos & 31) >> 32);
     };
     const uint16_t* const lut1 = &T.lut1[0][0];
     const uint16_t* const lutB = &T.lutB[0][0];
     // what the lane hands on, captured when it reaches the end of its subsequence (it free-runs after that)
     uint32_t x_state = 0;
     int x_blk = 0;
-    bool gen = false, first = true;
+    bool gen = false;
     const bool stamp = blockIdx.x == 0 && blockIdx.y == 0 && tid < 64;
     const unsigned long long c0 = clock64(), w0t = wall_clock64();
     int it = 0;
@@ -373,14 +377,11 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
         if (MODE == 2 && absblk >= total_blocks) active = false;  // what follows the last block is padding
         if (active) {
             top_up();
-            if (first) reload();
-            first = false;
             if (bitpos >= lim) {
                 gen = false;
                 if (bitpos >= nb_bits) {
                     // restart marker: byte aligned, block 0 of MCU nbk * ri, predictions zero (T.81 F.2.2.4 / E.2.4)
                     bitpos = nb_bits;
-                    reload();
                     b = 0; z = 0;
                     reset = 1;
                     nblk = 0;
@@ -392,25 +393,18 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
                 if (bitpos >= end_bits) {
                     active = false;
                     x_state = ((bitpos - end_bits) & 31) | ((uint32_t)b << 5) | ((uint32_t)z << 9);
-                    x_blk = reset ? (int32_t)(((uint32_t)absblk & 0x7fffffffu) | 0x80000000u) : nblk;
+                    // blocks since the last restart marker inside the subsequence (absblk = that marker's block), if any
+                    x_blk = reset ? (int32_t)(((uint32_t)(absblk + nblk) & 0x7fffffffu) | 0x80000000u) : nblk;
                 }
             } else if (gen) {
                 // one symbol the general way: codes outside the look-up tables, padding in front of a marker, errors
                 gen = false;
-                {
-                    const uint32_t wn = my_ring[dwi & (RING_DW - 1)];
-                    if (nb <= 32) {
-                        buf |= (uint64_t)wn << (32 - nb);
-                        nb += 32;
-                        ++dwi;
-                    }
-                }
-                const uint32_t win = (uint32_t)(buf >> 32);
+                const uint32_t win = window();
                 const bool dc = z == 0;
                 const uint32_t t = table_row(dc, b);
                 uint32_t e = T.lut1[t][win >> (32 - LB)];
                 if (e == 0 && (win >> 26) == 63) e = T.lutB[t][(win >> (26 - LB)) & ((1 << LB) - 1)];
-                int len = e & 31, s = (e >> 5) & 15, r = (e >> 9) & 15;
+                int len = e & 31, s = (e >> 5) & 15, adv = e >> 9;
                 bool invalid = false;
                 if (e == 0) {  // canonical search (T.81 F.2.2.3)
                     const uint32_t pk = win >> 16;
@@ -431,27 +425,23 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
                         len = 1;
                         sym = 0;
                     }
-                    s = dc ? sym : sym & 15;
-                    r = dc ? 0 : sym >> 4;
+                    s = sym & 15;
+                    adv = symbol_advance(dc, sym);
                 }
                 const int use = len + s;
                 const uint32_t np = bitpos + use;
                 if (np > nb_bits || (invalid && nb_bits - bitpos < 8)) {
                     bitpos = nb_bits;  // the padding bits in front of a restart marker, not a symbol
-                    reload();
                 } else if (invalid && MODE == 2) {
                     err |= ERR_HUFF;
                     active = false;
                 } else {
                     bitpos = np;
-                    buf <<= use;
-                    nb -= use;
-                    const uint32_t raw = s ? (uint32_t)(win << len) >> (32 - s) : 0u;
-                    const int v = (int)raw - ((int)raw < ((1 << s) >> 1) ? (1 << s) - 1 : 0);
-                    const int zc = dc ? 0 : z + r;
-                    const bool over = !dc && s && zc > 63;
-                    int zn = dc ? 1 : (s ? zc + 1 : (r == 15 ? z + 16 : 64));
+                    int zn = z + adv;
+                    const bool over = !dc && s && zn > 64;  // a coefficient beyond index 63
                     if (MODE == 2) {
+                        const uint32_t raw = s ? (uint32_t)(win << len) >> (32 - s) : 0u;
+                        const int v = (int)raw - ((int)raw < ((1 << s) >> 1) ? (1 << s) - 1 : 0);
                         if (over) {
                             err |= ERR_COEF;
                             active = false;
@@ -459,7 +449,7 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
                             if (dc) {
                                 frame_dc[absblk] = (int16_t)v;  // the difference; dc_scan_kernel adds the predictions up
                             } else if (s) {
-                                frame_coef[(size_t)absblk * 64 + zc] = (int16_t)v;
+                                frame_coef[(size_t)absblk * 64 + zn - 1] = (int16_t)v;
                             }
                         }
                     }
@@ -467,7 +457,7 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
                     if (zn >= 64) {
                         zn = 0;
                         ++nblk;
-                        ++absblk;
+                        if (MODE == 2) ++absblk;
                         if (++b >= bpm) b = 0;
                     }
                     z = zn;
@@ -475,58 +465,41 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
             }
         }
         // ---- the fast loop: straight-line code, every lane; left as soon as one active lane meets anything else.
-        // The LDS reads whose addresses do not depend on the symbol in hand (the ring dword of the next refill, the
-        // next block's tables) are issued one symbol ahead, so a symbol waits for one LDS round trip: its two table
-        // look-ups, made side by side.
+        // A symbol is two LDS round trips -- the window's two dwords from the ring, then the two table look-ups side by
+        // side -- and some sixty instructions; the passes are bound by instruction issue, not by those latencies.
         slow_cyc += clock64() - cs;
-        uint32_t wn = my_ring[dwi & (RING_DW - 1)];
         for (int k = 0; k < TOPUP; ++k, ++it) {
-            uint64_t fbuf = buf;
-            int fnb = nb;
-            uint32_t fdwi = dwi;
-            {
-                const bool need = fnb <= 32;
-                fbuf |= need ? (uint64_t)wn << ((32 - fnb) & 31) : 0ull;
-                fnb += need ? 32 : 0;
-                fdwi += need ? 1u : 0u;
-            }
-            const uint32_t wn_next = my_ring[fdwi & (RING_DW - 1)];
-            const uint32_t win = (uint32_t)(fbuf >> 32);
+            const uint32_t win = window();
             const bool dc = z == 0;
             const uint32_t tb = table_row(dc, b) << LB;
             uint32_t eA = lut1[tb + (win >> (32 - LB))];
             uint32_t eB = lutB[tb + ((win >> (26 - LB)) & ((1 << LB) - 1))];
             asm volatile("" : "+v"(eA), "+v"(eB));  // both look-ups in flight together, not the second behind a branch
             const uint32_t e = eA ? eA : ((win >> 26) == 63 ? eB : 0u);
-            const int len = e & 31, s = (e >> 5) & 15, r = (e >> 9) & 15;
+            const int len = e & 31, s = (e >> 5) & 15, adv = e >> 9;
             const int use = len + s;
             const uint32_t np = bitpos + use;
-            const int zc = dc ? 0 : z + r;
-            const bool rare = bitpos >= lim || e == 0 || np > nb_bits || zc > 63;
-            if (__ballot(active && rare)) {
+            const int zn = z + adv;  // DC: 1 | coefficient: past its zero run and itself | ZRL: + 16 | EOB: beyond 64
+            const bool rare = bitpos >= lim || e == 0 || np > nb_bits || (zn > 64 && adv < 64);
+            if (__builtin_amdgcn_ballot_w64(active && rare) != 0) {
                 gen = rare && bitpos < lim;
                 break;
             }
             // commit
             bitpos = np;
-            buf = fbuf << use;
-            nb = fnb - use;
-            dwi = fdwi;
-            wn = wn_next;
-            const int zn = dc ? 1 : (s ? zc + 1 : (r == 15 ? z + 16 : 64));  // DC | coefficient | ZRL | EOB
             if (MODE == 2) {
                 // the value (extra bits, T.81 F.2.2.1 EXTEND): nothing before the final pass needs it
                 const uint32_t raw = s ? (uint32_t)(win << len) >> ((32 - s) & 31) : 0u;
                 const int v = (int)raw - ((int)raw < ((1 << s) >> 1) ? (1 << s) - 1 : 0);
                 // one store: the DC difference (dc_scan_kernel adds the predictions up) or a non-zero AC coefficient
                 int16_t* const base = dc ? frame_dc : frame_coef;
-                const uint32_t off = dc ? (uint32_t)absblk : (uint32_t)absblk * 64u + (uint32_t)zc;
-                if (active && absblk < total_blocks && (dc || s)) base[off] = (int16_t)v;
+                const uint32_t off = dc ? (uint32_t)absblk : (uint32_t)absblk * 64u + (uint32_t)(zn - 1);
+                if (active && absblk < total_blocks && s) base[off] = (int16_t)v;
             }
             const bool bend = zn >= 64;
             z = bend ? 0 : zn;
             nblk += bend ? 1 : 0;
-            absblk += bend ? 1 : 0;
+            if (MODE == 2) absblk += bend ? 1 : 0;
             const int bn = b + 1 == bpm ? 0 : b + 1;
             b = bend ? bn : b;
         }
@@ -959,8 +932,7 @@ const char* parse_header(const uint8_t* d, size_t n, Parsed& P) {
 void build_hufftab(HuffTables& T, int t, const uint8_t* counts, const uint8_t* syms) {
     const bool dc = t < 2;
     auto entry = [&](int len, int sym) -> uint16_t {
-        const int s = sym & 15, r = dc ? 0 : (sym >> 4);
-        return (uint16_t)(len | (s << 5) | (r << 9));
+        return (uint16_t)(len | ((sym & 15) << 5) | (symbol_advance(dc, sym) << 9));
     };
     memset(T.lut1[t], 0, sizeof T.lut1[t]);
     memset(T.lutB[t], 0, sizeof T.lutB[t]);
@@ -1029,6 +1001,10 @@ struct pa_mjpeg {
     hipStream_t copy_stream = nullptr;
     hipEvent_t bits_ready = nullptr, bits_free = nullptr;
     bool bits_free_recorded = false;
+    // ... and so does the clearing of the coefficient buffers (400 MB for 64 1080p frames): under pass A and the verify
+    // passes of the same call, which do not touch them
+    hipEvent_t coef_clear = nullptr, coef_free = nullptr;
+    bool coef_free_recorded = false;
     bool staged_used[2] = {false, false};
     int turn = 0;
     int last_rounds = 0;
@@ -1060,6 +1036,8 @@ void pa_mjpeg_destroy(pa_mjpeg* h) {
     }
     if (h->bits_ready) (void)hipEventDestroy(h->bits_ready);
     if (h->bits_free) (void)hipEventDestroy(h->bits_free);
+    if (h->coef_clear) (void)hipEventDestroy(h->coef_clear);
+    if (h->coef_free) (void)hipEventDestroy(h->coef_free);
     delete h;
 }
 
@@ -1116,6 +1094,8 @@ int pa_mjpeg_create(int32_t device, int32_t max_frames, int32_t max_height, int3
     if (!chk(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking), "hipStreamCreate")) return PA_ERR_HIP;
     if (!chk(hipEventCreateWithFlags(&h->bits_ready, hipEventDisableTiming), "hipEventCreate")) return PA_ERR_HIP;
     if (!chk(hipEventCreateWithFlags(&h->bits_free, hipEventDisableTiming), "hipEventCreate")) return PA_ERR_HIP;
+    if (!chk(hipEventCreateWithFlags(&h->coef_clear, hipEventDisableTiming), "hipEventCreate")) return PA_ERR_HIP;
+    if (!chk(hipEventCreateWithFlags(&h->coef_free, hipEventDisableTiming), "hipEventCreate")) return PA_ERR_HIP;
     if (!chk(hipHostMalloc(&h->h_flag, n * sizeof(int32_t)), "hipHostMalloc")) return PA_ERR_HIP;
     return PA_OK;
 }
@@ -1304,8 +1284,11 @@ int pa_mjpeg_decode(pa_mjpeg* h, const uint8_t* data_host, const int64_t* spans_
     h->staged_used[k] = true;
     if (!chk(hipMemsetAsync(h->d_status, 0, (size_t)n * sizeof(int32_t), s), "clear status")) return PA_ERR_HIP;
     if (!chk(hipMemsetAsync(h->d_changed, 0, (size_t)(MAX_ROUNDS + 1) * h->max_frames * sizeof(int32_t), s), "clear flags")) return PA_ERR_HIP;
-    if (!chk(hipMemsetAsync(h->d_coef, 0, (size_t)n * g.blocks_per_frame * 64 * sizeof(int16_t), s), "clear coefficients")) return PA_ERR_HIP;
-    if (!chk(hipMemsetAsync(h->d_dc, 0, (size_t)n * g.mcus_x * g.mcus_y * g.blocks_per_mcu * sizeof(int16_t), s), "clear DC differences")) return PA_ERR_HIP;
+    // the coefficient buffers are cleared on the copy stream, once the inverse DCT of the call before this one has read them
+    if (h->coef_free_recorded && !chk(hipStreamWaitEvent(h->copy_stream, h->coef_free, 0), "hipStreamWaitEvent")) return PA_ERR_HIP;
+    if (!chk(hipMemsetAsync(h->d_coef, 0, (size_t)n * g.blocks_per_frame * 64 * sizeof(int16_t), h->copy_stream), "clear coefficients")) return PA_ERR_HIP;
+    if (!chk(hipMemsetAsync(h->d_dc, 0, (size_t)n * g.mcus_x * g.mcus_y * g.blocks_per_mcu * sizeof(int16_t), h->copy_stream), "clear DC differences")) return PA_ERR_HIP;
+    if (!chk(hipEventRecord(h->coef_clear, h->copy_stream), "hipEventRecord")) return PA_ERR_HIP;
     hipLaunchKernelGGL(unstuff_count_kernel, dim3(max_chunks, n), dim3(256), 0, s, h->d_bits, h->d_fd, h->d_chunk, max_chunks);
     hipLaunchKernelGGL(unstuff_write_kernel, dim3(max_chunks, n), dim3(256), 0, s, h->d_bits, h->d_fd, h->d_chunk, max_chunks, h->d_clean,
                        h->d_seg, h->d_clean_len, h->d_status);
@@ -1349,12 +1332,15 @@ int pa_mjpeg_decode(pa_mjpeg* h, const uint8_t* data_host, const int64_t* spans_
         h->last_rounds = rounds;
     }
     hipLaunchKernelGGL(sub_scan_kernel, dim3(n), dim3(1024), 0, s, h->d_fd, h->d_clean_len, h->d_cnt, h->d_entry, g.sub_shift);
+    if (!chk(hipStreamWaitEvent(s, h->coef_clear, 0), "hipStreamWaitEvent")) return PA_ERR_HIP;
     hipLaunchKernelGGL((sub_decode_kernel<2>), sgrid, dim3(256), 0, s, h->d_clean, h->d_fd, h->d_ts, h->d_seg, h->d_clean_len, g,
                        h->d_g[cur_g], (uint32_t*)nullptr, h->d_used, h->d_cnt, h->d_entry, h->d_coef, h->d_status, (int32_t*)nullptr,
                        h->d_changed + (size_t)last_slot * h->max_frames, (const int32_t*)nullptr, (const int32_t*)nullptr, h->d_dc);
     hipLaunchKernelGGL(dc_scan_kernel, dim3(n, g.ncomp), dim3(1024), 0, s, h->d_dc, h->d_fd, g);
     const long long nblk = (long long)n * g.blocks_per_frame;
     hipLaunchKernelGGL(idct_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, s, h->d_coef, h->d_dc, h->d_fd, h->d_ts, g, h->d_planes, n);
+    if (!chk(hipEventRecord(h->coef_free, s), "hipEventRecord")) return PA_ERR_HIP;
+    h->coef_free_recorded = true;
     const int fv = g.ncomp == 3 ? g.fv : 1, fhh = g.ncomp == 3 ? g.fh : 1;
     const dim3 grid((width + 511) / 512, (height + 4 * fv - 1) / (4 * fv), n);
     if (fhh == 2 && fv == 2) hipLaunchKernelGGL((ycc_kernel<2, 2>), grid, dim3(256), 0, s, h->d_planes, g, frames_dev, rgb);
