@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -97,6 +98,16 @@ struct Geom {
 
 // diagnostics (pa_mjpeg_debug_counters): shader-clock cycles, 100 MHz wall ticks and symbols of one wave's symbol loop
 __device__ unsigned long long g_dbg[16];
+
+// Frame descriptors and table sets, pinned host staging -> HBM, read over the link by the device itself. (hipMemcpyAsync
+// of a few KB on a stream that has just been told to wait for another stream's event blocked the calling thread for the
+// length of a whole decode, every third call, on ROCm 7.2: measured with PA_MJPEG_TRACE.)
+__global__ __launch_bounds__(256) void stage_copy_kernel(const uint32_t* __restrict__ a, uint32_t* __restrict__ da, int na,
+                                                         const uint32_t* __restrict__ b, uint32_t* __restrict__ db, int nb) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < na) da[i] = a[i];
+    else if (i - na < nb) db[i - na] = b[i - na];
+}
 
 // ---- byte un-stuffing + restart markers --------------------------------------------------------------------------------------
 //
@@ -619,21 +630,39 @@ __global__ __launch_bounds__(1024) void dc_scan_kernel(int16_t* __restrict__ dc,
     int16_t* __restrict__ p = dc + (size_t)f * mcus * bpm + b0;
     const int per = (n + 1023) / 1024;
     const int lo = min(tid * per, n), hi = min(lo + per, n);
-    int run = 0, flag = 0;
-    {
+    // a thread's run, eight blocks at a time: the eight loads are in flight together (one after the other they cost a
+    // memory latency each, 2 x 32 of them for the luma of a 1080p frame)
+    auto walk = [&](int& run, int& flag, bool store) {
         int mcu = lo / nbc, t = lo - mcu * nbc;
-        for (int k = lo; k < hi; ++k) {
-            if (t == 0 && ri > 0 && mcu % ri == 0) {
-                run = 0;
-                flag = 1;
+        for (int k0 = lo; k0 < hi; k0 += 8) {
+            int idx[8], val[8];
+            bool rst[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                idx[i] = mcu * bpm + t;
+                rst[i] = t == 0 && ri > 0 && mcu % ri == 0;
+                if (++t == nbc) {
+                    t = 0;
+                    ++mcu;
+                }
             }
-            run += p[(size_t)mcu * bpm + t];
-            if (++t == nbc) {
-                t = 0;
-                ++mcu;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) val[i] = k0 + i < hi ? (int)p[idx[i]] : 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (k0 + i < hi) {
+                    if (rst[i]) {
+                        run = 0;
+                        flag = 1;
+                    }
+                    run += val[i];
+                    if (store) p[idx[i]] = (int16_t)run;
+                }
             }
         }
-    }
+    };
+    int run = 0, flag = 0;
+    walk(run, flag, false);
     sh_sum[tid] = run;
     sh_flag[tid] = flag;
     __syncthreads();
@@ -652,16 +681,7 @@ __global__ __launch_bounds__(1024) void dc_scan_kernel(int16_t* __restrict__ dc,
         __syncthreads();
     }
     run = tid > 0 ? sh_sum[tid - 1] : 0;
-    int mcu = lo / nbc, t = lo - mcu * nbc;
-    for (int k = lo; k < hi; ++k) {
-        if (t == 0 && ri > 0 && mcu % ri == 0) run = 0;
-        run += p[(size_t)mcu * bpm + t];
-        p[(size_t)mcu * bpm + t] = (int16_t)run;
-        if (++t == nbc) {
-            t = 0;
-            ++mcu;
-        }
-    }
+    walk(run, flag, true);
 }
 
 // ---- de-quantisation + inverse DCT -------------------------------------------------------------------------------------------
@@ -725,16 +745,31 @@ __global__ __launch_bounds__(256) void idct_kernel(const int16_t* __restrict__ c
 
 // Chroma samples of 8 pixels x FV rows (pixel x0 .., rows y0 ..) by jdsample.c's fancy triangle filters. cw x ch = the
 // component's real (down-sampled) size: libjpeg replicates ITS last row / column, not the padding of the block raster.
+// With 2:1 horizontal sampling a thread needs six samples of a chroma row: four are one aligned dword, the outer two
+// are the neighbouring lanes' (the lanes of a wave walk along the row), fetched from memory only at the ends of the
+// wave and where the row's last column must be replicated.
+__device__ __forceinline__ void chroma_row6(const uint8_t* __restrict__ row, int cx0, int cw, int pc, int lane, int (&s)[6]) {
+    const uint32_t d = *reinterpret_cast<const uint32_t*>(row + min(cx0, pc - 4));
+    const uint32_t l = (uint32_t)__shfl_up((int)d, 1), r = (uint32_t)__shfl_down((int)d, 1);
+    if (cx0 + 5 > cw) {  // the row ends here: clamp every index
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s[i] = row[min(max(cx0 - 1 + i, 0), cw - 1)];
+        return;
+    }
+    s[1] = d & 0xff; s[2] = (d >> 8) & 0xff; s[3] = (d >> 16) & 0xff; s[4] = d >> 24;
+    s[0] = lane == 0 ? (int)row[max(cx0 - 1, 0)] : (int)(l >> 24);
+    s[5] = lane == 63 ? (int)row[cx0 + 4] : (int)(r & 0xff);
+}
+
 template <int FH, int FV>
-__device__ __forceinline__ void chroma8(const uint8_t* __restrict__ C, int pc, int cw, int ch, int x0, int y0, int (&o)[FV][8]) {
+__device__ __forceinline__ void chroma8(const uint8_t* __restrict__ C, int pc, int cw, int ch, int x0, int y0, int lane, int (&o)[FV][8]) {
     if (FH == 1 && FV == 1) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[0][i] = C[(size_t)y0 * pc + min(x0 + i, cw - 1)];
     } else if (FH == 2 && FV == 1) {
         const int cx0 = x0 >> 1;
         int s[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) s[i] = C[(size_t)y0 * pc + min(max(cx0 - 1 + i, 0), cw - 1)];
+        chroma_row6(C + (size_t)y0 * pc, cx0, cw, pc, lane, s);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int cx = cx0 + i;
@@ -745,13 +780,9 @@ __device__ __forceinline__ void chroma8(const uint8_t* __restrict__ C, int pc, i
         const int cx0 = x0 >> 1, cy = y0 >> 1;
         const int ya = max(cy - 1, 0), yb = min(cy + 1, ch - 1);
         int s0[6], sa[6], sb[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int cx = min(max(cx0 - 1 + i, 0), cw - 1);
-            s0[i] = C[(size_t)cy * pc + cx];
-            sa[i] = C[(size_t)ya * pc + cx];
-            sb[i] = C[(size_t)yb * pc + cx];
-        }
+        chroma_row6(C + (size_t)cy * pc, cx0, cw, pc, lane, s0);
+        chroma_row6(C + (size_t)ya * pc, cx0, cw, pc, lane, sa);
+        chroma_row6(C + (size_t)yb * pc, cx0, cw, pc, lane, sb);
 #pragma unroll
         for (int v = 0; v < FV; ++v) {
             int col[6];
@@ -767,13 +798,17 @@ __device__ __forceinline__ void chroma8(const uint8_t* __restrict__ C, int pc, i
     }
 }
 
-// 8 pixels x FV rows per thread: up-sampling, jdcolor.c's YCbCr -> RGB, three 8-byte stores per row.
+// 8 pixels x FV rows per thread: up-sampling, jdcolor.c's YCbCr -> RGB, three 8-byte stores per row. The 64 lanes of a
+// wave are 64 neighbouring groups of one row pair; lanes past the right or bottom edge stay in step (clamped addresses,
+// nothing stored): their neighbours take samples from them.
 template <int FH, int FV>
 __global__ __launch_bounds__(256) void ycc_kernel(const uint8_t* __restrict__ planes, const Geom g, uint8_t* __restrict__ out, int rgb) {
     using namespace dct;
-    const int f = blockIdx.z;
-    const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 8, y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * FV;
-    if (x0 >= g.width || y0 >= g.height) return;
+    const int f = blockIdx.z, lane = threadIdx.x & 63;
+    const int x0r = (blockIdx.x * 64 + lane) * 8, y0r = (blockIdx.y * 4 + (threadIdx.x >> 6)) * FV;
+    const bool valid = x0r < g.width && y0r < g.height;
+    if (y0r >= g.height) return;  // whole waves
+    const int x0 = min(x0r, g.bx[0] * 8 - 8), y0 = y0r;
     const uint8_t* fp = planes + (size_t)f * g.blocks_per_frame * 64;
     const int py = g.bx[0] * 8;
     const uint8_t* Y = fp + (size_t)g.blk_off[0] * 64;
@@ -782,9 +817,10 @@ __global__ __launch_bounds__(256) void ycc_kernel(const uint8_t* __restrict__ pl
     if (colour) {
         const int pc = g.bx[1] * 8;
         const int cw = (g.width + FH - 1) / FH, ch = (g.height + FV - 1) / FV;  // jdmaster.c: downsampled_width / _height
-        chroma8<FH, FV>(fp + (size_t)g.blk_off[1] * 64, pc, cw, ch, x0, y0, cb);
-        chroma8<FH, FV>(fp + (size_t)g.blk_off[2] * 64, pc, cw, ch, x0, y0, cr);
+        chroma8<FH, FV>(fp + (size_t)g.blk_off[1] * 64, pc, cw, ch, x0, y0, lane, cb);
+        chroma8<FH, FV>(fp + (size_t)g.blk_off[2] * 64, pc, cw, ch, x0, y0, lane, cr);
     }
+    if (!valid) return;
 #pragma unroll
     for (int v = 0; v < FV; ++v) {
         const int y = y0 + v;
@@ -1003,6 +1039,7 @@ struct pa_mjpeg {
     bool bits_free_recorded = false;
     // ... and so does the clearing of the coefficient buffers (400 MB for 64 1080p frames): under pass A and the verify
     // passes of the same call, which do not touch them
+    hipStream_t clear_stream = nullptr;  // its own: a copy queued behind a waiting fill blocked the calling thread
     hipEvent_t coef_clear = nullptr, coef_free = nullptr;
     bool coef_free_recorded = false;
     bool staged_used[2] = {false, false};
@@ -1033,6 +1070,10 @@ void pa_mjpeg_destroy(pa_mjpeg* h) {
     if (h->copy_stream) {
         (void)hipStreamSynchronize(h->copy_stream);
         (void)hipStreamDestroy(h->copy_stream);
+    }
+    if (h->clear_stream) {
+        (void)hipStreamSynchronize(h->clear_stream);
+        (void)hipStreamDestroy(h->clear_stream);
     }
     if (h->bits_ready) (void)hipEventDestroy(h->bits_ready);
     if (h->bits_free) (void)hipEventDestroy(h->bits_free);
@@ -1092,6 +1133,7 @@ int pa_mjpeg_create(int32_t device, int32_t max_frames, int32_t max_height, int3
         if (!chk(hipEventCreateWithFlags(&h->staged[i], hipEventDisableTiming), "hipEventCreate")) return PA_ERR_HIP;
     }
     if (!chk(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking), "hipStreamCreate")) return PA_ERR_HIP;
+    if (!chk(hipStreamCreateWithFlags(&h->clear_stream, hipStreamNonBlocking), "hipStreamCreate")) return PA_ERR_HIP;
     if (!chk(hipEventCreateWithFlags(&h->bits_ready, hipEventDisableTiming), "hipEventCreate")) return PA_ERR_HIP;
     if (!chk(hipEventCreateWithFlags(&h->bits_free, hipEventDisableTiming), "hipEventCreate")) return PA_ERR_HIP;
     if (!chk(hipEventCreateWithFlags(&h->coef_clear, hipEventDisableTiming), "hipEventCreate")) return PA_ERR_HIP;
@@ -1153,10 +1195,15 @@ int pa_mjpeg_decode(pa_mjpeg* h, const uint8_t* data_host, const int64_t* spans_
         h->last_error = std::string(what) + ": " + hipGetErrorString(e);
         return false;
     };
+    static const bool trace = getenv("PA_MJPEG_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_in = now();
+    double t_mark[8] = {0};
     if (!chk(hipSetDevice(h->device), "hipSetDevice")) return PA_ERR_HIP;
     const int k = h->turn;
     h->turn ^= 1;
     if (h->staged_used[k] && !chk(hipEventSynchronize(h->staged[k]), "hipEventSynchronize")) return PA_ERR_HIP;
+    t_mark[0] = now();
     FrameDesc* fd = h->h_fd[k];
     TableSet* ts = h->h_ts[k];
     Geom g;
@@ -1269,26 +1316,36 @@ int pa_mjpeg_decode(pa_mjpeg* h, const uint8_t* data_host, const int64_t* spans_
             max_sub = d.n_sub_cap > max_sub ? d.n_sub_cap : max_sub;
         }
     }
+    t_mark[1] = now();
     const int max_chunks = (int)(max_scan / CHUNK) + 2;
     if (max_chunks > h->max_chunks_cap) return bad(PA_ERR_CAPACITY, "pa_mjpeg_decode: scan longer than the handle's chunk table");
     if (seg_total > h->max_segs || sub_total > h->max_subs) return bad(PA_ERR_CAPACITY, "pa_mjpeg_decode: more restart intervals / subsequences than the handle holds");
     // compressed bytes: on the handle's copy stream, as soon as the call before this one has written its clean stream
     if (h->bits_free_recorded && !chk(hipStreamWaitEvent(h->copy_stream, h->bits_free, 0), "hipStreamWaitEvent")) return PA_ERR_HIP;
     if (!chk(hipMemcpyAsync(h->d_bits, data_host + base, (size_t)total, hipMemcpyHostToDevice, h->copy_stream), "upload bitstream")) return PA_ERR_HIP;
+    t_mark[4] = now();
     if (!chk(hipMemsetAsync(h->d_bits + total, 0, 64, h->copy_stream), "pad bitstream")) return PA_ERR_HIP;
     if (!chk(hipEventRecord(h->bits_ready, h->copy_stream), "hipEventRecord")) return PA_ERR_HIP;
     if (!chk(hipStreamWaitEvent(s, h->bits_ready, 0), "hipStreamWaitEvent")) return PA_ERR_HIP;
-    if (!chk(hipMemcpyAsync(h->d_fd, fd, (size_t)n * sizeof(FrameDesc), hipMemcpyHostToDevice, s), "upload descriptors")) return PA_ERR_HIP;
-    if (!chk(hipMemcpyAsync(h->d_ts, ts, (size_t)n_sets * sizeof(TableSet), hipMemcpyHostToDevice, s), "upload tables")) return PA_ERR_HIP;
+    t_mark[5] = now();
+    {
+        static_assert(sizeof(FrameDesc) % 4 == 0 && sizeof(TableSet) % 4 == 0, "copied as dwords");
+        const int na = (int)((size_t)n * sizeof(FrameDesc) / 4), nb = (int)((size_t)n_sets * sizeof(TableSet) / 4);
+        hipLaunchKernelGGL(stage_copy_kernel, dim3((na + nb + 255) / 256), dim3(256), 0, s, reinterpret_cast<const uint32_t*>(fd),
+                           reinterpret_cast<uint32_t*>(h->d_fd), na, reinterpret_cast<const uint32_t*>(ts),
+                           reinterpret_cast<uint32_t*>(h->d_ts), nb);
+    }
     if (!chk(hipEventRecord(h->staged[k], s), "hipEventRecord")) return PA_ERR_HIP;
     h->staged_used[k] = true;
+    t_mark[2] = now();
     if (!chk(hipMemsetAsync(h->d_status, 0, (size_t)n * sizeof(int32_t), s), "clear status")) return PA_ERR_HIP;
     if (!chk(hipMemsetAsync(h->d_changed, 0, (size_t)(MAX_ROUNDS + 1) * h->max_frames * sizeof(int32_t), s), "clear flags")) return PA_ERR_HIP;
-    // the coefficient buffers are cleared on the copy stream, once the inverse DCT of the call before this one has read them
-    if (h->coef_free_recorded && !chk(hipStreamWaitEvent(h->copy_stream, h->coef_free, 0), "hipStreamWaitEvent")) return PA_ERR_HIP;
-    if (!chk(hipMemsetAsync(h->d_coef, 0, (size_t)n * g.blocks_per_frame * 64 * sizeof(int16_t), h->copy_stream), "clear coefficients")) return PA_ERR_HIP;
-    if (!chk(hipMemsetAsync(h->d_dc, 0, (size_t)n * g.mcus_x * g.mcus_y * g.blocks_per_mcu * sizeof(int16_t), h->copy_stream), "clear DC differences")) return PA_ERR_HIP;
-    if (!chk(hipEventRecord(h->coef_clear, h->copy_stream), "hipEventRecord")) return PA_ERR_HIP;
+    // the coefficient buffers are cleared on a stream of their own, once the inverse DCT of the call before this one has read them
+    if (h->coef_free_recorded && !chk(hipStreamWaitEvent(h->clear_stream, h->coef_free, 0), "hipStreamWaitEvent")) return PA_ERR_HIP;
+    if (!chk(hipMemsetAsync(h->d_coef, 0, (size_t)n * g.blocks_per_frame * 64 * sizeof(int16_t), h->clear_stream), "clear coefficients")) return PA_ERR_HIP;
+    if (!chk(hipMemsetAsync(h->d_dc, 0, (size_t)n * g.mcus_x * g.mcus_y * g.blocks_per_mcu * sizeof(int16_t), h->clear_stream), "clear DC differences")) return PA_ERR_HIP;
+    if (!chk(hipEventRecord(h->coef_clear, h->clear_stream), "hipEventRecord")) return PA_ERR_HIP;
+    t_mark[3] = now();
     hipLaunchKernelGGL(unstuff_count_kernel, dim3(max_chunks, n), dim3(256), 0, s, h->d_bits, h->d_fd, h->d_chunk, max_chunks);
     hipLaunchKernelGGL(unstuff_write_kernel, dim3(max_chunks, n), dim3(256), 0, s, h->d_bits, h->d_fd, h->d_chunk, max_chunks, h->d_clean,
                        h->d_seg, h->d_clean_len, h->d_status);
@@ -1349,6 +1406,9 @@ int pa_mjpeg_decode(pa_mjpeg* h, const uint8_t* data_host, const int64_t* spans_
     if (status_dev && !chk(hipMemcpyAsync(status_dev, h->d_status, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, s), "copy status"))
         return PA_ERR_HIP;
     if (!chk(hipGetLastError(), "kernel launch")) return PA_ERR_HIP;
+    if (trace)
+        fprintf(stderr, "pa_mjpeg_decode host us: staging wait %.0f, headers %.0f, copies %.0f (bitstream %.0f, events %.0f), clears %.0f, launches %.0f\n", t_mark[0] - t_in,
+                t_mark[1] - t_mark[0], t_mark[2] - t_mark[1], t_mark[4] - t_mark[1], t_mark[5] - t_mark[4], t_mark[3] - t_mark[2], now() - t_mark[3]);
     return PA_OK;
 }
 

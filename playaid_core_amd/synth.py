@@ -297,10 +297,15 @@ def _hash_u32_torch(idx, seed: int):
     return x ^ (x >> 16)
 
 
-def make_frames_torch(n: int, height: int, width: int, seed: int = 7, first_frame: int = 0, device="cuda", out=None):
+def make_frames_torch(n: int, height: int, width: int, seed: int = 7, first_frame: int = 0, device="cuda", out=None,
+                      noise_mask: int = 31, fine_mask: int = 15):
     """``make_frames`` computed with torch ops on ``device``: bit-identical frames (same integer
     hash, same rectangles) without synthesising and uploading gigabytes on the host -- the
-    8192-frame clip of BASELINE.json configs[3] is 51 GB of raw BGR."""
+    8192-frame clip of BASELINE.json configs[3] is 51 GB of raw BGR.
+
+    ``noise_mask`` / ``fine_mask``: amplitude masks of the per-pixel noise on the background / inside the fighters. The
+    defaults are ``make_frames``' (five bits of white noise per sample: the hardest content a JPEG coder can meet, 1.05 MB
+    per 1080p frame at quality 95); 3 / 3 gives camera-like content (0.3-0.4 MB per frame) for the decode measurements."""
     import torch
 
     dev = torch.device(device)
@@ -315,7 +320,7 @@ def make_frames_torch(n: int, height: int, width: int, seed: int = 7, first_fram
         g2 = ((xs + ys + 3 * f) % 512) * 200 // 512
         img = torch.empty((height, width, 3), dtype=torch.int64, device=dev)
         for c, g in enumerate((g0, g1, g2)):
-            img[:, :, c] = g + (_hash_u32_torch(pix3 + c, seed * 7919 + f) & 31)
+            img[:, :, c] = g + (_hash_u32_torch(pix3 + c, seed * 7919 + f) & noise_mask)
         for p in range(2):
             cx, cy, w, h = fighter_box(f, p, height, width)
             x0, x1 = int((cx - w / 2) * width), int((cx + w / 2) * width)
@@ -330,7 +335,7 @@ def make_frames_torch(n: int, height: int, width: int, seed: int = 7, first_fram
             phase = f // 4
             for c in range(3):
                 base = _hash_u32_torch(blk3 + c, seed * 131 + p * 17 + phase * 1009) & 127
-                fine = _hash_u32_torch(fine3 + c, seed + p) & 15
+                fine = _hash_u32_torch(fine3 + c, seed + p) & fine_mask
                 img[y0c:y1c, x0c:x1c, c] = 96 + base + fine
         frames[i] = img.clamp_(0, 255).to(torch.uint8)
     return frames
