@@ -144,8 +144,8 @@ def decode_inclusive(eng, frames_dev, boxes_dev, steps=8, quality=95, restart_bl
     """decode -> labels: the clip as a Motion-JPEG stream (one baseline JPEG per frame, written by libjpeg-turbo at
     OpenCV's defaults: quality 95, 4:2:0) in pinned HOST memory; per clip the compressed bytes cross PCIe and are decoded
     on the device (pa_mjpeg_decode: un-stuffing, self-synchronising Huffman decoding, IDCT, up-sampling, colour
-    conversion) on a side stream into one of two frame buffers while the previous clip runs crops + CNN + head. Replaces
-    cv2.VideoCapture.read (ai_runner.py:153,404-405). Reported beside `value`, never as it."""
+    conversion) on a side stream into a frame buffer of its own while an earlier clip runs crops + CNN + head; three
+    decoders work at once. Replaces cv2.VideoCapture.read (ai_runner.py:153,404-405). Reported beside `value`, never as it."""
     from playaid_core_amd import video
 
     dev = eng.device
@@ -158,27 +158,33 @@ def decode_inclusive(eng, frames_dev, boxes_dev, steps=8, quality=95, restart_bl
     ends = np.cumsum(sizes)
     spans = np.stack([ends - sizes, ends], axis=1)
     data = torch.from_numpy(np.frombuffer(b"".join(blobs), np.uint8).copy()).pin_memory()
-    decs = [video.MjpegDecoder(n, h, w, int(ends[-1]) + 4096, device=str(dev)) for _ in range(2)]
-    bufs = [torch.empty_like(frames_dev), torch.empty_like(frames_dev)]
-    st = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(2)]
+    # ND decoders at once, each on a stream of its own with a frame buffer of its own: the entropy passes are bound by
+    # instruction issue and single-wave latency, so calls whose phases are out of step fill each other's idle time
+    ND = 3
+    decs = [video.MjpegDecoder(n, h, w, int(ends[-1]) + 4096, device=str(dev)) for _ in range(ND)]
+    for d_ in decs:
+        d_.set_groups(1)
+    bufs = [torch.empty_like(frames_dev) for _ in range(ND)]
+    st = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(ND)]
     rec = eng.alloc_records(n - 1)
-    side, main = torch.cuda.Stream(dev), torch.cuda.current_stream(dev)
-    ready = [torch.cuda.Event(), torch.cuda.Event()]
-    free = [torch.cuda.Event(), torch.cuda.Event()]
+    sides, main = [torch.cuda.Stream(dev) for _ in range(ND)], torch.cuda.current_stream(dev)
+    ready = [torch.cuda.Event() for _ in range(ND)]
+    free = [torch.cuda.Event() for _ in range(ND)]
 
     def run(k_steps, compute=True):
         for e in free:
             e.record(main)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        for k in range(k_steps + 1):
+        for k in range(k_steps + ND - 1):
             if k < k_steps:
-                with torch.cuda.stream(side):
-                    side.wait_event(free[k & 1])
-                    decs[k & 1].decode(data, spans, h, w, out=bufs[k & 1], status=st[k & 1])
-                    ready[k & 1].record(side)
-            if k > 0:
-                j = (k - 1) & 1
+                i = k % ND
+                with torch.cuda.stream(sides[i]):
+                    sides[i].wait_event(free[i])
+                    decs[i].decode(data, spans, h, w, out=bufs[i], status=st[i])
+                    ready[i].record(sides[i])
+            if k >= ND - 1:
+                j = (k - (ND - 1)) % ND
                 main.wait_event(ready[j])
                 if compute:
                     eng.infer_clip_device(bufs[j], boxes_dev, rec)
@@ -187,7 +193,7 @@ def decode_inclusive(eng, frames_dev, boxes_dev, steps=8, quality=95, restart_bl
         return (time.perf_counter() - t0) / k_steps
 
     try:
-        run(2)
+        run(ND)
         bad = int(sum(int((s != 0).sum()) for s in st))
         dt = run(steps)
         dt_dec = run(steps, compute=False)
@@ -212,7 +218,8 @@ def decode_inclusive(eng, frames_dev, boxes_dev, steps=8, quality=95, restart_bl
         "frames_with_decode_errors": bad,
         "content": content or "the headline's clip (five bits of white noise on every sample: the hardest input a JPEG coder meets)",
         "method": f"{steps} clips; compressed frames in pinned host memory; H2D copy + device Motion-JPEG decode of clip k+1 on a "
-        "side stream (two frame buffers) under crops + CNN + head of clip k on the decoded frames",
+        "side stream under crops + CNN + head of an earlier clip on its decoded frames; three decoders, each with a side stream and "
+        "a frame buffer of its own, work at once (clips k+1 .. k+3)",
     }
 
 

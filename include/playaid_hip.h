@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PA_ABI_VERSION 6
+#define PA_ABI_VERSION 7
 #define PA_WEIGHT_MAGIC 0x31574150 /* "PAW1" */
 #define PA_LSTM_MAGIC 0x314c4150   /* "PAL1" */
 #define PA_ENCODER_MAGIC 0x31454150 /* "PAE1" */
@@ -392,6 +392,11 @@ int pa_mjpeg_probe(const uint8_t* data_host, size_t nbytes, int32_t* info8, char
  * slowly and can need many). pa_mjpeg_last_sync_rounds: how many the last call ran. */
 int pa_mjpeg_set_sync_rounds(pa_mjpeg* h, int32_t rounds);
 int pa_mjpeg_last_sync_rounds(const pa_mjpeg* h);
+/* Frame groups per call, 1..4 (default 2): a call's frames are decoded in that many groups, each on a stream of the
+ * handle's own (uploads on a further one), joined to `stream` at the end -- a group's upload and its latency-bound late
+ * verify passes run under the other group's passes. 1 = everything on `stream`: the setting for a caller that keeps
+ * several decoders busy on several streams itself. The decoded frames are the same for every value. */
+int pa_mjpeg_set_groups(pa_mjpeg* h, int32_t groups);
 /* Diagnostics of the entropy decoder (scripts/mjpeg_rate.py): for pass kind m = 0 speculative, 1 verify, 2 final of the most
  * recent call, out8_host[2m] = shader-clock cycles the first wave of the first frame spent in its symbol loop,
  * out8_host[2m + 1] = (100 MHz wall ticks << 32) | symbols it walked; out8_host[8 + 2m] = cycles of those spent outside

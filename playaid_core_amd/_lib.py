@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # PA_LIB_PATH: load a differently built library (e.g. the ablation build used by scripts/)
 LIB_PATH = os.environ.get("PA_LIB_PATH") or os.path.join(HERE, "libplayaid_hip.so")
 
-PA_ABI_VERSION = 6
+PA_ABI_VERSION = 7
 PA_DTYPE_F32 = 0
 PA_DTYPE_BF16 = 1
 PA_WEIGHT_MAGIC = 0x31574150
@@ -172,6 +172,7 @@ SYMBOLS = [
     ("pa_mjpeg_last_error", C.c_char_p, [_P]),
     ("pa_mjpeg_probe", C.c_int, [_P, C.c_size_t, C.POINTER(C.c_int32), C.c_char_p, C.c_size_t]),
     ("pa_mjpeg_set_sync_rounds", C.c_int, [_P, C.c_int32]),
+    ("pa_mjpeg_set_groups", C.c_int, [_P, C.c_int32]),
     ("pa_mjpeg_last_sync_rounds", C.c_int, [_P]),
     ("pa_mjpeg_debug_counters", C.c_int, [_P]),
     ("pa_mjpeg_decode", C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),

@@ -93,6 +93,7 @@ struct Geom {
     int32_t height, width;
     int32_t fh, fv;         // chroma up-sampling factors (1 | 2)
     int32_t sub_shift;      // log2 of the subsequence size in bytes
+    int32_t f0;             // first frame of the launch: a call's frames are decoded in groups, each on a stream of its own
     uint8_t b_comp[MAX_BLOCKS_MCU], b_dy[MAX_BLOCKS_MCU], b_dx[MAX_BLOCKS_MCU];
 };
 
@@ -140,9 +141,9 @@ __device__ __forceinline__ void classify16(const uint8_t* bits, uint32_t a, uint
 
 // chunk_cnt[f][c] = (markers, kept bytes) of chunk c of frame f
 __global__ __launch_bounds__(256) void unstuff_count_kernel(const uint8_t* __restrict__ bits, const FrameDesc* __restrict__ fd,
-                                                            int2* __restrict__ chunk_cnt, int max_chunks) {
+                                                            int2* __restrict__ chunk_cnt, int max_chunks, int f0) {
     __shared__ int red[8];
-    const int f = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
+    const int f = blockIdx.y + f0, c = blockIdx.x, tid = threadIdx.x;
     const FrameDesc d = fd[f];
     const uint32_t lo = d.scan_off, hi = d.scan_off + d.scan_len;
     const uint32_t a = (lo & ~15u) + (uint32_t)c * CHUNK + tid * 16;
@@ -168,10 +169,10 @@ __global__ __launch_bounds__(256) void unstuff_count_kernel(const uint8_t* __res
 __global__ __launch_bounds__(256) void unstuff_write_kernel(const uint8_t* __restrict__ bits, const FrameDesc* __restrict__ fd,
                                                             const int2* __restrict__ chunk_cnt, int max_chunks,
                                                             uint8_t* __restrict__ clean, uint32_t* __restrict__ seg_start,
-                                                            uint32_t* __restrict__ clean_len, int32_t* __restrict__ status) {
+                                                            uint32_t* __restrict__ clean_len, int32_t* __restrict__ status, int f0) {
     __shared__ int red[16];
     __shared__ int2 scan[256];
-    const int f = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
+    const int f = blockIdx.y + f0, c = blockIdx.x, tid = threadIdx.x;
     const FrameDesc d = fd[f];
     const uint32_t lo = d.scan_off, hi = d.scan_off + d.scan_len;
     if ((lo & ~15u) + (uint32_t)c * CHUNK >= hi && c != 0) return;
@@ -273,10 +274,10 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
                                                          const int32_t* __restrict__ changed_last, const int32_t* __restrict__ todo,
                                                          const int32_t* __restrict__ todo_cnt, int16_t* __restrict__ dcdiff) {
     // verify pass: a frame whose previous verify pass changed nothing has settled (changed_last = that pass's flags)
-    if (MODE == 1 && changed_last && changed_last[blockIdx.y] == 0) return;
+    if (MODE == 1 && changed_last && changed_last[blockIdx.y + g.f0] == 0) return;
     __shared__ HuffTables T;
     __shared__ uint32_t ring[WG_SUBS * (RING_DW + 1)];
-    const int f = blockIdx.y, tid = threadIdx.x;
+    const int f = blockIdx.y + g.f0, tid = threadIdx.x;
     const FrameDesc d = fd[f];
     const uint32_t clen = clean_len[f];
     const int sh = g.sub_shift;
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
     uint32_t x_state = 0;
     int x_blk = 0;
     bool gen = false;
-    const bool stamp = blockIdx.x == 0 && blockIdx.y == 0 && tid < 64;
+    const bool stamp = blockIdx.x == 0 && f == 0 && tid < 64;
     const unsigned long long c0 = clock64(), w0t = wall_clock64();
     int it = 0;
     unsigned long long slow_cyc = 0;
@@ -537,9 +538,9 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
 __global__ __launch_bounds__(1024) void sub_verify_plan_kernel(const FrameDesc* __restrict__ fd, const uint32_t* __restrict__ clean_len,
                                                                int sub_shift, const uint32_t* __restrict__ g_in, uint32_t* __restrict__ g_out,
                                                                const uint32_t* __restrict__ used, int32_t* __restrict__ todo,
-                                                               int32_t* __restrict__ todo_cnt, const int32_t* __restrict__ changed_last) {
+                                                               int32_t* __restrict__ todo_cnt, const int32_t* __restrict__ changed_last, int f0) {
     __shared__ int sh[1024];
-    const int f = blockIdx.x, tid = threadIdx.x;
+    const int f = blockIdx.x + f0, tid = threadIdx.x;
     if (changed_last && changed_last[f] == 0) {  // settled: nothing to do (both state buffers already agree)
         if (tid == 0) todo_cnt[f] = 0;
         return;
@@ -575,9 +576,9 @@ __global__ __launch_bounds__(1024) void sub_verify_plan_kernel(const FrameDesc* 
 
 // entry[j] = what lanes 0 .. j-1 of the frame accumulated: the absolute block index at lane j's entry
 __global__ __launch_bounds__(1024) void sub_scan_kernel(const FrameDesc* __restrict__ fd, const uint32_t* __restrict__ clean_len,
-                                                        const SubCnt* __restrict__ cnt, SubCnt* __restrict__ entry, int sub_shift) {
+                                                        const SubCnt* __restrict__ cnt, SubCnt* __restrict__ entry, int sub_shift, int f0) {
     __shared__ SubCnt sh[1024];
-    const int f = blockIdx.x, tid = threadIdx.x;
+    const int f = blockIdx.x + f0, tid = threadIdx.x;
     const FrameDesc d = fd[f];
     int nsub = (int)((clean_len[f] + (1u << sub_shift) - 1) >> sub_shift);
     nsub = nsub < d.n_sub_cap ? nsub : d.n_sub_cap;
@@ -615,7 +616,7 @@ __global__ __launch_bounds__(1024) void sub_scan_kernel(const FrameDesc* __restr
 __global__ __launch_bounds__(1024) void dc_scan_kernel(int16_t* __restrict__ dc, const FrameDesc* __restrict__ fd, const Geom g) {
     __shared__ int sh_sum[1024];
     __shared__ int sh_flag[1024];
-    const int f = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
+    const int f = blockIdx.x + g.f0, c = blockIdx.y, tid = threadIdx.x;
     if (c >= g.ncomp) return;
     const int bpm = g.blocks_per_mcu;
     int b0 = 0, nbc = 0;  // the component's blocks inside an MCU: b0 .. b0 + nbc
@@ -697,7 +698,8 @@ __global__ __launch_bounds__(256) void idct_kernel(const int16_t* __restrict__ c
                             30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= (long long)n_frames * g.blocks_per_frame) return;
-    const int f = (int)(t / g.blocks_per_frame), r = (int)(t - (long long)f * g.blocks_per_frame);
+    const int fl = (int)(t / g.blocks_per_frame), r = (int)(t - (long long)fl * g.blocks_per_frame);
+    const int f = fl + g.f0;
     const int c = (g.ncomp > 2 && r >= g.blk_off[2]) ? 2 : ((g.ncomp > 1 && r >= g.blk_off[1]) ? 1 : 0);
     const int off_c = c == 0 ? g.blk_off[0] : (c == 1 ? g.blk_off[1] : g.blk_off[2]);
     const int bx_c = c == 0 ? g.bx[0] : (c == 1 ? g.bx[1] : g.bx[2]);
@@ -804,7 +806,7 @@ __device__ __forceinline__ void chroma8(const uint8_t* __restrict__ C, int pc, i
 template <int FH, int FV>
 __global__ __launch_bounds__(256) void ycc_kernel(const uint8_t* __restrict__ planes, const Geom g, uint8_t* __restrict__ out, int rgb) {
     using namespace dct;
-    const int f = blockIdx.z, lane = threadIdx.x & 63;
+    const int f = blockIdx.z + g.f0, lane = threadIdx.x & 63;
     const int x0r = (blockIdx.x * 64 + lane) * 8, y0r = (blockIdx.y * 4 + (threadIdx.x >> 6)) * FV;
     const bool valid = x0r < g.width && y0r < g.height;
     if (y0r >= g.height) return;  // whole waves
@@ -1001,6 +1003,11 @@ void build_hufftab(HuffTables& T, int t, const uint8_t* counts, const uint8_t* s
 
 using namespace pa::mj;
 
+namespace {
+constexpr int MAX_ROUNDS = 16;  // verify passes enqueued without looking at the result (pa_mjpeg_set_sync_rounds)
+constexpr int MAX_GROUPS = 4;   // frame groups of a call, each on its own stream (pa_mjpeg_set_groups)
+}
+
 struct pa_mjpeg {
     int device = 0, max_frames = 0, max_h = 0, max_w = 0;
     size_t max_bytes = 0;
@@ -1009,48 +1016,56 @@ struct pa_mjpeg {
     int max_chunks_cap = 0;
     int sync_rounds = 8;
     int sub_shift_override = 0;  // tuning: log2 of the subsequence size, 0 = chosen from the stream
-    uint8_t* d_bits = nullptr;
-    uint8_t* d_clean = nullptr;
-    FrameDesc* d_fd = nullptr;
-    TableSet* d_ts = nullptr;
-    int2* d_chunk = nullptr;
-    uint32_t* d_seg = nullptr;
-    uint32_t* d_clean_len = nullptr;
-    uint32_t* d_g[2] = {nullptr, nullptr};
-    uint32_t* d_used = nullptr;
-    SubCnt* d_cnt = nullptr;
-    SubCnt* d_entry = nullptr;
-    int32_t* d_changed = nullptr;  // [MAX_ROUNDS + 1][max_frames]
-    int32_t* d_todo = nullptr;     // [max_subs] compact lane lists of a verify pass
-    int32_t* d_todo_cnt = nullptr; // [max_frames]
-    int16_t* d_coef = nullptr;
-    int16_t* d_dc = nullptr;       // [max_frames][blocks of a frame in scan order] DC differences
-    uint8_t* d_planes = nullptr;
-    int32_t* d_status = nullptr;
+    // Device scratch, TWO sets used in turn (like the pinned staging below): a call never touches the memory of the call
+    // before it, so its first groups start while that call's last groups are still decoding.
+    struct Set {
+        uint8_t* d_bits = nullptr;
+        uint8_t* d_clean = nullptr;
+        FrameDesc* d_fd = nullptr;
+        TableSet* d_ts = nullptr;
+        int2* d_chunk = nullptr;
+        uint32_t* d_seg = nullptr;
+        uint32_t* d_clean_len = nullptr;
+        uint32_t* d_g[2] = {nullptr, nullptr};
+        uint32_t* d_used = nullptr;
+        SubCnt* d_cnt = nullptr;
+        SubCnt* d_entry = nullptr;
+        int32_t* d_changed = nullptr;  // [MAX_ROUNDS + 1][max_frames]
+        int32_t* d_todo = nullptr;     // [max_subs] compact lane lists of a verify pass
+        int32_t* d_todo_cnt = nullptr; // [max_frames]
+        int16_t* d_coef = nullptr;
+        int16_t* d_dc = nullptr;       // [max_frames][blocks of a frame in scan order] DC differences
+        uint8_t* d_planes = nullptr;
+        int32_t* d_status = nullptr;
+        hipEvent_t done[MAX_GROUPS] = {};  // group g of the set's last call has finished
+        bool used = false;
+    } set[2];
     // pinned host staging, two sets used in turn
     FrameDesc* h_fd[2] = {nullptr, nullptr};
     TableSet* h_ts[2] = {nullptr, nullptr};
     int32_t* h_flag = nullptr;
     hipEvent_t staged[2] = {nullptr, nullptr};
-    // the compressed bytes travel on a stream of the handle's own, so that the upload of one call overlaps the decode
-    // passes of the call before it (the raw bytes are dead once the clean stream is written)
+    // A call's frames are decoded in GROUPS, each on a stream of the handle's own: the entropy passes of a group are bound
+    // by instruction issue and by the latency of single waves (late verify passes keep a handful of waves busy), so groups
+    // whose phases are out of step fill each other's idle time, and the upload of one group runs under the passes of the
+    // group before it. The groups' uploads go one after the other (they share the link anyway), which is what puts their
+    // phases out of step. Measured on 64 x 1080p quality-95 frames per call (scripts/mjpeg_rate.py): 16.4 k frames/s with
+    // one group (everything on the caller's stream), 22.5 k with two, 20.9 k with three. A caller that keeps several
+    // DECODERS busy on streams of its own (bench.py's decode_inclusive: three) gets the same effect at the size of whole
+    // calls and should leave each at one group: 28.1 k with three decoders x one group, 22.3 k with three x two.
+    hipStream_t gstream[MAX_GROUPS] = {};
+    // The uploads have a stream to themselves that never waits for another stream: hipMemcpyAsync on a stream with a
+    // pending cross-stream wait blocks the CALLING THREAD until the wait is over (ROCm 7.2, seen with PA_MJPEG_TRACE).
+    // What they overwrite -- the set's bytes of two calls ago -- is known to be dead on the host: see `done`.
     hipStream_t copy_stream = nullptr;
-    hipEvent_t bits_ready = nullptr, bits_free = nullptr;
-    bool bits_free_recorded = false;
-    // ... and so does the clearing of the coefficient buffers (400 MB for 64 1080p frames): under pass A and the verify
-    // passes of the same call, which do not touch them
-    hipStream_t clear_stream = nullptr;  // its own: a copy queued behind a waiting fill blocked the calling thread
-    hipEvent_t coef_clear = nullptr, coef_free = nullptr;
-    bool coef_free_recorded = false;
+    hipEvent_t fork = nullptr, prologue = nullptr, up[MAX_GROUPS] = {};
+    int groups = 2;
     bool staged_used[2] = {false, false};
     int turn = 0;
     int last_rounds = 0;
     std::string last_error;
 };
 
-namespace {
-constexpr int MAX_ROUNDS = 16;  // verify passes enqueued without looking at the result (pa_mjpeg_set_sync_rounds)
-}
 
 extern "C" {
 
@@ -1058,27 +1073,32 @@ const char* pa_mjpeg_last_error(const pa_mjpeg* h) { return h ? h->last_error.c_
 
 void pa_mjpeg_destroy(pa_mjpeg* h) {
     if (!h) return;
-    void* dev[] = {h->d_bits, h->d_clean, h->d_fd, h->d_ts, h->d_chunk, h->d_seg, h->d_clean_len, h->d_g[0], h->d_g[1], h->d_used,
-                   h->d_cnt, h->d_entry, h->d_changed, h->d_todo, h->d_todo_cnt, h->d_coef, h->d_dc, h->d_planes, h->d_status};
-    for (void* p : dev) (void)hipFree(p);
+    for (auto& S : h->set) {
+        void* dev[] = {S.d_bits, S.d_clean, S.d_fd, S.d_ts, S.d_chunk, S.d_seg, S.d_clean_len, S.d_g[0], S.d_g[1], S.d_used,
+                       S.d_cnt, S.d_entry, S.d_changed, S.d_todo, S.d_todo_cnt, S.d_coef, S.d_dc, S.d_planes, S.d_status};
+        for (void* p : dev) (void)hipFree(p);
+        for (hipEvent_t e : S.done)
+            if (e) (void)hipEventDestroy(e);
+    }
     for (int i = 0; i < 2; ++i) {
         if (h->h_fd[i]) (void)hipHostFree(h->h_fd[i]);
         if (h->h_ts[i]) (void)hipHostFree(h->h_ts[i]);
         if (h->staged[i]) (void)hipEventDestroy(h->staged[i]);
     }
     if (h->h_flag) (void)hipHostFree(h->h_flag);
+    for (int g = 0; g < MAX_GROUPS; ++g) {
+        if (h->gstream[g]) {
+            (void)hipStreamSynchronize(h->gstream[g]);
+            (void)hipStreamDestroy(h->gstream[g]);
+        }
+        if (h->up[g]) (void)hipEventDestroy(h->up[g]);
+    }
     if (h->copy_stream) {
         (void)hipStreamSynchronize(h->copy_stream);
         (void)hipStreamDestroy(h->copy_stream);
     }
-    if (h->clear_stream) {
-        (void)hipStreamSynchronize(h->clear_stream);
-        (void)hipStreamDestroy(h->clear_stream);
-    }
-    if (h->bits_ready) (void)hipEventDestroy(h->bits_ready);
-    if (h->bits_free) (void)hipEventDestroy(h->bits_free);
-    if (h->coef_clear) (void)hipEventDestroy(h->coef_clear);
-    if (h->coef_free) (void)hipEventDestroy(h->coef_free);
+    if (h->fork) (void)hipEventDestroy(h->fork);
+    if (h->prologue) (void)hipEventDestroy(h->prologue);
     delete h;
 }
 
@@ -1106,38 +1126,45 @@ int pa_mjpeg_create(int32_t device, int32_t max_frames, int32_t max_height, int3
     h->max_subs = max_bytes / SUB_MIN + 2 * n + 2;
     h->max_segs = n * bw * bh + n;
     const size_t clean_bytes = max_bytes + 32 * n + 4096;
-    if (!chk(hipMalloc(&h->d_bits, max_bytes + 64), "hipMalloc bitstream")) return PA_ERR_HIP;
-    if (!chk(hipMalloc(&h->d_clean, clean_bytes), "hipMalloc clean stream")) return PA_ERR_HIP;
-    if (!chk(hipMalloc(&h->d_fd, n * sizeof(FrameDesc)), "hipMalloc descriptors")) return PA_ERR_HIP;
-    if (!chk(hipMalloc(&h->d_ts, n * sizeof(TableSet)), "hipMalloc tables")) return PA_ERR_HIP;
-    if (!chk(hipMalloc(&h->d_chunk, (n * h->max_chunks_cap) * sizeof(int2)), "hipMalloc chunk counts")) return PA_ERR_HIP;
-    if (!chk(hipMalloc(&h->d_seg, h->max_segs * sizeof(uint32_t)), "hipMalloc restart positions")) return PA_ERR_HIP;
-    if (!chk(hipMalloc(&h->d_clean_len, n * sizeof(uint32_t)), "hipMalloc clean lengths")) return PA_ERR_HIP;
-    for (int i = 0; i < 2; ++i)
-        if (!chk(hipMalloc(&h->d_g[i], h->max_subs * sizeof(uint32_t)), "hipMalloc states")) return PA_ERR_HIP;
-    if (!chk(hipMalloc(&h->d_used, h->max_subs * sizeof(uint32_t)), "hipMalloc states")) return PA_ERR_HIP;
-    if (!chk(hipMalloc(&h->d_cnt, h->max_subs * sizeof(SubCnt)), "hipMalloc counts")) return PA_ERR_HIP;
-    if (!chk(hipMalloc(&h->d_entry, h->max_subs * sizeof(SubCnt)), "hipMalloc entries")) return PA_ERR_HIP;
-    if (!chk(hipMalloc(&h->d_changed, (MAX_ROUNDS + 1) * n * sizeof(int32_t)), "hipMalloc flags")) return PA_ERR_HIP;
-    if (!chk(hipMalloc(&h->d_todo, h->max_subs * sizeof(int32_t)), "hipMalloc lane lists")) return PA_ERR_HIP;
-    if (!chk(hipMalloc(&h->d_todo_cnt, n * sizeof(int32_t)), "hipMalloc lane counts")) return PA_ERR_HIP;
-    if (!chk(hipMalloc(&h->d_coef, n * h->max_blocks * 64 * sizeof(int16_t)), "hipMalloc coefficients")) return PA_ERR_HIP;
-    if (!chk(hipMalloc(&h->d_dc, n * h->max_blocks * sizeof(int16_t)), "hipMalloc DC differences")) return PA_ERR_HIP;
-    if (!chk(hipMalloc(&h->d_planes, n * h->max_blocks * 64), "hipMalloc sample planes")) return PA_ERR_HIP;
-    if (!chk(hipMalloc(&h->d_status, n * sizeof(int32_t)), "hipMalloc status")) return PA_ERR_HIP;
-    if (!chk(hipMemset(h->d_bits, 0, max_bytes + 64), "hipMemset")) return PA_ERR_HIP;
-    if (!chk(hipMemset(h->d_clean, 0, clean_bytes), "hipMemset")) return PA_ERR_HIP;
+    if (const char* e = getenv("PA_MJPEG_GROUPS")) h->groups = atoi(e);  // tuning knob (scripts/mjpeg_rate.py)
+    h->groups = h->groups < 1 ? 1 : (h->groups > MAX_GROUPS ? MAX_GROUPS : h->groups);
+    for (auto& S : h->set) {
+        if (!chk(hipMalloc(&S.d_bits, max_bytes + 64), "hipMalloc bitstream")) return PA_ERR_HIP;
+        if (!chk(hipMalloc(&S.d_clean, clean_bytes), "hipMalloc clean stream")) return PA_ERR_HIP;
+        if (!chk(hipMalloc(&S.d_fd, n * sizeof(FrameDesc)), "hipMalloc descriptors")) return PA_ERR_HIP;
+        if (!chk(hipMalloc(&S.d_ts, n * sizeof(TableSet)), "hipMalloc tables")) return PA_ERR_HIP;
+        if (!chk(hipMalloc(&S.d_chunk, (n * h->max_chunks_cap) * sizeof(int2)), "hipMalloc chunk counts")) return PA_ERR_HIP;
+        if (!chk(hipMalloc(&S.d_seg, h->max_segs * sizeof(uint32_t)), "hipMalloc restart positions")) return PA_ERR_HIP;
+        if (!chk(hipMalloc(&S.d_clean_len, n * sizeof(uint32_t)), "hipMalloc clean lengths")) return PA_ERR_HIP;
+        for (int i = 0; i < 2; ++i)
+            if (!chk(hipMalloc(&S.d_g[i], h->max_subs * sizeof(uint32_t)), "hipMalloc states")) return PA_ERR_HIP;
+        if (!chk(hipMalloc(&S.d_used, h->max_subs * sizeof(uint32_t)), "hipMalloc states")) return PA_ERR_HIP;
+        if (!chk(hipMalloc(&S.d_cnt, h->max_subs * sizeof(SubCnt)), "hipMalloc counts")) return PA_ERR_HIP;
+        if (!chk(hipMalloc(&S.d_entry, h->max_subs * sizeof(SubCnt)), "hipMalloc entries")) return PA_ERR_HIP;
+        if (!chk(hipMalloc(&S.d_changed, (MAX_ROUNDS + 1) * n * sizeof(int32_t)), "hipMalloc flags")) return PA_ERR_HIP;
+        if (!chk(hipMalloc(&S.d_todo, h->max_subs * sizeof(int32_t)), "hipMalloc lane lists")) return PA_ERR_HIP;
+        if (!chk(hipMalloc(&S.d_todo_cnt, n * sizeof(int32_t)), "hipMalloc lane counts")) return PA_ERR_HIP;
+        if (!chk(hipMalloc(&S.d_coef, n * h->max_blocks * 64 * sizeof(int16_t)), "hipMalloc coefficients")) return PA_ERR_HIP;
+        if (!chk(hipMalloc(&S.d_dc, n * h->max_blocks * sizeof(int16_t)), "hipMalloc DC differences")) return PA_ERR_HIP;
+        if (!chk(hipMalloc(&S.d_planes, n * h->max_blocks * 64), "hipMalloc sample planes")) return PA_ERR_HIP;
+        if (!chk(hipMalloc(&S.d_status, n * sizeof(int32_t)), "hipMalloc status")) return PA_ERR_HIP;
+        if (!chk(hipMemset(S.d_bits, 0, max_bytes + 64), "hipMemset")) return PA_ERR_HIP;
+        if (!chk(hipMemset(S.d_clean, 0, clean_bytes), "hipMemset")) return PA_ERR_HIP;
+        for (int g = 0; g < MAX_GROUPS; ++g)
+            if (!chk(hipEventCreateWithFlags(&S.done[g], hipEventDisableTiming), "hipEventCreate")) return PA_ERR_HIP;
+    }
     for (int i = 0; i < 2; ++i) {
         if (!chk(hipHostMalloc(&h->h_fd[i], n * sizeof(FrameDesc)), "hipHostMalloc")) return PA_ERR_HIP;
         if (!chk(hipHostMalloc(&h->h_ts[i], n * sizeof(TableSet)), "hipHostMalloc")) return PA_ERR_HIP;
         if (!chk(hipEventCreateWithFlags(&h->staged[i], hipEventDisableTiming), "hipEventCreate")) return PA_ERR_HIP;
     }
+    for (int g = 0; g < MAX_GROUPS; ++g) {
+        if (!chk(hipStreamCreateWithFlags(&h->gstream[g], hipStreamNonBlocking), "hipStreamCreate")) return PA_ERR_HIP;
+        if (!chk(hipEventCreateWithFlags(&h->up[g], hipEventDisableTiming), "hipEventCreate")) return PA_ERR_HIP;
+    }
     if (!chk(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking), "hipStreamCreate")) return PA_ERR_HIP;
-    if (!chk(hipStreamCreateWithFlags(&h->clear_stream, hipStreamNonBlocking), "hipStreamCreate")) return PA_ERR_HIP;
-    if (!chk(hipEventCreateWithFlags(&h->bits_ready, hipEventDisableTiming), "hipEventCreate")) return PA_ERR_HIP;
-    if (!chk(hipEventCreateWithFlags(&h->bits_free, hipEventDisableTiming), "hipEventCreate")) return PA_ERR_HIP;
-    if (!chk(hipEventCreateWithFlags(&h->coef_clear, hipEventDisableTiming), "hipEventCreate")) return PA_ERR_HIP;
-    if (!chk(hipEventCreateWithFlags(&h->coef_free, hipEventDisableTiming), "hipEventCreate")) return PA_ERR_HIP;
+    if (!chk(hipEventCreateWithFlags(&h->fork, hipEventDisableTiming), "hipEventCreate")) return PA_ERR_HIP;
+    if (!chk(hipEventCreateWithFlags(&h->prologue, hipEventDisableTiming), "hipEventCreate")) return PA_ERR_HIP;
     if (!chk(hipHostMalloc(&h->h_flag, n * sizeof(int32_t)), "hipHostMalloc")) return PA_ERR_HIP;
     return PA_OK;
 }
@@ -1165,6 +1192,12 @@ int pa_mjpeg_set_sync_rounds(pa_mjpeg* h, int32_t rounds) {
 }
 
 int pa_mjpeg_last_sync_rounds(const pa_mjpeg* h) { return h ? h->last_rounds : 0; }
+
+int pa_mjpeg_set_groups(pa_mjpeg* h, int32_t groups) {
+    if (!h || groups < 1 || groups > MAX_GROUPS) return PA_ERR_INVALID_ARG;
+    h->groups = groups;
+    return PA_OK;
+}
 
 int pa_mjpeg_debug_counters(unsigned long long* out8_host) {
     if (!out8_host) return PA_ERR_INVALID_ARG;
@@ -1203,6 +1236,10 @@ int pa_mjpeg_decode(pa_mjpeg* h, const uint8_t* data_host, const int64_t* spans_
     const int k = h->turn;
     h->turn ^= 1;
     if (h->staged_used[k] && !chk(hipEventSynchronize(h->staged[k]), "hipEventSynchronize")) return PA_ERR_HIP;
+    // the set's call before last has finished (at most two calls are in flight): nothing enqueued below has to wait for it
+    if (h->set[k].used)
+        for (int o = 0; o < MAX_GROUPS; ++o)
+            if (!chk(hipEventSynchronize(h->set[k].done[o]), "hipEventSynchronize")) return PA_ERR_HIP;
     t_mark[0] = now();
     FrameDesc* fd = h->h_fd[k];
     TableSet* ts = h->h_ts[k];
@@ -1320,95 +1357,125 @@ int pa_mjpeg_decode(pa_mjpeg* h, const uint8_t* data_host, const int64_t* spans_
     const int max_chunks = (int)(max_scan / CHUNK) + 2;
     if (max_chunks > h->max_chunks_cap) return bad(PA_ERR_CAPACITY, "pa_mjpeg_decode: scan longer than the handle's chunk table");
     if (seg_total > h->max_segs || sub_total > h->max_subs) return bad(PA_ERR_CAPACITY, "pa_mjpeg_decode: more restart intervals / subsequences than the handle holds");
-    // compressed bytes: on the handle's copy stream, as soon as the call before this one has written its clean stream
-    if (h->bits_free_recorded && !chk(hipStreamWaitEvent(h->copy_stream, h->bits_free, 0), "hipStreamWaitEvent")) return PA_ERR_HIP;
-    if (!chk(hipMemcpyAsync(h->d_bits, data_host + base, (size_t)total, hipMemcpyHostToDevice, h->copy_stream), "upload bitstream")) return PA_ERR_HIP;
-    t_mark[4] = now();
-    if (!chk(hipMemsetAsync(h->d_bits + total, 0, 64, h->copy_stream), "pad bitstream")) return PA_ERR_HIP;
-    if (!chk(hipEventRecord(h->bits_ready, h->copy_stream), "hipEventRecord")) return PA_ERR_HIP;
-    if (!chk(hipStreamWaitEvent(s, h->bits_ready, 0), "hipStreamWaitEvent")) return PA_ERR_HIP;
-    t_mark[5] = now();
+    pa_mjpeg::Set& S = h->set[k];
+    // exact mode looks at flags on the host between passes: one group, on the caller's stream
+    const int G = h->sync_rounds > 0 ? (h->groups < n ? h->groups : n) : 1;
+    const bool forked = G > 1;
+    // Nothing below depends on what the caller's stream holds except the WRITES of the decoded frames (the caller may
+    // still be reading the output buffer): the groups wait for `fork` only in front of their last kernel, so a call's
+    // entropy passes start while the call before it -- which the caller's stream has to wait for -- is still decoding.
+    if (forked && !chk(hipEventRecord(h->fork, s), "hipEventRecord")) return PA_ERR_HIP;
+    hipStream_t q0 = forked ? h->gstream[0] : s;
+    // descriptors and tables -> HBM, flags cleared: on the first group's stream, which the other groups wait for
     {
         static_assert(sizeof(FrameDesc) % 4 == 0 && sizeof(TableSet) % 4 == 0, "copied as dwords");
         const int na = (int)((size_t)n * sizeof(FrameDesc) / 4), nb = (int)((size_t)n_sets * sizeof(TableSet) / 4);
-        hipLaunchKernelGGL(stage_copy_kernel, dim3((na + nb + 255) / 256), dim3(256), 0, s, reinterpret_cast<const uint32_t*>(fd),
-                           reinterpret_cast<uint32_t*>(h->d_fd), na, reinterpret_cast<const uint32_t*>(ts),
-                           reinterpret_cast<uint32_t*>(h->d_ts), nb);
+        hipLaunchKernelGGL(stage_copy_kernel, dim3((na + nb + 255) / 256), dim3(256), 0, q0, reinterpret_cast<const uint32_t*>(fd),
+                           reinterpret_cast<uint32_t*>(S.d_fd), na, reinterpret_cast<const uint32_t*>(ts),
+                           reinterpret_cast<uint32_t*>(S.d_ts), nb);
     }
-    if (!chk(hipEventRecord(h->staged[k], s), "hipEventRecord")) return PA_ERR_HIP;
+    if (!chk(hipEventRecord(h->staged[k], q0), "hipEventRecord")) return PA_ERR_HIP;
     h->staged_used[k] = true;
     t_mark[2] = now();
-    if (!chk(hipMemsetAsync(h->d_status, 0, (size_t)n * sizeof(int32_t), s), "clear status")) return PA_ERR_HIP;
-    if (!chk(hipMemsetAsync(h->d_changed, 0, (size_t)(MAX_ROUNDS + 1) * h->max_frames * sizeof(int32_t), s), "clear flags")) return PA_ERR_HIP;
-    // the coefficient buffers are cleared on a stream of their own, once the inverse DCT of the call before this one has read them
-    if (h->coef_free_recorded && !chk(hipStreamWaitEvent(h->clear_stream, h->coef_free, 0), "hipStreamWaitEvent")) return PA_ERR_HIP;
-    if (!chk(hipMemsetAsync(h->d_coef, 0, (size_t)n * g.blocks_per_frame * 64 * sizeof(int16_t), h->clear_stream), "clear coefficients")) return PA_ERR_HIP;
-    if (!chk(hipMemsetAsync(h->d_dc, 0, (size_t)n * g.mcus_x * g.mcus_y * g.blocks_per_mcu * sizeof(int16_t), h->clear_stream), "clear DC differences")) return PA_ERR_HIP;
-    if (!chk(hipEventRecord(h->coef_clear, h->clear_stream), "hipEventRecord")) return PA_ERR_HIP;
+    if (!chk(hipMemsetAsync(S.d_status, 0, (size_t)n * sizeof(int32_t), q0), "clear status")) return PA_ERR_HIP;
+    if (!chk(hipMemsetAsync(S.d_changed, 0, (size_t)(MAX_ROUNDS + 1) * h->max_frames * sizeof(int32_t), q0), "clear flags")) return PA_ERR_HIP;
+    if (forked && !chk(hipEventRecord(h->prologue, q0), "hipEventRecord")) return PA_ERR_HIP;
     t_mark[3] = now();
-    hipLaunchKernelGGL(unstuff_count_kernel, dim3(max_chunks, n), dim3(256), 0, s, h->d_bits, h->d_fd, h->d_chunk, max_chunks);
-    hipLaunchKernelGGL(unstuff_write_kernel, dim3(max_chunks, n), dim3(256), 0, s, h->d_bits, h->d_fd, h->d_chunk, max_chunks, h->d_clean,
-                       h->d_seg, h->d_clean_len, h->d_status);
-    if (!chk(hipEventRecord(h->bits_free, s), "hipEventRecord")) return PA_ERR_HIP;
-    h->bits_free_recorded = true;
-    const dim3 sgrid((max_sub + WG_SUBS - 1) / WG_SUBS, n);
-    int cur_g = 0;
-    hipLaunchKernelGGL((sub_decode_kernel<0>), sgrid, dim3(256), 0, s, h->d_clean, h->d_fd, h->d_ts, h->d_seg, h->d_clean_len, g,
-                       (const uint32_t*)nullptr, h->d_g[0], h->d_used, h->d_cnt, (const SubCnt*)nullptr, (int16_t*)nullptr, h->d_status,
-                       (int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, (int16_t*)nullptr);
-    auto verify = [&](int slot, int prev_slot) {
-        int32_t* flag = h->d_changed + (size_t)slot * h->max_frames;
-        const int32_t* prev = prev_slot >= 0 ? h->d_changed + (size_t)prev_slot * h->max_frames : nullptr;
-        hipLaunchKernelGGL(sub_verify_plan_kernel, dim3(n), dim3(1024), 0, s, h->d_fd, h->d_clean_len, g.sub_shift, h->d_g[cur_g],
-                           h->d_g[cur_g ^ 1], h->d_used, h->d_todo, h->d_todo_cnt, prev);
-        hipLaunchKernelGGL((sub_decode_kernel<1>), sgrid, dim3(256), 0, s, h->d_clean, h->d_fd, h->d_ts, h->d_seg, h->d_clean_len, g,
-                           h->d_g[cur_g], h->d_g[cur_g ^ 1], h->d_used, h->d_cnt, (const SubCnt*)nullptr, (int16_t*)nullptr, h->d_status, flag,
-                           prev, h->d_todo, h->d_todo_cnt, (int16_t*)nullptr);
-        cur_g ^= 1;
-    };
-    int last_slot = MAX_ROUNDS;  // an all-zero row unless a verify pass wrote it
-    if (h->sync_rounds > 0) {
-        for (int r = 0; r < h->sync_rounds; ++r) verify(r, r - 1);
-        last_slot = h->sync_rounds - 1;
-        h->last_rounds = h->sync_rounds;
-    } else {
-        // exact mode: verify until a pass changes nothing, looking at the flags on the host (synchronises the stream)
-        int rounds = 0;
-        for (;;) {
-            if (!chk(hipMemsetAsync(h->d_changed, 0, (size_t)h->max_frames * sizeof(int32_t), s), "clear flags")) return PA_ERR_HIP;
-            verify(0, -1);
-            ++rounds;
-            if (!chk(hipMemcpyAsync(h->h_flag, h->d_changed, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s), "read flags")) return PA_ERR_HIP;
-            if (!chk(hipStreamSynchronize(s), "hipStreamSynchronize")) return PA_ERR_HIP;
-            bool any = false;
-            for (int f = 0; f < n; ++f) any = any || h->h_flag[f] != 0;
-            if (!any) break;
-            if (rounds > max_sub + 2) return bad(PA_ERR_HIP, "pa_mjpeg_decode: synchronisation did not settle");
+    const int total_blocks = g.mcus_x * g.mcus_y * g.blocks_per_mcu;
+    int rounds_run = 0;
+    // the groups' compressed bytes (the byte range that covers a group's frames), one group after the other
+    for (int gi = 0; gi < G; ++gi) {
+        const int f0 = (int)((long long)n * gi / G), f1 = (int)((long long)n * (gi + 1) / G);
+        hipStream_t cq = forked ? h->copy_stream : s;
+        int64_t gb = spans_host[2 * f0], gt = spans_host[2 * f0 + 1];
+        for (int f = f0; f < f1; ++f) {
+            gb = spans_host[2 * f] < gb ? spans_host[2 * f] : gb;
+            gt = spans_host[2 * f + 1] > gt ? spans_host[2 * f + 1] : gt;
         }
-        last_slot = 0;
-        h->last_rounds = rounds;
+        if (!chk(hipMemcpyAsync(S.d_bits + (gb - base), data_host + gb, (size_t)(gt - gb), hipMemcpyHostToDevice, cq), "upload bitstream")) return PA_ERR_HIP;
+        // readers run a few bytes past the end of a scan: zeros behind the last byte of the call
+        if (gt == top && !chk(hipMemsetAsync(S.d_bits + total, 0, 64, cq), "pad bitstream")) return PA_ERR_HIP;
+        if (forked && !chk(hipEventRecord(h->up[gi], cq), "hipEventRecord")) return PA_ERR_HIP;
     }
-    hipLaunchKernelGGL(sub_scan_kernel, dim3(n), dim3(1024), 0, s, h->d_fd, h->d_clean_len, h->d_cnt, h->d_entry, g.sub_shift);
-    if (!chk(hipStreamWaitEvent(s, h->coef_clear, 0), "hipStreamWaitEvent")) return PA_ERR_HIP;
-    hipLaunchKernelGGL((sub_decode_kernel<2>), sgrid, dim3(256), 0, s, h->d_clean, h->d_fd, h->d_ts, h->d_seg, h->d_clean_len, g,
-                       h->d_g[cur_g], (uint32_t*)nullptr, h->d_used, h->d_cnt, h->d_entry, h->d_coef, h->d_status, (int32_t*)nullptr,
-                       h->d_changed + (size_t)last_slot * h->max_frames, (const int32_t*)nullptr, (const int32_t*)nullptr, h->d_dc);
-    hipLaunchKernelGGL(dc_scan_kernel, dim3(n, g.ncomp), dim3(1024), 0, s, h->d_dc, h->d_fd, g);
-    const long long nblk = (long long)n * g.blocks_per_frame;
-    hipLaunchKernelGGL(idct_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, s, h->d_coef, h->d_dc, h->d_fd, h->d_ts, g, h->d_planes, n);
-    if (!chk(hipEventRecord(h->coef_free, s), "hipEventRecord")) return PA_ERR_HIP;
-    h->coef_free_recorded = true;
-    const int fv = g.ncomp == 3 ? g.fv : 1, fhh = g.ncomp == 3 ? g.fh : 1;
-    const dim3 grid((width + 511) / 512, (height + 4 * fv - 1) / (4 * fv), n);
-    if (fhh == 2 && fv == 2) hipLaunchKernelGGL((ycc_kernel<2, 2>), grid, dim3(256), 0, s, h->d_planes, g, frames_dev, rgb);
-    else if (fhh == 2) hipLaunchKernelGGL((ycc_kernel<2, 1>), grid, dim3(256), 0, s, h->d_planes, g, frames_dev, rgb);
-    else hipLaunchKernelGGL((ycc_kernel<1, 1>), grid, dim3(256), 0, s, h->d_planes, g, frames_dev, rgb);
-    if (status_dev && !chk(hipMemcpyAsync(status_dev, h->d_status, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, s), "copy status"))
+    for (int gi = 0; gi < G; ++gi) {
+        const int f0 = (int)((long long)n * gi / G), f1 = (int)((long long)n * (gi + 1) / G), ng = f1 - f0;
+        hipStream_t q = forked ? h->gstream[gi] : s;
+        Geom gg = g;
+        gg.f0 = f0;
+        if (gi > 0 && !chk(hipStreamWaitEvent(q, h->prologue, 0), "hipStreamWaitEvent")) return PA_ERR_HIP;
+        // the group's coefficient buffers, cleared while its bytes are still on their way
+        if (!chk(hipMemsetAsync(S.d_coef + (size_t)f0 * total_blocks * 64, 0, (size_t)ng * total_blocks * 64 * sizeof(int16_t), q), "clear coefficients")) return PA_ERR_HIP;
+        if (!chk(hipMemsetAsync(S.d_dc + (size_t)f0 * total_blocks, 0, (size_t)ng * total_blocks * sizeof(int16_t), q), "clear DC differences")) return PA_ERR_HIP;
+        if (forked && !chk(hipStreamWaitEvent(q, h->up[gi], 0), "hipStreamWaitEvent")) return PA_ERR_HIP;
+        hipLaunchKernelGGL(unstuff_count_kernel, dim3(max_chunks, ng), dim3(256), 0, q, S.d_bits, S.d_fd, S.d_chunk, max_chunks, f0);
+        hipLaunchKernelGGL(unstuff_write_kernel, dim3(max_chunks, ng), dim3(256), 0, q, S.d_bits, S.d_fd, S.d_chunk, max_chunks, S.d_clean,
+                           S.d_seg, S.d_clean_len, S.d_status, f0);
+        const dim3 sgrid((max_sub + WG_SUBS - 1) / WG_SUBS, ng);
+        int cur_g = 0;
+        hipLaunchKernelGGL((sub_decode_kernel<0>), sgrid, dim3(256), 0, q, S.d_clean, S.d_fd, S.d_ts, S.d_seg, S.d_clean_len, gg,
+                           (const uint32_t*)nullptr, S.d_g[0], S.d_used, S.d_cnt, (const SubCnt*)nullptr, (int16_t*)nullptr, S.d_status,
+                           (int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, (int16_t*)nullptr);
+        auto verify = [&](int slot, int prev_slot) {
+            int32_t* flag = S.d_changed + (size_t)slot * h->max_frames;
+            const int32_t* prev = prev_slot >= 0 ? S.d_changed + (size_t)prev_slot * h->max_frames : nullptr;
+            hipLaunchKernelGGL(sub_verify_plan_kernel, dim3(ng), dim3(1024), 0, q, S.d_fd, S.d_clean_len, g.sub_shift, S.d_g[cur_g],
+                               S.d_g[cur_g ^ 1], S.d_used, S.d_todo, S.d_todo_cnt, prev, f0);
+            hipLaunchKernelGGL((sub_decode_kernel<1>), sgrid, dim3(256), 0, q, S.d_clean, S.d_fd, S.d_ts, S.d_seg, S.d_clean_len, gg,
+                               S.d_g[cur_g], S.d_g[cur_g ^ 1], S.d_used, S.d_cnt, (const SubCnt*)nullptr, (int16_t*)nullptr, S.d_status, flag,
+                               prev, S.d_todo, S.d_todo_cnt, (int16_t*)nullptr);
+            cur_g ^= 1;
+        };
+        int last_slot = MAX_ROUNDS;  // an all-zero row unless a verify pass wrote it
+        if (h->sync_rounds > 0) {
+            for (int r = 0; r < h->sync_rounds; ++r) verify(r, r - 1);
+            last_slot = h->sync_rounds - 1;
+            rounds_run = h->sync_rounds;
+        } else {
+            // exact mode: verify until a pass changes nothing, looking at the flags on the host (synchronises the stream)
+            int rounds = 0;
+            for (;;) {
+                if (!chk(hipMemsetAsync(S.d_changed, 0, (size_t)h->max_frames * sizeof(int32_t), q), "clear flags")) return PA_ERR_HIP;
+                verify(0, -1);
+                ++rounds;
+                if (!chk(hipMemcpyAsync(h->h_flag, S.d_changed, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, q), "read flags")) return PA_ERR_HIP;
+                if (!chk(hipStreamSynchronize(q), "hipStreamSynchronize")) return PA_ERR_HIP;
+                bool any = false;
+                for (int f = 0; f < n; ++f) any = any || h->h_flag[f] != 0;
+                if (!any) break;
+                if (rounds > max_sub + 2) return bad(PA_ERR_HIP, "pa_mjpeg_decode: synchronisation did not settle");
+            }
+            last_slot = 0;
+            rounds_run = rounds;
+        }
+        hipLaunchKernelGGL(sub_scan_kernel, dim3(ng), dim3(1024), 0, q, S.d_fd, S.d_clean_len, S.d_cnt, S.d_entry, g.sub_shift, f0);
+        hipLaunchKernelGGL((sub_decode_kernel<2>), sgrid, dim3(256), 0, q, S.d_clean, S.d_fd, S.d_ts, S.d_seg, S.d_clean_len, gg,
+                           S.d_g[cur_g], (uint32_t*)nullptr, S.d_used, S.d_cnt, S.d_entry, S.d_coef, S.d_status, (int32_t*)nullptr,
+                           S.d_changed + (size_t)last_slot * h->max_frames, (const int32_t*)nullptr, (const int32_t*)nullptr, S.d_dc);
+        hipLaunchKernelGGL(dc_scan_kernel, dim3(ng, g.ncomp), dim3(1024), 0, q, S.d_dc, S.d_fd, gg);
+        const long long nblk = (long long)ng * g.blocks_per_frame;
+        hipLaunchKernelGGL(idct_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, q, S.d_coef, S.d_dc, S.d_fd, S.d_ts, gg, S.d_planes, ng);
+        const int fv = g.ncomp == 3 ? g.fv : 1, fhh = g.ncomp == 3 ? g.fh : 1;
+        const dim3 grid((width + 511) / 512, (height + 4 * fv - 1) / (4 * fv), ng);
+        if (forked && !chk(hipStreamWaitEvent(q, h->fork, 0), "hipStreamWaitEvent")) return PA_ERR_HIP;  // the output buffer is the caller's
+        if (fhh == 2 && fv == 2) hipLaunchKernelGGL((ycc_kernel<2, 2>), grid, dim3(256), 0, q, S.d_planes, gg, frames_dev, rgb);
+        else if (fhh == 2) hipLaunchKernelGGL((ycc_kernel<2, 1>), grid, dim3(256), 0, q, S.d_planes, gg, frames_dev, rgb);
+        else hipLaunchKernelGGL((ycc_kernel<1, 1>), grid, dim3(256), 0, q, S.d_planes, gg, frames_dev, rgb);
+        if (!chk(hipEventRecord(S.done[gi], q), "hipEventRecord")) return PA_ERR_HIP;
+    }
+    // groups the call did not use: their events must not hold a later call back with a stale record
+    for (int gi = G; gi < MAX_GROUPS; ++gi)
+        if (!chk(hipEventRecord(S.done[gi], s), "hipEventRecord")) return PA_ERR_HIP;
+    S.used = true;
+    h->last_rounds = rounds_run;
+    if (forked)
+        for (int gi = 0; gi < G; ++gi)
+            if (!chk(hipStreamWaitEvent(s, S.done[gi], 0), "hipStreamWaitEvent")) return PA_ERR_HIP;
+    if (status_dev && !chk(hipMemcpyAsync(status_dev, S.d_status, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, s), "copy status"))
         return PA_ERR_HIP;
     if (!chk(hipGetLastError(), "kernel launch")) return PA_ERR_HIP;
     if (trace)
-        fprintf(stderr, "pa_mjpeg_decode host us: staging wait %.0f, headers %.0f, copies %.0f (bitstream %.0f, events %.0f), clears %.0f, launches %.0f\n", t_mark[0] - t_in,
-                t_mark[1] - t_mark[0], t_mark[2] - t_mark[1], t_mark[4] - t_mark[1], t_mark[5] - t_mark[4], t_mark[3] - t_mark[2], now() - t_mark[3]);
+        fprintf(stderr, "pa_mjpeg_decode host us: staging wait %.0f, headers %.0f, descriptors %.0f, clears %.0f, groups (copies + launches) %.0f\n",
+                t_mark[0] - t_in, t_mark[1] - t_mark[0], t_mark[2] - t_mark[1], t_mark[3] - t_mark[2], now() - t_mark[3]);
     return PA_OK;
 }
 

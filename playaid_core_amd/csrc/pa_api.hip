@@ -105,6 +105,9 @@ struct pa_engine {
     CropPlan* plans = nullptr;
     int32_t* coef = nullptr;
     int coef_dim = 0;
+    int32_t* coef_cache = nullptr;  // Pillow tables of the passes (2 * (d / 2) + 2 * padding -> d), built for one padding at a time
+    int coef_cache_pad = -1, coef_cache_dmax = 0;
+    AreaTabPacked* area_tabs = nullptr;
     uint8_t *t1 = nullptr, *t2 = nullptr;
     size_t t_stride = 0;
     int32_t* status_tmp = nullptr;
@@ -607,6 +610,11 @@ int run_preprocess(pa_engine* e, const uint8_t* frames, int n, int height, int w
     p.plans = e->plans;
     p.coef = e->coef;
     p.coef_dim = e->coef_dim;
+    // the cache holds the reference's padding (30); any other value computes its tables per crop, as every clipped crop does
+    p.coef_cache = e->coef_cache_pad == padding ? e->coef_cache : nullptr;
+    p.coef_cache_pad = padding;
+    p.coef_cache_dmax = e->coef_cache_dmax;
+    p.area_tabs = e->area_tabs;
     p.t1 = e->t1;
     p.t2 = e->t2;
     p.t_stride = e->t_stride;
@@ -948,6 +956,13 @@ int create_impl(const pa_config* cfg, const void* blob, size_t src_bytes, const 
     ALLOC(e->plans, (size_t)NC, true);
     ALLOC(e->fallback, (size_t)NC + 4, true);
     ALLOC(e->coef, (size_t)NC * 2 * e->coef_dim * (2 + PA_KSIZE_MAX), false);
+    // a crop side cannot exceed the shorter frame side without being clipped (and then it is not a cached pair); 1024 caps the
+    // cache at 36 MB
+    e->coef_cache_dmax = std::min(std::min(cfg->max_frame_height, cfg->max_frame_width), 1024);
+    ALLOC(e->coef_cache, coef_cache_ints(e->coef_cache_dmax), false);
+    e->coef_cache_pad = 30;  // the one padding the reference's runner passes (ai_runner.py:418)
+    HIPCHK(e, launch_build_coef_cache(e->coef_cache, e->coef_cache_pad, e->coef_cache_dmax, nullptr));
+    ALLOC(e->area_tabs, (size_t)NC * 2 * PA_CROP, true);
     ALLOC(e->t1, (size_t)NC * e->t_stride, false);
     ALLOC(e->t2, (size_t)NC * e->t_stride, false);
 #undef ALLOC

@@ -119,6 +119,16 @@ struct CropPlan {
     int32_t fused_rb;          // output rows per LDS sub-band of the fused kernel (8/4/2/1), 0 = multi-kernel fallback
     int32_t pad_;
     double scale_x, scale_y;
+    // Pillow coefficient tables of the two bicubic passes ([out][2 + PA_KSIZE_MAX]): the engine's cache of the
+    // (2 * (d / 2) + 2 * padding -> d) pairs, or this crop's own rows of PreprocParams::coef for any other pair
+    const int32_t* coef_h;
+    const int32_t* coef_v;
+};
+
+// One entry of cv::computeResizeAreaTab per destination column / row of a crop (plan kernel -> fused kernel)
+struct AreaTabPacked {
+    uint32_t bits;  // s_first | n_mid << 16 | has_first << 24 | has_last << 25
+    float a_first, a_mid, a_last;
 };
 
 struct CropWindow {  // == pa_crop_window of the public header
@@ -142,6 +152,9 @@ struct PreprocParams {
     CropPlan* plans;        // [ncrops]
     int32_t* coef;          // [ncrops][2][maxdim][1 + 1 + PA_KSIZE_MAX]: xmin, count, kk[]
     int32_t coef_dim;       // maxdim (entries per axis per crop)
+    const int32_t* coef_cache;  // tables of the pairs (2 * (d / 2) + 2 * coef_cache_pad -> d), d = 1 .. coef_cache_dmax, table d at row d * (d - 1) / 2
+    int32_t coef_cache_pad, coef_cache_dmax;
+    AreaTabPacked* area_tabs;   // [ncrops][2][128]: INTER_AREA tables of the 128 destination columns, then rows
     uint8_t* t1;            // [ncrops][t_stride] horizontally resampled slice
     uint8_t* t2;            // [ncrops][t_stride] fully resampled slice
     size_t t_stride;
@@ -158,6 +171,9 @@ struct PreprocParams {
 };
 
 hipError_t launch_preprocess(const PreprocParams& p, hipStream_t s);
+// fills the engine's coefficient cache for one padding value (once per engine, or when the padding changes)
+size_t coef_cache_ints(int dmax);
+hipError_t launch_build_coef_cache(int32_t* cache, int padding, int dmax, hipStream_t s);
 
 // crop images of any size -> runner inputs (ai_runner.py:446-459), see runner_input_kernel
 struct CropImageDesc {  // == pa_crop_image of the public header

@@ -106,11 +106,6 @@ __device__ __forceinline__ AreaTab area_tab(int dx, double scale, int ssize) {
 }
 
 // 16-byte LDS form of an AreaTab (s_first < 2^16, n_mid < 2^8 for any square side the plan accepts)
-struct AreaTabPacked {
-    uint32_t bits;  // s_first | n_mid << 16 | has_first << 24 | has_last << 25
-    float a_first, a_mid, a_last;
-};
-
 __device__ __forceinline__ AreaTabPacked area_pack(const AreaTab& t) {
     AreaTabPacked q;
     q.bits = (uint32_t)t.s_first | ((uint32_t)t.n_mid << 16) | ((uint32_t)t.has_first << 24) | ((uint32_t)t.has_last << 25);
@@ -133,10 +128,15 @@ __device__ __forceinline__ AreaTab area_unpack(const AreaTabPacked& q) {
     return t;
 }
 
-__device__ __forceinline__ float area_alpha(const AreaTab& t, int k) {
-    if (k < t.has_first) return t.a_first;
-    if (k < t.has_first + t.n_mid) return t.a_mid;
-    return t.a_last;
+// (by value, as selects of values: taking the table by reference made hipcc keep it in scratch memory and turn the
+// choice into an indexed scratch load -- which gave the whole fused kernel a private segment)
+__device__ __forceinline__ float area_alpha(const AreaTab t, int k) {
+    const float a_first = t.a_first, a_mid = t.a_mid, a_last = t.a_last;
+    const int hf = t.has_first, hm = t.has_first + t.n_mid;
+    float r = a_last;
+    r = k < hm ? a_mid : r;
+    r = k < hf ? a_first : r;
+    return r;
 }
 
 
@@ -240,7 +240,9 @@ __device__ __forceinline__ double bicubic_filter(double x) {
 
 // Pillow precompute_coeffs + normalize_coeffs_8bpc for output coordinate xx of a pass in_size -> out_size
 // into row[0] = first tap, row[1] = tap count, row[2..] = coefficients.
-__device__ void bicubic_coef_row(int in_size, int out_size, int xx, int32_t* row) {
+// (out of line: the plan kernel runs once per clip with its code cold, every line of it fetched from memory, and the
+// passes of almost every crop are in the engine's cache)
+__device__ __noinline__ void bicubic_coef_row(int in_size, int out_size, int xx, int32_t* row) {
     const double scale = (double)(float)in_size / out_size;
     const double filterscale = scale < 1.0 ? 1.0 : scale;
     const double support = 2.0 * filterscale;
@@ -289,6 +291,7 @@ __global__ __launch_bounds__(256) void crop_plan_kernel(const PreprocParams p) {
     pl.iscale_x = pl.iscale_y = 1;
     pl.fused_rb = 0;
     pl.pad_ = 0;
+    pl.coef_h = pl.coef_v = nullptr;
     pl.scale_x = pl.scale_y = 1.0;
     const double* b = p.boxes + (size_t)crop * 4;
     const int W = p.width, H = p.height, pad = p.padding;
@@ -381,10 +384,13 @@ __global__ __launch_bounds__(256) void crop_plan_kernel(const PreprocParams p) {
             }
         }
     }
-    if (pl.status == PA_CROP_OK && pl.area_mode != 4) {
+    if (p.ablate & 16) pl.fused_rb = 2;
+    if (pl.status == PA_CROP_OK && pl.area_mode != 4 && !(p.ablate & 16)) {
         // largest sub-band height whose LDS stages fit the fused kernel's budget
+#pragma unroll 1
         for (int rb = 8; rb >= 1 && pl.fused_rb == 0; rb >>= 1) {
             int worst = 0;
+#pragma unroll 1
             for (int r0 = lane * rb; r0 < PA_CROP; r0 += 64 * rb) {
                 const BandRows b = band_rows(pl, r0, r0 + rb);
                 const int need = band_lds(pl, b).total;
@@ -403,21 +409,49 @@ __global__ __launch_bounds__(256) void crop_plan_kernel(const PreprocParams p) {
             const int slot = atomicAdd(p.fallback_count, 1);
             p.fallback_list[slot] = crop;
         }
+        // coefficient tables: a pass (2 * (d / 2) + 2 * padding -> d) -- the slice of every crop the frame edge does not
+        // clip (fighter.py:334-343: centre -/+ int(d / 2) -/+ padding) -- reads the engine's cache; any other pair is
+        // computed below into this crop's own rows
+        for (int axis = 0; axis < 2; ++axis) {
+            const int in_size = axis ? pl.sh : pl.sw, out_size = axis ? pl.rh : pl.rw;
+            const bool cached = p.coef_cache && in_size == 2 * (out_size / 2) + 2 * p.coef_cache_pad && out_size >= 1 &&
+                                out_size <= p.coef_cache_dmax;
+            const int32_t* tab = cached ? p.coef_cache + (size_t)out_size * (out_size - 1) / 2 * COEF_ROW
+                                        : p.coef + (size_t)(crop * 2 + axis) * p.coef_dim * COEF_ROW;
+            if (axis) pl.coef_v = tab; else pl.coef_h = tab;
+        }
         p.plans[crop] = pl;
         plan_sh = pl;
         if (p.status) p.status[crop] = pl.status;
     }
     }
     __syncthreads();
-    // Pillow precompute_coeffs + normalize_coeffs_8bpc for both passes (one thread per output coordinate)
     const CropPlan pl = plan_sh;
     if (pl.status != PA_CROP_OK) return;
+    // cv::computeResizeAreaTab for the 128 destination columns and rows (fp64 with divisions): once per crop, not once
+    // per workgroup of the fused kernel
+    if (pl.area_mode == 3 && p.area_tabs && !(p.ablate & 32)) {
+        const int t = threadIdx.x;
+        AreaTabPacked q = {0u, 0.f, 0.f, 0.f};
+        if (t < PA_CROP) q = area_pack(area_tab(t, pl.scale_x, pl.d));
+        else if (t - PA_CROP < pl.out_h) q = area_pack(area_tab(t - PA_CROP, pl.scale_y, pl.d));
+        p.area_tabs[(size_t)crop * 2 * PA_CROP + t] = q;
+    }
+    // Pillow precompute_coeffs + normalize_coeffs_8bpc for the passes the cache does not hold (one thread per output coordinate)
     for (int axis = 0; axis < 2; ++axis) {
         if (!(axis ? pl.need_v : pl.need_h)) continue;
         const int in_size = axis ? pl.sh : pl.sw, out_size = axis ? pl.rh : pl.rw;
-        for (int xx = threadIdx.x; xx < out_size; xx += 256)
-            bicubic_coef_row(in_size, out_size, xx, p.coef + ((size_t)(crop * 2 + axis) * p.coef_dim + xx) * COEF_ROW);
+        int32_t* own = p.coef + (size_t)(crop * 2 + axis) * p.coef_dim * COEF_ROW;
+        if ((axis ? pl.coef_v : pl.coef_h) != own) continue;
+        for (int xx = threadIdx.x; xx < out_size; xx += 256) bicubic_coef_row(in_size, out_size, xx, own + (size_t)xx * COEF_ROW);
     }
+}
+
+// The engine's coefficient cache: table d = the pass (2 * (d / 2) + 2 * padding -> d), at row d * (d - 1) / 2.
+__global__ __launch_bounds__(256) void coef_cache_kernel(int32_t* __restrict__ cache, int padding, int dmax) {
+    const int d = blockIdx.y + 1, xx = blockIdx.x * 256 + threadIdx.x;
+    if (d > dmax || xx >= d) return;
+    bicubic_coef_row(2 * (d / 2) + 2 * padding, d, xx, cache + ((size_t)d * (d - 1) / 2 + xx) * COEF_ROW);
 }
 
 // Pillow clip8: (acc >> 22) clamped to 0..255. Returns a 32-bit value on purpose: with a
@@ -441,7 +475,7 @@ __device__ void fallback_h(const PreprocParams& p, int crop, const CropPlan& pl)
     size_t src_pitch;
     const uint8_t* src = slice_ptr(p, crop, pl, &src_pitch);
     uint8_t* dst = p.t1 + (size_t)crop * p.t_stride;
-    const int32_t* coef = p.coef + (size_t)(crop * 2 + 0) * p.coef_dim * COEF_ROW;
+    const int32_t* coef = pl.coef_h;
     for (int i = threadIdx.x; i < total; i += blockDim.x) {
         const int y = i / pl.rw;
         const int xx = i - y * pl.rw;
@@ -475,7 +509,7 @@ __device__ void fallback_v(const PreprocParams& p, int crop, const CropPlan& pl)
         src = slice_ptr(p, crop, pl, &src_pitch);
     }
     uint8_t* dst = p.t2 + (size_t)crop * p.t_stride;
-    const int32_t* coef = p.coef + (size_t)(crop * 2 + 1) * p.coef_dim * COEF_ROW;
+    const int32_t* coef = pl.coef_v;
     for (int i = threadIdx.x; i < total; i += blockDim.x) {
         const int yy = i / pl.rw;
         const int x = i - yy * pl.rw;
@@ -666,7 +700,8 @@ __device__ void fallback_area(const PreprocParams& p, int crop, const CropPlan& 
     }
 }
 
-__global__ __launch_bounds__(1024) void crop_fallback_kernel(const PreprocParams p) {
+// Runs as the LAST row of crop_fused_kernel's grid (blockIdx.y == number of crops): no launch of its own.
+__device__ void crop_fallback_body(const PreprocParams& p) {
     const int count = *p.fallback_count;
     for (int fb = blockIdx.x; fb < count; fb += gridDim.x) {
         const int crop = p.fallback_list[fb];
@@ -728,6 +763,10 @@ __global__ __launch_bounds__(CF_NT) void crop_fused_kernel(const PreprocParams p
     const unsigned long long st0 = __builtin_amdgcn_s_memrealtime();
 #endif
     const int crop = blockIdx.y;
+    if (crop == p.n_frames * p.fighters) {  // the grid's extra row: crops whose bands do not fit the LDS budget
+        crop_fallback_body(p);
+        return;
+    }
     const int band0 = blockIdx.x * 8;  // first of this workgroup's 8 output rows
     const int tid = threadIdx.x;
     const CropPlan pl = p.plans[crop];
@@ -739,8 +778,8 @@ __global__ __launch_bounds__(CF_NT) void crop_fused_kernel(const PreprocParams p
     if (!pl.fused_rb) return;
     size_t frame_pitch;
     const uint8_t* slice = slice_ptr(p, crop, pl, &frame_pitch);
-    const int32_t* coef_h = p.coef + (size_t)(crop * 2 + 0) * p.coef_dim * COEF_ROW;
-    const int32_t* coef_v = p.coef + (size_t)(crop * 2 + 1) * p.coef_dim * COEF_ROW;
+    const int32_t* coef_h = pl.coef_h;
+    const int32_t* coef_v = pl.coef_v;
     const int rb = pl.fused_rb;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -748,9 +787,9 @@ __global__ __launch_bounds__(CF_NT) void crop_fused_kernel(const PreprocParams p
     // destination rows, computed once (fp64 with divisions) and kept behind the stage buffers
     AreaTabPacked* tabs = reinterpret_cast<AreaTabPacked*>(pa_smem + p.fused_lds);
     if (pl.area_mode == 3) {
-        if (tid < PA_CROP) tabs[tid] = area_pack(area_tab(tid, pl.scale_x, pl.d));
-        else if (tid < PA_CROP + 8 && band0 + (tid - PA_CROP) < pl.out_h)
-            tabs[tid] = area_pack(area_tab(band0 + (tid - PA_CROP), pl.scale_y, pl.d));
+        const AreaTabPacked* at = p.area_tabs + (size_t)crop * 2 * PA_CROP;  // the plan kernel's
+        if (tid < PA_CROP) tabs[tid] = at[tid];
+        else if (tid < PA_CROP + 8 && band0 + (tid - PA_CROP) < pl.out_h) tabs[tid] = at[PA_CROP + band0 + (tid - PA_CROP)];
     }
     __syncthreads();
     for (int r0 = band0; r0 < band0 + 8; r0 += rb) {
@@ -1503,7 +1542,7 @@ hipError_t launch_preprocess(const PreprocParams& p_in, hipStream_t s) {
         p.dbg = reinterpret_cast<uint8_t*>(sd);
     }
 #endif
-    hipLaunchKernelGGL(crop_fused_kernel, dim3(PA_CROP / 8, ncrops), dim3(CF_NT), p.fused_lds + (PA_CROP + 8) * sizeof(AreaTabPacked), s, p);
+    hipLaunchKernelGGL(crop_fused_kernel, dim3(PA_CROP / 8, ncrops + 1), dim3(CF_NT), p.fused_lds + (PA_CROP + 8) * sizeof(AreaTabPacked), s, p);
     { hipError_t e1 = hipGetLastError(); if (e1 != hipSuccess) return e1; }
 #ifdef PA_STAMP_BUILD
     if (now) {
@@ -1515,7 +1554,14 @@ hipError_t launch_preprocess(const PreprocParams& p_in, hipStream_t s) {
         p.dbg = nullptr;
     }
 #endif
-    hipLaunchKernelGGL(crop_fallback_kernel, dim3(16), dim3(1024), 0, s, p);
+    return hipGetLastError();
+}
+
+size_t coef_cache_ints(int dmax) { return (size_t)dmax * (dmax + 1) / 2 * COEF_ROW; }
+
+hipError_t launch_build_coef_cache(int32_t* cache, int padding, int dmax, hipStream_t s) {
+    if (dmax <= 0) return hipSuccess;
+    hipLaunchKernelGGL(coef_cache_kernel, dim3((dmax + 255) / 256, dmax), dim3(256), 0, s, cache, padding, dmax);
     return hipGetLastError();
 }
 

@@ -212,17 +212,29 @@ class MjpegDecoder:
             pass
 
     def set_sync_rounds(self, rounds: int):
-        """Verify passes of the self-synchronising entropy decoder: 1..8 enqueued blindly (default 3; a frame that has
-        not settled gets status bit 8), 0 = repeat until settled (one stream synchronisation per pass)."""
+        """Verify passes of the self-synchronising entropy decoder: 1..16 enqueued blindly (default 8; a pass over a frame
+        that has settled returns at once; a frame that has not settled gets status bit 8), 0 = repeat until settled (one
+        stream synchronisation per pass)."""
         from . import _lib
         from .engine import EngineError
 
         rc = self._lib.pa_mjpeg_set_sync_rounds(self._h, int(rounds))
         if rc != _lib.PA_OK:
-            raise EngineError(rc, "sync rounds must be 0..8")
+            raise EngineError(rc, "sync rounds must be 0..16")
 
     def last_sync_rounds(self) -> int:
         return int(self._lib.pa_mjpeg_last_sync_rounds(self._h))
+
+    def set_groups(self, groups: int):
+        """Frame groups per call, 1..4 (default 2), each decoded on a stream of the handle's own and joined to the
+        current stream at the end. 1 = everything on the current stream: what a caller that runs several decoders on
+        several streams itself (``bench.py``'s decode_inclusive) wants."""
+        from . import _lib
+        from .engine import EngineError
+
+        rc = self._lib.pa_mjpeg_set_groups(self._h, int(groups))
+        if rc != _lib.PA_OK:
+            raise EngineError(rc, "groups must be 1..4")
 
     def decode(self, data, spans, height: int, width: int, out=None, status=None, rgb: bool = False):
         """``data``: the compressed bytes, a uint8 numpy array or CPU torch tensor (pin it for an asynchronous copy);

@@ -19,6 +19,7 @@ ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--variants", default="none,rows1,blk30,blk8,blk2")
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--noise-mask", type=int, default=31, help="amplitude mask of the clip's per-sample noise (31 = the headline's clip, 7 = camera-like)")
+ap.add_argument("--streams", type=int, default=1, help="decoders working at once, each on a stream of its own (calls alternate)")
 ap.add_argument("--rounds", type=int, default=-1, help="verify passes enqueued per call (default: the library's)")
 args = ap.parse_args()
 n, h, w = args.frames, args.height, args.width
@@ -49,6 +50,23 @@ for var in args.variants.split(","):
     dec.decode(data, spans, h, w, out=out)  # the device is idle: nothing holds the host back but its own work
     host_ms = (time.perf_counter() - th) * 1e3
     torch.cuda.synchronize()
+    if args.streams > 1:
+        decs = [dec] + [video.MjpegDecoder(n, h, w, int(ends[-1]) + 4096) for _ in range(args.streams - 1)]
+        outs = [out] + [torch.empty_like(out) for _ in range(args.streams - 1)]
+        strs = [torch.cuda.Stream() for _ in range(args.streams)]
+        for d_, o_, s_ in zip(decs, outs, strs):
+            with torch.cuda.stream(s_):
+                d_.decode(data, spans, h, w, out=o_)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for r in range(args.reps * args.streams):
+            with torch.cuda.stream(strs[r % args.streams]):
+                decs[r % args.streams].decode(data, spans, h, w, out=outs[r % args.streams])
+        torch.cuda.synchronize()
+        ms_multi = (time.perf_counter() - t0) * 1e3 / (args.reps * args.streams)
+        print(f"{var:8s} {args.streams} decoders on {args.streams} streams: {ms_multi:.3f} ms per {n} frames = {n / ms_multi * 1e3:.0f} frames/s", flush=True)
+        for d_ in decs[1:]:
+            d_.close()
     e0.record()
     for _ in range(args.reps):
         dec.decode(data, spans, h, w, out=out)
