@@ -160,7 +160,7 @@ def decode_inclusive(eng, frames_dev, boxes_dev, steps=8, quality=95, restart_bl
     data = torch.from_numpy(np.frombuffer(b"".join(blobs), np.uint8).copy()).pin_memory()
     # ND decoders at once, each on a stream of its own with a frame buffer of its own: the entropy passes are bound by
     # instruction issue and single-wave latency, so calls whose phases are out of step fill each other's idle time
-    ND = 3
+    ND = 4
     decs = [video.MjpegDecoder(n, h, w, int(ends[-1]) + 4096, device=str(dev)) for _ in range(ND)]
     for d_ in decs:
         d_.set_groups(1)
@@ -218,8 +218,8 @@ def decode_inclusive(eng, frames_dev, boxes_dev, steps=8, quality=95, restart_bl
         "frames_with_decode_errors": bad,
         "content": content or "the headline's clip (five bits of white noise on every sample: the hardest input a JPEG coder meets)",
         "method": f"{steps} clips; compressed frames in pinned host memory; H2D copy + device Motion-JPEG decode of clip k+1 on a "
-        "side stream under crops + CNN + head of an earlier clip on its decoded frames; three decoders, each with a side stream and "
-        "a frame buffer of its own, work at once (clips k+1 .. k+3)",
+        "side stream under crops + CNN + head of an earlier clip on its decoded frames; four decoders, each with a side stream and "
+        "a frame buffer of its own, work at once (clips k+1 .. k+4)",
     }
 
 

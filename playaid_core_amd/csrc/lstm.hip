@@ -264,6 +264,28 @@ __global__ __launch_bounds__(128) void lstm_decode_kernel(const float* __restric
 
 hipError_t launch_linear_f32(const float* X, int ld, const float* W, const float* bias, float* Cm, int ldc, int M, int N, int K, int relu,
                              hipStream_t s) {
+    // Enough rows and whole tiles: the implicit-GEMM engine's fp32 MFMA kernel, the rows addressed as the pixels of one
+    // 1 x M image under a 1x1 filter (the transformer's projections and 256 <-> 2048 feed-forward layers, the LSTM's
+    // input projections). Anything else -- the class heads' 63 columns, a 300-wide K -- stays on the VALU tiles below.
+    if (M >= 64 && N % 64 == 0 && K % 32 == 0 && (relu == 0 || relu == 1) && ld % 4 == 0 && ldc % 4 == 0) {
+        GemmParams p;
+        memset(&p, 0, sizeof(p));
+        p.act = X;
+        p.wgt = W;
+        p.bias = bias;
+        p.out = Cm;
+        p.M = M;
+        p.N = N;
+        p.taps = 1; p.kw_taps = 1; p.chunk = K; p.ktot = K;
+        p.howo = M; p.wo = M;
+        p.in_px_stride = ld; p.in_row_stride = 0; p.in_img_stride = 0;
+        p.stride = 1;
+        p.out_px_stride = ldc; p.out_row_stride = 0; p.out_img_stride = 0;
+        p.relu = relu;
+        p.splitk = 1;
+        const long long t128 = (long long)((M + 127) / 128) * (N / 64);
+        return launch_igemm(p, t128 >= 512 ? TILE_128x64 : TILE_64x64, s);
+    }
     hipLaunchKernelGGL(linear_f32_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, s, X, ld, W, bias, Cm, ldc, M, N, K, relu);
     return hipGetLastError();
 }
