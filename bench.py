@@ -140,7 +140,7 @@ def pcie_inclusive(eng, frames_dev, boxes_dev, steps=8):
     }
 
 
-def decode_inclusive(eng, frames_dev, boxes_dev, steps=8, quality=95, restart_blocks=0, content=None):
+def decode_inclusive(eng, frames_dev, boxes_dev, steps=24, quality=95, restart_blocks=0, content=None):
     """decode -> labels: the clip as a Motion-JPEG stream (one baseline JPEG per frame, written by libjpeg-turbo at
     OpenCV's defaults: quality 95, 4:2:0) in pinned HOST memory; per clip the compressed bytes cross PCIe and are decoded
     on the device (pa_mjpeg_decode: un-stuffing, self-synchronising Huffman decoding, IDCT, up-sampling, colour

@@ -144,6 +144,52 @@ def test_mjpeg_clip_with_changing_tables(decoder):
 
 
 @pytest.mark.gpu
+def test_mjpeg_groups_streams_and_calls_in_flight():
+    """The decoder's concurrency is invisible in the frames: 1 .. 4 frame groups per call (each on a stream of the
+    handle's own), spans given out of file order, and calls enqueued back to back on two streams without a
+    synchronisation in between (they alternate between the handle's two scratch sets) all give the oracle's frames."""
+    import torch
+
+    from oracle import jpeg
+
+    h, w = 360, 640
+    frames = synth.make_frames(13, h, w)
+    clips = []
+    for c in range(2):
+        blobs = []
+        for i, f in enumerate(frames if c == 0 else frames[::-1]):
+            kw = [dict(quality=95), dict(quality=70, restart_marker_blocks=11), dict(quality=90, optimize=True)][(i + c) % 3]
+            blobs += synth.encode_jpeg_frames([f], **kw)
+        order = np.random.default_rng(5 + c).permutation(len(blobs))       # frame f of the call = file order[f]
+        sizes = np.array([len(b) for b in blobs])
+        ends = np.cumsum(sizes)
+        spans = np.stack([ends - sizes, ends], axis=1)[order]
+        data = torch.from_numpy(np.frombuffer(b"".join(blobs), np.uint8).copy()).pin_memory()
+        want = np.stack([jpeg.decode_bgr(blobs[j]) for j in order])
+        clips.append((data, spans, want))
+    dec = video.MjpegDecoder(16, h, w, 8 << 20)
+    try:
+        for groups in (1, 2, 3, 4):
+            dec.set_groups(groups)
+            streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+            outs, sts = [], []
+            for k in range(6):  # six calls in flight, two clips, two caller streams
+                data, spans, _ = clips[k % 2]
+                with torch.cuda.stream(streams[k % 2]):
+                    st = torch.zeros(13, dtype=torch.int32, device="cuda")
+                    outs.append(dec.decode(data, spans, h, w, status=st))
+                    sts.append(st)
+            torch.cuda.synchronize()
+            for k in range(6):
+                assert int(sts[k].abs().sum()) == 0, (groups, k)
+                assert np.array_equal(outs[k].cpu().numpy(), clips[k % 2][2]), (groups, k)
+        with pytest.raises(Exception):
+            dec.set_groups(5)
+    finally:
+        dec.close()
+
+
+@pytest.mark.gpu
 def test_mjpeg_errors_are_reported(decoder):
     from PIL import Image
 
