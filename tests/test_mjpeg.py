@@ -190,6 +190,43 @@ def test_mjpeg_groups_streams_and_calls_in_flight():
 
 
 @pytest.mark.gpu
+def test_mjpeg_full_size_clip():
+    """BASELINE.json configs[1]'s clip as the decoder meets it in ``bench.py``: 64 x 1080p frames at OpenCV's defaults in
+    one call. Every frame equals the oracle (all 64: the oracle takes 0.8 s per frame), no frame is flagged, the call equals
+    its frames decoded one at a time (batch composition, groups and subsequence sizing do not enter the result), and the
+    decoded clip is the source clip up to JPEG's loss."""
+    import torch
+
+    from oracle import jpeg
+
+    n, h, w = 64, 1080, 1920
+    frames = synth.make_frames(n, h, w)
+    blobs = synth.encode_jpeg_frames(frames, quality=95)
+    sizes = np.array([len(b) for b in blobs])
+    ends = np.cumsum(sizes)
+    spans = np.stack([ends - sizes, ends], axis=1)
+    data = torch.from_numpy(np.frombuffer(b"".join(blobs), np.uint8).copy()).pin_memory()
+    dec = video.MjpegDecoder(n, h, w, int(ends[-1]) + 4096)
+    try:
+        st = torch.zeros(n, dtype=torch.int32, device="cuda")
+        out = dec.decode(data, spans, h, w, status=st)
+        torch.cuda.synchronize()
+        assert int(st.abs().sum()) == 0
+        got = out.cpu().numpy()
+        for i in range(n):
+            assert np.array_equal(got[i], jpeg.decode_bgr(blobs[i])), i
+        one = torch.empty((1, h, w, 3), dtype=torch.uint8, device="cuda")
+        for i in (0, 31, 63):
+            dec.decode(data, spans[i:i + 1], h, w, out=one)
+            torch.cuda.synchronize()
+            assert torch.equal(one[0], out[i]), i
+        d = got[::8].astype(np.float64) - frames[::8]
+        assert 10 * np.log10(255.0 ** 2 / (d * d).mean()) > 28.0
+    finally:
+        dec.close()
+
+
+@pytest.mark.gpu
 def test_mjpeg_errors_are_reported(decoder):
     from PIL import Image
 
