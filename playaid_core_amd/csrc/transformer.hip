@@ -108,6 +108,8 @@ struct pa_encoder {
     int in_dim = 0, hidden = 0, slots = 0, enc_dim = 0, heads = 0, layers = 0, ff = 0, actions = 0, max_rows = 0, D = 0;
     float* weights = nullptr;
     float *ffn_w = nullptr, *ffn_b = nullptr, *enc = nullptr, *cls_w = nullptr, *cls_b = nullptr;
+    float* ffn_pad = nullptr;  // [D][in_dim] + [D]: the front projection with zero rows for the encoding's columns, so that its
+                               // N is whole matrix tiles (247 -> 256) and it runs on the MFMA kernel; append_encoding overwrites them
     struct Layer { float *in_w, *in_b, *out_w, *out_b, *l1_w, *l1_b, *l2_w, *l2_b, *n1_g, *n1_b, *n2_g, *n2_b; };
     std::vector<Layer> layer;
     float *x = nullptr, *qkv = nullptr, *att = nullptr, *y = nullptr, *f1 = nullptr;
@@ -177,6 +179,13 @@ int pa_encoder_create(int32_t device, int32_t in_dim, int32_t hidden_dim, int32_
     }
     h->cls_w = take((size_t)num_actions * Dz);
     h->cls_b = take(num_actions);
+    if (enc_dim > 0 && hidden_dim % 64 != 0 && D % 64 == 0) {
+        const size_t nf = Dz * in_dim + Dz;
+        if (!chk(hipMalloc(&h->ffn_pad, nf * sizeof(float)), "hipMalloc padded projection")) return PA_ERR_HIP;
+        if (!chk(hipMemset(h->ffn_pad, 0, nf * sizeof(float)), "hipMemset")) return PA_ERR_HIP;
+        if (!chk(hipMemcpy(h->ffn_pad, h->ffn_w, (size_t)hidden_dim * in_dim * sizeof(float), hipMemcpyDeviceToDevice), "copy projection")) return PA_ERR_HIP;
+        if (!chk(hipMemcpy(h->ffn_pad + Dz * in_dim, h->ffn_b, (size_t)hidden_dim * sizeof(float), hipMemcpyDeviceToDevice), "copy projection bias")) return PA_ERR_HIP;
+    }
     const size_t R = max_rows;
     if (!chk(hipMalloc(&h->x, R * Dz * sizeof(float)), "hipMalloc x")) return PA_ERR_HIP;
     if (!chk(hipMalloc(&h->qkv, R * 3 * Dz * sizeof(float)), "hipMalloc qkv")) return PA_ERR_HIP;
@@ -189,6 +198,7 @@ int pa_encoder_create(int32_t device, int32_t in_dim, int32_t hidden_dim, int32_
 void pa_encoder_destroy(pa_encoder* h) {
     if (!h) return;
     (void)hipFree(h->weights);
+    (void)hipFree(h->ffn_pad);
     (void)hipFree(h->x);
     (void)hipFree(h->qkv);
     (void)hipFree(h->att);
@@ -211,7 +221,8 @@ int pa_encoder_forward(pa_encoder* h, const float* feats, int32_t ld, int32_t se
         hipError_t e__ = (call);                                                                      \
         if (e__ != hipSuccess) { h->last_error = std::string(#call) + ": " + hipGetErrorString(e__); return PA_ERR_HIP; } \
     } while (0)
-    EN_HIP(pa::launch_linear_f32(feats, ld, h->ffn_w, h->ffn_b, h->x, D, R, h->hidden, h->in_dim, 0, s));
+    if (h->ffn_pad) EN_HIP(pa::launch_linear_f32(feats, ld, h->ffn_pad, h->ffn_pad + (size_t)D * h->in_dim, h->x, D, R, D, h->in_dim, 0, s));
+    else EN_HIP(pa::launch_linear_f32(feats, ld, h->ffn_w, h->ffn_b, h->x, D, R, h->hidden, h->in_dim, 0, s));
     if (h->enc_dim > 0) {
         const int total = R * h->enc_dim;
         hipLaunchKernelGGL(pa::append_encoding_kernel, dim3((total + 255) / 256), dim3(256), 0, s, h->x, h->enc, R, batch, D, h->hidden, h->enc_dim);
