@@ -399,13 +399,20 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
     uint32_t x_state = 0;
     int x_blk = 0;
     bool gen = false;
-    const bool stamp = blockIdx.x == 0 && f == 0 && tid < 64;
-    const unsigned long long c0 = clock64(), w0t = wall_clock64();
+    // diagnostics: only the first wave of the first frame reads the clocks (s_memtime + a wait in every wave's slow step
+    // was 2 % of a pass)
+    const bool stamp = __builtin_amdgcn_readfirstlane((int)(blockIdx.x == 0 && f == 0 && tid < 64)) != 0;
+    unsigned long long c0 = 0, w0t = 0;
+    if (stamp) {
+        c0 = clock64();
+        w0t = wall_clock64();
+    }
     int it = 0;
     unsigned long long slow_cyc = 0;
     int outer = 0;
     while (__ballot(active)) {
-        const unsigned long long cs = clock64();
+        unsigned long long cs = 0;
+        if (stamp) cs = clock64();
         ++outer;
         // ---- the slow step: ring top-up, restart markers, end of the subsequence, symbols the fast loop does not take
         if (MODE == 2 && absblk >= total_blocks) active = false;  // what follows the last block is padding
@@ -501,7 +508,7 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
         // ---- the fast loop: straight-line code, every lane; left as soon as one active lane meets anything else.
         // A symbol is two LDS round trips -- the window's two dwords from the ring, then the two table look-ups side by
         // side -- and some sixty instructions; the passes are bound by instruction issue, not by those latencies.
-        slow_cyc += clock64() - cs;
+        if (stamp) slow_cyc += clock64() - cs;
         for (int k = 0; k < TOPUP; ++k, ++it) {
             const uint32_t win = window();
             const bool dc = z == 0;
