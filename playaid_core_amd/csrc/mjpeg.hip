@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
                 const bool dc = z == 0;
                 const uint32_t t = table_row(dc, b);
                 uint32_t e = T.lut1[t][win >> (32 - LB)];
-                if (e == 0 && (win >> 26) == 63) e = T.lutB[t][(win >> (26 - LB)) & ((1 << LB) - 1)];
+                if (e == 0 && !dc && (win >> 26) == 63) e = T.lutB[t][(win >> (26 - LB)) & ((1 << LB) - 1)];
                 int len = e & 31, s = (e >> 5) & 15, adv = e >> 9;
                 bool invalid = false;
                 if (e == 0) {  // canonical search (T.81 F.2.2.3)
@@ -509,19 +509,31 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
         // A symbol is two LDS round trips -- the window's two dwords from the ring, then the two table look-ups side by
         // side -- and some sixty instructions; the passes are bound by instruction issue, not by those latencies.
         if (stamp) slow_cyc += clock64() - cs;
-        for (int k = 0; k < TOPUP; ++k, ++it) {
+#pragma unroll
+        for (int k = 0; k < TOPUP; ++k, ++it) {  // (`it` counts steps: a pair is one)
             const uint32_t win = window();
             const bool dc = z == 0;
             const uint32_t tb = table_row(dc, b) << LB;
             uint32_t eA = lut1[tb + (win >> (32 - LB))];
             uint32_t eB = lutB[tb + ((win >> (26 - LB)) & ((1 << LB) - 1))];
-            asm volatile("" : "+v"(eA), "+v"(eB));  // both look-ups in flight together, not the second behind a branch
-            const uint32_t e = eA ? eA : ((win >> 26) == 63 ? eB : 0u);
-            const int len = e & 31, s = (e >> 5) & 15, adv = e >> 9;
-            const int use = len + s;
+            // passes A / verify: the AC table's pair entry for these ten bits (lutB row = AC table number)
+            uint32_t eP = MODE != 2 ? lutB[(tb & (1u << LB)) + (win >> (32 - LB))] : 0u;
+            asm volatile("" : "+v"(eA), "+v"(eB), "+v"(eP));  // the look-ups in flight together, none behind a branch
+            const uint32_t e = eA ? eA : (!dc && (win >> 26) == 63 ? eB : 0u);
+            const int len = e & 31, s = (e >> 5) & 15;
+            int adv = e >> 9, use = len + s;
+            // two symbols in one step where the pair neither ends the block nor reaches the end of the subsequence / a
+            // restart boundary (the exit state is taken at the FIRST symbol boundary behind the end)
+            // (bitwise, not short-circuit: hipcc turns && chains over lane values into exec-mask branches)
+            const int p_use = (int)(eP & 15), p_adv = (int)((eP >> 4) & 63), p_eob = (int)((eP >> 4) & 64);
+            const bool pair = (MODE != 2) & !dc & ((eP >> 15) != 0) & (z + p_adv < 64) & (bitpos + (uint32_t)p_use < lim);
+            if (MODE != 2) {
+                use = pair ? p_use : use;
+                adv = pair ? p_adv + p_eob : adv;  // (an EOB behind the coefficients ends the block: index beyond 64)
+            }
             const uint32_t np = bitpos + use;
             const int zn = z + adv;  // DC: 1 | coefficient: past its zero run and itself | ZRL: + 16 | EOB: beyond 64
-            const bool rare = bitpos >= lim || e == 0 || np > nb_bits || (zn > 64 && adv < 64);
+            const bool rare = !pair & ((bitpos >= lim) | (e == 0) | (np > nb_bits) | ((zn > 64) & (adv < 64)));
             if (__builtin_amdgcn_ballot_w64(active && rare) != 0) {
                 gen = rare && bitpos < lim;
                 break;
@@ -1069,8 +1081,10 @@ void build_hufftab(HuffTables& T, int t, const uint8_t* counts, const uint8_t* s
             if (l <= LB) {
                 const int lo = code << (LB - l), hi = (code + 1) << (LB - l);
                 for (int e = lo; e < hi; ++e) T.lut1[t][e] = entry(l, syms[k]);
-            } else if ((code >> (l - 6)) == 63) {
-                // six leading 1-bits: found under bits 6 .. 6 + LB - 1 of the window
+            } else if (!dc && (code >> (l - 6)) == 63) {
+                // six leading 1-bits: found under bits 6 .. 6 + LB - 1 of the window (AC tables only: rows 0 / 1 of
+                // lutB hold the AC tables' PAIR entries, see below; a DC code of more than LB bits -- a difference
+                // of 1024 or more -- takes the canonical search)
                 const int rest = l - 6;  // <= 10 bits after them
                 const int lo = (code & ((1 << rest) - 1)) << (LB - rest), hi = lo + (1 << (LB - rest));
                 for (int e = lo; e < hi; ++e) T.lutB[t][e] = entry(l, syms[k]);
@@ -1082,6 +1096,27 @@ void build_hufftab(HuffTables& T, int t, const uint8_t* counts, const uint8_t* s
     T.maxcode[t][17] = 0x7fffffff;
     T.maxcode[t][0] = -1;
     T.valoff[t][0] = 0;
+    if (!dc) {
+        // PAIR entries of AC table t - 2 (lutB row t - 2): where the first LB bits of the window hold TWO whole symbols
+        // (code + extra bits each) -- a coefficient or ZRL, then a coefficient, ZRL or EOB -- the entry gives what they
+        // consume and how far they move the zig-zag index together: bit 15 set, bits 0-3 total bits (2 .. 10), bits 4-9
+        // the advance of the coefficients / ZRLs (1 .. 32), bit 10: the second symbol is EOB. The passes that only look
+        // for the decoder state (A, verify) take such a pair in one step.
+        uint16_t* pair = T.lutB[t - 2];
+        for (int w = 0; w < (1 << LB); ++w) {
+            pair[w] = 0;
+            const uint16_t e1 = T.lut1[t][w];
+            if (!e1) continue;
+            const int use1 = (e1 & 31) + ((e1 >> 5) & 15), adv1 = e1 >> 9;
+            if (use1 >= LB || adv1 >= 64) continue;
+            const uint16_t e2 = T.lut1[t][(w << use1) & ((1 << LB) - 1)];
+            if (!e2) continue;
+            const int use2 = (e2 & 31) + ((e2 >> 5) & 15), adv2 = e2 >> 9;
+            if (use1 + use2 > LB) continue;
+            pair[w] = adv2 >= 64 ? (uint16_t)(0x8000 | 0x400 | (use1 + use2) | (adv1 << 4))
+                                 : (uint16_t)(0x8000 | (use1 + use2) | ((adv1 + adv2) << 4));
+        }
+    }
 }
 
 }  // namespace mj
