@@ -7,10 +7,11 @@
 // replication (jdsample.c h2v2 / h2v1, jdmainct.c), YCbCr -> RGB (jdcolor.c). Bit-exact against oracle/jpeg.py::decode,
 // which is pinned byte for byte against PIL.Image.open (live libjpeg-turbo).
 //
-// Pipeline per call (all on the caller's stream):
+// Pipeline per call (a call's frames go in GROUPS, each on a stream of the handle's own; see struct pa_mjpeg):
 //   host : marker segments of every frame (SOF0/SOF1, DQT, DHT, DRI, SOS) -> frame descriptors + Huffman / quantisation
 //          table sets (consecutive frames with identical tables share one set)
-//   copy : the compressed bytes, the descriptors and the table sets, host -> HBM
+//   copy : the compressed bytes of each group (a copy stream that never waits); descriptors and table sets by
+//          stage_copy_kernel out of the pinned staging buffers
 //   unstuff_count_kernel / unstuff_write_kernel : the CLEAN stream of every frame (stuffed zeros and RSTm markers taken
 //                  out, restart positions recorded)
 //   sub_decode_kernel<0|1> + sub_verify_plan_kernel : one lane per subsequence of the clean stream finds the decoder
@@ -21,7 +22,7 @@
 //   dc_scan_kernel : DC differences -> DC coefficients (running sums per component, from zero at every restart interval)
 //   idct_kernel  : one thread per 8x8 block of the component rasters gathers its block from the scan-order buffer
 //                  (de-zig-zag by constant indices), block in registers -> uint8 sample planes (padded to whole MCUs)
-//   ycc_kernel   : up-sampling + colour conversion, 8 pixels x FV rows per thread, 8-byte stores
+//   ycc420_kernel / ycc_kernel : up-sampling + colour conversion, 8 pixels x 4 (4:2:0) or FV rows per thread, 8-byte stores
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -506,8 +507,8 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
             }
         }
         // ---- the fast loop: straight-line code, every lane; left as soon as one active lane meets anything else.
-        // A symbol is two LDS round trips -- the window's two dwords from the ring, then the two table look-ups side by
-        // side -- and some sixty instructions; the passes are bound by instruction issue, not by those latencies.
+        // A step is two LDS round trips -- the window's two dwords from the ring, then the table look-ups side by side
+        // -- and some seventy vector instructions; the passes are bound by instruction issue, not by those latencies.
         if (stamp) slow_cyc += clock64() - cs;
 #pragma unroll
         for (int k = 0; k < TOPUP; ++k, ++it) {  // (`it` counts steps: a pair is one)
