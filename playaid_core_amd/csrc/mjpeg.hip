@@ -656,8 +656,8 @@ __global__ __launch_bounds__(1024) void sub_scan_kernel(const FrameDesc* __restr
 // the component's blocks in scan order, starting again from zero at every restart interval (T.81 F.2.1.3.1 / F.2.2.4).
 // One workgroup per (frame, component); every thread owns a run of consecutive blocks of the component.
 __global__ __launch_bounds__(1024) void dc_scan_kernel(int16_t* __restrict__ dc, const FrameDesc* __restrict__ fd, const Geom g) {
-    __shared__ int sh_sum[1024];
-    __shared__ int sh_flag[1024];
+    __shared__ int w_sum[16];
+    __shared__ int w_flag[16];
     const int f = blockIdx.x + g.f0, c = blockIdx.y, tid = threadIdx.x;
     if (c >= g.ncomp) return;
     const int bpm = g.blocks_per_mcu;
@@ -673,26 +673,30 @@ __global__ __launch_bounds__(1024) void dc_scan_kernel(int16_t* __restrict__ dc,
     int16_t* __restrict__ p = dc + (size_t)f * mcus * bpm + b0;
     const int per = (n + 1023) / 1024;
     const int lo = min(tid * per, n), hi = min(lo + per, n);
-    // a thread's run, eight blocks at a time: the eight loads are in flight together (one after the other they cost a
+    // a thread's run, sixteen blocks at a time: the sixteen loads are in flight together (one after the other they cost a
     // memory latency each, 2 x 32 of them for the luma of a 1080p frame)
+    constexpr int DCB = 16;  // loads in flight per thread
     auto walk = [&](int& run, int& flag, bool store) {
         int mcu = lo / nbc, t = lo - mcu * nbc;
-        for (int k0 = lo; k0 < hi; k0 += 8) {
-            int idx[8], val[8];
-            bool rst[8];
+        int in_ri = ri > 0 ? mcu % ri : 1;  // MCU's place in its restart interval, kept by counting (a modulo per block was
+                                            // most of this kernel's instructions); without restart markers never 0
+        for (int k0 = lo; k0 < hi; k0 += DCB) {
+            int idx[DCB], val[DCB];
+            bool rst[DCB];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < DCB; ++i) {
                 idx[i] = mcu * bpm + t;
-                rst[i] = t == 0 && ri > 0 && mcu % ri == 0;
+                rst[i] = t == 0 && in_ri == 0;
                 if (++t == nbc) {
                     t = 0;
                     ++mcu;
+                    if (ri > 0 && ++in_ri == ri) in_ri = 0;
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) val[i] = k0 + i < hi ? (int)p[idx[i]] : 0;
+            for (int i = 0; i < DCB; ++i) val[i] = k0 + i < hi ? (int)p[idx[i]] : 0;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < DCB; ++i) {
                 if (k0 + i < hi) {
                     if (rst[i]) {
                         run = 0;
@@ -706,24 +710,32 @@ __global__ __launch_bounds__(1024) void dc_scan_kernel(int16_t* __restrict__ dc,
     };
     int run = 0, flag = 0;
     walk(run, flag, false);
-    sh_sum[tid] = run;
-    sh_flag[tid] = flag;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {  // segmented inclusive scan: a run with a restart inside forgets what precedes it
-        int vs = 0, vf = 0;
-        const bool has = tid >= o;
-        if (has) {
-            vs = sh_sum[tid - o];
-            vf = sh_flag[tid - o];
+    // segmented inclusive scan of the threads' (sum, restart seen): a run with a restart inside forgets what precedes
+    // it. Inside a wave by lane shuffles, across the sixteen waves through LDS: one barrier (twenty of them, ten scan steps
+    // over 1024 threads, were most of this kernel's 54 us).
+    const int lane = tid & 63, wave = tid >> 6;
+    int ssum = run, sflag = flag;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int vs = __shfl_up(ssum, o), vf = __shfl_up(sflag, o);
+        if (lane >= o && !sflag) {
+            ssum += vs;
+            sflag = vf;
         }
-        __syncthreads();
-        if (has && !sh_flag[tid]) {
-            sh_sum[tid] += vs;
-            sh_flag[tid] = vf;
-        }
-        __syncthreads();
     }
-    run = tid > 0 ? sh_sum[tid - 1] : 0;
+    if (lane == 63) {
+        w_sum[wave] = ssum;
+        w_flag[wave] = sflag;
+    }
+    __syncthreads();
+    int psum = 0;  // what the waves before this one leave
+    for (int w = 0; w < wave; ++w) psum = w_flag[w] ? w_sum[w] : psum + w_sum[w];
+    int esum = __shfl_up(ssum, 1), eflag = __shfl_up(sflag, 1);  // exclusive: the lanes before this one
+    if (lane == 0) {
+        esum = 0;
+        eflag = 0;
+    }
+    run = eflag ? esum : psum + esum;
     walk(run, flag, true);
 }
 
