@@ -19,11 +19,16 @@ ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--variants", default="none,rows1,blk30,blk8,blk2")
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--noise-mask", type=int, default=31, help="amplitude mask of the clip's per-sample noise (31 = the headline's clip, 7 = camera-like)")
+ap.add_argument("--host-synth", action="store_true", help="generate the clip with numpy on the host (rocprofv3 counter passes do not get through the torch integer kernels of the device generator)")
 ap.add_argument("--streams", type=int, default=1, help="decoders working at once, each on a stream of its own (calls alternate)")
 ap.add_argument("--rounds", type=int, default=-1, help="verify passes enqueued per call (default: the library's)")
 args = ap.parse_args()
 n, h, w = args.frames, args.height, args.width
-frames = synth.make_frames_torch(n, h, w, device="cuda", noise_mask=args.noise_mask, fine_mask=min(args.noise_mask, 15)).cpu().numpy()
+if args.host_synth:
+    assert args.noise_mask == 31, "the host generator makes the headline's clip only"
+    frames = synth.make_frames(n, h, w)
+else:
+    frames = synth.make_frames_torch(n, h, w, device="cuda", noise_mask=args.noise_mask, fine_mask=min(args.noise_mask, 15)).cpu().numpy()
 for var in args.variants.split(","):
     kw = {}
     if var.startswith("rows"):
