@@ -731,6 +731,9 @@ def main():
                 result["roofline_preprocess"] = {
                     "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(gbs / PEAK_HBM_GBS, 4),
+                    "note": "the stage's compulsory bytes against HBM, as the contract asks; by the counters (profiles/r03_crop_pmc_per_kernel.txt, "
+                            "committed rocprofv3 PMC pass at configs[1]) the fused crop kernel is bound by vector issue -- 0.64 of the VALU slots "
+                            "over the whole launch -- and moves 0.86 TB/s",
                 }
         if world == 1 and not long_clip and not args.no_pcie:
             result["pcie_inclusive"] = pcie_inclusive(eng, frames[:n_clip], boxes[:n_clip])
