@@ -454,6 +454,29 @@ def clip_batch_side(eng, n_clip, kb, height, width, S, delta, lanes_n, clips=160
         big.close()
 
 
+def _free_port():
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(argv, gpus, run=None):
+    """`python bench.py --gpus N` without torch.distributed.run around it: start the N ranks as a CHILD process
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`), wait, and return its exit
+    code. Called before this process has made any GPU call -- it never execs, and it never touches the device itself; rank 0 of
+    the child prints the one JSON line on the inherited stdout."""
+    import subprocess
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return (run or subprocess.call)(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -506,9 +529,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(sys.argv[1:], args.gpus))   # (nothing above has touched the GPU)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        sys.exit(f"bench.py --gpus {args.gpus} inside a torch.distributed.run of {world} rank(s): the two must agree")
     dev_index = local_rank % max(torch.cuda.device_count(), 1)  # (== local_rank on a real N-GPU node)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)

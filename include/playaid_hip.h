@@ -238,6 +238,10 @@ const char* pa_detector_last_error(const pa_detector* h);
 int pa_detector_rows(const pa_detector* h); /* rows of pred per image: 3 x sum over the decode layers of in_h x in_w */
 /* frames uint8[n,H,W,3] BGR (device) -> pred float32[n][rows][5 + nc] (device). */
 int pa_detector_forward(pa_detector* h, const uint8_t* frames, int32_t n, int32_t height, int32_t width, float* pred, void* stream);
+/* Measurement aid: the same call with a HIP event between the table's layers; layer_us[i] (host, cap >= n_layers) = microseconds
+ * layer i took on `stream`. Synchronises the stream. */
+int pa_detector_forward_timed(pa_detector* h, const uint8_t* frames, int32_t n, int32_t height, int32_t width, float* pred, void* stream,
+                              float* layer_us, int32_t cap);
 
 /* Replaces AIRunner.clean_yolo_crops / clean_yolo_crops_for_fighter (ai_runner.py:226-289, 306-424) on the table
  * pa_detect_postprocess wrote (dets float32[n_labels][max_det][6], counts int32[n_labels]; label n = index n - 1), with no

@@ -121,6 +121,7 @@ SYMBOLS = [
     ("pa_detector_last_error", C.c_char_p, [_P]),
     ("pa_detector_rows", C.c_int, [_P]),
     ("pa_detector_forward", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    ("pa_detector_forward_timed", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32]),
     ("pa_clean_detections", C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
     ("pa_save_one_box_crops", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int32, _P, _P, C.c_int32, C.c_int32, _P,
                                         C.c_size_t, _P, _P]),

@@ -273,7 +273,8 @@ int pa_detector_create(int32_t device, const pa_net_layer* layers, int32_t n_lay
     return PA_OK;
 }
 
-int pa_detector_forward(pa_detector* h, const uint8_t* frames, int32_t n, int32_t height, int32_t width, float* pred, void* stream) {
+static int detector_run(pa_detector* h, const uint8_t* frames, int32_t n, int32_t height, int32_t width, float* pred, void* stream,
+                        std::vector<hipEvent_t>* ev) {
     if (!h) return PA_ERR_INVALID_ARG;
     auto fail = [&](int code, const std::string& msg) { h->last_error = msg; return code; };
     if (!frames || !pred || n < 1 || height < 1 || width < 1) return fail(PA_ERR_INVALID_ARG, "pa_detector_forward: bad argument");
@@ -298,6 +299,7 @@ int pa_detector_forward(pa_detector* h, const uint8_t* frames, int32_t n, int32_
     int row0 = 0, di = 0;
     for (size_t li = 0; li < h->layers.size(); ++li) {
         const pa_net_layer& L = h->layers[li];
+        if (ev) DT_HIP(hipEventRecord((*ev)[li], s));  // (profiling call only: layer li runs between events li and li + 1)
         if (L.kind == 3) {
             // the 6x6 / 2 stem as an implicit GEMM: one tap per kernel row, its K chunk = 8 consecutive NHWC4 pixels of
             // the letter-boxed image (kx 6, 7 and channel 3 meet zero weights), K = 6 x 32
@@ -383,8 +385,30 @@ int pa_detector_forward(pa_detector* h, const uint8_t* frames, int32_t n, int32_
         const hipError_t pe = pa::launch_igemm(p, tile, s);
         if (pe != hipSuccess) return fail(PA_ERR_HIP, "layer " + std::to_string(li) + ": " + hipGetErrorString(pe));
     }
+    if (ev) DT_HIP(hipEventRecord(ev->back(), s));
 #undef DT_HIP
     return PA_OK;
+}
+
+int pa_detector_forward(pa_detector* h, const uint8_t* frames, int32_t n, int32_t height, int32_t width, float* pred, void* stream) {
+    return detector_run(h, frames, n, height, width, pred, stream, nullptr);
+}
+
+int pa_detector_forward_timed(pa_detector* h, const uint8_t* frames, int32_t n, int32_t height, int32_t width, float* pred, void* stream,
+                              float* layer_us, int32_t cap) {
+    if (!h || !layer_us || cap < (int32_t)h->layers.size()) return PA_ERR_INVALID_ARG;
+    std::vector<hipEvent_t> ev(h->layers.size() + 1);
+    for (hipEvent_t& e : ev)
+        if (hipEventCreate(&e) != hipSuccess) return PA_ERR_HIP;
+    int rc = detector_run(h, frames, n, height, width, pred, stream, &ev);
+    if (rc == PA_OK && hipEventSynchronize(ev.back()) != hipSuccess) rc = PA_ERR_HIP;
+    for (size_t i = 0; rc == PA_OK && i < h->layers.size(); ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) != hipSuccess) rc = PA_ERR_HIP;
+        layer_us[i] = ms * 1000.f;
+    }
+    for (hipEvent_t& e : ev) (void)hipEventDestroy(e);
+    return rc;
 }
 
 }  // extern "C"
