@@ -19,6 +19,7 @@ ARCH = "gfx950"
 # bit-for-bit and must not have its multiplies and adds fused.
 SOURCES = [
     ("igemm.hip", []),
+    ("pigemm.hip", []),
     ("igemm_bf16.hip", []),
     ("patchconv.hip", []),
     ("patchconv_bf16.hip", []),

@@ -1147,6 +1147,7 @@ struct pa_mjpeg {
     size_t max_bytes = 0;
     size_t max_blocks = 0;      // per frame
     size_t max_subs = 0, max_segs = 0;
+    size_t clean_bytes = 0;     // size of a set's clean stream
     int max_chunks_cap = 0;
     int sync_rounds = 8;
     int sub_shift_override = 0;  // tuning: log2 of the subsequence size, 0 = chosen from the stream
@@ -1260,6 +1261,7 @@ int pa_mjpeg_create(int32_t device, int32_t max_frames, int32_t max_height, int3
     h->max_subs = max_bytes / SUB_MIN + 2 * n + 2;
     h->max_segs = n * bw * bh + n;
     const size_t clean_bytes = max_bytes + 32 * n + 4096;
+    h->clean_bytes = clean_bytes;
     if (const char* e = getenv("PA_MJPEG_GROUPS")) h->groups = atoi(e);  // tuning knob (scripts/mjpeg_rate.py)
     h->groups = h->groups < 1 ? 1 : (h->groups > MAX_GROUPS ? MAX_GROUPS : h->groups);
     for (auto& S : h->set) {
@@ -1491,6 +1493,9 @@ int pa_mjpeg_decode(pa_mjpeg* h, const uint8_t* data_host, const int64_t* spans_
     const int max_chunks = (int)(max_scan / CHUNK) + 2;
     if (max_chunks > h->max_chunks_cap) return bad(PA_ERR_CAPACITY, "pa_mjpeg_decode: scan longer than the handle's chunk table");
     if (seg_total > h->max_segs || sub_total > h->max_subs) return bad(PA_ERR_CAPACITY, "pa_mjpeg_decode: more restart intervals / subsequences than the handle holds");
+    // spans may overlap or repeat (the same frame several times): what bounds the clean stream is the SUM of the scans, not
+    // the byte range the spans cover
+    if (clean_total + 4096 > h->clean_bytes) return bad(PA_ERR_CAPACITY, "pa_mjpeg_decode: the frames' entropy-coded segments add up to more than max_bytes");
     pa_mjpeg::Set& S = h->set[k];
     // exact mode looks at flags on the host between passes: one group, on the caller's stream
     const int G = h->sync_rounds > 0 ? (h->groups < n ? h->groups : n) : 1;

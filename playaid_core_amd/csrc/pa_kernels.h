@@ -56,6 +56,9 @@ struct GemmParams {
 enum GemmTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x64 = 2, TILE_128x64_K64 = 3, TILE_64x64_K64 = 4 };
 
 hipError_t launch_igemm(const GemmParams& p, GemmTile tile, hipStream_t s);
+// persistent form of the same engine for short tiles (pigemm.hip): conv mode, no residual / second source / split-K;
+// bm = 128 | 64, 64 output channels per tile; results bit-identical to launch_igemm
+hipError_t launch_pgemm(const GemmParams& p, int bm, hipStream_t s);
 // bf16 activations / weights (uint16_t storage behind the float* fields, every count in elements),
 // f32 accumulate on v_mfma_f32_32x32x16_bf16; conv mode only (igemm_bf16.hip)
 hipError_t launch_igemm_bf16(const GemmParams& p, GemmTile tile, hipStream_t s);

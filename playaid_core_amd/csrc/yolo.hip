@@ -7,9 +7,10 @@
 // buffer (offset + pixel pitch), which is how the network's concatenations cost nothing: the producers write straight
 // into their slice of the consumer's input. Kinds:
 //   0  convolution 1x1 | 3x3, stride 1 | 2, + bias, activation (none / ReLU / SiLU), residual before or after it
-//      (implicit GEMM on the matrix cores, igemm.hip; cin % 32 == 0, cout % 64 == 0: the table pads with zero weights)
-//   3  the 6x6 / 2 stem on the letter-boxed RGB image + bias + SiLU: the same GEMM kernel, one tap per kernel row whose K
-//      chunk is 8 consecutive NHWC4 pixels (weights [cout][6][8 px][4 ch], kx >= 6 and channel 3 zero)
+//      (implicit GEMM on the matrix cores; cin % 32 == 0, cout % 64 == 0: the table pads with zero weights). Layers without
+//      a residual -- every 1x1 and stride-2 convolution -- run on the persistent engine (pigemm.hip), the others on igemm.hip
+//   3  the 6x6 / 2 stem (3 -> 32 channels) on the letter-boxed RGB image + bias + SiLU: a direct convolution on the matrix
+//      cores with K = 108 exactly (stem6x6_direct_kernel below; weights in its lane layout [64][56])
 //   4  max-pool 5x5 / 1 (SPPF), slice to slice
 //   5  nearest-neighbour 2x up-sampling, slice to slice
 //   6  Detect decode of one scale: sigmoid, grid / anchor arithmetic -> rows (cx, cy, w, h, obj, classes) in net pixels
@@ -17,6 +18,7 @@
 // the un-padded size, a 114-grey border up to the network input (a multiple of 32), BGR -> RGB, / 255.
 #include "pa_kernels.h"
 #include "../../include/playaid_hip.h"
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -122,28 +124,120 @@ __global__ __launch_bounds__(256) void upsample2_kernel(const float* __restrict_
 }
 
 // models/yolo.py Detect.forward (inference): y = sigmoid(conv out); xy = (y * 2 + grid) * stride with grid = index - 0.5;
-// wh = (y * 2)^2 * anchor; rows of one scale in (anchor, y, x) order at row0.
+// wh = (y * 2)^2 * anchor; rows of one scale in (anchor, y, x) order at row0. One thread per output VALUE: consecutive
+// threads write consecutive floats of pred and read runs of `no` consecutive channels.
 __global__ __launch_bounds__(256) void detect_decode_kernel(const float* __restrict__ in, SliceGeom gi, int n, int na, int no, float stride,
                                                             const float* __restrict__ anchors_px, float* __restrict__ pred, int rows_total,
                                                             int row0) {
-    const long long total = (long long)n * na * gi.h * gi.w;
+    const long long total = (long long)n * na * gi.h * gi.w * no;
     for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
         long long r = t;
+        const int k = (int)(r % no);
+        r /= no;
         const int x = (int)(r % gi.w);
         r /= gi.w;
         const int y = (int)(r % gi.h);
         r /= gi.h;
         const int a = (int)(r % na), img = (int)(r / na);
-        const float* v = in + px_off(gi, img, y, x) + a * no;
-        float* o = pred + ((size_t)img * rows_total + row0 + ((size_t)a * gi.h + y) * gi.w + x) * no;
-        for (int k = 0; k < no; ++k) {
-            const float s = 1.f / (1.f + expf(-v[k]));
-            float val = s;
-            if (k == 0) val = (s * 2.f + ((float)x - 0.5f)) * stride;
-            else if (k == 1) val = (s * 2.f + ((float)y - 0.5f)) * stride;
-            else if (k == 2) val = (s * 2.f) * (s * 2.f) * anchors_px[a * 2];
-            else if (k == 3) val = (s * 2.f) * (s * 2.f) * anchors_px[a * 2 + 1];
-            o[k] = val;
+        const float v = in[px_off(gi, img, y, x) + a * no + k];
+        const float s = 1.f / (1.f + expf(-v));
+        float val = s;
+        if (k == 0) val = (s * 2.f + ((float)x - 0.5f)) * stride;
+        else if (k == 1) val = (s * 2.f + ((float)y - 0.5f)) * stride;
+        else if (k == 2) val = (s * 2.f) * (s * 2.f) * anchors_px[a * 2];
+        else if (k == 3) val = (s * 2.f) * (s * 2.f) * anchors_px[a * 2 + 1];
+        pred[((size_t)img * rows_total + row0 + ((size_t)a * gi.h + y) * gi.w + x) * no + k] = val;
+    }
+}
+
+// The 6x6 / 2 stem (models/yolov5s.yaml layer 0: Conv(3, 32, 6, 2, 2) + BatchNorm + SiLU) as a direct convolution on the
+// matrix cores, operands straight from global memory -- no LDS, no barrier. One wave = a strip of 32 output columns x `rows`
+// output rows x all 32 output channels:
+//   * v_mfma_f32_32x32x2_f32 with the WEIGHTS as the row operand (lane = channel) and the pixels as the column operand
+//     (lane = output column); the k pair of a step is (kx = j, kx = 3 + j) of one (ky, channel): lanes 0-31 carry the first,
+//     lanes 32-63 the second. K = 6 ky x 3 j x 3 channels x 2 = 108 exactly -- the im2col form of this layer (igemm.hip, one
+//     8-pixel x 4-channel chunk per kernel row, 64 output channels) executed 384 for the same result;
+//   * a lane's 54 weights stay in registers for the whole kernel ([lane][ky][j][c], laid out by the host);
+//   * per (input row, j) a lane reads ONE NHWC4 pixel (16 bytes: column 2 ox + 3 (lane >> 5) + j) and feeds its three
+//     channels to three matrix instructions; the six input rows of an output row live in an eight-row register window that
+//     slides by two rows per output row (six new 16-byte loads per 54 matrix instructions, issued one output row ahead);
+//   * a lane ends up with ONE output pixel and runs of four consecutive channels: bias + SiLU + four 16-byte stores.
+struct StemDirectParams {
+    const float* x;      // [n][net_h + 4][net_w + 4][4], 2-pixel zero border, channel 3 = 0
+    const float* wlane;  // [64 lanes][56]: W[lane & 31][c][ky][3 * (lane >> 5) + j] at ky * 9 + j * 3 + c
+    const float* bias;   // [32]
+    float* out;          // slice of a zero-bordered NHWC buffer
+    int32_t n, net_h, net_w, oh, ow;
+    int32_t out_px_stride, out_row_stride, out_img_stride, out_pad;
+    int32_t rows, row_blocks, col_blocks;  // rows % 4 == 0
+};
+
+__global__ __launch_bounds__(256, 2) void stem6x6_direct_kernel(const StemDirectParams p) {
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, lr = lane & 31, lh = lane >> 5;
+    const long long strip = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long strips = (long long)p.n * p.row_blocks * p.col_blocks;
+    if (strip >= strips) return;  // (whole waves; the kernel has no barrier)
+    const int cb = (int)(strip % p.col_blocks);
+    const int rb = (int)((strip / p.col_blocks) % p.row_blocks);
+    const int img = (int)(strip / ((long long)p.col_blocks * p.row_blocks));
+    const int ox = cb * 32 + lr, oy0 = rb * p.rows;
+    const int oxc = ox < p.ow ? ox : p.ow - 1;
+    const int in_w = p.net_w + 4, in_h = p.net_h + 4;
+    const float* xin = p.x + ((size_t)img * in_h * in_w + 2 * oxc + 3 * lh) * 4;
+    float w[56];
+    {
+        const f32x4* wl = reinterpret_cast<const f32x4*>(p.wlane + lane * 56);
+#pragma unroll
+        for (int i = 0; i < 14; ++i) {
+            const f32x4 v = wl[i];
+            w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+        }
+    }
+    f32x4 bias4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias4[g] = *reinterpret_cast<const f32x4*>(p.bias + 8 * g + 4 * lh);
+    float* const outp = p.out + (size_t)img * p.out_img_stride + (size_t)(ox + p.out_pad) * p.out_px_stride + 4 * lh;
+
+    f32x4 win[8][3];
+    auto load_row = [&](int slot, int row) {  // input row `row` (clamped: rows past the image feed output rows nobody stores)
+        const int rc = row < in_h ? row : in_h - 1;
+        const float* r = xin + (size_t)rc * in_w * 4;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) win[slot][j] = *reinterpret_cast<const f32x4*>(r + j * 4);
+    };
+#pragma unroll
+    for (int ky = 0; ky < 6; ++ky) load_row(ky, 2 * oy0 + ky);
+    for (int rr = 0; rr < p.rows; rr += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int oy = oy0 + rr + u;
+            // the next output row's two new input rows, into the slots of the two rows this one no longer needs
+            load_row((2 * u + 6) & 7, 2 * oy + 6);
+            load_row((2 * u + 7) & 7, 2 * oy + 7);
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 6; ++ky)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const f32x4 px = win[(2 * u + ky) & 7][j];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ky * 9 + j * 3 + 0], px.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ky * 9 + j * 3 + 1], px.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ky * 9 + j * 3 + 2], px.z, acc, 0, 0, 0);
+                }
+            if (oy < p.oh && ox < p.ow) {
+                float* o = outp + (size_t)(oy + p.out_pad) * p.out_row_stride;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]} + bias4[g];
+                    v.x = v.x / (1.f + expf(-v.x)); v.y = v.y / (1.f + expf(-v.y));
+                    v.z = v.z / (1.f + expf(-v.z)); v.w = v.w / (1.f + expf(-v.w));
+                    *reinterpret_cast<f32x4*>(o + 8 * g) = v;
+                }
+            }
         }
     }
 }
@@ -223,8 +317,9 @@ int pa_detector_create(int32_t device, const pa_net_layer* layers, int32_t n_lay
                 (size_t)L.b_off + L.cout > n_weights)
                 return bad(i, "weights outside the blob");
         } else if (L.kind == 3) {
-            if (L.in_h != net_h || L.in_w != net_w || L.cout % 64 || L.w_off < 0 || (size_t)L.w_off + (size_t)L.cout * 192 > n_weights ||
-                L.b_off < 0 || (size_t)L.b_off + L.cout > n_weights || !slice_ok(L.out_buf, net_h / 2, net_w / 2, L.out_pad, L.out_cstride, L.out_coff, L.cout))
+            if (L.in_h != net_h || L.in_w != net_w || L.cout != 32 || L.w_off < 0 || (size_t)L.w_off + (size_t)64 * 56 > n_weights || (L.w_off & 3) ||
+                L.b_off < 0 || (size_t)L.b_off + L.cout > n_weights || (L.b_off & 3) ||
+                !slice_ok(L.out_buf, net_h / 2, net_w / 2, L.out_pad, L.out_cstride, L.out_coff, L.cout))
                 return bad(i, "bad stem");
         } else if (L.kind == 4 || L.kind == 5) {
             if (L.cin % 4 || !slice_ok(L.in_buf, L.in_h, L.in_w, L.in_pad, L.in_cstride, L.in_coff, L.cin) ||
@@ -301,31 +396,23 @@ static int detector_run(pa_detector* h, const uint8_t* frames, int32_t n, int32_
         const pa_net_layer& L = h->layers[li];
         if (ev) DT_HIP(hipEventRecord((*ev)[li], s));  // (profiling call only: layer li runs between events li and li + 1)
         if (L.kind == 3) {
-            // the 6x6 / 2 stem as an implicit GEMM: one tap per kernel row, its K chunk = 8 consecutive NHWC4 pixels of
-            // the letter-boxed image (kx 6, 7 and channel 3 meet zero weights), K = 6 x 32
             const int oh = h->net_h / 2, ow = h->net_w / 2;
-            pa::GemmParams p;
-            memset(&p, 0, sizeof(p));
-            p.act = h->x0;
-            p.wgt = h->weights + L.w_off;
-            p.bias = h->weights + L.b_off;
-            p.out = h->bufs[L.out_buf] + L.out_coff;
-            p.M = n * oh * ow;
-            p.N = L.cout;
-            p.taps = 6; p.kw_taps = 1; p.chunk = 32; p.ktot = 192;
-            p.howo = oh * ow; p.wo = ow;
-            p.in_px_stride = 4;
-            p.in_row_stride = (h->net_w + 4) * 4;
-            p.in_img_stride = (h->net_h + 4) * (h->net_w + 4) * 4;
-            p.stride = 2;
-            p.out_px_stride = L.out_cstride;
-            p.out_row_stride = (ow + 2 * L.out_pad) * L.out_cstride;
-            p.out_img_stride = (oh + 2 * L.out_pad) * (ow + 2 * L.out_pad) * L.out_cstride;
-            p.out_pad = L.out_pad;
-            p.relu = 2;
-            p.splitk = 1;
-            const hipError_t pe = pa::launch_igemm(p, pa::TILE_128x64, s);
-            if (pe != hipSuccess) return fail(PA_ERR_HIP, "stem: " + std::string(hipGetErrorString(pe)));
+            pa::StemDirectParams q;
+            q.x = h->x0;
+            q.wlane = h->weights + L.w_off;
+            q.bias = h->weights + L.b_off;
+            q.out = h->bufs[L.out_buf] + L.out_coff;
+            q.n = n; q.net_h = h->net_h; q.net_w = h->net_w; q.oh = oh; q.ow = ow;
+            q.out_px_stride = L.out_cstride;
+            q.out_row_stride = (ow + 2 * L.out_pad) * L.out_cstride;
+            q.out_img_stride = (oh + 2 * L.out_pad) * (ow + 2 * L.out_pad) * L.out_cstride;
+            q.out_pad = L.out_pad;
+            q.rows = 12;  // 64 x 384 x 640: 10240 strips = five rounds of two waves per SIMD
+            q.row_blocks = (oh + q.rows - 1) / q.rows;
+            q.col_blocks = (ow + 31) / 32;
+            const long long strips = (long long)n * q.row_blocks * q.col_blocks;
+            hipLaunchKernelGGL(pa::stem6x6_direct_kernel, dim3((unsigned)((strips + 3) / 4)), dim3(256), 0, s, q);
+            DT_HIP(hipGetLastError());
             continue;
         }
         if (L.kind == 4 || L.kind == 5) {
@@ -381,8 +468,15 @@ static int detector_run(pa_detector* h, const uint8_t* frames, int32_t n, int32_
         p.res_after = L.res_after;
         p.splitk = 1;
         const long long t128 = (long long)((p.M + 127) / 128) * (p.N / 64);
-        const pa::GemmTile tile = (p.N % 128 == 0 && t128 / 2 >= 512) ? pa::TILE_128x128 : (t128 >= 512 ? pa::TILE_128x64 : pa::TILE_64x64);
-        const hipError_t pe = pa::launch_igemm(p, tile, s);
+        hipError_t pe;
+        static const int use_pgemm = getenv("PA_DET_PGEMM") ? atoi(getenv("PA_DET_PGEMM")) : 1;  // 0: the one-tile-per-workgroup engine (A/B)
+        if (use_pgemm && !p.residual) {
+            // 1x1 and stride-2 convolutions: persistent workgroups over runs of tiles (pigemm.hip)
+            pe = pa::launch_pgemm(p, t128 >= 1024 ? 128 : 64, s);
+        } else {
+            const pa::GemmTile tile = (p.N % 128 == 0 && t128 / 2 >= 512) ? pa::TILE_128x128 : (t128 >= 512 ? pa::TILE_128x64 : pa::TILE_64x64);
+            pe = pa::launch_igemm(p, tile, s);
+        }
         if (pe != hipSuccess) return fail(PA_ERR_HIP, "layer " + std::to_string(li) + ": " + hipGetErrorString(pe));
     }
     if (ev) DT_HIP(hipEventRecord(ev->back(), s));

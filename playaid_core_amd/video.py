@@ -110,8 +110,13 @@ def read_avi_mjpeg(path: str) -> Tuple[np.ndarray, np.ndarray, dict]:
                 scale, rate = struct.unpack_from("<II", data, body + 20)
                 if scale:
                     meta["fps"] = rate / scale
-            elif in_movi and cid[2:4] in (b"dc", b"db") and size > 0:
-                frames.append((body, body + size))
+            elif in_movi and cid[2:4] in (b"dc", b"db"):
+                # a zero-length chunk is a dropped frame: the player repeats the previous picture, and the frame numbers
+                # (cv2's CAP_PROP_POS_FRAMES, which the label files are keyed on) keep counting
+                if size > 0:
+                    frames.append((body, body + size))
+                elif frames:
+                    frames.append(frames[-1])
             p = body + size + (size & 1)
 
     walk(12, data.size, False)
@@ -268,7 +273,9 @@ class MjpegDecoder:
                                        stream)
         if rc != _lib.PA_OK:
             raise EngineError(rc, self._lib.pa_mjpeg_last_error(self._h).decode())
-        self._keep = (data, off)  # the copy is asynchronous: the host bytes must outlive it
+        # the copy is asynchronous and the handle keeps TWO calls in flight (two scratch sets): the host bytes of the call
+        # before this one may still be crossing the link, so the last two calls' buffers stay referenced
+        self._keep = (getattr(self, "_keep", (None,))[-1], (data, off))
         return out
 
 
@@ -321,7 +328,7 @@ class VideoCapture:
             if torch.cuda.is_available():
                 self._data = self._data.pin_memory()  # asynchronous host -> device copies
             self._opened = True
-        except (OSError, VideoError, ValueError):
+        except (OSError, VideoError, ValueError, struct.error):
             self._opened = False
 
     # -- cv2's interface ---------------------------------------------------------

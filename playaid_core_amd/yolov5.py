@@ -163,15 +163,18 @@ def build_yolov5s_table(sd: Mapping, net_hw: Tuple[int, int], nc: int):
     C19 = B(16, 0, 2 * c3)   # [model.18 | model.14]
     C22 = B(32, 0, 2 * c4)   # [model.21 | model.10]
     # backbone
-    B0 = B(2, 1, 64)  # 32 real channels + 32 of padding: the GEMM kernel writes 64 at a time
+    assert c1 == 32, "the direct stem kernel is built for 32 output channels"
+    B0 = B(2, 1, c1)
     w0, b0 = _fold(sd, "model.0")
-    stem = np.zeros((64, 6, 8, 4), np.float64)   # one K chunk per kernel row: 8 pixels x 4 channels
-    stem[:c1, :, :6, :3] = w0.transpose(0, 2, 3, 1)
-    b0 = np.concatenate([b0, np.zeros(64 - c1)])
+    # stem weights in the direct kernel's lane layout: lane = (kx half) * 32 + channel holds W[channel][c][ky][3 * half + j]
+    # at ky * 9 + j * 3 + c (csrc/yolo.hip::stem6x6_direct_kernel)
+    stem = np.zeros((2, 32, 56), np.float64)
+    for half in range(2):
+        stem[half, :, :54] = w0[:, :, :, 3 * half:3 * half + 3].transpose(0, 2, 3, 1).reshape(32, 54)
     L = _lib.pa_net_layer()
-    L.kind, L.cin, L.cout, L.ksize, L.stride, L.in_h, L.in_w = 3, 3, 64, 6, 2, H, W
+    L.kind, L.cin, L.cout, L.ksize, L.stride, L.in_h, L.in_w = 3, 3, c1, 6, 2, H, W
     L.in_buf, L.res_buf = -1, -1
-    L.out_buf, L.out_coff, L.out_cstride, L.out_pad = B0, 0, 64, 1
+    L.out_buf, L.out_coff, L.out_cstride, L.out_pad = B0, 0, c1, 1
     L.act = 2
     L.w_off, L.b_off = T.put(stem), T.put(b0)
     T.layers.append(L)
@@ -268,7 +271,7 @@ class YoloV5Detector:
             if L.kind == 0:
                 self.flops_per_image += 2.0 * oh * ow * L.cout * L.ksize * L.ksize * L.cin
             elif L.kind == 3:
-                self.flops_per_image += 2.0 * oh * ow * L.cout * 192
+                self.flops_per_image += 2.0 * oh * ow * L.cout * 108
 
     def close(self):
         if getattr(self, "_h", None):

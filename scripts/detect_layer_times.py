@@ -33,7 +33,7 @@ for i, L in enumerate(layers):
     if L.kind == 0:
         gf = 2.0 * n * oh * ow * L.cout * L.ksize * L.ksize * L.cin / 1e9
     elif L.kind == 3:
-        gf = 2.0 * n * oh * ow * L.cout * 192 / 1e9
+        gf = 2.0 * n * oh * ow * L.cout * 108 / 1e9
     tot_us += med[i]
     tot_gf += gf
     print(f"{i:3d} {names[L.kind]:6s} k{L.ksize} s{L.stride} {L.in_h:3d}x{L.in_w:3d} cin {L.cin:4d} cout {L.cout:4d} M {n * oh * ow:8d} "

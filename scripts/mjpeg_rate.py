@@ -24,6 +24,10 @@ ap.add_argument("--streams", type=int, default=1, help="decoders working at once
 ap.add_argument("--rounds", type=int, default=-1, help="verify passes enqueued per call (default: the library's)")
 args = ap.parse_args()
 n, h, w = args.frames, args.height, args.width
+if not args.host_synth and (any(k.startswith(("ROCPROF", "ROCP_TOOL")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")):
+    # profiles/README.md (round 3): under rocprofv3 --pmc the torch integer kernels of the device frame generator never came
+    # back (three passes, 900 s). It is third-party code off the product path; counter passes take the host generator.
+    sys.exit("mjpeg_rate.py under rocprofv3 needs --host-synth (the device frame generator hangs under counter collection)")
 if args.host_synth:
     assert args.noise_mask == 31, "the host generator makes the headline's clip only"
     frames = synth.make_frames(n, h, w)

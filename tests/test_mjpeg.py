@@ -80,6 +80,21 @@ def test_containers(tmp_path):
     assert video.jpeg_frame_size(np.frombuffer(blobs[0], np.uint8)) == (72, 128)
     with pytest.raises(video.VideoError):
         video.read_avi_mjpeg(__file__)
+    # a dropped frame (zero-length chunk, what AVI writers emit for a repeated picture) keeps its frame number: it maps to the
+    # previous frame's bytes, so the frames behind it stay aligned with cv2's CAP_PROP_POS_FRAMES
+    raw_avi = bytearray(open(path, "rb").read())
+    k = raw_avi.index(b"00dc", raw_avi.index(b"movi"))
+    k = raw_avi.index(b"00dc", k + 4)   # in front of the second frame
+    raw_avi[k:k] = b"00dc" + (0).to_bytes(4, "little")
+    path2 = str(tmp_path / "dropped.avi")
+    open(path2, "wb").write(bytes(raw_avi))
+    data2, off2, _ = video.read_avi_mjpeg(path2)
+    assert off2.shape == (6, 2) and tuple(off2[1]) == tuple(off2[0])
+    assert [bytes(data2[a:b]) for a, b in off2] == [blobs[0], blobs[0]] + blobs[1:]
+    # a truncated header is "not opened", not an exception out of the constructor
+    open(str(tmp_path / "cut.avi"), "wb").write(bytes(raw_avi[:60]))
+    cap = video.VideoCapture(str(tmp_path / "cut.avi"))
+    assert not cap.isOpened()
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -246,6 +261,29 @@ def test_mjpeg_errors_are_reported(decoder):
     with pytest.raises(EngineError) as ei:
         _decode(decoder, [good] * 17, h, w)
     assert ei.value.code == _lib.PA_ERR_CAPACITY
+    # the SAME frame many times over (spans may repeat): the clean stream is bounded by the sum of the scans, not by the byte
+    # range the spans cover -- a handle sized for one copy must refuse, not write past its buffer
+    big = synth.encode_jpeg_frames([synth.make_frame(3, 256, 384)], quality=95)[0]
+    small = video.MjpegDecoder(max_frames=16, max_height=256, max_width=384, max_bytes=len(big) + 64)
+    try:
+        got, st = _decode(small, [big], 256, 384)
+        assert st[0] == 0
+        data = np.frombuffer(big, np.uint8)
+        spans = np.array([[0, len(big)]] * 12, np.int64)
+        with pytest.raises(EngineError) as ei:
+            small.decode(data, spans, 256, 384)
+        assert ei.value.code == _lib.PA_ERR_CAPACITY
+        two = np.array([[0, len(big)]] * 2, np.int64)   # (two copies still fit the slack or are refused: never a fault)
+        try:
+            out2 = small.decode(data, two, 256, 384)
+            import torch
+
+            torch.cuda.synchronize()
+            assert np.array_equal(out2[0].cpu().numpy(), got[0]) and np.array_equal(out2[1].cpu().numpy(), got[0])
+        except EngineError as exc:
+            assert exc.code == _lib.PA_ERR_CAPACITY
+    finally:
+        small.close()
     # a scan cut short: restart markers are missing -> status bit 2, no fault, the intact frame beside it is fine
     cut = good[: len(good) // 2]
     got, st = _decode(decoder, [cut, good], h, w)
