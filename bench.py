@@ -140,6 +140,27 @@ def pcie_inclusive(eng, frames_dev, boxes_dev, steps=8):
     }
 
 
+_ENCODED = {}
+
+
+def _encoded_clip(frames_dev, quality, restart_blocks):
+    """The clip as a Motion-JPEG stream in pinned host memory (libjpeg-turbo via Pillow, outside every timed region); encoded
+    once per (clip, quality) and shared by the side measurements."""
+    key = (frames_dev.data_ptr(), tuple(frames_dev.shape), quality, restart_blocks)
+    if key not in _ENCODED:
+        t0 = time.perf_counter()
+        kw = {"restart_marker_blocks": restart_blocks} if restart_blocks else {}
+        blobs = synth.encode_jpeg_frames(frames_dev.cpu().numpy(), quality=quality, **kw)
+        enc_s = time.perf_counter() - t0
+        sizes = np.array([len(b) for b in blobs], dtype=np.int64)
+        ends = np.cumsum(sizes)
+        spans = np.stack([ends - sizes, ends], axis=1)
+        data = torch.from_numpy(np.frombuffer(b"".join(blobs), np.uint8).copy()).pin_memory()
+        _ENCODED.clear()   # (one clip at a time: the pinned bytes of the previous one are released)
+        _ENCODED[key] = (data, spans, sizes, ends, enc_s)
+    return _ENCODED[key]
+
+
 def decode_inclusive(eng, frames_dev, boxes_dev, steps=24, quality=95, restart_blocks=0, content=None):
     """decode -> labels: the clip as a Motion-JPEG stream (one baseline JPEG per frame, written by libjpeg-turbo at
     OpenCV's defaults: quality 95, 4:2:0) in pinned HOST memory; per clip the compressed bytes cross PCIe and are decoded
@@ -150,14 +171,7 @@ def decode_inclusive(eng, frames_dev, boxes_dev, steps=24, quality=95, restart_b
 
     dev = eng.device
     n, h, w, _ = frames_dev.shape
-    t0 = time.perf_counter()
-    kw = {"restart_marker_blocks": restart_blocks} if restart_blocks else {}
-    blobs = synth.encode_jpeg_frames(frames_dev.cpu().numpy(), quality=quality, **kw)
-    enc_s = time.perf_counter() - t0
-    sizes = np.array([len(b) for b in blobs], dtype=np.int64)
-    ends = np.cumsum(sizes)
-    spans = np.stack([ends - sizes, ends], axis=1)
-    data = torch.from_numpy(np.frombuffer(b"".join(blobs), np.uint8).copy()).pin_memory()
+    data, spans, sizes, ends, enc_s = _encoded_clip(frames_dev, quality, restart_blocks)
     # ND decoders at once, each on a stream of its own with a frame buffer of its own: the entropy passes are bound by
     # instruction issue and single-wave latency, so calls whose phases are out of step fill each other's idle time
     ND = 4
@@ -220,6 +234,161 @@ def decode_inclusive(eng, frames_dev, boxes_dev, steps=24, quality=95, restart_b
         "method": f"{steps} clips; compressed frames in pinned host memory; H2D copy + device Motion-JPEG decode of clip k+1 on a "
         "side stream under crops + CNN + head of an earlier clip on its decoded frames; four decoders, each with a side stream and "
         "a frame buffer of its own, work at once (clips k+1 .. k+4)",
+    }
+
+
+def synthetic_head_rows(boxes_dev, rows, nc, height, width, net_hw=(384, 640)):
+    """Head rows float32[n, rows, 5 + nc] (device) as pa_detector_forward lays them out, carrying the clip's TRUE fighter boxes:
+    three near-duplicate candidates per fighter (classes 2 and 3, objectness 0.95 / 0.85 / 0.75) among clutter below the
+    objectness gate -- what a trained detector would hand to NMS. Seeded random-init weights detect nothing, so the chain's
+    post-processing consumes these while the network's own rows (computed in full) are discarded."""
+    n = boxes_dev.shape[0]
+    dev = boxes_dev.device
+    gain = min(net_hw[0] / height, net_hw[1] / width)
+    pad_x, pad_y = (net_hw[1] - width * gain) / 2, (net_hw[0] - height * gain) / 2
+    g = torch.Generator(device="cpu").manual_seed(99)
+    pred = torch.zeros((n, rows, 5 + nc), dtype=torch.float32)
+    pred[:, :, 4] = torch.rand((n, rows), generator=g) * 0.2
+    pred[:, :, :4] = 10 + torch.rand((n, rows, 4), generator=g) * 290
+    pred = pred.to(dev)
+    b = boxes_dev.to(torch.float32)
+    for p in range(2):
+        for k in range(3):
+            r = 10 * p + k
+            pred[:, r, 0] = b[:, p, 0] * width * gain + pad_x + k
+            pred[:, r, 1] = b[:, p, 1] * height * gain + pad_y - k
+            pred[:, r, 2] = b[:, p, 2] * width * gain
+            pred[:, r, 3] = b[:, p, 3] * height * gain
+            pred[:, r, 4] = 0.95 - 0.1 * k
+            pred[:, r, 5:] = 0.0
+            pred[:, r, 5 + 2 + p] = 0.9
+    return pred
+
+
+def chain_inclusive(eng, sd, frames_dev, boxes_dev, steps=12, quality=95):
+    """The path north_star names, chained (ai_runner.py:181-189 run_detection_setup -> :191-224 YOLO -> :226-424 repair -> :426-520
+    windows -> CNN -> labels): the clip as Motion-JPEG bytes in pinned host memory -> pa_mjpeg_decode -> pa_detector_forward
+    (YOLOv5s) -> pa_detect_postprocess (NMS, --max-det 2 --classes 2 3) -> pa_clean_detections -> pa_save_one_box_crops (+ the
+    crops' 4:4:4 JPEG write / read; square_crop repairs where the detector lost a fighter) -> pa_backbone_crop_images (runner
+    resize / letterbox + ResNet-18) -> temporal head -> records. Clips are pipelined three deep: decode of clip k on a decoder
+    stream, detector + NMS + repair of clip k-1 on a second stream, crops + CNN + head of clip k-2 on a third; the host waits
+    once per clip, for the repair's five words. Reported beside `value`, never as it."""
+    from playaid_core_amd import detector_path, video
+    from playaid_core_amd.yolov5 import YoloV5Detector
+
+    dev = eng.device
+    n, h, w, _ = frames_dev.shape
+    data, spans, sizes, ends, _ = _encoded_clip(frames_dev, quality, 0)
+    ND = 3
+    decs = [video.MjpegDecoder(n, h, w, int(ends[-1]) + 4096, device=str(dev)) for _ in range(ND)]
+    bufs = [torch.empty_like(frames_dev) for _ in range(ND)]
+    st = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(ND)]
+    det = YoloV5Detector(synth.make_yolov5s_state_dict(), 6, (384, 640), max_images=n, device=str(dev))
+    front_eng = Engine(sd, device=str(dev), max_batch_frames=8, max_clip_frames=max(n, 64), max_frame_height=h, max_frame_width=w)
+    pred_syn = synthetic_head_rows(boxes_dev, det.rows, 6, h, w)
+    pred_net = torch.empty((n, det.rows, 11), dtype=torch.float32, device=dev)
+    s_dec = [torch.cuda.Stream(dev) for _ in range(ND)]
+    s_front, s_back = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    ready = [torch.cuda.Event() for _ in range(ND)]
+    free = [torch.cuda.Event() for _ in range(ND)]
+    import ctypes as C
+
+    def detector(frames):
+        rc = det._lib.pa_detector_forward(det._h, C.c_void_p(frames.data_ptr()), n, h, w, C.c_void_p(pred_net.data_ptr()),
+                                          C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        assert rc == 0, det._lib.pa_detector_last_error(det._h)
+
+    def front(i):
+        detector(bufs[i])
+        dets, counts = front_eng.detect_postprocess(pred_syn, det.net_hw, (h, w))
+        return detector_path.begin(front_eng, bufs[i], dets, counts)
+
+    def run(k_steps):
+        keep, tickets, last = [], {}, None
+        for e in free:
+            e.record(torch.cuda.current_stream(dev))
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for k in range(k_steps + 2):
+            if k >= 2:   # crops + CNN + head of clip k - 2
+                c = k - 2
+                with torch.cuda.stream(s_back):
+                    t = tickets.pop(c)
+                    s_back.wait_event(t.event)
+                    last = detector_path.finish(eng, t, jpeg_quality=95, device_results=True)
+                    free[c % ND].record(s_back)
+                    keep.append((t, last))   # (tensors of one stream read on another: alive until the run's final synchronisation)
+            if 1 <= k <= k_steps:   # detector + NMS + repair of clip k - 1
+                c = k - 1
+                with torch.cuda.stream(s_front):
+                    s_front.wait_event(ready[c % ND])
+                    tickets[c] = front(c % ND)
+            if k < k_steps:   # decode of clip k
+                i = k % ND
+                with torch.cuda.stream(s_dec[i]):
+                    s_dec[i].wait_event(free[i])
+                    decs[i].decode(data, spans, h, w, out=bufs[i], status=st[i])
+                    ready[i].record(s_dec[i])
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / k_steps, last
+
+    def stage_ms(fn, reps=3):
+        ts = []
+        for _ in range(reps + 1):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(dev)
+            a.record()
+            out = fn()
+            b.record()
+            torch.cuda.synchronize(dev)
+            ts.append(a.elapsed_time(b))
+        return float(np.median(ts[1:])), out
+
+    try:
+        run(3)
+        bad = int(sum(int((s_ != 0).sum()) for s_ in st))
+        dt, last = run(steps)
+        front_eng.check_device_errors()
+        eng.check_device_errors()
+        rec = Engine.decode_records(last["records"])
+        finite = bool(torch.isfinite(last["logp"]).all())
+        # per-stage times, one clip alone on one stream (nothing overlaps; the pipelined rate above is what counts)
+        ms_decode, _ = stage_ms(lambda: decs[0].decode(data, spans, h, w, out=bufs[0], status=st[0]))
+        ms_det, _ = stage_ms(lambda: detector(bufs[0]))
+        ms_nms, tk = stage_ms(lambda: front(0))
+        ms_nms -= ms_det
+        tk.event.synchronize()
+
+        def back():
+            return detector_path.finish(eng, tk, jpeg_quality=95, device_results=True)
+
+        ms_back, _ = stage_ms(back)
+        ms_cnn, _ = stage_ms(lambda: eng.infer_clip_device(bufs[0], boxes_dev, eng.alloc_records(n - 1)))
+    finally:
+        for d_ in decs:
+            d_.close()
+        det.close()
+        front_eng.close()
+    stages = {"mjpeg_decode": round(ms_decode, 3), "detector_network": round(ms_det, 3), "nms_and_label_repair": round(ms_nms, 3),
+              "detector_crops_jpeg_runner_inputs_cnn_head": round(ms_back, 3)}
+    return {
+        "value": round(n / dt, 1),
+        "unit": "frames/s",
+        "ms_per_clip": round(dt * 1e3, 3),
+        "stage_ms_per_clip_alone": stages,
+        "stage_sum_ms": round(sum(stages.values()), 3),
+        "bound_by": max(stages, key=stages.get),
+        "crops_plus_cnn_of_the_headline_formulation_ms": round(ms_cnn, 3),
+        "compressed_MB_per_clip": round(float(ends[-1]) / 1e6, 2),
+        "frames_with_decode_errors": bad,
+        "labels_finite": finite,
+        "actions_in_last_clip": int(len(np.unique(rec["action_id"]))),
+        "detections": "the detection NETWORK runs in full on the decoded frames (YOLOv5s v7.0, 384 x 640, seeded random-init weights: its "
+                      "rows detect nothing and are discarded); NMS, repair, crops and labels consume synthetic head rows of the same shape "
+                      "carrying the clip's true fighter boxes (bench.py::synthetic_head_rows)",
+        "method": f"{steps} clips of {n} frames, three in flight: decode (clip k) | detector + NMS + repair (k - 1) | save_one_box crops + "
+                  "4:4:4 JPEG + runner inputs + ResNet-18 + head (k - 2), each on its own stream; one host wait per clip (five words of "
+                  "the repair); compressed bytes cross PCIe inside the decode stage",
     }
 
 
@@ -768,6 +937,10 @@ def main():
                                                                   restart_blocks=args.jpeg_restart_blocks)
                 except Exception as exc:  # a side measurement must never cost the line its headline
                     result["decode_inclusive"] = {"error": f"{type(exc).__name__}: {exc}"}
+                try:
+                    result["chain_inclusive"] = chain_inclusive(eng, sd, frames[:n_clip], boxes[:n_clip], quality=args.jpeg_quality)
+                except Exception as exc:
+                    result["chain_inclusive"] = {"error": f"{type(exc).__name__}: {exc}"}
                 try:  # the same clip with three bits of noise: the compressed size of real 1080p footage at quality 95
                     quiet = synth.make_frames_torch(n_clip, args.height, args.width, first_frame=lo, device=device, noise_mask=7, fine_mask=7)
                     result["decode_inclusive_camera_like"] = decode_inclusive(

@@ -373,8 +373,8 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const GemmParams p) {
                 v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
                 v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
             } else if (p.relu == 2) {
-                v.x = v.x / (1.f + expf(-v.x)); v.y = v.y / (1.f + expf(-v.y));
-                v.z = v.z / (1.f + expf(-v.z)); v.w = v.w / (1.f + expf(-v.w));
+                v.x = silu_fast(v.x); v.y = silu_fast(v.y);
+                v.z = silu_fast(v.z); v.w = silu_fast(v.w);
             }
             if (p.res_after) v += res_t[i];
             *reinterpret_cast<f32x4*>(p.out + o_t[i]) = v;
@@ -409,8 +409,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
             s.x = s.x > 0.f ? s.x : 0.f; s.y = s.y > 0.f ? s.y : 0.f;
             s.z = s.z > 0.f ? s.z : 0.f; s.w = s.w > 0.f ? s.w : 0.f;
         } else if (p.relu == 2) {
-            s.x = s.x / (1.f + expf(-s.x)); s.y = s.y / (1.f + expf(-s.y));
-            s.z = s.z / (1.f + expf(-s.z)); s.w = s.w / (1.f + expf(-s.w));
+            s.x = silu_fast(s.x); s.y = silu_fast(s.y);
+            s.z = silu_fast(s.z); s.w = silu_fast(s.w);
         }
         if (p.res_after) { s.x += rv.x; s.y += rv.y; s.z += rv.z; s.w += rv.w; }
         *reinterpret_cast<float4*>(p.out + o) = s;

@@ -6,6 +6,13 @@
 
 namespace pa {
 
+// SiLU x * sigmoid(x) of the conv epilogues (the detection network): v_exp_f32 + v_rcp_f32 (1 ulp each; the exponent's
+// pre-multiply adds |x| * 6e-8 relative) instead of expf + an IEEE division -- ~6 instead of ~30 vector instructions per
+// value, which for a 64-deep 1x1 convolution was as much issue time as the tile's matrix instructions.
+__device__ __forceinline__ float silu_fast(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
+}
+
 // ---------------------------------------------------------------------------
 // implicit-GEMM engine (igemm.hip)
 // ---------------------------------------------------------------------------
@@ -49,6 +56,10 @@ struct GemmParams {
     int32_t patch_slots, patch_pitch, img_px, tiles_per_img, p0_img, p0_row, total_px;
     int32_t swz_a, magic_pitch, magic_img, img_px_patch;  // chunk-swizzle key of a patch pixel (see patchconv.hip)
     int32_t xcd_m, xcd_n;  // the 8 XCDs as an xcd_m x xcd_n grid over (pixel tiles, channel tiles); 0 = contiguous runs of tiles
+    // blocked form of the patch-resident kernel (maps whose width is not 32 / 16 / 8 / 4: the detection network's): output
+    // pixel m = (block * blk_rows + r) * blk_cols + c, blocks row-major over each image; a tile's patch = the
+    // (blk_rows + 2) x (blk_cols + 2) input rectangles of its blocks back to back. Set by launch_conv3x3_patch_blocked.
+    int32_t blk_rows, blk_cols, blk_shift_c, blk_shift_px, blk_per_row, blk_per_img, n_blocks, src_pitch;
     unsigned long long* clk;  // ablation builds only: in-kernel clock stamps
 };
 
@@ -94,6 +105,9 @@ hipError_t launch_stem_pool(const StemPoolParams& p, hipStream_t s);
 hipError_t launch_splitk_reduce(const GemmParams& p, hipStream_t s);
 // stride-1 3x3 convolution with the input patch resident in LDS across the nine taps (patchconv.hip); bm = 128 | 64
 hipError_t launch_conv3x3_patch(const GemmParams& p, int bm, hipStream_t s);
+// the same kernel over rectangular blocks of output pixels (8 x 16, 8 x 8 or 4 x 4, whichever divides the map): any map whose
+// sides are multiples of 4; in_pad == 1; epilogue: bias, ReLU / SiLU, residual before or after the activation
+hipError_t launch_conv3x3_patch_blocked(const GemmParams& p, hipStream_t s);
 
 // ---------------------------------------------------------------------------
 // crop preprocessing (preprocess.hip)

@@ -56,6 +56,26 @@ __device__ __forceinline__ void split_m(const GemmParams& p, int m, int& img, in
     }
 }
 
+// m / d for 0 <= m < 2^24, 1 <= d < 2^16
+__device__ __forceinline__ int pc_div(int m, int d) {
+    int q = (int)((float)m * (1.0f / (float)d));
+    int r = m - q * d;
+    if (r < 0) { --q; r += d; }
+    if (r >= d) ++q;
+    return q;
+}
+
+// blocked pixel order (GemmParams::blk_*): m -> (img, oy, ox) and the pixel's place (r, c) inside its block
+__device__ __forceinline__ void split_m_blk(const GemmParams& p, int m, int& img, int& oy, int& ox) {
+    const int blk = m >> p.blk_shift_px, rem = m & ((1 << p.blk_shift_px) - 1);
+    const int r = rem >> p.blk_shift_c, c = rem & (p.blk_cols - 1);
+    img = pc_div(blk, p.blk_per_img);
+    const int sr = blk - img * p.blk_per_img;
+    const int by = pc_div(sr, p.blk_per_row);
+    oy = by * p.blk_rows + r;
+    ox = (sr - by * p.blk_per_row) * p.blk_cols + c;
+}
+
 }  // namespace
 
 // Patch buffer capacity in pixels: 128-row tiles of the 32- and 16-wide maps need 204 / 180,
@@ -69,7 +89,7 @@ template <int BM> struct PatchCap { static constexpr int slots = BM == 128 ? 224
 // own pair of patch buffers; the two partial tiles meet in LDS in the epilogue. Same occupancy as
 // two 256-thread split-K workgroups per CU, but no slab round trip through HBM and no reduce
 // kernel behind the launch (the layer-4 convs: M = 2048 gives only 256 tiles of 64 x 64).
-template <int BM, bool K2, bool KS2>
+template <int BM, bool K2, bool KS2, bool BLK = false>
 __global__ __launch_bounds__(KS2 ? 512 : 256, 2) void conv3x3_patch_kernel(const GemmParams p) {
     constexpr int BN = 64;
     constexpr int MI = BM / 64;
@@ -118,6 +138,29 @@ __global__ __launch_bounds__(KS2 ? 512 : 256, 2) void conv3x3_patch_kernel(const
     // (brute-forced for W = 32, 16, 8, 4; keying on the linear patch pixel instead cost 5-10 % of
     // the cycles in bank conflicts on the 16/8/4-wide maps: SQ_LDS_BANK_CONFLICT).
     const int band_row0 = p.p0_row ? (tile_m % p.tiles_per_img) * (p.p0_row / p.patch_pitch) : 0;
+    // BLK: the patch is not one contiguous pixel range but the rectangles of the tile's blocks, so every DMA pass's source
+    // offset (the same for every channel chunk) is worked out once: patch pixel -> (block of the tile, row, column) -> pixel of
+    // the zero-bordered input
+    int voffb[7];
+    if (BLK) {
+#pragma unroll
+        for (int qq = 0; qq < 7; ++qq) {
+            const int pp_ = row0 + 32 * qq;
+            const int im_ = (pp_ * p.magic_img) >> 16;
+            const int rem_ = pp_ - im_ * p.img_px_patch;
+            const int rw_ = (rem_ * p.magic_pitch) >> 16;
+            const int col_ = rem_ - rw_ * p.patch_pitch;
+            const int key_ = ((p.swz_a * rw_ + col_) >> 1) & 7;
+            int blk_ = tile_m * (BM >> p.blk_shift_px) + im_;
+            blk_ = blk_ < p.n_blocks ? blk_ : p.n_blocks - 1;   // (slots past the tile's blocks, blocks past a partial last tile)
+            const int img_ = pc_div(blk_, p.blk_per_img);
+            const int sr_ = blk_ - img_ * p.blk_per_img;
+            const int by_ = pc_div(sr_, p.blk_per_row);
+            int px_ = img_ * p.img_px + (by_ * p.blk_rows + rw_) * p.src_pitch + (sr_ - by_ * p.blk_per_row) * p.blk_cols + col_;
+            px_ = px_ < p.total_px ? px_ : p.total_px - 1;
+            voffb[qq] = (px_ * p.in_px_stride + ((tid & 7) ^ key_) * 4) * 4;
+        }
+    }
     const int n_ch = p.chunk >> 5;                          // 32-channel chunks
     const int ch_begin = z * p.ksteps_per_split;            // (per split: whole chunks)
     int ch_end = ch_begin + p.ksteps_per_split;
@@ -152,6 +195,9 @@ __global__ __launch_bounds__(KS2 ? 512 : 256, 2) void conv3x3_patch_kernel(const
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.act), 0, -1, 0x00020000);
 #define PC_PATCH_PASS(CH, PB, Q)                                                                   \
     {                                                                                              \
+    if (BLK) {                                                                                     \
+        blds16(act_rsrc, voffb[Q], (CH) * 128, patch0 + (PB) * PP + (Q) * 1024 + wave_id * 256);   \
+    } else {                                                                                       \
         int px_ = p0 + row0 + 32 * (Q);                                                            \
         px_ = px_ < p.total_px ? px_ : p.total_px - 1;                                             \
         const int pp_ = row0 + 32 * (Q);                       /* pixel inside the patch */           \
@@ -161,6 +207,7 @@ __global__ __launch_bounds__(KS2 ? 512 : 256, 2) void conv3x3_patch_kernel(const
         const int key_ = ((p.swz_a * (rw_ + band_row0) + rem_ - rw_ * p.patch_pitch) >> 1) & 7;        \
         blds16(act_rsrc, (px_ * p.in_px_stride + ((tid & 7) ^ key_) * 4) * 4, (CH) * 128,              \
                patch0 + (PB) * PP + (Q) * 1024 + wave_id * 256);                                   \
+    }                                                                                              \
     }
 
     const int lane = tid & 63;
@@ -198,10 +245,18 @@ __global__ __launch_bounds__(KS2 ? 512 : 256, 2) void conv3x3_patch_kernel(const
     for (int mi = 0; mi < MI; ++mi) {
         int m = tile_m * BM + wm * (BM / 2) + mi * 32 + lr;
         m = m < p.M ? m : p.M - 1;
-        int img, oy, ox;
-        split_m(p, m, img, oy, ox);
-        pbase[mi] = img * p.img_px + oy * p.patch_pitch + ox - p0;
-        rbase[mi] = p.swz_a * oy + ox;
+        if (BLK) {
+            const int ml = wm * (BM / 2) + mi * 32 + lr;   // row of the tile
+            const int rem = ml & ((1 << p.blk_shift_px) - 1);
+            const int r = rem >> p.blk_shift_c, c = rem & (p.blk_cols - 1);
+            pbase[mi] = (ml >> p.blk_shift_px) * p.img_px_patch + r * p.patch_pitch + c;
+            rbase[mi] = p.swz_a * r + c;
+        } else {
+            int img, oy, ox;
+            split_m(p, m, img, oy, ox);
+            pbase[mi] = img * p.img_px + oy * p.patch_pitch + ox - p0;
+            rbase[mi] = p.swz_a * oy + ox;
+        }
     }
 
     f32x16 acc[MI];
@@ -214,7 +269,13 @@ __global__ __launch_bounds__(KS2 ? 512 : 256, 2) void conv3x3_patch_kernel(const
 
     // ---- prologue: first patch, weights of the first two steps ------------------------------
     if (ch_begin < ch_end) {
-        for (int qq = 0; qq < npass; ++qq) PC_PATCH_PASS(ch_begin, 0, qq);
+        if (BLK) {
+#pragma unroll
+            for (int qq = 0; qq < 7; ++qq)
+                if (qq < npass) PC_PATCH_PASS(ch_begin, 0, qq);
+        } else {
+            for (int qq = 0; qq < npass; ++qq) PC_PATCH_PASS(ch_begin, 0, qq);
+        }
         PC_LOAD_B(0, ch_begin, 0);
         PC_LOAD_B(1, ch_begin, 1);
     }
@@ -255,8 +316,8 @@ __global__ __launch_bounds__(KS2 ? 512 : 256, 2) void conv3x3_patch_kernel(const
             }
             if (to_k2) {
                 if (tap < ROWS2) PC_TILE2_PASS(0, pb ^ 1, tap);
-            } else if (tap < npass) {
-                PC_PATCH_PASS(chn, pb ^ 1, tap);
+            } else if (tap < npass && (!BLK || tap < 7)) {
+                PC_PATCH_PASS(chn, pb ^ 1, tap < 7 || !BLK ? tap : 0);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -385,7 +446,7 @@ __global__ __launch_bounds__(KS2 ? 512 : 256, 2) void conv3x3_patch_kernel(const
         const int m = tile_m * BM + wm * (BM / 2) + mi * 32 + lr;
         if (m >= p.M) continue;
         int img, oy, ox;
-        split_m(p, m, img, oy, ox);
+        if (BLK) split_m_blk(p, m, img, oy, ox); else split_m(p, m, img, oy, ox);
         const int o_px = img * p.out_img_stride + (oy + p.out_pad) * p.out_row_stride + (ox + p.out_pad) * p.out_px_stride + ch0;
         f32x4 res4[4];
 #pragma unroll
@@ -397,10 +458,22 @@ __global__ __launch_bounds__(KS2 ? 512 : 256, 2) void conv3x3_patch_kernel(const
             if (!direct_out) {
                 *reinterpret_cast<f32x4*>(p.slab + ((size_t)z * p.M + m) * p.N + ch0 + 8 * g) = v;
             } else {
-                v += bias4[g] + res4[g];
-                if (p.relu) {
-                    v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
-                    v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+                if (BLK) {  // the detection network's epilogues: SiLU, residual after the activation
+                    v += p.res_after ? bias4[g] : bias4[g] + res4[g];
+                    if (p.relu == 1) {
+                        v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+                        v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+                    } else if (p.relu == 2) {
+                        v.x = silu_fast(v.x); v.y = silu_fast(v.y);
+                        v.z = silu_fast(v.z); v.w = silu_fast(v.w);
+                    }
+                    if (p.res_after) v += res4[g];
+                } else {
+                    v += bias4[g] + res4[g];
+                    if (p.relu) {
+                        v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+                        v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+                    }
                 }
                 *reinterpret_cast<f32x4*>(p.out + o_px + 8 * g) = v;
             }
@@ -536,6 +609,61 @@ hipError_t launch_conv3x3_patch(const GemmParams& p_in, int bm, hipStream_t s) {
     if (err != hipSuccess) return err;
     if (p.splitk > 1) return launch_splitk_reduce(p, s);
     return hipSuccess;
+}
+
+// Blocked form for maps of any width (see GemmParams::blk_*): 8 x 16 blocks in 128-row tiles (LDS image of a 16-wide map),
+// 8 x 8 blocks (one or two per tile: an 8-wide map's) or 4 x 4 blocks (four per 64-row tile: a 4-wide map's) -- the three
+// layouts whose chunk swizzles were searched, so the operand reads stay free of bank conflicts.
+hipError_t launch_conv3x3_patch_blocked(const GemmParams& p_in, hipStream_t s) {
+    GemmParams p = p_in;
+    if (p.gather || p.taps != 9 || p.kw_taps != 3 || p.stride != 1 || p.chunk % 32 != 0 || p.N % 64 != 0 || p.M <= 0 || p.k2_steps ||
+        p.ktot != 9 * p.chunk || p.off_y != 0 || p.off_x != 0 || p.M >= (1 << 24))
+        return hipErrorInvalidValue;
+    const int ho = p.howo / p.wo;
+    if (p.M % p.howo != 0) return hipErrorInvalidValue;
+    int br, bc, bm;
+    if (p.wo % 16 == 0 && ho % 8 == 0) { br = 8; bc = 16; bm = 128; }
+    else if (p.wo % 8 == 0 && ho % 8 == 0) { br = 8; bc = 8; bm = ((p.M + 127) / 128) * (p.N / 64) >= 512 ? 128 : 64; }
+    else if (p.wo % 4 == 0 && ho % 4 == 0) { br = 4; bc = 4; bm = 64; }
+    else return hipErrorInvalidValue;
+    auto ilog2 = [](int v) { int sh = 0; while ((1 << sh) < v) ++sh; return sh; };
+    p.blk_rows = br; p.blk_cols = bc;
+    p.blk_shift_c = ilog2(bc); p.blk_shift_px = ilog2(br * bc);
+    p.blk_per_row = p.wo / bc;
+    p.blk_per_img = (ho / br) * p.blk_per_row;
+    p.n_blocks = p.M / (br * bc);
+    p.src_pitch = p.in_row_stride / p.in_px_stride;
+    p.img_px = p.in_img_stride / p.in_px_stride;
+    p.patch_pitch = bc + 2;
+    const int sub_px = (br + 2) * (bc + 2);
+    p.img_px_patch = sub_px;
+    p.magic_img = (65536 + sub_px - 1) / sub_px;
+    p.magic_pitch = (65536 + p.patch_pitch - 1) / p.patch_pitch;
+    p.swz_a = bc & 15;
+    p.patch_slots = ((bm / (br * bc)) * sub_px + 31) & ~31;
+    if (p.patch_slots > (bm == 128 ? PatchCap<128>::slots : PatchCap<64>::slots) || p.patch_slots > 7 * 32) return hipErrorInvalidValue;
+    p.total_px = (p.M / p.howo) * p.img_px;
+    p.howo_shift = p.wo_shift = -1;
+    p.tiles_m = (p.M + bm - 1) / bm;
+    p.tiles_n = p.N / 64;
+    p.tiles_per_img = 1; p.p0_img = 0; p.p0_row = 0;
+    p.splitk = 1;
+    p.ksteps_per_split = p.chunk / 32;
+    const int grid = p.tiles_m * p.tiles_n;
+    p.xcd_m = p.xcd_n = 0;
+    if (grid % 8 == 0) {  // (as launch_conv3x3_patch: the XCDs as a grid over pixel and channel tiles when that fetches less)
+        const double act = (double)p.total_px * p.chunk * 4.0, wgt = (double)p.N * p.ktot * 4.0;
+        double best = act / 8 + wgt;
+        for (int a = 4; a >= 1; a >>= 1) {
+            const int bb = 8 / a;
+            if (p.tiles_m % a || p.tiles_n % bb) continue;
+            const double cost = act / a + wgt / bb;
+            if (cost < 0.9 * best) { best = cost; p.xcd_m = a; p.xcd_n = bb; }
+        }
+    }
+    if (bm == 128) hipLaunchKernelGGL((conv3x3_patch_kernel<128, false, false, true>), dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((conv3x3_patch_kernel<64, false, false, true>), dim3(grid), dim3(256), 0, s, p);
+    return hipGetLastError();
 }
 
 }  // namespace pa

@@ -206,8 +206,8 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const GemmParams p) {
                     v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
                     v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
                 } else if (p.relu == 2) {
-                    v.x = v.x / (1.f + expf(-v.x)); v.y = v.y / (1.f + expf(-v.y));
-                    v.z = v.z / (1.f + expf(-v.z)); v.w = v.w / (1.f + expf(-v.w));
+                    v.x = silu_fast(v.x); v.y = silu_fast(v.y);
+                    v.z = silu_fast(v.z); v.w = silu_fast(v.w);
                 }
                 // (rows past M of a partial last tile were computed on clamped addresses and are dropped)
                 if (m < p.M) *reinterpret_cast<f32x4*>(p.out + o_px + 8 * gq) = v;
@@ -216,22 +216,35 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const GemmParams p) {
     }
 }
 
-// Conv mode of GemmParams (no gather, no second source, no residual, no split-K); bm = 128 | 64.
+// Conv mode of GemmParams (no gather, no second source, no residual, no split-K); bm = 128 | 64 | 0 (chosen here).
 hipError_t launch_pgemm(const GemmParams& p_in, int bm, hipStream_t s) {
     GemmParams p = p_in;
     if (p.gather || p.k2_steps || p.residual || p.chunk % 32 != 0 || p.N % 64 != 0 || p.M <= 0 || p.M >= (1 << 24) || p.howo >= (1 << 16) ||
-        p.ktot != p.taps * p.chunk || (bm != 128 && bm != 64))
+        p.ktot != p.taps * p.chunk || (bm != 128 && bm != 64 && bm != 0))
         return hipErrorInvalidValue;
-    p.tiles_m = (p.M + bm - 1) / bm;
     p.tiles_n = p.N / 64;
     if (p.tiles_n > 64) return hipErrorInvalidValue;
-    // two workgroups per CU; per XCD a multiple of the channel columns, and no more per column than it has pixel tiles
-    int per = 64;
-    const int tm_xcd = (p.tiles_m + 7) / 8;
-    int lm = per / p.tiles_n;
-    if (lm < 1) lm = 1;
-    if (lm > tm_xcd) lm = tm_xcd;
-    per = lm * p.tiles_n;
+    // Two workgroups per CU = 64 per XCD, a multiple of the channel columns, and no more per column than the XCD's share
+    // of pixel tiles. bm = 0: the tile height whose slowest workgroup finishes first (128-row tiles do ~10 % more per
+    // matrix instruction's worth of copies, but a layer of 480 such tiles leaves workgroups with one tile or two).
+    auto plan = [&](int bm_, int* lm_out) {
+        const int tm = (p.M + bm_ - 1) / bm_, share = (tm + 7) / 8;
+        int lm = 64 / p.tiles_n;
+        lm = lm < 1 ? 1 : (lm > share ? share : lm);
+        *lm_out = lm;
+        return (double)tm / 8.0 / lm / (double)((share + lm - 1) / lm) * (bm_ == 128 ? 1.0 : 0.9);
+    };
+    int lm = 1;
+    if (bm == 0) {
+        int lm128, lm64;
+        const double e128 = plan(128, &lm128), e64 = plan(64, &lm64);
+        bm = e128 >= e64 ? 128 : 64;
+        lm = bm == 128 ? lm128 : lm64;
+    } else {
+        (void)plan(bm, &lm);
+    }
+    p.tiles_m = (p.M + bm - 1) / bm;
+    const int per = lm * p.tiles_n;
     const int grid = per * 8;
     if (bm == 128) hipLaunchKernelGGL((pgemm_kernel<128>), dim3(grid), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((pgemm_kernel<64>), dim3(grid), dim3(256), 0, s, p);

@@ -233,8 +233,8 @@ __global__ __launch_bounds__(256, 2) void stem6x6_direct_kernel(const StemDirect
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 v = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]} + bias4[g];
-                    v.x = v.x / (1.f + expf(-v.x)); v.y = v.y / (1.f + expf(-v.y));
-                    v.z = v.z / (1.f + expf(-v.z)); v.w = v.w / (1.f + expf(-v.w));
+                    v.x = silu_fast(v.x); v.y = silu_fast(v.y);
+                    v.z = silu_fast(v.z); v.w = silu_fast(v.w);
                     *reinterpret_cast<f32x4*>(o + 8 * g) = v;
                 }
             }
@@ -470,9 +470,14 @@ static int detector_run(pa_detector* h, const uint8_t* frames, int32_t n, int32_
         const long long t128 = (long long)((p.M + 127) / 128) * (p.N / 64);
         hipError_t pe;
         static const int use_pgemm = getenv("PA_DET_PGEMM") ? atoi(getenv("PA_DET_PGEMM")) : 1;  // 0: the one-tile-per-workgroup engine (A/B)
-        if (use_pgemm && !p.residual) {
+        static const int use_patch = getenv("PA_DET_PATCH") ? atoi(getenv("PA_DET_PATCH")) : 1;  // 0: im2col for the 3x3 convolutions (A/B)
+        pe = hipErrorInvalidValue;
+        if (use_patch && L.ksize == 3 && L.stride == 1 && L.in_pad == 1)
+            pe = pa::launch_conv3x3_patch_blocked(p, s);  // input patch resident in LDS across the nine taps (patchconv.hip)
+        if (pe != hipErrorInvalidValue) {
+        } else if (use_pgemm && !p.residual) {
             // 1x1 and stride-2 convolutions: persistent workgroups over runs of tiles (pigemm.hip)
-            pe = pa::launch_pgemm(p, t128 >= 1024 ? 128 : 64, s);
+            pe = pa::launch_pgemm(p, 0, s);
         } else {
             const pa::GemmTile tile = (p.N % 128 == 0 && t128 / 2 >= 512) ? pa::TILE_128x128 : (t128 >= 512 ? pa::TILE_128x64 : pa::TILE_64x64);
             pe = pa::launch_igemm(p, tile, s);

@@ -11,8 +11,11 @@ table ``pa_detect_postprocess`` wrote:
     pa_backbone_crop_images  every crop image through the runner's resize / letterbox and the backbone
     pa_head_frames           windows, temporal head, log-softmax, argmax
 
-Only two small things come back to the host before the end: the repair's ``info`` words (last labelled frame, the
-reference's assertions as error codes) and the list of repaired entries (to size the square-crop call).
+ONE small thing comes back to the host in the middle: five words -- the repair's ``info`` (last labelled frame, the
+reference's assertions as error codes) and the number of repaired entries -- because the clip's length decides every later
+launch. ``begin`` enqueues the repair and that copy, ``finish`` waits for the five words and enqueues the rest; pixels,
+boxes, crop images and descriptors never leave the device, nothing else synchronises (``finish(..., device_results=True)``
+does not even wait for the results), so a caller can put the next clip's detector under this clip's wait.
 """
 from __future__ import annotations
 
@@ -33,21 +36,44 @@ _REPAIR_ERRORS = {
 }
 
 
-def run_detections_to_labels(engine, frames_dev: torch.Tensor, dets: torch.Tensor, counts: torch.Tensor,
-                             jpeg_quality: int = 95, want_crops: bool = False) -> Dict:
-    """frames uint8[n,H,W,3] (device), dets float32[n,max_det,6] / counts int32[n] (device, ``Engine.detect_postprocess``)
-    -> the result dict of ``Engine.infer_clip`` for frames 1 .. max_frames - 1, plus ``cleaned`` (the repair tables, host
-    copies) and ``max_frames``."""
-    dev = engine.device
-    n_decoded = frames_dev.shape[0]
-    F = engine.F
-    tab = engine.clean_detections(dets, counts, n_decoded)
-    info = tab["info"].cpu().numpy()  # synchronises: the clip's length decides every later launch
+class Ticket:
+    """A clip between ``begin`` and ``finish``: the repair tables (device), the five host words and the event behind them."""
+
+    def __init__(self, frames_dev, tab, words, event):
+        self.frames_dev, self.tab, self.words, self.event = frames_dev, tab, words, event
+
+
+def begin(engine, frames_dev: torch.Tensor, dets: torch.Tensor, counts: torch.Tensor) -> Ticket:
+    """Enqueue the label repair (``pa_clean_detections``) and the copy of its five host words on the current stream."""
+    tab = engine.clean_detections(dets, counts, frames_dev.shape[0])
+    words_dev = torch.cat([tab["info"], (tab["crop_kind"] == 2).sum().to(torch.int32).reshape(1)])
+    words = torch.empty(5, dtype=torch.int32).pin_memory()
+    words.copy_(words_dev, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(engine.device))
+    return Ticket(frames_dev, tab, words, ev)
+
+
+def _crop_buffer(engine, nbytes: int) -> torch.Tensor:
+    """The packed crop-image buffer, kept on the engine between clips (the worst case is large: every crop a whole frame)."""
+    buf = getattr(engine, "_detector_crop_buf", None)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=engine.device)
+        engine._detector_crop_buf = buf
+    return buf
+
+
+def finish(engine, t: Ticket, jpeg_quality: int = 95, want_crops: bool = False, device_results: bool = False) -> Dict:
+    """Wait for the clip's five words, then enqueue crops -> runner inputs -> backbone -> head on the current stream."""
+    t.event.synchronize()  # the only wait in the middle of a clip
+    info = t.words.numpy().copy()
     if info[1]:
         raise LabelRepairError(f"{_REPAIR_ERRORS.get(int(info[1]), 'label repair failed')} (label {int(info[2])})")
-    n = int(info[0])
+    n, n_rep = int(info[0]), int(info[4])
     if n < 2:
         raise ValueError("no detections in any label")
+    dev, F, tab, frames_dev = engine.device, engine.F, t.tab, t.frames_dev
+    h, w = frames_dev.shape[1], frames_dev.shape[2]
     kind = tab["crop_kind"][:n]
     src = tab["pixel_frame"][:n]
     slot = torch.arange(F, dtype=torch.int32, device=dev)[None, :].expand(n, F)
@@ -55,37 +81,56 @@ def run_detections_to_labels(engine, frames_dev: torch.Tensor, dets: torch.Tenso
     src_own = torch.where(kind == 1, src, torch.zeros_like(src)).contiguous()
     row_counts = torch.full((n,), F, dtype=torch.int32, device=dev)
     step = engine.max_batch_frames
-    parts, descs, base = [], [], 0
-    for f0 in range(0, n, step):
+    # every chunk of frames packs its crop images into a region of its own (the offsets inside a region are the kernel's
+    # prefix sums), so no chunk has to know where the one before it ended
+    region = step * F * min(h * w, 1 << 20) * 3 + 64
+    n_chunks = (n + step - 1) // step
+    sq_bytes = n_rep * 128 * 128 * 3
+    images = _crop_buffer(engine, n_chunks * region + sq_bytes + 64)
+    desc = torch.zeros((n * F, 2), dtype=torch.int64, device=dev)
+    for k, f0 in enumerate(range(0, n, step)):
         cnt = min(step, n - f0)
-        images, desc = engine.save_one_box_crops(frames_dev, tab["crop_row"][f0:f0 + cnt].contiguous(), row_counts[f0:f0 + cnt],
-                                                 det_index=det_index[f0:f0 + cnt], jpeg_quality=jpeg_quality,
-                                                 src_frame=src_own[f0:f0 + cnt])
-        used = int((desc[:, 0] + ((desc[:, 1] & 0xFFFFFFFF) * (desc[:, 1] >> 32) * 3 + 15) // 16 * 16).max().item())
-        desc = desc.clone()
-        desc[:, 0] += base
-        parts.append(images[:used])
-        descs.append(desc)
-        base += used
-    engine.check_device_errors()
-    desc = torch.cat(descs)
-    rep = torch.nonzero(kind == 2)  # [k, 2] = (frame, fighter) of the square_crop repairs
-    if rep.shape[0]:
-        boxes = tab["pixel_box"][:n][rep[:, 0], rep[:, 1]]              # [k, 4]
-        fr = frames_dev[src[rep[:, 0], rep[:, 1]].long()]
+        d = desc[f0 * F:(f0 + cnt) * F]
+        engine.save_one_box_crops(frames_dev, tab["crop_row"][f0:f0 + cnt].contiguous(), row_counts[f0:f0 + cnt],
+                                  det_index=det_index[f0:f0 + cnt], jpeg_quality=jpeg_quality, src_frame=src_own[f0:f0 + cnt],
+                                  images=images[k * region:(k + 1) * region], desc=d)
+        if k:
+            d[:, 0] += k * region
+    sq_status = None
+    if n_rep:
+        # the square_crop repairs, n_rep of them: their (frame, fighter) entries come out of a stable sort (no host round
+        # trip: the count is already here), their pixels are cut on the device into the tail of the same buffer
+        e = torch.argsort((kind != 2).reshape(-1).to(torch.int8), stable=True)[:n_rep]
+        boxes = tab["pixel_box"][:n].reshape(-1, 4)[e]
+        fr = frames_dev[src.reshape(-1)[e].long()]
+        base = n_chunks * region
+        sq = images[base:base + sq_bytes].view(n_rep, 128, 128, 3)
         engine.set_crop_jpeg_quality(jpeg_quality)
         try:
-            sq, st = engine.square_crops(fr, boxes[:, None, :].expand(-1, F, -1).contiguous(), padding=engine.cfg.crop_padding)
+            sq_status = engine.square_crops_device(fr, boxes, sq, padding=engine.cfg.crop_padding)
         finally:
             engine.set_crop_jpeg_quality(0)
-        if (st[:, 0] != 0).any():
-            raise AssertionError(f"Failed to get square crop from frame {int(rep[np.nonzero(st[:, 0])[0][0], 0]) + 1}")  # ai_runner.py:418
-        parts.append(torch.from_numpy(np.ascontiguousarray(sq[:, 0])).to(dev).reshape(-1))
-        e = rep[:, 0] * F + rep[:, 1]
-        desc[e, 0] = base + torch.arange(rep.shape[0], device=dev, dtype=torch.int64) * (128 * 128 * 3)
+        desc[e, 0] = base + torch.arange(n_rep, device=dev, dtype=torch.int64) * (128 * 128 * 3)
         desc[e, 1] = (128 << 32) | 128
-    images = torch.cat(parts + [torch.zeros(64, dtype=torch.uint8, device=dev)])
-    out = engine.infer_clip_from_packed_crop_images(images, desc, n, want_crops=want_crops)
+    out = engine.infer_clip_from_packed_crop_images(images, desc, n, want_crops=want_crops, device_results=device_results)
     out["max_frames"] = n
-    out["cleaned"] = {k: v[:n].cpu().numpy() if k != "info" else info for k, v in tab.items()}
+    if device_results:
+        out["cleaned"], out["info"], out["square_crop_status"] = tab, info, sq_status
+        return out
+    # (infer_clip_from_packed_crop_images synchronised: the checks below cost nothing more)
+    engine.check_device_errors()
+    if sq_status is not None:
+        st = sq_status.cpu().numpy()
+        if (st != 0).any():
+            bad = int(torch.div(e[int(np.nonzero(st)[0][0])], F, rounding_mode="floor"))
+            raise AssertionError(f"Failed to get square crop from frame {bad + 1}")  # ai_runner.py:418
+    out["cleaned"] = {k: (v[:n].cpu().numpy() if k != "info" else info[:4]) for k, v in tab.items()}
     return out
+
+
+def run_detections_to_labels(engine, frames_dev: torch.Tensor, dets: torch.Tensor, counts: torch.Tensor,
+                             jpeg_quality: int = 95, want_crops: bool = False) -> Dict:
+    """frames uint8[n,H,W,3] (device), dets float32[n,max_det,6] / counts int32[n] (device, ``Engine.detect_postprocess``)
+    -> the result dict of ``Engine.infer_clip`` for frames 1 .. max_frames - 1, plus ``cleaned`` (the repair tables, host
+    copies) and ``max_frames``."""
+    return finish(engine, begin(engine, frames_dev, dets, counts), jpeg_quality=jpeg_quality, want_crops=want_crops)

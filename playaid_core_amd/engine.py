@@ -242,6 +242,25 @@ class Engine:
         torch.cuda.synchronize(self.device)
         return crops[:, :nf].cpu().numpy(), status[:, :nf].cpu().numpy()
 
+    def square_crops_device(self, frames_dev: torch.Tensor, boxes_dev: torch.Tensor, out: torch.Tensor,
+                            padding: int = constants.CROP_PADDING, swap_rb: bool = False) -> torch.Tensor:
+        """One ``square_crop`` per frame, everything on the device and nothing waited for: frames uint8[k,H,W,3], boxes
+        float64[k,4] -> ``out`` uint8[k,128,128,3] (written in place); returns the status int32[k] (device)."""
+        k, h, w, _ = frames_dev.shape
+        assert tuple(out.shape) == (k, 128, 128, 3) and out.is_cuda and out.is_contiguous()
+        status = torch.empty((k,), dtype=torch.int32, device=self.device)
+        step = self.max_batch_frames
+        for i0 in range(0, k, step):
+            cnt = min(step, k - i0)
+            bd = boxes_dev[i0:i0 + cnt, None, :].expand(-1, self.F, -1).contiguous()
+            crops = torch.empty((cnt, self.F, 128, 128, 3), dtype=torch.uint8, device=self.device)
+            st = torch.empty((cnt, self.F), dtype=torch.int32, device=self.device)
+            self._check(self._lib.pa_square_crops(self._h, _ptr(frames_dev[i0:]), cnt, h, w, _ptr(bd), padding, int(swap_rb), _ptr(crops),
+                                                  _ptr(st), self._stream()))
+            out[i0:i0 + cnt].copy_(crops[:, 0])
+            status[i0:i0 + cnt].copy_(st[:, 0])
+        return status
+
     # -- a5: crop images -> runner inputs ------------------------------------
     def _pack_crop_images(self, images):
         """list of uint8[h_i, w_i, 3] -> (device byte tensor, device descriptor tensor int64[n, 2])."""
@@ -303,9 +322,11 @@ class Engine:
             out["crops_rgb"] = crops.cpu().numpy()
         return out
 
-    def infer_clip_from_packed_crop_images(self, images: torch.Tensor, desc: torch.Tensor, n: int, want_crops: bool = False):
+    def infer_clip_from_packed_crop_images(self, images: torch.Tensor, desc: torch.Tensor, n: int, want_crops: bool = False,
+                                           device_results: bool = False):
         """``infer_clip_from_crop_images`` for crop images that are already on the device (``save_one_box_crops``):
-        packed bytes + descriptors int64[n * F, 2] in (frame, fighter) order."""
+        packed bytes + descriptors int64[n * F, 2] in (frame, fighter) order. ``device_results``: only enqueue, and return
+        the device tensors (records, logp, crop_status, crops_rgb) without waiting for them."""
         records = self.alloc_records(n - 1)
         logp = torch.empty((n - 1, self.F, self.A), dtype=torch.float32, device=self.device)
         status = torch.empty((n, self.F), dtype=torch.int32, device=self.device)
@@ -318,6 +339,8 @@ class Engine:
                                                           _ptr(crops[f0 : f0 + cnt]) if want_crops else C.c_void_p(0),
                                                           _ptr(status[f0 : f0 + cnt]), self._stream()))
         self.head_frames(1, n, records, logp)
+        if device_results:
+            return {"records": records, "logp": logp, "crop_status": status, "crops_rgb": crops}
         torch.cuda.synchronize(self.device)
         out = self.decode_records(records)
         out["logp"] = logp.cpu().numpy()
