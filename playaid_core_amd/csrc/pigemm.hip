@@ -225,20 +225,21 @@ hipError_t launch_pgemm(const GemmParams& p_in, int bm, hipStream_t s) {
     p.tiles_n = p.N / 64;
     if (p.tiles_n > 64) return hipErrorInvalidValue;
     // Two workgroups per CU = 64 per XCD, a multiple of the channel columns, and no more per column than the XCD's share
-    // of pixel tiles. bm = 0: the tile height whose slowest workgroup finishes first (128-row tiles do ~10 % more per
-    // matrix instruction's worth of copies, but a layer of 480 such tiles leaves workgroups with one tile or two).
-    auto plan = [&](int bm_, int* lm_out) {
+    // of pixel tiles. bm = 0: the tile height whose slowest workgroup finishes first.
+    auto plan = [&](int bm_, int* lm_out) {   // -> relative time of the slowest workgroup
         const int tm = (p.M + bm_ - 1) / bm_, share = (tm + 7) / 8;
         int lm = 64 / p.tiles_n;
         lm = lm < 1 ? 1 : (lm > share ? share : lm);
         *lm_out = lm;
-        return (double)tm / 8.0 / lm / (double)((share + lm - 1) / lm) * (bm_ == 128 ? 1.0 : 0.9);
+        // tiles of its slowest workgroup x cost of a tile (a 64-row tile: half the matrix work + the same copies of the
+        // weights), and a workgroup alone on its CU (<= 32 per XCD) runs ~1.6x as fast as one of a pair
+        return (double)((share + lm - 1) / lm) * (bm_ == 128 ? 1.0 : 0.55) * (lm * p.tiles_n <= 32 ? 0.6 : 1.0);
     };
     int lm = 1;
     if (bm == 0) {
         int lm128, lm64;
         const double e128 = plan(128, &lm128), e64 = plan(64, &lm64);
-        bm = e128 >= e64 ? 128 : 64;
+        bm = e128 <= e64 ? 128 : 64;
         lm = bm == 128 ? lm128 : lm64;
     } else {
         (void)plan(bm, &lm);

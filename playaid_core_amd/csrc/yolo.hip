@@ -172,17 +172,23 @@ struct StemDirectParams {
     int32_t rows, row_blocks, col_blocks;  // rows % 4 == 0
 };
 
+// ROWS output rows per wave, fully unrolled and without a branch: hipcc's s_waitcnt placement is exact in straight-line code
+// only -- with a row loop and a branch around the stores it waited for the row's own prefetch (vmcnt(2) behind six loads
+// that nothing needed for another 54 matrix instructions), which cost the kernel half its matrix-pipe time. Rows and
+// columns past the image are loaded from clamped addresses and their stores are dropped by the buffer's bounds check.
+template <int ROWS>
 __global__ __launch_bounds__(256, 2) void stem6x6_direct_kernel(const StemDirectParams p) {
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     typedef float f32x4 __attribute__((ext_vector_type(4)));
+    static_assert(ROWS % 4 == 0, "the register window rotates with period four");
     const int lane = threadIdx.x & 63, lr = lane & 31, lh = lane >> 5;
-    const long long strip = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const long long strips = (long long)p.n * p.row_blocks * p.col_blocks;
+    const int strip = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (wave-uniform, and the compiler knows)
+    const int strips = p.n * p.row_blocks * p.col_blocks;
     if (strip >= strips) return;  // (whole waves; the kernel has no barrier)
-    const int cb = (int)(strip % p.col_blocks);
-    const int rb = (int)((strip / p.col_blocks) % p.row_blocks);
-    const int img = (int)(strip / ((long long)p.col_blocks * p.row_blocks));
-    const int ox = cb * 32 + lr, oy0 = rb * p.rows;
+    const int cb = strip % p.col_blocks;
+    const int rb = (strip / p.col_blocks) % p.row_blocks;
+    const int img = strip / (p.col_blocks * p.row_blocks);
+    const int ox = cb * 32 + lr, oy0 = rb * ROWS;
     const int oxc = ox < p.ow ? ox : p.ow - 1;
     const int in_w = p.net_w + 4, in_h = p.net_h + 4;
     const float* xin = p.x + ((size_t)img * in_h * in_w + 2 * oxc + 3 * lh) * 4;
@@ -198,7 +204,10 @@ __global__ __launch_bounds__(256, 2) void stem6x6_direct_kernel(const StemDirect
     f32x4 bias4[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) bias4[g] = *reinterpret_cast<const f32x4*>(p.bias + 8 * g + 4 * lh);
-    float* const outp = p.out + (size_t)img * p.out_img_stride + (size_t)(ox + p.out_pad) * p.out_px_stride + 4 * lh;
+    // this image's slice of the output as a buffer: a store at offset >= num_records (0xFFFFFFFF here) goes nowhere
+    const __amdgpu_buffer_rsrc_t out_rs =
+        __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)img * p.out_img_stride, 0, p.out_img_stride * 4, 0x00020000);
+    const unsigned col_off = ox < p.ow ? (unsigned)(((ox + p.out_pad) * p.out_px_stride + 4 * lh) * 4) : 0xFFFFFFFFu;
 
     f32x4 win[8][3];
     auto load_row = [&](int slot, int row) {  // input row `row` (clamped: rows past the image feed output rows nobody stores)
@@ -209,35 +218,37 @@ __global__ __launch_bounds__(256, 2) void stem6x6_direct_kernel(const StemDirect
     };
 #pragma unroll
     for (int ky = 0; ky < 6; ++ky) load_row(ky, 2 * oy0 + ky);
-    for (int rr = 0; rr < p.rows; rr += 4) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int oy = oy0 + rr + u;
-            // the next output row's two new input rows, into the slots of the two rows this one no longer needs
+    for (int t = 0; t < ROWS; ++t) {
+        const int u = t & 3, oy = oy0 + t;
+        // the next output row's two new input rows, into the slots of the two rows this one no longer needs
+        if (t + 1 < ROWS) {
             load_row((2 * u + 6) & 7, 2 * oy + 6);
             load_row((2 * u + 7) & 7, 2 * oy + 7);
-            f32x16 acc;
+        }
+        __builtin_amdgcn_sched_barrier(0);  // (hipcc otherwise sinks the loads to their first use, one output row later)
+        f32x16 acc;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
-            for (int ky = 0; ky < 6; ++ky)
+        for (int ky = 0; ky < 6; ++ky)
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const f32x4 px = win[(2 * u + ky) & 7][j];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ky * 9 + j * 3 + 0], px.x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ky * 9 + j * 3 + 1], px.y, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ky * 9 + j * 3 + 2], px.z, acc, 0, 0, 0);
-                }
-            if (oy < p.oh && ox < p.ow) {
-                float* o = outp + (size_t)(oy + p.out_pad) * p.out_row_stride;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 v = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]} + bias4[g];
-                    v.x = silu_fast(v.x); v.y = silu_fast(v.y);
-                    v.z = silu_fast(v.z); v.w = silu_fast(v.w);
-                    *reinterpret_cast<f32x4*>(o + 8 * g) = v;
-                }
+            for (int j = 0; j < 3; ++j) {
+                const f32x4 px = win[(2 * u + ky) & 7][j];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ky * 9 + j * 3 + 0], px.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ky * 9 + j * 3 + 1], px.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ky * 9 + j * 3 + 2], px.z, acc, 0, 0, 0);
             }
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned row_off = oy < p.oh ? col_off + (unsigned)((oy + p.out_pad) * p.out_row_stride * 4) : 0xFFFFFFFFu;
+        const unsigned off = col_off == 0xFFFFFFFFu ? 0xFFFFFFFFu : row_off;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]} + bias4[g];
+            v.x = silu_fast(v.x); v.y = silu_fast(v.y);
+            v.z = silu_fast(v.z); v.w = silu_fast(v.w);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), out_rs,
+                                                   off == 0xFFFFFFFFu ? off : off + 32u * g, 0, 0);
         }
     }
 }
@@ -410,8 +421,9 @@ static int detector_run(pa_detector* h, const uint8_t* frames, int32_t n, int32_
             q.rows = 12;  // 64 x 384 x 640: 10240 strips = five rounds of two waves per SIMD
             q.row_blocks = (oh + q.rows - 1) / q.rows;
             q.col_blocks = (ow + 31) / 32;
+            if ((long long)q.out_img_stride * 4 >= (1ll << 32)) return fail(PA_ERR_INVALID_ARG, "stem: output image larger than a buffer descriptor spans");
             const long long strips = (long long)n * q.row_blocks * q.col_blocks;
-            hipLaunchKernelGGL(pa::stem6x6_direct_kernel, dim3((unsigned)((strips + 3) / 4)), dim3(256), 0, s, q);
+            hipLaunchKernelGGL(pa::stem6x6_direct_kernel<12>, dim3((unsigned)((strips + 3) / 4)), dim3(256), 0, s, q);
             DT_HIP(hipGetLastError());
             continue;
         }
