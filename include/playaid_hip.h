@@ -218,7 +218,7 @@ typedef struct pa_net_layer {
     int32_t kind;      /* 0 convolution, 3 stem 6x6/2 + SiLU on the letter-boxed image (cout == 32; weights float32[64][56]: lane l =
                           (kx / 3) * 32 + channel holds W[channel][c][ky][3 * (l / 32) + j] at ky * 9 + j * 3 + c), 4 max-pool 5x5/1,
                           5 nearest 2x up-sampling, 6 Detect decode of one scale (3 anchors) */
-    int32_t cin, cout; /* kind 0: cin % 32 == 0, cout % 64 == 0 (pad with zero weights); kinds 4 / 5: cin = channels moved */
+    int32_t cin, cout; /* kind 0: cin % 32 == 0, cout % 32 == 0 (pad with zero weights; cout % 64 != 0 needs in_pad == 1 for a 3x3 and no residual for a 1x1); kinds 4 / 5: cin = channels moved */
     int32_t ksize, stride;           /* kind 0: 1 | 3, 1 | 2 */
     int32_t in_h, in_w;              /* interior of the input */
     int32_t in_buf, in_coff, in_cstride, in_pad;

@@ -89,10 +89,11 @@ template <int BM> struct PatchCap { static constexpr int slots = BM == 128 ? 224
 // own pair of patch buffers; the two partial tiles meet in LDS in the epilogue. Same occupancy as
 // two 256-thread split-K workgroups per CU, but no slab round trip through HBM and no reduce
 // kernel behind the launch (the layer-4 convs: M = 2048 gives only 256 tiles of 64 x 64).
-template <int BM, bool K2, bool KS2, bool BLK = false>
+template <int BM, bool K2, bool KS2, bool BLK = false, int BN = 64>
 __global__ __launch_bounds__(KS2 ? 512 : 256, 2) void conv3x3_patch_kernel(const GemmParams p) {
-    constexpr int BN = 64;
-    constexpr int MI = BM / 64;
+    static_assert(BN == 64 || (BN == 32 && BLK && !K2 && !KS2), "32 output channels per tile: blocked form only");
+    constexpr int WM = BN == 64 ? 2 : 4;   // waves along the pixel rows (BN = 32: 4 x 1 waves, no zero-padded channels)
+    constexpr int MI = BM / WM / 32;
     constexpr int PP = PatchCap<BM>::slots * 32;  // floats per patch buffer
     __shared__ __attribute__((aligned(16))) float pc_lds[(KS2 ? 2 : 1) * 2 * PP];
     const int half = KS2 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(KS2 ? 512 : 256, 2) void conv3x3_patch_kernel(const
 
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = BN == 64 ? wave >> 1 : wave, wn = BN == 64 ? wave & 1 : 0;
     const int lr = lane & 31;
     const int lh = lane >> 5;
 
@@ -243,10 +244,10 @@ __global__ __launch_bounds__(KS2 ? 512 : 256, 2) void conv3x3_patch_kernel(const
     int pbase[MI], rbase[MI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-        int m = tile_m * BM + wm * (BM / 2) + mi * 32 + lr;
+        int m = tile_m * BM + wm * (BM / WM) + mi * 32 + lr;
         m = m < p.M ? m : p.M - 1;
         if (BLK) {
-            const int ml = wm * (BM / 2) + mi * 32 + lr;   // row of the tile
+            const int ml = wm * (BM / WM) + mi * 32 + lr;   // row of the tile
             const int rem = ml & ((1 << p.blk_shift_px) - 1);
             const int r = rem >> p.blk_shift_c, c = rem & (p.blk_cols - 1);
             pbase[mi] = (ml >> p.blk_shift_px) * p.img_px_patch + r * p.patch_pitch + c;
@@ -443,7 +444,7 @@ __global__ __launch_bounds__(KS2 ? 512 : 256, 2) void conv3x3_patch_kernel(const
         bias4[g] = (direct_out && p.bias) ? *reinterpret_cast<const f32x4*>(p.bias + ch0 + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-        const int m = tile_m * BM + wm * (BM / 2) + mi * 32 + lr;
+        const int m = tile_m * BM + wm * (BM / WM) + mi * 32 + lr;
         if (m >= p.M) continue;
         int img, oy, ox;
         if (BLK) split_m_blk(p, m, img, oy, ox); else split_m(p, m, img, oy, ox);
@@ -616,15 +617,16 @@ hipError_t launch_conv3x3_patch(const GemmParams& p_in, int bm, hipStream_t s) {
 // layouts whose chunk swizzles were searched, so the operand reads stay free of bank conflicts.
 hipError_t launch_conv3x3_patch_blocked(const GemmParams& p_in, hipStream_t s) {
     GemmParams p = p_in;
-    if (p.gather || p.taps != 9 || p.kw_taps != 3 || p.stride != 1 || p.chunk % 32 != 0 || p.N % 64 != 0 || p.M <= 0 || p.k2_steps ||
+    if (p.gather || p.taps != 9 || p.kw_taps != 3 || p.stride != 1 || p.chunk % 32 != 0 || p.N % 32 != 0 || p.M <= 0 || p.k2_steps ||
         p.ktot != 9 * p.chunk || p.off_y != 0 || p.off_x != 0 || p.M >= (1 << 24))
         return hipErrorInvalidValue;
+    const int bn = p.N % 64 == 0 ? 64 : 32;
     const int ho = p.howo / p.wo;
     if (p.M % p.howo != 0) return hipErrorInvalidValue;
     int br, bc, bm;
     if (p.wo % 16 == 0 && ho % 8 == 0) { br = 8; bc = 16; bm = 128; }
-    else if (p.wo % 8 == 0 && ho % 8 == 0) { br = 8; bc = 8; bm = ((p.M + 127) / 128) * (p.N / 64) >= 512 ? 128 : 64; }
-    else if (p.wo % 4 == 0 && ho % 4 == 0) { br = 4; bc = 4; bm = 64; }
+    else if (p.wo % 8 == 0 && ho % 8 == 0) { br = 8; bc = 8; bm = ((p.M + 127) / 128) * (p.N / 64) >= 512 || bn == 32 ? 128 : 64; }
+    else if (p.wo % 4 == 0 && ho % 4 == 0 && bn == 64) { br = 4; bc = 4; bm = 64; }
     else return hipErrorInvalidValue;
     auto ilog2 = [](int v) { int sh = 0; while ((1 << sh) < v) ++sh; return sh; };
     p.blk_rows = br; p.blk_cols = bc;
@@ -645,7 +647,7 @@ hipError_t launch_conv3x3_patch_blocked(const GemmParams& p_in, hipStream_t s) {
     p.total_px = (p.M / p.howo) * p.img_px;
     p.howo_shift = p.wo_shift = -1;
     p.tiles_m = (p.M + bm - 1) / bm;
-    p.tiles_n = p.N / 64;
+    p.tiles_n = p.N / bn;
     p.tiles_per_img = 1; p.p0_img = 0; p.p0_row = 0;
     p.splitk = 1;
     p.ksteps_per_split = p.chunk / 32;
@@ -661,7 +663,8 @@ hipError_t launch_conv3x3_patch_blocked(const GemmParams& p_in, hipStream_t s) {
             if (cost < 0.9 * best) { best = cost; p.xcd_m = a; p.xcd_n = bb; }
         }
     }
-    if (bm == 128) hipLaunchKernelGGL((conv3x3_patch_kernel<128, false, false, true>), dim3(grid), dim3(256), 0, s, p);
+    if (bn == 32) hipLaunchKernelGGL((conv3x3_patch_kernel<128, false, false, true, 32>), dim3(grid), dim3(256), 0, s, p);
+    else if (bm == 128) hipLaunchKernelGGL((conv3x3_patch_kernel<128, false, false, true>), dim3(grid), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((conv3x3_patch_kernel<64, false, false, true>), dim3(grid), dim3(256), 0, s, p);
     return hipGetLastError();
 }

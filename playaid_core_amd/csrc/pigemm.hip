@@ -39,11 +39,12 @@ template <int N> __device__ __forceinline__ void pg_wait_vm() { asm volatile("s_
 
 }  // namespace
 
-// BM x 64 tiles, 256 threads = 2 x 2 waves, three LDS stages of (BM + 64) rows x 32 floats.
-template <int BM>
+// BM x BN tiles, 256 threads = 2 x 2 waves (BN = 64) or 4 x 1 (BN = 32: layers with 32 output channels run without zero
+// padding), three LDS stages of (BM + BN) rows x 32 floats.
+template <int BM, int BN = 64>
 __global__ __launch_bounds__(256, 2) void pgemm_kernel(const GemmParams p) {
-    constexpr int BN = 64;
-    constexpr int MI = BM / 64;
+    constexpr int WM = BN == 64 ? 2 : 4;      // waves along the pixel rows
+    constexpr int MI = BM / WM / 32;
     constexpr int A_ROWS = BM / 32, B_ROWS = BN / 32;
     constexpr int NLD = A_ROWS + B_ROWS;  // LDS-DMA wave instructions per k-step
     constexpr int NST = MI * 4;           // store wave instructions per tile
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const GemmParams p) {
     const int row0 = tid >> 3;
     const int colq = (tid & 7) ^ ((row0 >> 1) & 7);  // LDS chunk c of row r holds logical chunk c ^ ((r >> 1) & 7)
     const int lane = tid & 63, lr = lane & 31, lh = lane >> 5;
-    const int wm = wave_id >> 1, wn = wave_id & 1;
+    const int wm = BN == 64 ? wave_id >> 1 : wave_id, wn = BN == 64 ? wave_id & 1 : 0;
     const float rcp_howo = 1.0f / (float)p.howo, rcp_wo = 1.0f / (float)p.wo;
 
     const __amdgpu_buffer_rsrc_t act_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.act), 0, -1, 0x00020000);
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const GemmParams p) {
         }
     };
 
-    const int a_rd = (wm * (BM / 2) + lr) * 32, b_rd = BM * 32 + (wn * 32 + lr) * 32;
+    const int a_rd = (wm * (BM / WM) + lr) * 32, b_rd = BM * 32 + (wn * 32 + lr) * 32;
     const int swz = (lr >> 1) & 7;
 
     issue(0);
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const GemmParams p) {
         // epilogue of the tile, straight from the accumulators: lane = pixel lr of its 32-pixel block, channels ch0 + 8 g + 0..3
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-            const int m = tile_m * BM + wm * (BM / 2) + mi * 32 + lr;
+            const int m = tile_m * BM + wm * (BM / WM) + mi * 32 + lr;
             const int mc = m < p.M ? m : p.M - 1;
             const int img = pg_div(mc, p.howo, rcp_howo);
             const int rem = mc - img * p.howo;
@@ -219,10 +220,12 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const GemmParams p) {
 // Conv mode of GemmParams (no gather, no second source, no residual, no split-K); bm = 128 | 64 | 0 (chosen here).
 hipError_t launch_pgemm(const GemmParams& p_in, int bm, hipStream_t s) {
     GemmParams p = p_in;
-    if (p.gather || p.k2_steps || p.residual || p.chunk % 32 != 0 || p.N % 64 != 0 || p.M <= 0 || p.M >= (1 << 24) || p.howo >= (1 << 16) ||
+    if (p.gather || p.k2_steps || p.residual || p.chunk % 32 != 0 || p.N % 32 != 0 || p.M <= 0 || p.M >= (1 << 24) || p.howo >= (1 << 16) ||
         p.ktot != p.taps * p.chunk || (bm != 128 && bm != 64 && bm != 0))
         return hipErrorInvalidValue;
-    p.tiles_n = p.N / 64;
+    const int bn = p.N % 64 == 0 ? 64 : 32;   // 32: output channels that are not a multiple of 64 (128-row tiles only)
+    if (bn == 32) bm = 128;
+    p.tiles_n = p.N / bn;
     if (p.tiles_n > 64) return hipErrorInvalidValue;
     // Two workgroups per CU = 64 per XCD, a multiple of the channel columns, and no more per column than the XCD's share
     // of pixel tiles. bm = 0: the tile height whose slowest workgroup finishes first.
@@ -247,7 +250,8 @@ hipError_t launch_pgemm(const GemmParams& p_in, int bm, hipStream_t s) {
     p.tiles_m = (p.M + bm - 1) / bm;
     const int per = lm * p.tiles_n;
     const int grid = per * 8;
-    if (bm == 128) hipLaunchKernelGGL((pgemm_kernel<128>), dim3(grid), dim3(256), 0, s, p);
+    if (bn == 32) hipLaunchKernelGGL((pgemm_kernel<128, 32>), dim3(grid), dim3(256), 0, s, p);
+    else if (bm == 128) hipLaunchKernelGGL((pgemm_kernel<128>), dim3(grid), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((pgemm_kernel<64>), dim3(grid), dim3(256), 0, s, p);
     return hipGetLastError();
 }

@@ -7,7 +7,7 @@
 // buffer (offset + pixel pitch), which is how the network's concatenations cost nothing: the producers write straight
 // into their slice of the consumer's input. Kinds:
 //   0  convolution 1x1 | 3x3, stride 1 | 2, + bias, activation (none / ReLU / SiLU), residual before or after it
-//      (implicit GEMM on the matrix cores; cin % 32 == 0, cout % 64 == 0: the table pads with zero weights). Layers without
+//      (implicit GEMM on the matrix cores; cin % 32 == 0, cout % 32 == 0). Layers without
 //      a residual -- every 1x1 and stride-2 convolution -- run on the persistent engine (pigemm.hip), the others on igemm.hip
 //   3  the 6x6 / 2 stem (3 -> 32 channels) on the letter-boxed RGB image + bias + SiLU: a direct convolution on the matrix
 //      cores with K = 108 exactly (stem6x6_direct_kernel below; weights in its lane layout [64][56])
@@ -316,7 +316,7 @@ int pa_detector_create(int32_t device, const pa_net_layer* layers, int32_t n_lay
         const int oh = L.kind == 5 ? L.in_h * 2 : L.in_h / (L.stride > 0 ? L.stride : 1);
         const int ow = L.kind == 5 ? L.in_w * 2 : L.in_w / (L.stride > 0 ? L.stride : 1);
         if (L.kind == 0) {
-            if ((L.ksize != 1 && L.ksize != 3) || (L.stride != 1 && L.stride != 2) || L.cin % 32 || L.cout % 64 || L.in_h % L.stride ||
+            if ((L.ksize != 1 && L.ksize != 3) || (L.stride != 1 && L.stride != 2) || L.cin % 32 || L.cout % 32 || L.in_h % L.stride ||
                 L.in_w % L.stride || L.in_pad < (L.ksize - 1) / 2 || L.act < 0 || L.act > 2)
                 return bad(i, "unsupported convolution");
             if (!slice_ok(L.in_buf, L.in_h, L.in_w, L.in_pad, L.in_cstride, L.in_coff, L.cin) || (L.in_coff % 32) ||
@@ -487,13 +487,13 @@ static int detector_run(pa_detector* h, const uint8_t* frames, int32_t n, int32_
         if (use_patch && L.ksize == 3 && L.stride == 1 && L.in_pad == 1)
             pe = pa::launch_conv3x3_patch_blocked(p, s);  // input patch resident in LDS across the nine taps (patchconv.hip)
         if (pe != hipErrorInvalidValue) {
-        } else if (use_pgemm && !p.residual) {
+        } else if ((use_pgemm || p.N % 64) && !p.residual) {
             // 1x1 and stride-2 convolutions: persistent workgroups over runs of tiles (pigemm.hip)
             pe = pa::launch_pgemm(p, 0, s);
-        } else {
+        } else if (p.N % 64 == 0) {
             const pa::GemmTile tile = (p.N % 128 == 0 && t128 / 2 >= 512) ? pa::TILE_128x128 : (t128 >= 512 ? pa::TILE_128x64 : pa::TILE_64x64);
             pe = pa::launch_igemm(p, tile, s);
-        }
+        }   // (32 output channels: the persistent and the patch kernel only -- the table builder keeps such layers on them)
         if (pe != hipSuccess) return fail(PA_ERR_HIP, "layer " + std::to_string(li) + ": " + hipGetErrorString(pe));
     }
     if (ev) DT_HIP(hipEventRecord(ev->back(), s));

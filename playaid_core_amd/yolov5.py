@@ -71,7 +71,7 @@ class _Table:
     def conv(self, w, b, src, dst, k, s, act=2, res=None, res_after=0):
         """w [cout, cin, k, k] / b [cout] float64 (already padded to the kernel's multiples); src / dst / res = (buf, coff, c)."""
         cout, cin = w.shape[0], w.shape[1]
-        assert cin % 32 == 0 and cout % 64 == 0 and src[2] == cin and dst[2] == cout, (w.shape, src, dst)
+        assert cin % 32 == 0 and cout % 32 == 0 and src[2] == cin and dst[2] == cout, (w.shape, src, dst)
         ih, iw, ipad, ic = self.bufs[src[0]]
         oh, ow, opad, oc = self.bufs[dst[0]]
         assert (ih // s, iw // s) == (oh, ow) and ipad >= k // 2, (self.bufs[src[0]], self.bufs[dst[0]], k, s)
@@ -127,18 +127,18 @@ def build_yolov5s_table(sd: Mapping, net_hw: Tuple[int, int], nc: int):
         w2, b2 = _fold(sd, prefix + ".cv2")
         w3, b3 = _fold(sd, prefix + ".cv3")
         if c_ % 64:
-            # c_ = 32 (model.2): cv1 and cv2 read the same input -> ONE convolution writes [cv1 | cv2]; the bottleneck's
-            # convolutions are padded to 64 output channels with zero weights, and its residual -- added after the SiLU,
-            # SiLU(0) = 0 -- drops cv2's half of that buffer into the padding: the concatenation appears by itself
+            # c_ = 32 (model.2): cv1 and cv2 read the same input -> ONE convolution writes [cv1 | cv2]; the bottleneck's two
+            # convolutions run on 32-channel tiles, the second adding its residual -- cv1's half of that buffer -- IN PLACE,
+            # so cv3's input [bottleneck | cv2] is the same buffer and no concatenation is ever written
             assert n == 1 and shortcut and 2 * c_ == 64
-            P, Q = B(scale, 0, 64), B(scale, 0, 64)
-            R = B(scale, 1, 64)
+            P = B(scale, 0, 64)
+            R = B(scale, 1, c_)
             T.conv(np.concatenate([w1, w2]), np.concatenate([b1, b2]), src, (P, 0, 64), 1, 1)
             wa, ba = _fold(sd, prefix + ".m.0.cv1")
-            T.conv(*_pad_rows(wa, ba, 64), (P, 0, c_), (R, 0, 64), 1, 1)
+            T.conv(wa, ba, (P, 0, c_), (R, 0, c_), 1, 1)
             wb, bb = _fold(sd, prefix + ".m.0.cv2")
-            T.conv(*_pad_rows(wb, bb, 64), (R, 0, c_), (Q, 0, 64), 3, 1, res=(P, 0, 64), res_after=1)
-            T.conv(w3, b3, (Q, 0, 64), dst, 1, 1)
+            T.conv(wb, bb, (R, 0, c_), (P, 0, c_), 3, 1, res=(P, 0, c_), res_after=1)
+            T.conv(w3, b3, (P, 0, 64), dst, 1, 1)
             return
         P, Q = B(scale, 0, 2 * c_), B(scale, 0, 2 * c_)
         R = B(scale, 1, c_)

@@ -20,7 +20,9 @@ def test_table_covers_the_published_graph():
     assert rows == 3 * (48 * 80 + 24 * 40 + 12 * 20)
     n_params = sum(int(np.prod(v.shape)) for k, v in sd.items() if k.endswith("conv.weight") or k.startswith("model.24.m"))
     assert 7.0e6 < n_params < 7.3e6  # yolov5s: 7.0 M weights (7.2 M parameters with the BatchNorm vectors)
-    assert all(l.cin % 32 == 0 and l.cout % 64 == 0 for l in layers if l.kind == 0)
+    # (round 4: model.2's 32-channel bottleneck runs on 32-channel tiles instead of being zero-padded to 64)
+    assert all(l.cin % 32 == 0 and l.cout % 32 == 0 for l in layers if l.kind == 0)
+    assert sum(1 for l in layers if l.kind == 0 and l.cout % 64) == 2
 
 
 def test_oracle_front_end():
