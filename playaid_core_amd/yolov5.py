@@ -121,37 +121,24 @@ def build_yolov5s_table(sd: Mapping, net_hw: Tuple[int, int], nc: int):
         return T.buf(size[scale][0], size[scale][1], pad, c)
 
     def C3(prefix, src, dst, scale, cin, cout, n, shortcut):
-        """src / dst slices; writes cv3's output into dst."""
+        """src / dst slices; writes cv3's output into dst. cv1 and cv2 read the same input, so ONE convolution writes
+        X = [cv1 | cv2]; every bottleneck reads X's first half through its 1x1 into R and its 3x3 writes that half back IN
+        PLACE (adding it as the residual after the SiLU when the block has shortcuts), so cv3's input [bottlenecks | cv2] is
+        X itself: no concatenation, no ping-pong buffers, src read once. (c_ = 32, model.2: the bottleneck's convolutions run
+        on 32-channel tiles.)"""
         c_ = cout // 2
         w1, b1 = _fold(sd, prefix + ".cv1")
         w2, b2 = _fold(sd, prefix + ".cv2")
         w3, b3 = _fold(sd, prefix + ".cv3")
-        if c_ % 64:
-            # c_ = 32 (model.2): cv1 and cv2 read the same input -> ONE convolution writes [cv1 | cv2]; the bottleneck's two
-            # convolutions run on 32-channel tiles, the second adding its residual -- cv1's half of that buffer -- IN PLACE,
-            # so cv3's input [bottleneck | cv2] is the same buffer and no concatenation is ever written
-            assert n == 1 and shortcut and 2 * c_ == 64
-            P = B(scale, 0, 64)
-            R = B(scale, 1, c_)
-            T.conv(np.concatenate([w1, w2]), np.concatenate([b1, b2]), src, (P, 0, 64), 1, 1)
-            wa, ba = _fold(sd, prefix + ".m.0.cv1")
-            T.conv(wa, ba, (P, 0, c_), (R, 0, c_), 1, 1)
-            wb, bb = _fold(sd, prefix + ".m.0.cv2")
-            T.conv(wb, bb, (R, 0, c_), (P, 0, c_), 3, 1, res=(P, 0, c_), res_after=1)
-            T.conv(w3, b3, (P, 0, 64), dst, 1, 1)
-            return
-        P, Q = B(scale, 0, 2 * c_), B(scale, 0, 2 * c_)
+        X = B(scale, 0, 2 * c_)
         R = B(scale, 1, c_)
-        T.conv(w1, b1, src, (P, 0, c_), 1, 1)
-        cur, other = P, Q
+        T.conv(np.concatenate([w1, w2]), np.concatenate([b1, b2]), src, (X, 0, 2 * c_), 1, 1)
         for j in range(n):
             wa, ba = _fold(sd, f"{prefix}.m.{j}.cv1")
-            T.conv(wa, ba, (cur, 0, c_), (R, 0, c_), 1, 1)
+            T.conv(wa, ba, (X, 0, c_), (R, 0, c_), 1, 1)
             wb, bb = _fold(sd, f"{prefix}.m.{j}.cv2")
-            T.conv(wb, bb, (R, 0, c_), (other, 0, c_), 3, 1, res=(cur, 0, c_) if shortcut else None, res_after=1)
-            cur, other = other, cur
-        T.conv(w2, b2, src, (cur, c_, c_), 1, 1)
-        T.conv(w3, b3, (cur, 0, 2 * c_), dst, 1, 1)
+            T.conv(wb, bb, (R, 0, c_), (X, 0, c_), 3, 1, res=(X, 0, c_) if shortcut else None, res_after=1)
+        T.conv(w3, b3, (X, 0, 2 * c_), dst, 1, 1)
 
     def conv(prefix, src, dst, k, s):
         w, b = _fold(sd, prefix)

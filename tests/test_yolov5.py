@@ -14,9 +14,9 @@ def test_table_covers_the_published_graph():
     sd = synth.make_yolov5s_state_dict()
     layers, bufs, weights, rows = build_yolov5s_table(sd, NET, NC)
     kinds = [l.kind for l in layers]
-    # the 6x6 stem + 55 GEMM convolutions of the graph (56 Conv modules besides the stem, model.2's cv1 / cv2 merged
-    # into one) + the 3 Detect convolutions, 3 SPPF max-pools, 2 up-samplings, 3 decodes
-    assert kinds.count(3) == 1 and kinds.count(0) == 55 + 3 and kinds.count(4) == 3 and kinds.count(5) == 2 and kinds.count(6) == 3
+    # the 6x6 stem + 48 GEMM convolutions of the graph (56 Conv modules besides the stem; round 4: cv1 / cv2 of all eight C3
+    # blocks merged into one convolution each) + the 3 Detect convolutions, 3 SPPF max-pools, 2 up-samplings, 3 decodes
+    assert kinds.count(3) == 1 and kinds.count(0) == 48 + 3 and kinds.count(4) == 3 and kinds.count(5) == 2 and kinds.count(6) == 3
     assert rows == 3 * (48 * 80 + 24 * 40 + 12 * 20)
     n_params = sum(int(np.prod(v.shape)) for k, v in sd.items() if k.endswith("conv.weight") or k.startswith("model.24.m"))
     assert 7.0e6 < n_params < 7.3e6  # yolov5s: 7.0 M weights (7.2 M parameters with the BatchNorm vectors)
@@ -68,7 +68,7 @@ def test_detection_network_against_the_oracle(engine):
             assert got.shape == want.shape == (n, det.rows, 5 + NC)
             # boxes in network pixels, scores in 0..1: fp32 through 60 layers whose synthetic weights amplify on purpose
             assert np.abs(got[..., :4] - want[..., :4]).max() <= 2e-2, np.abs(got[..., :4] - want[..., :4]).max()
-            assert np.abs(got[..., 4:] - want[..., 4:]).max() <= 2e-4, np.abs(got[..., 4:] - want[..., 4:]).max()
+            assert np.abs(got[..., 4:] - want[..., 4:]).max() <= 1e-4, np.abs(got[..., 4:] - want[..., 4:]).max()  # measured 1.4e-5: profiles/r04_yolov5_parity.txt
             assert want[..., 4].max() > 0.05 and want[..., 5:].std() > 0.05  # a live network, not a bias echo
         # through the post-processing the reference's subprocess runs (thresholds lowered so that the seeded network
         # "detects" something): same label text as the oracle's NMS on the oracle's rows wherever the scores are apart
@@ -81,7 +81,7 @@ def test_detection_network_against_the_oracle(engine):
             got_rows = np.array([[float(v) for v in l.split(" ")] for l in labels[i].splitlines()])
             assert got_rows.shape == rows.shape and len(rows) >= 1
             assert np.array_equal(got_rows[:, 0], rows[:, 0])
-            assert np.abs(got_rows[:, 1:5] - rows[:, 1:5]).max() <= 2e-3 and np.abs(got_rows[:, 5] - rows[:, 5]).max() <= 2e-4
+            assert np.abs(got_rows[:, 1:5] - rows[:, 1:5]).max() <= 2e-3 and np.abs(got_rows[:, 5] - rows[:, 5]).max() <= 1e-4
         assert pdet.label_lines(np.zeros((0, 6), np.float32)) == ""
     finally:
         det.close()
@@ -104,7 +104,7 @@ def test_detection_network_batches_and_small_frames():
         torch.cuda.synchronize()
         x = torch.from_numpy(np.stack([oy.letterbox(f, NET) for f in frames]))
         want = oy.forward(x, sd, NC).numpy()
-        assert np.abs(got.cpu().numpy()[..., 4:] - want[..., 4:]).max() <= 2e-4
+        assert np.abs(got.cpu().numpy()[..., 4:] - want[..., 4:]).max() <= 1e-4
         assert np.abs(got.cpu().numpy()[..., :4] - want[..., :4]).max() <= 2e-2
     finally:
         det.close()
