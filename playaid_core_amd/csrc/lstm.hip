@@ -124,34 +124,33 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict_
 }
 
 
-// One LAYER in one launch (round 3): the H / 8 workgroups of lstm_step_kernel stay resident for all time steps. Each
-// keeps its 32 rows of W_hh (8 hidden units x 4 gates, 64 KB at H = 512) in LDS and its c state in registers, so a step
-// moves only h(t-1) (N x H floats) in and 8 x N values out; the steps are separated by a grid barrier (one atomic counter,
-// agent-scope release / acquire fences: the XCDs' L2s are not coherent for plain stores). The barrier gives up after
-// 20 ms (*err = 1) so that a grid that is not fully resident cannot hang the queue (pa_lstm_last_status reports it, the
-// handle then falls back to one launch per step).
-// The recurrent product of a step, [32 rows] x [N] dots of length H, is spread as thread = (row, eighth of k): 16-byte
-// LDS reads of the weights (row pitch H + 32 floats: the 16 lanes of a read phase fall on distinct banks) and of h
-// (broadcast across rows), H / 8 x N FMAs per thread, three shuffle steps to add the eighths. Measured per step (us):
-// barrier wait 3.5, h load 3.0, product 46.7 with lstm_step_kernel's wave-per-gate loop -> see profiles/README.md.
-constexpr int LSTM_WPITCH_PAD = 32;
+// One LAYER in one launch, on the whole chip (round 4): H / U workgroups (U = 2 hidden units each at H = 512: 256 workgroups,
+// one per CU; round 3 ran 64) stay resident for all time steps. A workgroup's 4 U rows of W_hh live in REGISTERS -- thread =
+// (row, part), part strides the row in 16-byte pieces, 16 floats per thread at H = 512 -- and its c state too, so a step moves
+// only h(t-1) (N x H floats -> LDS) in and U x N values out. The steps are separated by a grid barrier (one atomic counter,
+// agent-scope release / acquire fences: the XCDs' L2s are not coherent for plain stores); the launch is COOPERATIVE, so the
+// runtime refuses a grid that cannot be co-resident instead of letting it spin, and the barrier still gives up after 20 ms
+// (*err = 1: the decoder then writes NaN rows, pa_lstm_last_status reports it once and the handle falls back to one launch
+// per step). Per thread and step: H / P float4 products x N rows, log2(P) shuffle steps (P = 256 / (4 U) lanes share a row).
+template <int U>
 __global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict__ pre_all, const float* __restrict__ w_hh,
                                                          const float* __restrict__ b_hh, float* __restrict__ hseq, int L, int N, int H,
                                                          int* __restrict__ counter, int* __restrict__ err) {
+    constexpr int R = 4 * U, P = 256 / R, KQ = 128 / P;  // rows, lanes per row, float4 pieces per lane (H <= 512)
     extern __shared__ float sm[];
-    const int WP = H + LSTM_WPITCH_PAD;
-    float* ws = sm;                              // [32][WP]: rows (gate * 8 + u) of this workgroup's units
-    float* hs = ws + (size_t)32 * WP;            // [N][H]
-    float* gs = hs + (size_t)N * H;              // [32][LSTM_NMAX]
+    float* hs = sm;                              // [N][H]
+    float* gs = hs + (size_t)N * H;              // [R][LSTM_NMAX]
     __shared__ int go;
-    const int j0 = blockIdx.x * 8, nwg = gridDim.x;
-    const int row = threadIdx.x >> 3, part = threadIdx.x & 7;
-    for (int i = threadIdx.x; i < 32 * H; i += 256) {
-        const int r = i / H, k = i - r * H;
-        ws[(size_t)r * WP + k] = w_hh[(size_t)((r >> 3) * H + j0 + (r & 7)) * H + k];
+    const int j0 = blockIdx.x * U, nwg = gridDim.x;
+    const int row = threadIdx.x / P, part = threadIdx.x % P;   // row = gate * U + unit
+    const int hq = H >> 2;
+    float4 wreg[KQ];
+    {
+        const float4* wr = reinterpret_cast<const float4*>(w_hh + (size_t)((row / U) * H + j0 + (row % U)) * H);
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) wreg[q] = q * P + part < hq ? wr[q * P + part] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    float c_reg = 0.f;  // thread (u, n) = threadIdx.x < 8 * LSTM_NMAX owns c[n][j0 + u]
-    __syncthreads();
+    float c_reg = 0.f;  // thread (u, n) = threadIdx.x < U * LSTM_NMAX owns c[n][j0 + u]
     for (int t = 0; t < L; ++t) {
         const float* pre = pre_all + (size_t)t * N * 4 * H;
         if (t > 0) {
@@ -165,7 +164,7 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict
                         ok = 0;
                         break;
                     }
-                    __builtin_amdgcn_s_sleep(2);
+                    __builtin_amdgcn_s_sleep(1);
                 }
                 go = ok;
             }
@@ -173,44 +172,45 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict
             if (!go) return;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             const float4* h_prev = reinterpret_cast<const float4*>(hseq + (size_t)(t - 1) * N * H);
-            for (int i = threadIdx.x; i < N * H / 4; i += 256) reinterpret_cast<float4*>(hs)[i] = h_prev[i];
+            for (int i = threadIdx.x; i < N * hq; i += 256) reinterpret_cast<float4*>(hs)[i] = h_prev[i];
             __syncthreads();
             float acc[LSTM_NMAX];
 #pragma unroll
             for (int n = 0; n < LSTM_NMAX; ++n) acc[n] = 0.f;
-            const float4* wr = reinterpret_cast<const float4*>(ws + (size_t)row * WP);
-            for (int i = 0; i < H / 32; ++i) {
-                const int q = i * 8 + part;  // float4 index along k
-                const float4 w = wr[q];
 #pragma unroll
-                for (int n = 0; n < LSTM_NMAX; ++n)
-                    if (n < N) {
-                        const float4 hv = reinterpret_cast<const float4*>(hs + (size_t)n * H)[q];
-                        acc[n] = fmaf(w.x, hv.x, acc[n]);
-                        acc[n] = fmaf(w.y, hv.y, acc[n]);
-                        acc[n] = fmaf(w.z, hv.z, acc[n]);
-                        acc[n] = fmaf(w.w, hv.w, acc[n]);
-                    }
+            for (int q = 0; q < KQ; ++q) {
+                const int k4 = q * P + part;  // consecutive lanes read consecutive 16-byte pieces of h: no bank conflicts
+                if (k4 < hq) {
+                    const float4 w = wreg[q];
+#pragma unroll
+                    for (int n = 0; n < LSTM_NMAX; ++n)
+                        if (n < N) {
+                            const float4 hv = reinterpret_cast<const float4*>(hs + (size_t)n * H)[k4];
+                            acc[n] = fmaf(w.x, hv.x, acc[n]);
+                            acc[n] = fmaf(w.y, hv.y, acc[n]);
+                            acc[n] = fmaf(w.z, hv.z, acc[n]);
+                            acc[n] = fmaf(w.w, hv.w, acc[n]);
+                        }
+                }
             }
 #pragma unroll
             for (int n = 0; n < LSTM_NMAX; ++n)
                 if (n < N) {
                     float v = acc[n];
-                    v += __shfl_xor(v, 1, 64);
-                    v += __shfl_xor(v, 2, 64);
-                    v += __shfl_xor(v, 4, 64);
+#pragma unroll
+                    for (int d = 1; d < P; d <<= 1) v += __shfl_xor(v, d, 64);
                     if (part == 0) gs[row * LSTM_NMAX + n] = v;
                 }
             __syncthreads();
         }
-        if (threadIdx.x < 8 * LSTM_NMAX) {
+        if (threadIdx.x < U * LSTM_NMAX) {
             const int u = threadIdx.x / LSTM_NMAX, n = threadIdx.x % LSTM_NMAX;
             if (n < N) {
                 const int j = j0 + u;
                 float g4[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const float rec = (t > 0 ? gs[(g * 8 + u) * LSTM_NMAX + n] : 0.f) + b_hh[g * H + j];
+                    const float rec = (t > 0 ? gs[(g * U + u) * LSTM_NMAX + n] : 0.f) + b_hh[g * H + j];
                     g4[g] = pre[(size_t)n * 4 * H + g * H + j] + rec;
                 }
                 const float ig = sigmoidf(g4[0]), fg = sigmoidf(g4[1]), gg = tanhf(g4[2]), og = sigmoidf(g4[3]);
@@ -231,10 +231,18 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict
 // action_decoder + log_softmax for one row: Linear(H,128) + ReLU -> Linear(128,A) -> log_softmax
 __global__ __launch_bounds__(128) void lstm_decode_kernel(const float* __restrict__ h, const float* __restrict__ w1,
                                                           const float* __restrict__ b1, const float* __restrict__ w2,
-                                                          const float* __restrict__ b2, float* __restrict__ logp, int H, int A) {
+                                                          const float* __restrict__ b2, float* __restrict__ logp, int H, int A,
+                                                          const int* __restrict__ sync_words, int n_layers) {
     __shared__ float hid[128];
     __shared__ float lg[64];
     const int row = blockIdx.x, t = threadIdx.x;
+    // a layer kernel whose grid barrier gave up left garbage behind: say so in the result instead of passing it on
+    bool failed = false;
+    for (int l = 0; l < n_layers; ++l) failed |= sync_words[2 * l + 1] != 0;
+    if (failed) {
+        if (t < A) logp[(size_t)row * A + t] = __builtin_nanf("");
+        return;
+    }
     const float* hr = h + (size_t)row * H;
     {
         const float* w = w1 + (size_t)t * H;
@@ -365,25 +373,24 @@ int pa_lstm_create(int32_t device, int32_t input_dim, int32_t hidden_dim, int32_
     if (!chk(hipMalloc(&h->sync_words, 2 * 8 * sizeof(int)), "hipMalloc barrier words")) return PA_ERR_HIP;
     if (!chk(hipHostMalloc(&h->sync_host, 2 * 8 * sizeof(int)), "hipHostMalloc")) return PA_ERR_HIP;
     memset(h->sync_host, 0, 2 * 8 * sizeof(int));
-    {
-        // W_hh rows + h(t-1) + gate scratch in LDS: beyond the 64 KB default
-        const size_t lds = ((size_t)32 * (H + pa::LSTM_WPITCH_PAD) + (size_t)pa::LSTM_NMAX * H + 4 * 8 * pa::LSTM_NMAX) * sizeof(float);
-        if (lds > 160 * 1024 || H % 32 != 0 || getenv("PA_LSTM_STEPS")) h->persistent = false;
-        else if (!chk(hipFuncSetAttribute(reinterpret_cast<const void*>(&pa::lstm_layer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)lds), "hipFuncSetAttribute")) return PA_ERR_HIP;
-    }
+    // one launch per layer needs H / U workgroups co-resident (U = 2 above 256 hidden units): PA_LSTM_STEPS=1 forces the
+    // per-step kernels (A/B); a cooperative launch the runtime refuses switches to them by itself
+    if (getenv("PA_LSTM_STEPS")) h->persistent = false;
     return PA_OK;
 }
 
 int pa_lstm_last_status(pa_lstm* h) {
     if (!h) return PA_ERR_INVALID_ARG;
+    bool failed = false;
     for (int l = 0; l < h->layers; ++l)
-        if (h->sync_host && h->sync_host[2 * l + 1]) {
-            h->last_error = "pa_lstm_forward: the grid barrier of the per-layer kernel timed out (its workgroups were not all resident); "
-                            "the results of that call are invalid, later calls launch one kernel per time step";
-            return PA_ERR_HIP;
-        }
-    return PA_OK;
+        if (h->sync_host && h->sync_host[2 * l + 1]) failed = true;
+    if (!failed) return PA_OK;
+    // reported ONCE: the handle leaves the per-layer path for good, so the words are cleared and later calls are valid
+    h->persistent = false;
+    memset(h->sync_host, 0, 2 * 8 * sizeof(int));
+    h->last_error = "pa_lstm_forward: the grid barrier of the per-layer kernel timed out (its workgroups were not all resident); "
+                    "that call's log-probabilities are NaN, later calls launch one kernel per time step";
+    return PA_ERR_HIP;
 }
 
 void pa_lstm_destroy(pa_lstm* h) {
@@ -408,30 +415,36 @@ int pa_lstm_forward(pa_lstm* h, const float* x, int32_t ld, int32_t seq_len, int
     hipStream_t s = (hipStream_t)stream;
     const int H = h->hid, M = (int)rows;
     const size_t step_lds = ((size_t)batch * H + 4 * 8 * pa::LSTM_NMAX) * sizeof(float);
+    (void)hipMemsetAsync(h->sync_words, 0, 2 * 8 * sizeof(int), s);  // barrier counters and error words of this call (the decoder reads the latter)
     for (int l = 0; l < h->layers; ++l) {
         const float* in = l == 0 ? x : h->hseq[(l - 1) & 1];
         const int in_ld = l == 0 ? ld : H, K = l == 0 ? h->in_dim : H;
         (void)pa::launch_linear_f32(in, in_ld, h->w_ih[l], h->b_ih[l], h->pre, 4 * H, M, 4 * H, K, 0, s);
         float* hs = h->hseq[l & 1];
+        if (h->persistent && h->sync_host[2 * l + 1]) h->persistent = false;  // (a timeout the caller has not asked about yet)
         if (h->persistent) {
-            // all time steps of the layer in one launch; a barrier that timed out in an earlier call (grid not resident)
-            // switches this handle to one launch per step for good
-            if (h->sync_host[2 * l + 1]) h->persistent = false;
-        }
-        if (h->persistent) {
-            const size_t lds = ((size_t)32 * (H + pa::LSTM_WPITCH_PAD) + (size_t)batch * H + 4 * 8 * pa::LSTM_NMAX) * sizeof(float);
-            (void)hipMemsetAsync(h->sync_words + 2 * l, 0, 2 * sizeof(int), s);
-            hipLaunchKernelGGL(pa::lstm_layer_kernel, dim3(H / 8), dim3(256), lds, s, h->pre, h->w_hh[l], h->b_hh[l], hs, seq_len, batch, H,
-                               h->sync_words + 2 * l, h->sync_words + 2 * l + 1);
-            (void)hipMemcpyAsync(h->sync_host + 2 * l, h->sync_words + 2 * l, 2 * sizeof(int), hipMemcpyDeviceToHost, s);
-            continue;
+            // all time steps of the layer in one cooperative launch
+            const int U = H > 256 ? 2 : 1;
+            const size_t lds = ((size_t)batch * H + (size_t)4 * U * pa::LSTM_NMAX) * sizeof(float);
+            const float* a_pre = h->pre; const float* a_w = h->w_hh[l]; const float* a_b = h->b_hh[l];
+            int a_L = seq_len, a_N = batch, a_H = H;
+            int* a_cnt = h->sync_words + 2 * l; int* a_err = a_cnt + 1;
+            void* args[] = {&a_pre, &a_w, &a_b, &hs, &a_L, &a_N, &a_H, &a_cnt, &a_err};
+            const void* fn = U == 2 ? reinterpret_cast<const void*>(&pa::lstm_layer_kernel<2>) : reinterpret_cast<const void*>(&pa::lstm_layer_kernel<1>);
+            const hipError_t ce = hipLaunchCooperativeKernel(fn, dim3(H / U), dim3(256), args, (unsigned)lds, s);
+            if (ce == hipSuccess) {
+                (void)hipMemcpyAsync(h->sync_host + 2 * l, h->sync_words + 2 * l, 2 * sizeof(int), hipMemcpyDeviceToHost, s);
+                continue;
+            }
+            (void)hipGetLastError();   // the grid cannot be co-resident on this device (or no cooperative launches): per-step kernels
+            h->persistent = false;
         }
         for (int t = 0; t < seq_len; ++t)
             hipLaunchKernelGGL(pa::lstm_step_kernel, dim3(H / 8), dim3(256), step_lds, s, h->pre + (size_t)t * batch * 4 * H, h->w_hh[l],
                                h->b_hh[l], t ? hs + (size_t)(t - 1) * batch * H : nullptr, h->c, hs + (size_t)t * batch * H, batch, H);
     }
     hipLaunchKernelGGL(pa::lstm_decode_kernel, dim3(M), dim3(128), 0, s, h->hseq[(h->layers - 1) & 1], h->w1, h->b1, h->w2, h->b2, logp, H,
-                       h->actions);
+                       h->actions, h->sync_words, h->layers);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return bad(PA_ERR_HIP, hipGetErrorString(e));
     return PA_OK;

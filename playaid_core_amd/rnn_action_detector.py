@@ -170,7 +170,7 @@ class RNNActionDetector:
         if rc != 0:
             raise EngineError(rc, self._lib.pa_lstm_last_error(self._h).decode())
         if x.is_cuda:
-            return out
+            return out  # (enqueued only: should the per-layer kernel's barrier ever give up, these rows are NaN; check() says why)
         res = out.cpu()  # synchronises
         self.check()
         return res

@@ -1,0 +1,102 @@
+"""The chain north_star names, end to end on the device, against the oracle chain: Motion-JPEG bytes -> pa_mjpeg_decode ->
+pa_detector_forward (YOLOv5s) -> pa_detect_postprocess -> pa_clean_detections -> pa_save_one_box_crops / square-crop repairs
+(+ their JPEG round trips) -> runner inputs -> ResNet-18 -> temporal head -> labels (playaid/ai_runner.py:153, 181-224,
+226-424, 426-520), vs oracle/jpeg.decode_bgr -> oracle/yolov5.forward -> oracle/detect -> oracle crops -> oracle/pipeline."""
+import numpy as np
+import pytest
+
+from playaid_core_amd import synth
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+NET = (384, 640)
+
+
+def test_chain_from_mjpeg_bytes_to_labels(engine, state_dict):
+    import torch
+
+    from oracle import detect as odet
+    from oracle import jpeg, pipeline, yolo_crop
+    from oracle import yolov5 as oy
+    from playaid_core_amd import detect as pdet
+    from playaid_core_amd import video
+    from playaid_core_amd.detector_path import run_detections_to_labels
+    from playaid_core_amd.fighter import YoloCrop
+    from playaid_core_amd.yolov5 import YoloV5Detector
+
+    n, h, w = 20, 720, 1280
+    blobs = synth.encode_jpeg_frames(synth.make_frames(n, h, w), quality=95)
+    # 1. decode: device frames == the oracle's, bit for bit
+    data = np.frombuffer(b"".join(blobs), np.uint8)
+    ends = np.cumsum([len(b) for b in blobs])
+    spans = np.stack([ends - [len(b) for b in blobs], ends], axis=1)
+    dec = video.MjpegDecoder(n, h, w, int(ends[-1]) + 4096)
+    sdy = synth.make_yolov5s_state_dict()
+    det = YoloV5Detector(sdy, 6, NET, max_images=n)
+    try:
+        st = torch.zeros(n, dtype=torch.int32, device="cuda")
+        fd = dec.decode(data, spans, h, w, status=st)
+        torch.cuda.synchronize()
+        of = np.stack([jpeg.decode_bgr(b) for b in blobs])
+        assert int(st.abs().sum()) == 0 and np.array_equal(fd.cpu().numpy(), of)
+        # 2. the detection network on the decoded frames
+        pred = det(fd)
+        torch.cuda.synchronize()
+        want = oy.forward(torch.from_numpy(np.stack([oy.letterbox(f, NET) for f in of])), sdy, 6).numpy()
+        got = pred.cpu().numpy()
+        e_box, e_score = np.abs(got[..., :4] - want[..., :4]).max(), np.abs(got[..., 4:] - want[..., 4:]).max()
+        print(f"chain: network rows vs oracle: boxes {e_box:.2e} px, scores {e_score:.2e}")
+        assert e_box <= 2e-2 and e_score <= 1e-4
+        # 3. Seeded random-init weights detect nothing a runner could use, so BOTH sides get the same candidate rows written
+        # over the first six rows of their own network output: the clip's true fighter boxes as a trained detector would
+        # report them (three near-duplicates each), fighter 1 lost in frames 6-8. Everything the network itself emits stays
+        # in the race: no row of it may come near the confidence gate, or the two sides could disagree about it.
+        net_conf = (want[..., 4:5] * want[..., 5:])[..., [2, 3]].max()
+        assert net_conf < 0.25 - 1e-3, net_conf
+        boxes = synth.make_boxes(n, h, w)
+        cand = np.zeros((n, 6, 11), F32)
+        for i in range(n):
+            for p in range(2):  # network-input pixels: gain 0.5, 12 px letterbox (720p in 384 x 640)
+                cx, cy, bw, bh = boxes[i, p] * np.array([w, h, w, h]) * 0.5 + np.array([0, 12, 0, 0])
+                for k in range(3):
+                    cand[i, 3 * p + k, :5] = [cx + k, cy - k, bw, bh, 0.95 - 0.1 * k]
+                    cand[i, 3 * p + k, 5 + 2 + p] = 0.9
+        cand[5:8, 3:6, 4] = 0.0
+        pred[:, :6] = torch.from_numpy(cand).cuda()
+        want[:, :6] = cand
+        dets, counts = engine.detect_postprocess(pred, NET, (h, w))
+        torch.cuda.synchronize()
+        d, c = dets.cpu().numpy(), counts.cpu().numpy()
+        labels_dev = [pdet.label_lines(d[i, : c[i]]) for i in range(n)]
+        labels_orc = [odet.detect_frame(want[i], NET, (h, w))[1] for i in range(n)]
+        assert labels_dev == labels_orc and labels_orc[0].count("\n") == 2 and labels_orc[6].count("\n") == 1
+        # 4. the device chain from the detection table
+        res = run_detections_to_labels(engine, fd, dets, counts, jpeg_quality=95, want_crops=True)
+        assert res["max_frames"] == n and (res["cleaned"]["crop_kind"] == 2).sum() == 3
+        # 5. the oracle chain from the oracle's label text, composed from the oracle pieces (not from label_cleaning.py's tables)
+        full = [{c.class_id: c for c in map(YoloCrop.from_string, t.splitlines())} for t in labels_orc]
+
+        def row(cr):  # the label row as the file holds it ('%g', six digits), read back
+            cr = YoloCrop.from_string(str(cr))
+            return np.array([cr.class_id, cr.center_x, cr.center_y, cr.crop_width, cr.crop_height, cr.confidence], F32)
+
+        crops = np.zeros((n, 2, 128, 128, 3), np.uint8)
+        for i in range(n):
+            for p in range(2):
+                j = i + 1
+                if p == 1 and j in (6, 7, 8):  # interpolated from the END frame, pixels from VideoCapture position j (ai_runner.py:389-405)
+                    it = full[4][3].interp(full[8][3], (9 - j) / (9 - 5))
+                    ok, sq = yolo_crop.square_crop(of[j], np.array(it.yolo_crop()), 128, padding=30)
+                    assert ok
+                    bgr = jpeg.roundtrip_bgr(np.ascontiguousarray(sq), 95)
+                else:
+                    bgr = odet.save_one_box(row(full[i][2 + p]), of[i], 95)
+                crops[i, p] = yolo_crop.runner_input_from_crop(bgr)
+        ref = pipeline.run_action_recognition(of, np.zeros((n, 2, 4)), state_dict, mode="cached", crops_rgb=crops)
+        assert np.array_equal(res["crops_rgb"], crops)
+        e_logp = np.abs(res["logp"] - ref["logp"]).max()
+        print(f"chain: log-probabilities vs oracle: {e_logp:.2e}")
+        assert e_logp <= 1e-4 and np.array_equal(res["action_id"], ref["action_id"])
+    finally:
+        dec.close()
+        det.close()
