@@ -492,9 +492,9 @@ const char* pa_lstm_last_error(const pa_lstm* h);
  * without batch_first fed [B, S, 300]) seq_len is the number of WINDOWS and batch (<= 16) the frames of a
  * window: the state runs from one window to the next. */
 int pa_lstm_forward(pa_lstm* h, const float* x, int32_t ld, int32_t seq_len, int32_t batch, float* logp, void* stream);
-/* A layer's time steps run in ONE cooperative launch (H / 2 workgroups at H = 512: one per CU) whose workgroups meet at a
- * grid barrier per step; a grid the device cannot hold co-resident is refused by the runtime and the handle launches one
- * kernel per time step instead. The barrier still gives up after 20 ms: that call's logp rows are then NaN (never garbage).
+/* A layer's time steps run in ONE cooperative launch (H / 4 workgroups) that hand h(t) to each other as tagged 8-byte
+ * granules; a grid the device cannot hold co-resident is refused by the runtime and the handle launches one kernel per time
+ * step instead. A granule that does not arrive within 20 ms ends the launch: that call's logp rows are then NaN (never garbage).
  * Call this after synchronising the stream of a pa_lstm_forward: PA_ERR_HIP ONCE if that happened (the handle launches one
  * kernel per time step from then on and later calls are valid), PA_OK otherwise. */
 int pa_lstm_last_status(pa_lstm* h);

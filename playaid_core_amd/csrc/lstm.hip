@@ -14,6 +14,7 @@
 // the hot loop: no MFMA tiling here on purpose.
 #include "pa_kernels.h"
 #include "../../include/playaid_hip.h"
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -23,6 +24,9 @@ namespace pa {
 namespace {
 
 constexpr int LSTM_NMAX = 16;  // batch rows of a time step (the reference's S <= 15)
+constexpr int LSTM_UNITS_DEFAULT = 4;  // hidden units per workgroup of lstm_layer_kernel: 128 workgroups at H = 512. Measured per (layer, step), us:
+                                       // 8 units 11.0, 4 units 8.8 (sweep 3.3 + product 4.6 + gates 0.7), 2 units 9.4 (5.2 + 3.4 + 0.8: 256 CUs
+                                       // sweeping the same 28 KB), 1 unit 13.5 (profiles/r04_lstm_units.txt)
 
 // C[m*ldc + n] = act(sum_k X[m*ld + k] * W[n*K + k] + bias[n])   (M x K) x (N x K)^T, 64 x 64 tiles, 4 x 4 per thread
 __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict__ X, int ld, const float* __restrict__ W,
@@ -124,26 +128,33 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict_
 }
 
 
-// One LAYER in one launch, on the whole chip (round 4): H / U workgroups (U = 2 hidden units each at H = 512: 256 workgroups,
-// one per CU; round 3 ran 64) stay resident for all time steps. A workgroup's 4 U rows of W_hh live in REGISTERS -- thread =
+// One LAYER in one launch (round 4): H / U workgroups (U = 4 hidden units each at H = 512: 128 workgroups; round 3 ran 64; 256
+// were measured slower, see LSTM_UNITS_DEFAULT) stay resident for all time steps. A workgroup's 4 U rows of W_hh live in REGISTERS -- thread =
 // (row, part), part strides the row in 16-byte pieces, 16 floats per thread at H = 512 -- and its c state too, so a step moves
-// only h(t-1) (N x H floats -> LDS) in and U x N values out. The steps are separated by a grid barrier (one atomic counter,
-// agent-scope release / acquire fences: the XCDs' L2s are not coherent for plain stores); the launch is COOPERATIVE, so the
-// runtime refuses a grid that cannot be co-resident instead of letting it spin, and the barrier still gives up after 20 ms
-// (*err = 1: the decoder then writes NaN rows, pa_lstm_last_status reports it once and the handle falls back to one launch
-// per step). Per thread and step: H / P float4 products x N rows, log2(P) shuffle steps (P = 256 / (4 U) lanes share a row).
+// only h(t-1) in and U x N values out.
+// Between the steps there is no barrier and no fence. Round 3's step (one atomic counter + agent-scope release / acquire
+// fences around plain stores and loads) cost 20-27 us whatever the arithmetic: five dependent trips to memory, two of them
+// whole-L2 maintenance. Here every h value travels as ONE 8-byte GRANULE {value, tag = t + 1} written by one write-through
+// (sc1) store into a double-buffered [2][N][H] array; a consumer sweeps the N x H granules of step t - 1 with sc1 loads (up to
+// sixteen in flight per thread) and simply re-reads a granule whose tag is not t yet: arrival and payload are the same 8 bytes, so
+// nothing has to be ordered against anything (MI355X_MICROARCH.md, "allgather": ~3 us for this size). Two buffers suffice: who
+// writes h(t + 1) has read all of h(t), which nobody could write before everybody had read h(t - 1). hseq gets the same
+// values by plain stores for the next layer / the decoder (visible at the end of the launch). The launch is COOPERATIVE (the
+// runtime refuses a grid that cannot be co-resident); a granule that does not arrive within 20 ms sets *err: the decoder then
+// writes NaN rows, pa_lstm_last_status reports it once and the handle falls back to one launch per step.
 template <int U>
 __global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict__ pre_all, const float* __restrict__ w_hh,
                                                          const float* __restrict__ b_hh, float* __restrict__ hseq, int L, int N, int H,
-                                                         int* __restrict__ counter, int* __restrict__ err) {
-    constexpr int R = 4 * U, P = 256 / R, KQ = 128 / P;  // rows, lanes per row, float4 pieces per lane (H <= 512)
+                                                         unsigned long long* __restrict__ gran, int* __restrict__ err,
+                                                         unsigned long long* __restrict__ dbg) {
+    constexpr int R = 4 * U, P = 256 / R, KQ = 128 / P;
+    unsigned long long d_sweep = 0, d_prod = 0, d_gate = 0, d_t = 0;  // PA_LSTM_STAMP=1: where a step's time goes (100 MHz ticks)  // rows, lanes per row, float4 pieces per lane (H <= 512)
     extern __shared__ float sm[];
     float* hs = sm;                              // [N][H]
     float* gs = hs + (size_t)N * H;              // [R][LSTM_NMAX]
-    __shared__ int go;
-    const int j0 = blockIdx.x * U, nwg = gridDim.x;
+    const int j0 = blockIdx.x * U;
     const int row = threadIdx.x / P, part = threadIdx.x % P;   // row = gate * U + unit
-    const int hq = H >> 2;
+    const int hq = H >> 2, nh = N * H;
     float4 wreg[KQ];
     {
         const float4* wr = reinterpret_cast<const float4*>(w_hh + (size_t)((row / U) * H + j0 + (row % U)) * H);
@@ -154,26 +165,40 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict
     for (int t = 0; t < L; ++t) {
         const float* pre = pre_all + (size_t)t * N * 4 * H;
         if (t > 0) {
-            // every workgroup has published h(t-1)
-            if (threadIdx.x == 0) {
+            // h(t - 1): sweep its granules; a tag that is not t yet means the producer has not stored it -- read it again
+            const unsigned long long* g = gran + (size_t)((t - 1) & 1) * nh;
+            int failed = 0;
+            if (dbg) d_t = wall_clock64();
+            for (int base = threadIdx.x; base < nh; base += 256 * 16) {
+                // every pass re-reads ALL granules still missing at once (one trip to memory per pass, not one per granule)
+                unsigned pending = 0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    if (base + k * 256 < nh) pending |= 1u << k;
                 const unsigned long long t0 = wall_clock64();
-                int ok = 1;
-                while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < t * nwg) {
-                    if (wall_clock64() - t0 > 2000000ull || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ok = 0;
-                        break;
+                while (pending) {
+                    unsigned long long v[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                        if (pending & (1u << k)) v[k] = __hip_atomic_load(g + base + k * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                        if ((pending & (1u << k)) && (unsigned)(v[k] >> 32) == (unsigned)t) {
+                            hs[base + k * 256] = __uint_as_float((unsigned)v[k]);
+                            pending &= ~(1u << k);
+                        }
+                    if (pending) {
+                        if (wall_clock64() - t0 > 2000000ull || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                            __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            failed = 1;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
                     }
-                    __builtin_amdgcn_s_sleep(1);
                 }
-                go = ok;
             }
-            __syncthreads();
-            if (!go) return;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            const float4* h_prev = reinterpret_cast<const float4*>(hseq + (size_t)(t - 1) * N * H);
-            for (int i = threadIdx.x; i < N * hq; i += 256) reinterpret_cast<float4*>(hs)[i] = h_prev[i];
-            __syncthreads();
+            if (__syncthreads_or(failed)) return;
+            if (dbg) { const unsigned long long n_ = wall_clock64(); d_sweep += n_ - d_t; d_t = n_; }
             float acc[LSTM_NMAX];
 #pragma unroll
             for (int n = 0; n < LSTM_NMAX; ++n) acc[n] = 0.f;
@@ -202,6 +227,7 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict
                     if (part == 0) gs[row * LSTM_NMAX + n] = v;
                 }
             __syncthreads();
+            if (dbg) { const unsigned long long n_ = wall_clock64(); d_prod += n_ - d_t; d_t = n_; }
         }
         if (threadIdx.x < U * LSTM_NMAX) {
             const int u = threadIdx.x / LSTM_NMAX, n = threadIdx.x % LSTM_NMAX;
@@ -216,16 +242,16 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict
                 const float ig = sigmoidf(g4[0]), fg = sigmoidf(g4[1]), gg = tanhf(g4[2]), og = sigmoidf(g4[3]);
                 const float cn = fg * (t > 0 ? c_reg : 0.f) + ig * gg;
                 c_reg = cn;
-                hseq[(size_t)t * N * H + n * H + j] = og * tanhf(cn);
+                const float hv = og * tanhf(cn);
+                hseq[(size_t)t * nh + n * H + j] = hv;
+                __hip_atomic_store(gran + (size_t)(t & 1) * nh + n * H + j, ((unsigned long long)(unsigned)(t + 1) << 32) | __float_as_uint(hv),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        // publish h(t): stores first, then the arrival
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        // (gs is read above and rewritten only behind the next step's first barrier; hs likewise)
+        if (dbg && t > 0) d_gate += wall_clock64() - d_t;
     }
+    if (dbg && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) { dbg[0] = d_sweep; dbg[1] = d_prod; dbg[2] = d_gate; dbg[3] = (unsigned long long)L; }
 }
 
 // action_decoder + log_softmax for one row: Linear(H,128) + ReLU -> Linear(128,A) -> log_softmax
@@ -306,7 +332,9 @@ struct pa_lstm {
     float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
     float *weights = nullptr;            // one allocation behind all of the above
     float *pre = nullptr, *hseq[2] = {nullptr, nullptr}, *c = nullptr;
-    int* sync_words = nullptr;            // [2 * layers]: per layer the grid barrier's counter and its error word
+    int* sync_words = nullptr;            // [2 * layers]: per layer an unused word and the error word of its launch
+    unsigned long long* gran = nullptr;   // [2][LSTM_NMAX][512] h granules {value, tag} of the layer in flight
+    unsigned long long* dbg = nullptr;    // PA_LSTM_STAMP=1: in-kernel clock sums of the last layer launch
     int* sync_host = nullptr;             // pinned copy of the error words
     bool persistent = true;               // one launch per layer (lstm_layer_kernel); false after a barrier timeout
     std::string last_error;
@@ -371,6 +399,8 @@ int pa_lstm_create(int32_t device, int32_t input_dim, int32_t hidden_dim, int32_
         if (!chk(hipMalloc(&h->hseq[i], (size_t)max_rows * H * sizeof(float)), "hipMalloc h")) return PA_ERR_HIP;
     if (!chk(hipMalloc(&h->c, (size_t)pa::LSTM_NMAX * H * sizeof(float)), "hipMalloc c")) return PA_ERR_HIP;
     if (!chk(hipMalloc(&h->sync_words, 2 * 8 * sizeof(int)), "hipMalloc barrier words")) return PA_ERR_HIP;
+    if (!chk(hipMalloc(&h->gran, (size_t)2 * pa::LSTM_NMAX * 512 * sizeof(unsigned long long)), "hipMalloc granules")) return PA_ERR_HIP;
+    if (getenv("PA_LSTM_STAMP") && !chk(hipMalloc(&h->dbg, 4 * sizeof(unsigned long long)), "hipMalloc stamps")) return PA_ERR_HIP;
     if (!chk(hipHostMalloc(&h->sync_host, 2 * 8 * sizeof(int)), "hipHostMalloc")) return PA_ERR_HIP;
     memset(h->sync_host, 0, 2 * 8 * sizeof(int));
     // one launch per layer needs H / U workgroups co-resident (U = 2 above 256 hidden units): PA_LSTM_STEPS=1 forces the
@@ -401,6 +431,8 @@ void pa_lstm_destroy(pa_lstm* h) {
     (void)hipFree(h->hseq[1]);
     (void)hipFree(h->c);
     (void)hipFree(h->sync_words);
+    (void)hipFree(h->gran);
+    (void)hipFree(h->dbg);
     if (h->sync_host) (void)hipHostFree(h->sync_host);
     delete h;
 }
@@ -424,13 +456,20 @@ int pa_lstm_forward(pa_lstm* h, const float* x, int32_t ld, int32_t seq_len, int
         if (h->persistent && h->sync_host[2 * l + 1]) h->persistent = false;  // (a timeout the caller has not asked about yet)
         if (h->persistent) {
             // all time steps of the layer in one cooperative launch
-            const int U = H > 256 ? 2 : 1;
+            static const int u_env = getenv("PA_LSTM_UNITS") ? atoi(getenv("PA_LSTM_UNITS")) : 0;   // tuning: hidden units per workgroup
+            int U = u_env == 1 || u_env == 2 || u_env == 4 || u_env == 8 ? u_env : pa::LSTM_UNITS_DEFAULT;
+            while (U > 1 && H % U) U >>= 1;
             const size_t lds = ((size_t)batch * H + (size_t)4 * U * pa::LSTM_NMAX) * sizeof(float);
             const float* a_pre = h->pre; const float* a_w = h->w_hh[l]; const float* a_b = h->b_hh[l];
             int a_L = seq_len, a_N = batch, a_H = H;
-            int* a_cnt = h->sync_words + 2 * l; int* a_err = a_cnt + 1;
-            void* args[] = {&a_pre, &a_w, &a_b, &hs, &a_L, &a_N, &a_H, &a_cnt, &a_err};
-            const void* fn = U == 2 ? reinterpret_cast<const void*>(&pa::lstm_layer_kernel<2>) : reinterpret_cast<const void*>(&pa::lstm_layer_kernel<1>);
+            unsigned long long* a_gran = h->gran; int* a_err = h->sync_words + 2 * l + 1;
+            unsigned long long* a_dbg = h->dbg;
+            void* args[] = {&a_pre, &a_w, &a_b, &hs, &a_L, &a_N, &a_H, &a_gran, &a_err, &a_dbg};
+            (void)hipMemsetAsync(h->gran, 0, (size_t)2 * batch * H * sizeof(unsigned long long), s);   // tag 0 = not written
+            const void* fn = U == 8   ? reinterpret_cast<const void*>(&pa::lstm_layer_kernel<8>)
+                             : U == 4 ? reinterpret_cast<const void*>(&pa::lstm_layer_kernel<4>)
+                             : U == 2 ? reinterpret_cast<const void*>(&pa::lstm_layer_kernel<2>)
+                                      : reinterpret_cast<const void*>(&pa::lstm_layer_kernel<1>);
             const hipError_t ce = hipLaunchCooperativeKernel(fn, dim3(H / U), dim3(256), args, (unsigned)lds, s);
             if (ce == hipSuccess) {
                 (void)hipMemcpyAsync(h->sync_host + 2 * l, h->sync_words + 2 * l, 2 * sizeof(int), hipMemcpyDeviceToHost, s);
@@ -447,6 +486,15 @@ int pa_lstm_forward(pa_lstm* h, const float* x, int32_t ld, int32_t seq_len, int
                        h->actions, h->sync_words, h->layers);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return bad(PA_ERR_HIP, hipGetErrorString(e));
+    if (h->dbg) {   // (measurement aid: synchronises)
+        unsigned long long d[4];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(d, h->dbg, sizeof d, hipMemcpyDeviceToHost);
+        static int printed = 0;
+        if (printed++ < 3 && d[3] > 1)
+            fprintf(stderr, "[lstm stamps] per step of the last layer: sweep %.2f us, product %.2f us, gates + stores %.2f us\n",
+                    d[0] * 0.01 / (d[3] - 1), d[1] * 0.01 / (d[3] - 1), d[2] * 0.01 / (d[3] - 1));
+    }
     return PA_OK;
 }
 
