@@ -524,6 +524,27 @@ def bench_detect(args):
     eng.close()
 
 
+def bench_chain(args):
+    """The chain north_star names as its own line (the default run reports it as the side measurement `chain_inclusive`):
+    Motion-JPEG bytes in pinned host memory -> decode -> YOLOv5s -> NMS -> repair -> detector crops -> CNN -> labels."""
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(device)
+    n = args.frames
+    sd = synth.make_state_dict(seed=1234)
+    eng = Engine(sd, device=str(device), max_batch_frames=n, max_clip_frames=max(n, 64), max_frame_height=args.height, max_frame_width=args.width)
+    frames = torch.from_numpy(synth.make_frames(n, args.height, args.width)).to(device)
+    boxes = torch.from_numpy(synth.make_boxes(n, args.height, args.width)).to(device)
+    r = chain_inclusive(eng, sd, frames, boxes, steps=max(args.steps, 3), quality=args.jpeg_quality)
+    print(json.dumps({
+        "metric": f"{args.height}p frames/sec, Motion-JPEG bytes -> decode -> detector -> NMS -> repair -> crops -> CNN -> labels (all on the device)",
+        "value": r["value"], "unit": "frames/s", "n_gpus": 1, "steps": max(args.steps, 3), "warmup": 3, "ms_per_step": r["ms_per_clip"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"chain: {n} x {args.height}x{args.width} frames per clip, quality-{args.jpeg_quality} 4:2:0 Motion-JPEG, YOLOv5s at 384 x 640, "
+                               "ResNet-18 action CNN; three clips in flight"},
+        "chain": r}), flush=True)
+    eng.close()
+
+
 def bench_mixed(args):
     """BASELINE.json configs[4]: a 1080p/720p interleaved clip, frames resident in HBM per resolution bucket, fixed-size
     batches through hipGraph-captured "crop + backbone + scatter into the feature cache" sequences, one head pass per
@@ -662,7 +683,7 @@ def main():
     ap.add_argument("--inner-repeat", type=int, default=20,
                     help="configs[1]/[2] only: clips per timed step (ms_per_step stays per clip)")
     ap.add_argument("--f4-windows", type=int, default=64, help="--workload rnn | resformer: windows per call")
-    ap.add_argument("--workload", default="clip", choices=["clip", "mixed", "rnn", "resformer", "detect"],
+    ap.add_argument("--workload", default="clip", choices=["clip", "mixed", "rnn", "resformer", "detect", "chain"],
                     help="clip = the headline / configs[1-3] workloads; mixed = BASELINE.json configs[4] (mixed-resolution stream, "
                     "bucketing + hipGraph replay; single GPU, reported under its own metric)")
     ap.add_argument("--lanes", type=int, default=2,
@@ -697,6 +718,8 @@ def main():
         return bench_f4(args)
     if args.workload == "detect":
         return bench_detect(args)
+    if args.workload == "chain":
+        return bench_chain(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Measurement set of the detection stage (YOLOv5s layer table) for profiles/: bench line + rocprofv3 kernel stats + share-of-time summary.
 set -u
-O=${1:-gpurun_out/r3_detect}
+O=${1:-gpurun_out/r4_detect}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout -k 10 300 python3 bench.py --workload detect --steps 10 --warmup 2 > $O/bench_line.json 2> $O/bench.err
