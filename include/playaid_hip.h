@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PA_ABI_VERSION 7
+#define PA_ABI_VERSION 8
 #define PA_WEIGHT_MAGIC 0x31574150 /* "PAW1" */
 #define PA_LSTM_MAGIC 0x314c4150   /* "PAL1" */
 #define PA_ENCODER_MAGIC 0x31454150 /* "PAE1" */

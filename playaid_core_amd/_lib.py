@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # PA_LIB_PATH: load a differently built library (e.g. the ablation build used by scripts/)
 LIB_PATH = os.environ.get("PA_LIB_PATH") or os.path.join(HERE, "libplayaid_hip.so")
 
-PA_ABI_VERSION = 7
+PA_ABI_VERSION = 8
 PA_DTYPE_F32 = 0
 PA_DTYPE_BF16 = 1
 PA_WEIGHT_MAGIC = 0x31574150
