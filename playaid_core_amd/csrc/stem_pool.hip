@@ -96,27 +96,31 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams 
 
     // weights of this lane's output channel, resident for the whole kernel
     const int n = wn * 32 + lr;
-    float bw[7][4][3];   // fp32: k = ky*32 + px*4 + c
+    float bw[25][3];     // fp32: step s multiplies taps (2 s, 2 s + 1) of the 49 (ky, kx): this lane (half lh) holds tap 2 s + lh, channels 0-2
     u32x4 bwh[14];       // bf16: 16-wide k groups, this lane's 8 k = group*16 + 8*lh
     if constexpr (BF16) {
         const uint16_t* w = reinterpret_cast<const uint16_t*>(p.wgt) + (size_t)n * KTOT + 8 * lh;
 #pragma unroll
         for (int g = 0; g < 14; ++g) bwh[g] = *reinterpret_cast<const u32x4*>(w + g * 16);
     } else {
+        // K = 7 x 7 x 3 = 147 exactly (round 4): the k pair of a matrix instruction is two consecutive TAPS of the 49, one per
+        // lane half, instead of two of the eight pixels of a kernel row (whose eighth met zero weights: 168 executed).
+        // 25 steps x 3 channels = 75 instructions per 32 pixels instead of 84; tap 49 (step 24, upper half) is a zero weight.
         const float* w = reinterpret_cast<const float*>(p.wgt) + (size_t)n * KTOT;
 #pragma unroll
-        for (int ky = 0; ky < 7; ++ky)
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(w + ky * 32 + (2 * kk + lh) * 4);
-                bw[ky][kk][0] = v.x;
-                bw[ky][kk][1] = v.y;
-                bw[ky][kk][2] = v.z;
-            }
+        for (int st = 0; st < 25; ++st) {
+            const int t0 = 2 * st, t1 = 2 * st + 1;
+            const int o0 = (t0 / 7) * 32 + (t0 % 7) * 4, o1 = t1 < 49 ? (t1 / 7) * 32 + (t1 % 7) * 4 : -1;
+            f32x4 v = *reinterpret_cast<const f32x4*>(w + (lh && o1 >= 0 ? o1 : o0));
+            if (lh && o1 < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            bw[st][0] = v.x;
+            bw[st][1] = v.y;
+            bw[st][2] = v.z;
+        }
     }
     const float bias = p.bias[n];
     // chunk of (ky 0, pixel block 0, first k) for this lane
-    const int c_lane = BF16 ? (2 * wm) * G::ROW_CH + lr + lh : (2 * wm) * IN_W + 2 * lr + lh;
+    const int c_lane = BF16 ? (2 * wm) * G::ROW_CH + lr + lh : (2 * wm) * IN_W + 2 * lr;
 
     // pooling: thread -> pooled pixels px = (tid >> 4) + 16 i (i = 0, 1), channels c4 .. c4+3
     const int c4 = (tid & 15) * 4;
@@ -140,6 +144,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams 
         if (more) SP_ISSUE(n_crop, n_rr, buf ^ 1);
         __builtin_amdgcn_sched_barrier(0);
         const float* patch = lds + buf * (G::STAGE_CH * 4);
+        const bool warm = rr < r0;  // the row pair above the run: computed for the pooling's carry, not stored
 
         f32x16 acc[2];
 #pragma unroll
@@ -170,30 +175,34 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams 
 #undef SP_FRAGS_H
         } else {
             f32x4 af[2][2];
-#define SP_FRAGS(SET, GG)                                                                          \
+            // chunk of this lane's tap of step ST: (ky, kx) = divmod(2 ST + lh, 7); the upper half's tap 49 reads tap 48's pixel
+#define SP_FRAGS(SET, ST)                                                                          \
     {                                                                                              \
+        const int t0_ = 2 * (ST), t1_ = 2 * (ST) + 1 < 49 ? 2 * (ST) + 1 : 48;                      \
+        const int off_ = lh ? (t1_ / 7) * IN_W + (t1_ % 7) : (t0_ / 7) * IN_W + (t0_ % 7);        \
         _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) {                                         \
-            const int c = c_lane + ((GG) >> 2) * IN_W + 64 * mi + 2 * ((GG)&3);                    \
+            const int c = c_lane + off_ + 64 * mi;                                                 \
             af[SET][mi] = *reinterpret_cast<const f32x4*>(patch + (c ^ ((c >> 4) & 1)) * 4);       \
         }                                                                                          \
     }
+            if (!(warm && wm == 0)) {  // (a warm-up tile is there for its SECOND stem row only: the first row's waves sit it out)
             SP_FRAGS(0, 0);
 #pragma unroll
-            for (int g = 0; g < 28; ++g) {  // g = ky*4 + kk
-                const int ky = g >> 2, kk = g & 3;
+            for (int g = 0; g < 25; ++g) {
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi) {
                     const f32x4 a4 = af[g & 1][mi];
-                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, bw[ky][kk][0], acc[mi], 0, 0, 0);
+                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, bw[g][0], acc[mi], 0, 0, 0);
                     if (mi == 0) {
-                        // next group's operands: issued behind the first MFMA, >= 5 MFMAs (320 cycles) ahead of use
+                        // next step's operands: issued behind the first MFMA, >= 5 MFMAs (320 cycles) ahead of use
                         __builtin_amdgcn_sched_barrier(0);
-                        if (g + 1 < 28) SP_FRAGS((g + 1) & 1, g + 1);
+                        if (g + 1 < 25) SP_FRAGS((g + 1) & 1, g + 1);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, bw[ky][kk][1], acc[mi], 0, 0, 0);
-                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, bw[ky][kk][2], acc[mi], 0, 0, 0);
+                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, bw[g][1], acc[mi], 0, 0, 0);
+                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, bw[g][2], acc[mi], 0, 0, 0);
                 }
+            }
             }
 #undef SP_FRAGS
         }
