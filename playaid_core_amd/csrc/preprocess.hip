@@ -1270,18 +1270,11 @@ __device__ __forceinline__ void area_pixel_wh(const RunnerInPlan& pl, const WhCa
     }
 }
 
-__global__ __launch_bounds__(256) void runner_input_kernel(const RunnerInParams q) {
-    __shared__ int32_t coef[2][PA_CROP][COEF_ROW];  // [axis][output coordinate]: both passes end at <= 128 outputs
-    const int crop = blockIdx.x;
-    const int tid = threadIdx.x;
-    PreprocParams out;  // write_crop_pixel() only reads these fields
-    out.swap_rb = q.swap_rb;
-    out.crops_u8 = q.inputs_u8;
-    out.crops_f32 = q.inputs_f32;
-    out.crops_f32_is_bf16 = q.inputs_f32_is_bf16;
-    RunnerInPlan pl;
+// What get_action_recognition_input_for_frame does to one crop image (ai_runner.py:446-459), decided once per image: the
+// INTER_AREA destination, the branch of cv::resize it takes, ImageOps.pad's contain size / paste offset / bicubic passes.
+__device__ void runner_plan(const RunnerInParams& q, int crop, RunnerInPlan& pl, long long& off) {
     pl.status = PA_CROP_OK;
-    const long long off = q.desc[crop].offset;
+    off = q.desc[crop].offset;
     pl.sh = q.desc[crop].height;
     pl.sw = q.desc[crop].width;
     pl.ow = PA_CROP; pl.oh = 0; pl.mode = 0; pl.isx = pl.isy = 1; pl.scale_x = pl.scale_y = 1.0;
@@ -1332,38 +1325,57 @@ __global__ __launch_bounds__(256) void runner_input_kernel(const RunnerInParams 
         }
         if ((size_t)(pl.oh + (pl.need_v ? pl.rh : 0)) * PA_CROP * 3 > q.t_stride) pl.status = PA_CROP_FILTER_TOO_WIDE;  // scratch
     }
-    if (tid == 0 && q.status) q.status[crop] = pl.status;
+}
+
+// The three steps of a runner input as three launches over (image, part) grids -- INTER_AREA | Pillow's horizontal pass | its
+// vertical pass fused with the paste -- instead of one workgroup per image walking all of them between barriers (round 3:
+// 128 workgroups on a 256-CU part, 0.39 ms per 128 crop images; the kernel boundaries are the barriers now, and every
+// launch has 4 x as many workgroups). Every workgroup works the image's plan out again (a few dozen scalar operations).
+// Same arithmetic, same order per output value: bit-identical results.
+constexpr int RI_PARTS = 4;
+template <int STAGE>
+__global__ __launch_bounds__(256) void runner_input_stage_kernel(const RunnerInParams q) {
+    __shared__ int32_t coef[PA_CROP][COEF_ROW];  // the pad step's table of this stage's axis: <= 128 output coordinates
+    const int crop = blockIdx.x, part = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int i0 = part * 256 + tid, istep = RI_PARTS * 256;
+    PreprocParams out;  // write_crop_pixel() only reads these fields
+    out.swap_rb = q.swap_rb;
+    out.crops_u8 = q.inputs_u8;
+    out.crops_f32 = q.inputs_f32;
+    out.crops_f32_is_bf16 = q.inputs_f32_is_bf16;
+    RunnerInPlan pl;
+    long long off;
+    runner_plan(q, crop, pl, off);
+    if (STAGE == 0 && part == 0 && tid == 0 && q.status) q.status[crop] = pl.status;
     if (pl.status != PA_CROP_OK) {
-        for (int i = tid; i < PA_CROP * PA_CROP; i += 256) write_crop_pixel(out, crop, i, 0, 0, 0);
+        if (STAGE == 2)
+            for (int i = i0; i < PA_CROP * PA_CROP; i += istep) write_crop_pixel(out, crop, i, 0, 0, 0);
         return;
     }
-    // ---- INTER_AREA: image -> A = t1[crop] as [oh][128][3]
-    uint8_t* A = q.t1 + (size_t)crop * q.t_stride;
-    {
+    uint8_t* A = q.t1 + (size_t)crop * q.t_stride;   // [oh][128][3] behind INTER_AREA
+    uint8_t* B = q.t2 + (size_t)crop * q.t_stride;   // [oh][rw][3] behind the horizontal pass
+    if (STAGE == 0) {
         WhCanvas cv;
         cv.src = q.images + off;
         cv.pitch = pl.sw * 3;
-        for (int i = tid; i < pl.oh * PA_CROP; i += 256) {
+        for (int i = i0; i < pl.oh * PA_CROP; i += istep) {
             const int dy = i >> 7, dx = i & 127;
             int o0, o1, o2;
             area_pixel_wh(pl, cv, dy, dx, o0, o1, o2);
             uint8_t* o = A + (size_t)i * 3;
             o[0] = (uint8_t)o0; o[1] = (uint8_t)o1; o[2] = (uint8_t)o2;
         }
+        return;
     }
-    // coefficient tables of the pad step (fp64, one output coordinate per thread)
-    if (pl.need_h && tid < pl.rw) bicubic_coef_row(PA_CROP, pl.rw, tid, coef[0][tid]);
-    if (pl.need_v && tid >= 128 && tid - 128 < pl.rh) bicubic_coef_row(pl.oh, pl.rh, tid - 128, coef[1][tid - 128]);
-    __threadfence();
-    __syncthreads();
-    const uint8_t* cur = A;
-    int cur_w = PA_CROP, cur_h = pl.oh;
-    if (pl.need_h) {  // ImagingResampleHorizontal_8bpc: [oh][128] -> B = t2[crop] as [oh][rw]
-        uint8_t* B = q.t2 + (size_t)crop * q.t_stride;
-        for (int i = tid; i < pl.oh * pl.rw; i += 256) {
+    if (STAGE == 1) {  // ImagingResampleHorizontal_8bpc: [oh][128] -> B as [oh][rw]
+        if (!pl.need_h) return;
+        if (tid < pl.rw) bicubic_coef_row(PA_CROP, pl.rw, tid, coef[tid]);  // (fp64, one output coordinate per thread)
+        __syncthreads();
+        for (int i = i0; i < pl.oh * pl.rw; i += istep) {
             const int y = i / pl.rw, xx = i - y * pl.rw;
-            const int32_t* row = coef[0][xx];
-            const uint8_t* sp = cur + ((size_t)y * cur_w + row[0]) * 3;
+            const int32_t* row = coef[xx];
+            const uint8_t* sp = A + ((size_t)y * PA_CROP + row[0]) * 3;
             int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
             for (int t = 0; t < row[1]; ++t) {
                 const int k = row[2 + t];
@@ -1374,40 +1386,37 @@ __global__ __launch_bounds__(256) void runner_input_kernel(const RunnerInParams 
             uint8_t* o = B + (size_t)i * 3;
             o[0] = (uint8_t)clip8(a0); o[1] = (uint8_t)clip8(a1); o[2] = (uint8_t)clip8(a2);
         }
-        __threadfence();
-        __syncthreads();
-        cur = B;
-        cur_w = pl.rw;
+        return;
     }
-    if (pl.need_v) {  // ImagingResampleVertical_8bpc: [oh][cur_w] -> C = second half of t1[crop] as [rh][cur_w]
-        uint8_t* Cb = A + (size_t)pl.oh * PA_CROP * 3;
-        for (int i = tid; i < pl.rh * cur_w; i += 256) {
-            const int yy = i / cur_w, x = i - yy * cur_w;
-            const int32_t* row = coef[1][yy];
-            const uint8_t* sp = cur + ((size_t)row[0] * cur_w + x) * 3;
-            int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
-            for (int t = 0; t < row[1]; ++t) {
-                const int k = row[2 + t];
-                a0 += __mul24((int)sp[0], k);
-                a1 += __mul24((int)sp[1], k);
-                a2 += __mul24((int)sp[2], k);
-                sp += (size_t)cur_w * 3;
-            }
-            uint8_t* o = Cb + (size_t)i * 3;
-            o[0] = (uint8_t)clip8(a0); o[1] = (uint8_t)clip8(a1); o[2] = (uint8_t)clip8(a2);
-        }
-        __threadfence();
+    // STAGE 2: ImagingResampleVertical_8bpc for the canvas pixels that need it, paste on the black 128 x 128 canvas, channel
+    // swap, u8 + model input
+    const uint8_t* cur = pl.need_h ? B : A;
+    const int cur_w = pl.need_h ? pl.rw : PA_CROP;
+    const int cur_h = pl.need_v ? pl.rh : pl.oh;
+    if (pl.need_v) {
+        if (tid < pl.rh) bicubic_coef_row(pl.oh, pl.rh, tid, coef[tid]);
         __syncthreads();
-        cur = Cb;
-        cur_h = pl.rh;
     }
-    // paste on the black 128 x 128 canvas, channel swap, u8 + model input
-    for (int i = tid; i < PA_CROP * PA_CROP; i += 256) {
+    for (int i = i0; i < PA_CROP * PA_CROP; i += istep) {
         const int y = (i >> 7) - pl.py, x = (i & 127) - pl.px;
         int o0 = 0, o1 = 0, o2 = 0;
         if ((unsigned)y < (unsigned)cur_h && (unsigned)x < (unsigned)cur_w) {
-            const uint8_t* sp = cur + ((size_t)y * cur_w + x) * 3;
-            o0 = sp[0]; o1 = sp[1]; o2 = sp[2];
+            if (pl.need_v) {
+                const int32_t* row = coef[y];
+                const uint8_t* sp = cur + ((size_t)row[0] * cur_w + x) * 3;
+                int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
+                for (int t = 0; t < row[1]; ++t) {
+                    const int k = row[2 + t];
+                    a0 += __mul24((int)sp[0], k);
+                    a1 += __mul24((int)sp[1], k);
+                    a2 += __mul24((int)sp[2], k);
+                    sp += (size_t)cur_w * 3;
+                }
+                o0 = clip8(a0); o1 = clip8(a1); o2 = clip8(a2);
+            } else {
+                const uint8_t* sp = cur + ((size_t)y * cur_w + x) * 3;
+                o0 = sp[0]; o1 = sp[1]; o2 = sp[2];
+            }
         }
         write_crop_pixel(out, crop, i, o0, o1, o2);
     }
@@ -1415,7 +1424,10 @@ __global__ __launch_bounds__(256) void runner_input_kernel(const RunnerInParams 
 
 hipError_t launch_runner_inputs(const RunnerInParams& q, hipStream_t s) {
     if (q.n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(runner_input_kernel, dim3(q.n), dim3(256), 0, s, q);
+    const dim3 grid(q.n, RI_PARTS);
+    hipLaunchKernelGGL(runner_input_stage_kernel<0>, grid, dim3(256), 0, s, q);
+    hipLaunchKernelGGL(runner_input_stage_kernel<1>, grid, dim3(256), 0, s, q);
+    hipLaunchKernelGGL(runner_input_stage_kernel<2>, grid, dim3(256), 0, s, q);
     return hipGetLastError();
 }
 

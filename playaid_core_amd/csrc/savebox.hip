@@ -104,8 +104,13 @@ __device__ __forceinline__ void block444(int* d, const int* __restrict__ q) {
     for (int x = 0; x < 8; ++x) fdct8<false>(d + x, 8);
 #pragma unroll
     for (int i = 0; i < 64; ++i) {
+        // (|d| + dv / 2) / dv without an integer division (~25 instructions each, 192 per block): both operands are
+        // below 2^24, so the float quotient is off by at most one and one correction step makes it exact
         const int qv = q[i], dv = qv << 3;
-        const int a = (abs(d[i]) + (dv >> 1)) / dv;
+        const int x = abs(d[i]) + (dv >> 1);
+        int a = (int)((float)x * __builtin_amdgcn_rcpf((float)dv));
+        const int r = x - a * dv;
+        a += r >= dv ? 1 : (r < 0 ? -1 : 0);
         d[i] = (d[i] < 0 ? -a : a) * qv;
     }
 #pragma unroll

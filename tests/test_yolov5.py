@@ -108,3 +108,31 @@ def test_detection_network_batches_and_small_frames():
         assert np.abs(got.cpu().numpy()[..., :4] - want[..., :4]).max() <= 2e-2
     finally:
         det.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("net", [(320, 320), (352, 608)])
+def test_detection_network_other_network_inputs(net):
+    """Network inputs other than 384 x 640: the map sizes decide which kernel form a layer takes (round 4) -- 8 x 16, 8 x 8 or
+    4 x 4 blocks on the patch-resident kernel, the im2col engine where no block divides the map (10 x 10, 38-wide), partial
+    row / column blocks in the direct stem, partial pixel tiles in the persistent GEMM -- and every form must equal the oracle."""
+    import torch
+
+    from oracle import yolov5 as oy
+    from playaid_core_amd.yolov5 import YoloV5Detector
+
+    sd = synth.make_yolov5s_state_dict()
+    det = YoloV5Detector(sd, NC, net, max_images=3)
+    try:
+        frames = synth.make_frames(3, 360, 640, seed=11)
+        got = det(frames)
+        torch.cuda.synchronize()
+        got = got.cpu().numpy()
+        x = torch.from_numpy(np.stack([oy.letterbox(f, net) for f in frames]))
+        want = oy.forward(x, sd, NC).numpy()
+        assert got.shape == want.shape
+        e_box, e_score = np.abs(got[..., :4] - want[..., :4]).max(), np.abs(got[..., 4:] - want[..., 4:]).max()
+        print(f"net {net}: boxes {e_box:.2e} px, scores {e_score:.2e}")
+        assert e_score <= 1e-4 and e_box <= 2e-2
+    finally:
+        det.close()
