@@ -107,6 +107,61 @@ __global__ __launch_bounds__(256) void maxpool5_kernel(const float* __restrict__
     }
 }
 
+// SPPF's three cascaded 5x5 / 1 max-pools in one launch (models/common.py::SPPF: y1 = m(x), y2 = m(y1), y3 = m(y2)). With
+// -inf padding a cascade of stride-1 max-pools is the max over the union of their windows: y1 = 5x5, y2 = 9x9, y3 = 13x13 of
+// x, clipped at the border. One workgroup = one image x CG channels with the whole map in LDS: separable, the three
+// horizontal maxima of every pixel, then the three vertical ones -> the three output slices. (Three launches of
+// maxpool5_kernel: 28 us each on a 12 x 20 map -- launch latency, not work.)
+template <int CG>
+__global__ __launch_bounds__(256) void sppf_pools_kernel(const float* __restrict__ in, SliceGeom gi, float* __restrict__ out, SliceGeom g1,
+                                                         SliceGeom g2, SliceGeom g3) {
+    extern __shared__ float sm[];
+    constexpr int Q = CG / 4;
+    const int hw = gi.h * gi.w, img = blockIdx.y, c0 = blockIdx.x * CG;
+    float4* xs = reinterpret_cast<float4*>(sm);   // [hw][Q]
+    float4* h5 = xs + hw * Q;
+    float4* h9 = h5 + hw * Q;
+    float4* h13 = h9 + hw * Q;
+    auto mx = [](float4 a, float4 b) { return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)); };
+    for (int i = threadIdx.x; i < hw * Q; i += 256) {
+        const int q = i % Q, pix = i / Q;
+        xs[i] = *reinterpret_cast<const float4*>(in + px_off(gi, img, pix / gi.w, pix % gi.w) + c0 + q * 4);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < hw * Q; i += 256) {
+        const int q = i % Q, pix = i / Q, y = pix / gi.w, x = pix % gi.w;
+        float4 m = xs[i];
+        float4 m5 = m, m9 = m, m13 = m;
+#pragma unroll
+        for (int d = 1; d <= 6; ++d) {
+            if (x - d >= 0) m = mx(m, xs[i - d * Q]);
+            if (x + d < gi.w) m = mx(m, xs[i + d * Q]);
+            if (d == 2) m5 = m;
+            if (d == 4) m9 = m;
+        }
+        m13 = m;
+        h5[i] = m5; h9[i] = m9; h13[i] = m13;
+        (void)y; (void)q;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < hw * Q; i += 256) {
+        const int q = i % Q, pix = i / Q, y = pix / gi.w, x = pix % gi.w;
+        const int row = gi.w * Q;
+        float4 a = h5[i], b = h9[i], c = h13[i];
+#pragma unroll
+        for (int d = 1; d <= 6; ++d) {
+            const bool up = y - d >= 0, dn = y + d < gi.h;
+            if (d <= 2) { if (up) a = mx(a, h5[i - d * row]); if (dn) a = mx(a, h5[i + d * row]); }
+            if (d <= 4) { if (up) b = mx(b, h9[i - d * row]); if (dn) b = mx(b, h9[i + d * row]); }
+            if (up) c = mx(c, h13[i - d * row]);
+            if (dn) c = mx(c, h13[i + d * row]);
+        }
+        *reinterpret_cast<float4*>(out + px_off(g1, img, y, x) + c0 + q * 4) = a;
+        *reinterpret_cast<float4*>(out + px_off(g2, img, y, x) + c0 + q * 4) = b;
+        *reinterpret_cast<float4*>(out + px_off(g3, img, y, x) + c0 + q * 4) = c;
+    }
+}
+
 // nn.Upsample(scale_factor=2, mode="nearest"): out[y][x] = in[y / 2][x / 2]
 __global__ __launch_bounds__(256) void upsample2_kernel(const float* __restrict__ in, SliceGeom gi, float* __restrict__ out, SliceGeom go, int n,
                                                         int c) {
@@ -426,6 +481,36 @@ static int detector_run(pa_detector* h, const uint8_t* frames, int32_t n, int32_
             hipLaunchKernelGGL(pa::stem6x6_direct_kernel<12>, dim3((unsigned)((strips + 3) / 4)), dim3(256), 0, s, q);
             DT_HIP(hipGetLastError());
             continue;
+        }
+        if (L.kind == 4 && li + 2 < h->layers.size()) {
+            // SPPF: three max-pools in a row, each reading the slice the one before wrote, all in one buffer -> one launch
+            const pa_net_layer& L2 = h->layers[li + 1];
+            const pa_net_layer& L3 = h->layers[li + 2];
+            auto chained = [](const pa_net_layer& a, const pa_net_layer& b) {
+                return b.kind == 4 && b.in_buf == a.out_buf && b.in_coff == a.out_coff && b.in_pad == a.out_pad && b.in_cstride == a.out_cstride &&
+                       b.in_h == a.in_h && b.in_w == a.in_w && b.cin == a.cin && b.out_buf == a.out_buf;
+            };
+            static const int fuse = getenv("PA_DET_SPPF") ? atoi(getenv("PA_DET_SPPF")) : 1;  // 0: three launches (A/B)
+            const int hw = L.in_h * L.in_w;
+            if (fuse && chained(L, L2) && chained(L2, L3) && L.out_buf == L.in_buf && L.cin % 16 == 0 && hw <= 480) {
+                const int cg = hw <= 240 ? 16 : 8;   // four float arrays of the map x cg channels in <= 60 KB of LDS
+                pa::SliceGeom gi = {L.in_h, L.in_w, L.in_pad, L.in_cstride, L.in_coff};
+                pa::SliceGeom g1 = {L.in_h, L.in_w, L.out_pad, L.out_cstride, L.out_coff};
+                pa::SliceGeom g2 = {L.in_h, L.in_w, L2.out_pad, L2.out_cstride, L2.out_coff};
+                pa::SliceGeom g3 = {L.in_h, L.in_w, L3.out_pad, L3.out_cstride, L3.out_coff};
+                const size_t lds = (size_t)4 * hw * cg * sizeof(float);
+                if (cg == 16)
+                    hipLaunchKernelGGL(pa::sppf_pools_kernel<16>, dim3(L.cin / 16, n), dim3(256), lds, s, h->bufs[L.in_buf], gi, h->bufs[L.out_buf], g1, g2, g3);
+                else
+                    hipLaunchKernelGGL(pa::sppf_pools_kernel<8>, dim3(L.cin / 8, n), dim3(256), lds, s, h->bufs[L.in_buf], gi, h->bufs[L.out_buf], g1, g2, g3);
+                DT_HIP(hipGetLastError());
+                if (ev) {  // (profiling call: the two absorbed layers show as empty)
+                    DT_HIP(hipEventRecord((*ev)[li + 1], s));
+                    DT_HIP(hipEventRecord((*ev)[li + 2], s));
+                }
+                li += 2;
+                continue;
+            }
         }
         if (L.kind == 4 || L.kind == 5) {
             pa::SliceGeom gi = {L.in_h, L.in_w, L.in_pad, L.in_cstride, L.in_coff};
