@@ -577,8 +577,9 @@ class Engine:
             out["crops_rgb"] = crops.cpu().numpy()
         return out
 
-    def features_export(self, frame0: int, n: int) -> torch.Tensor:
-        out = torch.empty((n, self.F, _lib.PA_FEATURE_STRIDE), dtype=torch.float32, device=self.device)
+    def features_export(self, frame0: int, n: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if out is None:
+            out = torch.empty((n, self.F, _lib.PA_FEATURE_STRIDE), dtype=torch.float32, device=self.device)
         self._check(self._lib.pa_features_export(self._h, frame0, n, _ptr(out), self._stream()))
         return out
 

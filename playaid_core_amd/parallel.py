@@ -189,11 +189,21 @@ class FrameParallelClip:
             return [], []
         recvs, sends = halo_plan(n_total, self.world, self.rank, self.reach)
         ops, bufs = [], []
+        # the halo buffers of a clip shape are allocated once and reused by every pass (the exchange of pass k has been
+        # waited for in finish_halo before pass k + 1 exports into them again)
+        cache = self.__dict__.setdefault("_halo_bufs", {})
         for peer, f0, cnt in sends:
-            t = self.engine.features_export(f0, cnt)
+            key = ("s", peer, f0, cnt)
+            if key not in cache:
+                cache[key] = self.engine.features_buffer(cnt)
+            t = (self.engine.features_export(f0, cnt, out=cache[key]) if getattr(self.engine, "supports_pipelining", False)
+                 else self.engine.features_export(f0, cnt))   # (the CPU stand-in of the gloo tests allocates its own)
             ops.append(dist.P2POp(dist.isend, t.cpu() if self._staged else t, peer, self.group))
         for peer, f0, cnt in recvs:
-            t = self.engine.features_buffer(cnt)
+            key = ("r", peer, f0, cnt)
+            if key not in cache:
+                cache[key] = self.engine.features_buffer(cnt)
+            t = cache[key]
             if self._staged:
                 t = torch.empty(t.shape, dtype=t.dtype)
             bufs.append((f0, t))
