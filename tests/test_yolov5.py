@@ -136,3 +136,35 @@ def test_detection_network_other_network_inputs(net):
         assert e_score <= 1e-4 and e_box <= 2e-2
     finally:
         det.close()
+
+
+@pytest.mark.gpu
+def test_detection_network_full_batch_of_configs1():
+    """The batch BASELINE.json's configs[1] names -- 64 frames in one pa_detector_forward -- against the oracle, every row: the
+    persistent GEMM then walks ~15 tiles per workgroup on the 96 x 160 maps (one-k-step tiles on the 32-channel layer, where a
+    wave's counted wait spans the stores of two closed tiles), which the small batches above never reach."""
+    import torch
+
+    from oracle import yolov5 as oy
+    from playaid_core_amd.yolov5 import YoloV5Detector
+
+    n = 64
+    sd = synth.make_yolov5s_state_dict()
+    det = YoloV5Detector(sd, NC, NET, max_images=n)
+    try:
+        frames = synth.make_frames(n, 720, 1280, seed=3)
+        got = det(frames)
+        torch.cuda.synchronize()
+        got = got.cpu().numpy()
+        x = torch.from_numpy(np.stack([oy.letterbox(f, NET) for f in frames]))
+        want = np.concatenate([oy.forward(x[i:i + 8], sd, NC).numpy() for i in range(0, n, 8)])
+        e_box, e_score = np.abs(got[..., :4] - want[..., :4]).max(), np.abs(got[..., 4:] - want[..., 4:]).max()
+        print(f"64-frame batch: boxes {e_box:.2e} px, scores {e_score:.2e}")
+        assert e_score <= 1e-4 and e_box <= 2e-2
+        # and the same frames in another order give the same rows, bit for bit (no tile depends on its neighbours in the launch)
+        perm = np.random.default_rng(0).permutation(n)
+        got2 = det(frames[perm])
+        torch.cuda.synchronize()
+        assert np.array_equal(got2.cpu().numpy(), got[perm])
+    finally:
+        det.close()
