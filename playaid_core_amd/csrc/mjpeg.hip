@@ -286,8 +286,8 @@ struct SubCnt {     // what a subsequence contributes to the scan
 };
 
 
-template <int MODE>
-__global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restrict__ clean, const FrameDesc* __restrict__ fd,
+template <int MODE, int LANES = WG_SUBS>
+__global__ __launch_bounds__(LANES) void sub_decode_kernel(const uint8_t* __restrict__ clean, const FrameDesc* __restrict__ fd,
                                                          const TableSet* __restrict__ ts, const uint32_t* __restrict__ seg_start,
                                                          const uint32_t* __restrict__ clean_len, const Geom g,
                                                          const uint32_t* __restrict__ g_in, uint32_t* __restrict__ g_out,
@@ -299,13 +299,13 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
     // verify pass: a frame whose previous verify pass changed nothing has settled (changed_last = that pass's flags)
     if (MODE == 1 && changed_last && changed_last[blockIdx.y + g.f0] == 0) return;
     __shared__ HuffTables T;
-    __shared__ uint32_t ring[WG_SUBS * (RING_DW + 1)];
+    __shared__ uint32_t ring[LANES * (RING_DW + 1)];
     const int f = blockIdx.y + g.f0, tid = threadIdx.x;
     const FrameDesc d = fd[f];
     const uint32_t clen = clean_len[f];
     const int sh = g.sub_shift;
     const int nsub = (int)((clen + (1u << sh) - 1) >> sh);
-    const int j0 = blockIdx.x * WG_SUBS;
+    const int j0 = blockIdx.x * LANES;
     int j = j0 + tid;
     bool active;
     if (MODE == 1) {
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void sub_decode_kernel(const uint8_t* __restri
     {   // tables, block layout of an MCU
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&ts[d.tabset].h);
         uint32_t* dst = reinterpret_cast<uint32_t*>(&T);
-        for (int i = tid; i < (int)(sizeof(HuffTables) / 4); i += 256) dst[i] = src[i];
+        for (int i = tid; i < (int)(sizeof(HuffTables) / 4); i += LANES) dst[i] = src[i];
     }
     // Huffman table of every block position of an MCU (baseline: two DC, two AC tables), one bit each, wave-uniform:
     // bit b = the DC table of block b, bit 16 + b = its AC table
@@ -1151,6 +1151,8 @@ struct pa_mjpeg {
     int max_chunks_cap = 0;
     int sync_rounds = 8;
     int sub_shift_override = 0;  // tuning: log2 of the subsequence size, 0 = chosen from the stream
+    int wg_lanes = WG_SUBS;      // lanes per workgroup of the entropy passes: 256, or 128 (34.8 KB of LDS instead of 51.7: fits beside two
+                                 // workgroups of the fp32 convolution kernel on a CU; PA_MJPEG_WG_LANES)
     // Device scratch, TWO sets used in turn (like the pinned staging below): a call never touches the memory of the call
     // before it, so its first groups start while that call's last groups are still decoding.
     struct Set {
@@ -1263,6 +1265,7 @@ int pa_mjpeg_create(int32_t device, int32_t max_frames, int32_t max_height, int3
     const size_t clean_bytes = max_bytes + 32 * n + 4096;
     h->clean_bytes = clean_bytes;
     if (const char* e = getenv("PA_MJPEG_GROUPS")) h->groups = atoi(e);  // tuning knob (scripts/mjpeg_rate.py)
+    if (const char* e = getenv("PA_MJPEG_WG_LANES")) h->wg_lanes = atoi(e) == 128 ? 128 : WG_SUBS;
     h->groups = h->groups < 1 ? 1 : (h->groups > MAX_GROUPS ? MAX_GROUPS : h->groups);
     for (auto& S : h->set) {
         if (!chk(hipMalloc(&S.d_bits, max_bytes + 64), "hipMalloc bitstream")) return PA_ERR_HIP;
@@ -1549,19 +1552,25 @@ int pa_mjpeg_decode(pa_mjpeg* h, const uint8_t* data_host, const int64_t* spans_
         hipLaunchKernelGGL(unstuff_count_kernel, dim3(max_chunks, ng), dim3(256), 0, q, S.d_bits, S.d_fd, S.d_chunk, max_chunks, f0);
         hipLaunchKernelGGL(unstuff_write_kernel, dim3(max_chunks, ng), dim3(256), 0, q, S.d_bits, S.d_fd, S.d_chunk, max_chunks, S.d_clean,
                            S.d_seg, S.d_clean_len, S.d_status, f0);
-        const dim3 sgrid((max_sub + WG_SUBS - 1) / WG_SUBS, ng);
+        const int wl = h->wg_lanes;
+        const dim3 sgrid((max_sub + wl - 1) / wl, ng);
         int cur_g = 0;
-        hipLaunchKernelGGL((sub_decode_kernel<0>), sgrid, dim3(256), 0, q, S.d_clean, S.d_fd, S.d_ts, S.d_seg, S.d_clean_len, gg,
-                           (const uint32_t*)nullptr, S.d_g[0], S.d_used, S.d_cnt, (const SubCnt*)nullptr, (int16_t*)nullptr, S.d_status,
-                           (int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, (int16_t*)nullptr);
+#define MJ_LAUNCH(MODE_, ...)                                                                                         \
+    do {                                                                                                              \
+        if (wl == 128) hipLaunchKernelGGL((sub_decode_kernel<MODE_, 128>), sgrid, dim3(128), 0, q, __VA_ARGS__);      \
+        else hipLaunchKernelGGL((sub_decode_kernel<MODE_, WG_SUBS>), sgrid, dim3(WG_SUBS), 0, q, __VA_ARGS__);        \
+    } while (0)
+        MJ_LAUNCH(0, S.d_clean, S.d_fd, S.d_ts, S.d_seg, S.d_clean_len, gg,
+                  (const uint32_t*)nullptr, S.d_g[0], S.d_used, S.d_cnt, (const SubCnt*)nullptr, (int16_t*)nullptr, S.d_status,
+                  (int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, (int16_t*)nullptr);
         auto verify = [&](int slot, int prev_slot) {
             int32_t* flag = S.d_changed + (size_t)slot * h->max_frames;
             const int32_t* prev = prev_slot >= 0 ? S.d_changed + (size_t)prev_slot * h->max_frames : nullptr;
             hipLaunchKernelGGL(sub_verify_plan_kernel, dim3(ng), dim3(1024), 0, q, S.d_fd, S.d_clean_len, g.sub_shift, S.d_g[cur_g],
                                S.d_g[cur_g ^ 1], S.d_used, S.d_todo, S.d_todo_cnt, prev, f0);
-            hipLaunchKernelGGL((sub_decode_kernel<1>), sgrid, dim3(256), 0, q, S.d_clean, S.d_fd, S.d_ts, S.d_seg, S.d_clean_len, gg,
-                               S.d_g[cur_g], S.d_g[cur_g ^ 1], S.d_used, S.d_cnt, (const SubCnt*)nullptr, (int16_t*)nullptr, S.d_status, flag,
-                               prev, S.d_todo, S.d_todo_cnt, (int16_t*)nullptr);
+            MJ_LAUNCH(1, S.d_clean, S.d_fd, S.d_ts, S.d_seg, S.d_clean_len, gg,
+                      S.d_g[cur_g], S.d_g[cur_g ^ 1], S.d_used, S.d_cnt, (const SubCnt*)nullptr, (int16_t*)nullptr, S.d_status, flag,
+                      prev, S.d_todo, S.d_todo_cnt, (int16_t*)nullptr);
             cur_g ^= 1;
         };
         int last_slot = MAX_ROUNDS;  // an all-zero row unless a verify pass wrote it
@@ -1587,9 +1596,10 @@ int pa_mjpeg_decode(pa_mjpeg* h, const uint8_t* data_host, const int64_t* spans_
             rounds_run = rounds;
         }
         hipLaunchKernelGGL(sub_scan_kernel, dim3(ng), dim3(1024), 0, q, S.d_fd, S.d_clean_len, S.d_cnt, S.d_entry, g.sub_shift, f0);
-        hipLaunchKernelGGL((sub_decode_kernel<2>), sgrid, dim3(256), 0, q, S.d_clean, S.d_fd, S.d_ts, S.d_seg, S.d_clean_len, gg,
-                           S.d_g[cur_g], (uint32_t*)nullptr, S.d_used, S.d_cnt, S.d_entry, S.d_coef, S.d_status, (int32_t*)nullptr,
-                           S.d_changed + (size_t)last_slot * h->max_frames, (const int32_t*)nullptr, (const int32_t*)nullptr, S.d_dc);
+        MJ_LAUNCH(2, S.d_clean, S.d_fd, S.d_ts, S.d_seg, S.d_clean_len, gg,
+                  S.d_g[cur_g], (uint32_t*)nullptr, S.d_used, S.d_cnt, S.d_entry, S.d_coef, S.d_status, (int32_t*)nullptr,
+                  S.d_changed + (size_t)last_slot * h->max_frames, (const int32_t*)nullptr, (const int32_t*)nullptr, S.d_dc);
+#undef MJ_LAUNCH
         hipLaunchKernelGGL(dc_scan_kernel, dim3(ng, g.ncomp), dim3(1024), 0, q, S.d_dc, S.d_fd, gg);
         const long long nblk = (long long)ng * g.blocks_per_frame;
         hipLaunchKernelGGL(idct_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, q, S.d_coef, S.d_dc, S.d_fd, S.d_ts, gg, S.d_planes, ng);
