@@ -77,6 +77,8 @@ struct pa_engine {
     bool adopt = false;
     int32_t* dev_errors = nullptr;  // [4] device-side error counters ([0] = scatter ids outside the clip, [1] = crop images that did not fit)
     int32_t* savebox_rects = nullptr;  // [max_crops][4] scratch of pa_save_one_box_crops
+    double* clean_g6 = nullptr;        // scratch of pa_clean_detections: the detection table through '%g' (grown on demand)
+    size_t clean_g6_cap = 0;
     float* x0 = nullptr;      // slot 0 of the model-input double buffer [max_crops][134][134][4]
     float* x0_slot[2] = {nullptr, nullptr};
     int32_t* pre_status[2] = {nullptr, nullptr};  // per-slot crop status written by the preprocess stage
@@ -1010,6 +1012,7 @@ void pa_destroy(pa_engine* e) {
     if (e->side) (void)hipStreamDestroy(e->side);
     if (e->gate_flag) (void)hipHostFree(e->gate_flag);
     for (void* p : e->allocs) (void)hipFree(p);
+    (void)hipFree(e->clean_g6);
     delete e;
 }
 
@@ -1344,6 +1347,15 @@ int pa_clean_detections(pa_engine* e, const float* dets, const int32_t* counts, 
     p.fighters = e->cfg.num_fighters;
     for (int i = 0; i < 4; ++i) p.class_ids[i] = e->cfg.fighter_class_ids[i];
     p.lab = labels; p.pixel_frame = pixel_frame; p.pixel_box = pixel_box; p.crop_kind = crop_kind; p.crop_row = crop_row; p.info = info4;
+    const size_t need = (size_t)n_labels * max_det * 6;
+    if (need > e->clean_g6_cap) {  // (first call, or a longer clip than any before: the old scratch may still be read by a call in flight)
+        HIPCHK(e, hipDeviceSynchronize());
+        (void)hipFree(e->clean_g6);
+        e->clean_g6 = nullptr; e->clean_g6_cap = 0;
+        HIPCHK(e, hipMalloc(&e->clean_g6, need * sizeof(double)));
+        e->clean_g6_cap = need;
+    }
+    p.g6v = e->clean_g6;
     HIPCHK(e, pa::launch_clean_labels(p, (hipStream_t)stream));
     return PA_OK;
 }

@@ -234,6 +234,7 @@ struct CleanParams {
     int32_t* crop_kind;     // [n_labels][F]
     float* crop_row;        // [n_labels][F][6]
     int32_t* info;          // [4]: max_frames, error code, error frame, duplicates resolved
+    double* g6v;            // scratch [n_labels][max_det][6]: every row value through the label file's '%g' (filled by the launcher's first kernel)
 };
 hipError_t launch_clean_labels(const CleanParams& p, hipStream_t s);
 
