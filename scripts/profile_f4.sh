@@ -1,7 +1,7 @@
 #!/bin/bash
 # Measurement set of the alternative temporal models for profiles/: bench lines + rocprofv3 kernel stats.
 set -u
-O=${1:-gpurun_out/r3_f4}
+O=${1:-gpurun_out/r4_f4}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for w in rnn resformer; do
