@@ -495,7 +495,9 @@ def bench_detect(args):
     device = torch.device("cuda", 0)
     torch.cuda.set_device(device)
     n = args.frames
-    frames = synth.make_frames_torch(n, args.height, args.width, device=device)
+    # (the host generator: rocprofv3 counter passes do not survive the torch integer kernels of the device one -- under
+    # --pmc this workload crashed inside the next hipMemcpy)
+    frames = torch.from_numpy(synth.make_frames(n, args.height, args.width)).to(device)
     eng = Engine(synth.make_state_dict(seed=1234), device=str(device), max_batch_frames=8, max_clip_frames=64, max_frame_height=args.height,
                  max_frame_width=args.width)
     det = YoloV5Detector(synth.make_yolov5s_state_dict(), 6, (384, 640), max_images=n, device=str(device))
