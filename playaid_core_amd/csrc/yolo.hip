@@ -413,6 +413,11 @@ int pa_detector_create(int32_t device, const pa_net_layer* layers, int32_t n_lay
     h->bufs.assign(n_bufs, nullptr);
     h->buf_floats.assign(buf_floats_per_image, buf_floats_per_image + n_bufs);
     for (int b = 0; b < n_bufs; ++b) {
+        // the convolution kernels address a buffer with 32-bit BYTE offsets (buffer_load ... lds): 2 GB per buffer
+        if ((unsigned long long)max_images * (unsigned long long)h->buf_floats[b] + 128ull * 2048 >= (1ull << 29)) {
+            h->last_error = "activation buffer " + std::to_string(b) + " would exceed 2 GB: lower max_images (frames are run in chunks of it)";
+            return PA_ERR_CAPACITY;
+        }
         // (+ slack: a partial last tile of the GEMM reads rows past the last image)
         const size_t bytes = ((size_t)max_images * h->buf_floats[b] + 128 * 2048) * sizeof(float);
         if (!chk(hipMalloc(&h->bufs[b], bytes), "hipMalloc activations")) return PA_ERR_HIP;
@@ -420,6 +425,10 @@ int pa_detector_create(int32_t device, const pa_net_layer* layers, int32_t n_lay
     }
     // (+ slack: the stem's 8-pixel K chunks of the last row run two pixels past it, a partial last GEMM tile further)
     const size_t x0_bytes = ((size_t)max_images * (net_h + 4) * (net_w + 4) * 4 + 128 * 2048) * sizeof(float);
+    if (x0_bytes >= (1ull << 31)) {
+        h->last_error = "the letter-boxed input would exceed 2 GB: lower max_images";
+        return PA_ERR_CAPACITY;
+    }
     if (!chk(hipMalloc(&h->x0, x0_bytes), "hipMalloc input")) return PA_ERR_HIP;
     if (!chk(hipMemset(h->x0, 0, x0_bytes), "hipMemset input")) return PA_ERR_HIP;
     std::vector<float> anc((size_t)n_decode * 8, 0.f);

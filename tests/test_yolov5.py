@@ -88,6 +88,19 @@ def test_detection_network_against_the_oracle(engine):
 
 
 @pytest.mark.gpu
+def test_detector_refuses_batches_its_32_bit_offsets_cannot_address():
+    """The convolution kernels address an activation buffer with 32-bit byte offsets: a handle whose largest buffer would pass
+    2 GB is refused at creation (frames are run in chunks of max_images, so a smaller handle does the same work)."""
+    from playaid_core_amd import _lib
+    from playaid_core_amd.engine import EngineError
+    from playaid_core_amd.yolov5 import YoloV5Detector
+
+    with pytest.raises(EngineError) as ei:
+        YoloV5Detector(synth.make_yolov5s_state_dict(), NC, NET, max_images=300)
+    assert ei.value.code == _lib.PA_ERR_CAPACITY and "2 GB" in str(ei.value)
+
+
+@pytest.mark.gpu
 def test_detection_network_batches_and_small_frames():
     """More frames than the handle's max_images are run in chunks; a frame smaller than the network input is enlarged
     (letterbox scales up as well) -- both equal the oracle."""
