@@ -181,3 +181,30 @@ def test_detection_network_full_batch_of_configs1():
         assert np.array_equal(got2.cpu().numpy(), got[perm])
     finally:
         det.close()
+
+
+@pytest.mark.gpu
+def test_detection_network_is_bitwise_repeatable():
+    """The persistent GEMM orders LDS-DMA copies, operand reads and stores by COUNTED waits; a miscounted wait shows as rare wrong
+    tiles that come and go with timing. Forty forwards of the same 16 frames (3-4 tiles per workgroup on the large maps), a
+    second stream keeping the chip busy under half of them: every result must equal the first, bit for bit."""
+    import torch
+
+    from playaid_core_amd.yolov5 import YoloV5Detector
+
+    det = YoloV5Detector(synth.make_yolov5s_state_dict(), NC, NET, max_images=16)
+    try:
+        frames = torch.from_numpy(synth.make_frames(16, 720, 1280, seed=21)).cuda()
+        first = det(frames).clone()
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        noise = torch.empty(64 << 20, dtype=torch.float32, device="cuda")
+        for it in range(40):
+            if it & 1:
+                with torch.cuda.stream(side):
+                    noise.normal_()   # memory traffic and other workgroups beside the forward
+            got = det(frames)
+            torch.cuda.synchronize()
+            assert torch.equal(got, first), f"forward {it} differs from the first"
+    finally:
+        det.close()
