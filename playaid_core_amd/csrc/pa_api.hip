@@ -425,7 +425,9 @@ int run_conv(pa_engine* e, const ConvLayer& L, int crop0, int ncrops, size_t sla
         if (pe == hipErrorInvalidValue) pe = launch_igemm(p, tile, s);  // geometry the patch kernel does not cover
         HIPCHK(e, pe);
     } else {
-        // stride-2 3x3 convolutions that need no split-K: the persistent form of the engine (pigemm.hip; same k order, bit-identical)
+        // A/B knob (PA_S2_PGEMM=1): stride-2 3x3 convolutions that need no split-K on the persistent form of the engine (pigemm.hip;
+        // same k order, bit-identical). Measured at configs[1]: 48.39 k against 48.53 k frames/s -- one tile per workgroup slot here, nothing
+        // for persistence to win; off by default
         static const int use_pgemm = getenv("PA_S2_PGEMM") ? atoi(getenv("PA_S2_PGEMM")) : 0;
         hipError_t pe = hipErrorInvalidValue;
         if (use_pgemm && L.kh == 3 && L.stride == 2 && !p.act2 && !p.residual && p.splitk <= 1 && !p.gather) pe = launch_pgemm(p, 0, s);
