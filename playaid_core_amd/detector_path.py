@@ -55,7 +55,9 @@ def begin(engine, frames_dev: torch.Tensor, dets: torch.Tensor, counts: torch.Te
 
 
 def _crop_buffer(engine, nbytes: int) -> torch.Tensor:
-    """The packed crop-image buffer, kept on the engine between clips (the worst case is large: every crop a whole frame)."""
+    """The packed crop-image buffer, kept on the engine between clips (the worst case is large: every crop a whole frame).
+    Successive ``finish`` calls on one engine therefore belong on ONE stream (stream order keeps clip k + 1's writes behind
+    clip k's reads; the engine's activation buffers demand the same anyway)."""
     buf = getattr(engine, "_detector_crop_buf", None)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(nbytes, dtype=torch.uint8, device=engine.device)
