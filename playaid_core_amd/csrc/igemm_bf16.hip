@@ -370,6 +370,7 @@ hipError_t launch_igemm_bf16(const GemmParams& p_in, GemmTile tile, hipStream_t 
     if (p.gather) return hipErrorInvalidValue;
     auto dims = [](GemmTile t, int* bm, int* bn, int* bk) {
         switch (t) {
+            case TILE_256x128: *bm = 256; *bn = 128; *bk = 64; break;
             case TILE_128x128: *bm = 128; *bn = 128; *bk = 64; break;
             case TILE_128x64: *bm = 128; *bn = 64; *bk = 64; break;
             case TILE_64x64: *bm = 64; *bn = 64; *bk = 64; break;
@@ -398,6 +399,7 @@ hipError_t launch_igemm_bf16(const GemmParams& p_in, GemmTile tile, hipStream_t 
     p.splitk = (nk + p.ksteps_per_split - 1) / p.ksteps_per_split;
     hipError_t err;
     switch (tile) {
+        case TILE_256x128: err = launch_tile_bf16<256, 128, 64>(p, s); break;
         case TILE_128x128: err = launch_tile_bf16<128, 128, 64>(p, s); break;
         case TILE_128x64: err = launch_tile_bf16<128, 64, 64>(p, s); break;
         case TILE_64x64: err = launch_tile_bf16<64, 64, 64>(p, s); break;

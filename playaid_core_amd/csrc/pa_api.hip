@@ -383,7 +383,7 @@ int run_conv(pa_engine* e, const ConvLayer& L, int crop0, int ncrops, size_t sla
         d.relu = 0; d.splitk = 1;
         ProfScope ps(e, s, prof_name, 2.0 * d.M * d.N * L.in2_c,
                      2.0 * ((double)ncrops * L.in2_hw * L.in2_hw * L.in2_c / (L.in2_stride * L.in2_stride) + (double)d.M * d.N + (double)d.N * L.in2_c));
-        HIPCHK(e, launch_igemm_bf16(d, TILE_128x64, s));
+        HIPCHK(e, launch_igemm_bf16(d, TILE_128x64, s));  // (128x128 / 256x128 tiles measured 2-7 us slower here)
         p.residual = d.out;
     } else if (L.in2) {
         const int w2 = L.in2_hw + 2;  // zero-bordered block input
@@ -414,7 +414,13 @@ int run_conv(pa_engine* e, const ConvLayer& L, int crop0, int ncrops, size_t sla
     if (bf) {
         hipError_t pe = hipErrorInvalidValue;
         if (use_bf16_patch && L.stride == 1 && !p.act2) pe = launch_conv3x3_bf16_patch(p, s);
-        if (pe == hipErrorInvalidValue) pe = launch_igemm_bf16(p, tile, s);  // stride-2 convs, fused 1x1/2 second source
+        if (pe == hipErrorInvalidValue) {  // stride-2 convs, fused 1x1/2 second source
+            // a 256-pixel tile halves the weight fill per pixel (this kernel is bound by its L2 -> LDS copies) where it
+            // still leaves every CU a workgroup; PA_BF16_T256=0 for A/B runs
+            static const int t256 = getenv("PA_BF16_T256") ? atoi(getenv("PA_BF16_T256")) : 1;
+            if (t256 && tile == TILE_128x128 && p.splitk == 1 && ((p.M + 255) / 256) * (p.N / 128) >= 256) tile = TILE_256x128;
+            pe = launch_igemm_bf16(p, tile, s);
+        }
         HIPCHK(e, pe);
     } else if (use_patch && L.kh == 3 && L.stride == 1) {
         int bm = tile == TILE_64x64 || tile == TILE_64x64_K64 ? 64 : 128;

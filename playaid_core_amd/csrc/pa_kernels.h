@@ -64,7 +64,8 @@ struct GemmParams {
 };
 
 // BM x BN (x BK; 32 unless named)
-enum GemmTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x64 = 2, TILE_128x64_K64 = 3, TILE_64x64_K64 = 4 };
+enum GemmTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x64 = 2, TILE_128x64_K64 = 3, TILE_64x64_K64 = 4,
+                TILE_256x128 = 5 /* igemm_bf16.hip only */ };
 
 hipError_t launch_igemm(const GemmParams& p, GemmTile tile, hipStream_t s);
 // persistent form of the same engine for short tiles (pigemm.hip): conv mode, no residual / second source / split-K;
