@@ -2,7 +2,8 @@
 //
 // Same structure as igemm.hip -- zero-bordered NHWC activations, im2col rows and weight rows
 // copied global -> LDS with global_load_lds_dwordx4 into a three-stage ring, XOR swizzle on the
-// DMA source address, 2x2 waves over a BM x BN tile, fused bias / residual / ReLU epilogue,
+// DMA source address, 2x2 waves over a BM x BN tile, fused bias / residual / ReLU epilogue (here straight from the
+// accumulators: the weights are the matrix instruction's row operand, a lane owns one pixel and stores 16 bytes),
 // deterministic split-K, optional second source (fused 1x1/2 downsample) -- but activations and
 // BatchNorm-folded weights are stored as bf16 and the inner product runs on
 // v_mfma_f32_32x32x16_bf16 (f32 accumulate): one ds_read_b128 per operand now feeds ONE matrix
@@ -54,7 +55,13 @@ __device__ __forceinline__ void split_m(const GemmParams& p, int m, int& img, in
 }  // namespace
 
 // BK in bf16 elements: 64 (128-byte LDS rows) or 128 (256-byte rows).
-template <int BM, int BN, int BK>
+//
+// DS (the stride-2 3x3 convolution that opens layers 2-4): the block's 1x1/2 downsample branch reads exactly the pixels
+// of this convolution's CENTRE tap, so its product rides on the k-steps of that tap -- the same im2col rows in LDS times
+// a second weight tile (p.wgt2, copied only in those k-steps, which therefore count B_ROWS more copies in the waits)
+// into a second accumulator set, stored to p.out2 by a second pass of the epilogue. The matrix pipe idles in this kernel
+// (it is bound by its copies), so the branch costs its weight copies and its stores instead of a launch of its own.
+template <int BM, int BN, int BK, bool DS = false>
 __global__ __launch_bounds__(256) void igemm_bf16_kernel(const GemmParams p) {
     constexpr int MI = BM / 64;
     constexpr int NI = BN / 64;
@@ -64,7 +71,8 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const GemmParams p) {
     constexpr int PASS_ROWS = 256 / CH;
     constexpr int A_ROWS = BM / PASS_ROWS;
     constexpr int B_ROWS = BN / PASS_ROWS;
-    constexpr int STAGE = (BM + BN) * ROW_F;  // floats per LDS stage
+    constexpr int STAGE = (BM + BN + (DS ? BN : 0)) * ROW_F;  // floats per LDS stage
+    static_assert(!DS || BK == 64, "the centre tap is found by 64-deep k-steps");
     __shared__ __attribute__((aligned(16))) float lds[3 * STAGE];
 
     const bf16_t* act = reinterpret_cast<const bf16_t*>(p.act);
@@ -103,6 +111,11 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const GemmParams p) {
     }
 #pragma unroll
     for (int i = 0; i < B_ROWS; ++i) b_off[i] = (tile_n * BN + row0 + PASS_ROWS * i) * p.ktot + colq * 8;
+    int b2_off[DS ? B_ROWS : 1];
+    if constexpr (DS) {
+#pragma unroll
+        for (int i = 0; i < B_ROWS; ++i) b2_off[i] = (tile_n * BN + row0 + PASS_ROWS * i) * p.chunk + colq * 8;
+    }
 
     const int nk_main = (p.ktot - p.k2_steps * BK) / BK;
     const int nk = p.ktot / BK;
@@ -125,6 +138,9 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const GemmParams p) {
     const __amdgpu_buffer_rsrc_t wgt_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(wgt), 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t act2_rs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(act2 ? act2 : act), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wgt2_rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DS ? p.wgt2 : p.wgt), 0, -1, 0x00020000);
+    bool newest_ctr = false;  // DS: the stage issued last carried the second weight tile
 
 #define PA_ISSUE_STAGE(BUF)                                                                                   \
     {                                                                                                         \
@@ -141,6 +157,13 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const GemmParams p) {
             _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i) glds16(act_rs, a_off[i] + tapoff, As_w + i * 1024); \
             const int koff = tap * p.chunk + cur_kc;                                                          \
             _Pragma("unroll") for (int i = 0; i < B_ROWS; ++i) glds16(wgt_rs, b_off[i] + koff, Bs_w + i * 1024); \
+            if constexpr (DS) {                                                                               \
+                newest_ctr = cur_ky == 1 && cur_kx == 1;                                                      \
+                if (newest_ctr) {                                                                             \
+                    float* B2s_w = Bs_w + BN * ROW_F;                                                         \
+                    _Pragma("unroll") for (int i = 0; i < B_ROWS; ++i) glds16(wgt2_rs, b2_off[i] + cur_kc, B2s_w + i * 1024); \
+                }                                                                                             \
+            }                                                                                                 \
             cur_kc += BK;                                                                                     \
             if (cur_kc == p.chunk) {                                                                          \
                 cur_kc = 0;                                                                                   \
@@ -167,39 +190,21 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const GemmParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
+    f32x16 acc2[DS ? MI : 1][DS ? NI : 1];
+    if constexpr (DS) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc2[mi][ni][e] = 0.f;
+    }
+
     const int a_rd_off = (wm * (BM / 2) + lr) * ROW_F;
     const int b_rd_off = BM * ROW_F + (wn * (BN / 2) + lr) * ROW_F;
     const int swz = CH == 8 ? ((lr >> 1) & 7) : (lr & 15);
 
-    // Epilogue operands (thread-mapped, see the epilogue) are fetched now so their latency hides
-    // under the k loop: thread t owns channels [c8, c8+8) of rows r_t + ROWS_PP * i.
-    constexpr int TS = BN;                 // fp32 row of the transposed tile (see igemm.hip)
-    constexpr int CPR = BN / 8;            // 16-byte (8 x bf16) chunks per output row
-    constexpr int ROWS_PP = 256 / CPR;
-    constexpr int EP_IT = BM / ROWS_PP;
-    static_assert(BM * TS <= 3 * STAGE, "transposed tile must fit the LDS ring");
     const bool direct_out = p.splitk <= 1;
-    const int c8 = (tid & (CPR - 1)) * 8;
-    const int r_t = tid / CPR;
-    int o_t[EP_IT];
-    uint4 res_t[EP_IT];
-#pragma unroll
-    for (int i = 0; i < EP_IT; ++i) {
-        int m = tile_m * BM + r_t + ROWS_PP * i;
-        m = m < p.M ? m : p.M - 1;
-        int img, oy, ox;
-        split_m(p, m, img, oy, ox);
-        o_t[i] = img * p.out_img_stride + (oy + p.out_pad) * p.out_row_stride + (ox + p.out_pad) * p.out_px_stride +
-                 tile_n * BN + c8;
-        res_t[i] = make_uint4(0u, 0u, 0u, 0u);
-    }
-    if (direct_out && residual) {
-#pragma unroll
-        for (int i = 0; i < EP_IT; ++i) res_t[i] = *reinterpret_cast<const uint4*>(residual + o_t[i]);
-    }
-    float bias8[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) bias8[k] = (direct_out && p.bias) ? p.bias[tile_n * BN + c8 + k] : 0.f;
 
     f32x4 af[2][MI], bf[2][NI];
 #define PA_LOAD_FRAGS(SET, STAGE_PTR, G)                                                                      \
@@ -217,13 +222,25 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const GemmParams p) {
     // whole ring (every copy would be waited for one k-step after its issue: the round-2 profile of this kernel).
     constexpr int NCOPY = A_ROWS + B_ROWS;
     static_assert(NCOPY == 12 || NCOPY == 8 || NCOPY == 6 || NCOPY == 4, "extend the counted wait below");
+    static_assert(!DS || NCOPY + B_ROWS == 12 || NCOPY + B_ROWS == 8, "extend the counted wait below");
+#define PA_WAIT_COUNT(N_)                                                        \
+    {                                                                            \
+        if constexpr ((N_) == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); \
+        else if constexpr ((N_) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); \
+        else if constexpr ((N_) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); \
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                    \
+    }
+    // all but the newest stage's copies have landed
+#define PA_WAIT_NEWEST()                                                         \
+    {                                                                            \
+        if constexpr (DS) {                                                      \
+            if (newest_ctr) PA_WAIT_COUNT(NCOPY + B_ROWS) else PA_WAIT_COUNT(NCOPY) \
+        } else PA_WAIT_COUNT(NCOPY)                                              \
+    }
     if (ks_begin < ks_end) PA_ISSUE_STAGE(0);
     if (ks_begin + 1 < ks_end) PA_ISSUE_STAGE(1);
     if (ks_begin + 1 < ks_end) {
-        if constexpr (NCOPY == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if constexpr (NCOPY == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if constexpr (NCOPY == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        PA_WAIT_NEWEST();
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -240,6 +257,29 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const GemmParams p) {
         __builtin_amdgcn_sched_barrier(0);
         const float* st_cur = lds + buf * STAGE;
         const float* st_next = lds + buf1 * STAGE;
+        if constexpr (DS) {
+            // centre tap (k-steps 4 cpt .. 5 cpt - 1): the same rows times the second weight tile
+            const int cpt = p.chunk / BK;
+            if (ks >= 4 * cpt && ks < 5 * cpt) {
+#pragma unroll
+                for (int g = 0; g < KG; ++g) {
+                    const int ch = ((g * 2 + lh) ^ swz) * 4;
+                    f32x4 a2[MI], w2[NI];
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) a2[mi] = *reinterpret_cast<const f32x4*>(st_cur + a_rd_off + mi * 32 * ROW_F + ch);
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        w2[ni] = *reinterpret_cast<const f32x4*>(st_cur + b_rd_off + BN * ROW_F + ni * 32 * ROW_F + ch);
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni)
+                            acc2[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                __builtin_bit_cast(bf16x8, w2[ni]), __builtin_bit_cast(bf16x8, a2[mi]), acc2[mi][ni], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
 #pragma unroll
         for (int g = 0; g < KG; ++g) {
             // operands of the next group (or of the next stage's first group) are requested before
@@ -251,10 +291,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const GemmParams p) {
                 // close the stage: this wave's reads of it are in registers; the next stage has landed for this
                 // wave once only the newest copies are outstanding, and for everyone behind the barrier
                 if (issued) {
-                    if constexpr (NCOPY == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                    else if constexpr (NCOPY == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                    else if constexpr (NCOPY == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    PA_WAIT_NEWEST();
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
@@ -269,55 +306,86 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const GemmParams p) {
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        __builtin_bit_cast(bf16x8, af[g & 1][mi]), __builtin_bit_cast(bf16x8, bf[g & 1][ni]), acc[mi][ni], 0, 0, 0);
+                        __builtin_bit_cast(bf16x8, bf[g & 1][ni]), __builtin_bit_cast(bf16x8, af[g & 1][mi]), acc[mi][ni], 0, 0, 0);
         }
         buf = buf1;
     }
-    __syncthreads();  // (the transposed tile below reuses the ring)
 #undef PA_LOAD_FRAGS
 #undef PA_ISSUE_STAGE
+#undef PA_WAIT_NEWEST
+#undef PA_WAIT_COUNT
 
-    // Epilogue: the fp32 accumulators are transposed through the idle LDS ring (rows of BN floats) so that each thread converts and stores 8 channels = 16 bytes per row, EP_IT
-    // wide stores (and residual loads) per thread instead of 16*MI*NI two-byte ones per lane.
-    float* const tbuf = lds;  // every wave left the k loop through its final barrier
+    // Epilogue, straight from the accumulators. The WEIGHTS are the matrix instruction's row operand, so a lane owns
+    // ONE pixel (tile row wm BM/2 + 32 mi + lr) and, per 32-channel block, the runs 8 j + 4 lh + 0..3 (element e = 4 j + i).
+    // Swapping halves between lanes l and l + 32 (v_permlane32_swap) turns two runs into eight consecutive channels
+    // 16 j2 + 8 lh + 0..7 = one 16-byte store per lane: no transposition through LDS, no barrier.
+    int obase[MI], mrow[MI];
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = wm * (BM / 2) + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                tbuf[row * TS + wn * (BN / 2) + ni * 32 + lr] = acc[mi][ni][e];
-            }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < EP_IT; ++i) {
-        const int row = r_t + ROWS_PP * i;
-        const int m = tile_m * BM + row;
-        if (m >= p.M) continue;
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(tbuf + row * TS + c8);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(tbuf + row * TS + c8 + 4);
-        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-        if (!direct_out) {
-            float* dst = p.slab + ((size_t)z * p.M + m) * p.N + tile_n * BN + c8;
-            *reinterpret_cast<f32x4*>(dst) = v0;
-            *reinterpret_cast<f32x4*>(dst + 4) = v1;
-        } else {
-            const uint32_t rw[4] = {res_t[i].x, res_t[i].y, res_t[i].z, res_t[i].w};
-            uint32_t pk[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float a = v[2 * k] + bias8[2 * k] + __uint_as_float(rw[k] << 16);
-                float b = v[2 * k + 1] + bias8[2 * k + 1] + __uint_as_float(rw[k] & 0xffff0000u);
-                if (p.relu) {
-                    a = a > 0.f ? a : 0.f;
-                    b = b > 0.f ? b : 0.f;
-                }
-                pk[k] = (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
-            }
-            *reinterpret_cast<uint4*>(out + o_t[i]) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-        }
+    for (int mi = 0; mi < MI; ++mi) {
+        mrow[mi] = tile_m * BM + wm * (BM / 2) + mi * 32 + lr;
+        const int m = mrow[mi] < p.M ? mrow[mi] : p.M - 1;
+        int img, oy, ox;
+        split_m(p, m, img, oy, ox);
+        obase[mi] = img * p.out_img_stride + (oy + p.out_pad) * p.out_row_stride + (ox + p.out_pad) * p.out_px_stride +
+                    tile_n * BN + wn * (BN / 2) + 8 * lh;
     }
+    if (!direct_out) {
+        // split-K: fp32 partial sums, a lane's runs of four channels as 16-byte stores
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            if (mrow[mi] >= p.M) continue;
+            float* dst = p.slab + ((size_t)z * p.M + mrow[mi]) * p.N + tile_n * BN + wn * (BN / 2) + 4 * lh;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *reinterpret_cast<f32x4*>(dst + ni * 32 + 8 * j) =
+                        f32x4{acc[mi][ni][4 * j], acc[mi][ni][4 * j + 1], acc[mi][ni][4 * j + 2], acc[mi][ni][4 * j + 3]};
+        }
+        return;
+    }
+    // FULL: bias + residual + activation (the convolution's own output); else plain rounding (the DS branch's)
+#define PA_STORE_TILE(ACC, DST, FULL)                                                                          \
+    {                                                                                                          \
+        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                      \
+            _Pragma("unroll") for (int j2 = 0; j2 < 2; ++j2) {                                                 \
+                float b8_[8];                                                                                  \
+                _Pragma("unroll") for (int k = 0; k < 8; ++k)                                                  \
+                    b8_[k] = ((FULL) && p.bias) ? p.bias[tile_n * BN + wn * (BN / 2) + ni * 32 + 16 * j2 + 8 * lh + k] : 0.f; \
+                _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                            \
+                    float vv_[8];                                                                              \
+                    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
+                        const uint32_t x_ = __float_as_uint((ACC)[mi][ni][8 * j2 + i]);                        \
+                        const uint32_t y_ = __float_as_uint((ACC)[mi][ni][8 * j2 + 4 + i]);                    \
+                        const auto r_ = __builtin_amdgcn_permlane32_swap(x_, y_, false, false);                \
+                        vv_[i] = __uint_as_float(r_[0]);                                                       \
+                        vv_[4 + i] = __uint_as_float(r_[1]);                                                   \
+                    }                                                                                          \
+                    const int o_ = obase[mi] + ni * 32 + 16 * j2;                                              \
+                    uint4 rv_ = make_uint4(0u, 0u, 0u, 0u);                                                    \
+                    if ((FULL) && residual && mrow[mi] < p.M) rv_ = *reinterpret_cast<const uint4*>(residual + o_); \
+                    const uint32_t rw_[4] = {rv_.x, rv_.y, rv_.z, rv_.w};                                      \
+                    uint32_t pk_[4];                                                                           \
+                    _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                            \
+                        float a_ = vv_[2 * k] + b8_[2 * k] + __uint_as_float(rw_[k] << 16);                    \
+                        float c_ = vv_[2 * k + 1] + b8_[2 * k + 1] + __uint_as_float(rw_[k] & 0xffff0000u);    \
+                        if ((FULL) && p.relu) {                                                                \
+                            a_ = a_ > 0.f ? a_ : 0.f;                                                          \
+                            c_ = c_ > 0.f ? c_ : 0.f;                                                          \
+                        }                                                                                      \
+                        pk_[k] = (uint32_t)f2bf(a_) | ((uint32_t)f2bf(c_) << 16);                              \
+                    }                                                                                          \
+                    if (mrow[mi] < p.M) *reinterpret_cast<uint4*>((DST) + o_) = make_uint4(pk_[0], pk_[1], pk_[2], pk_[3]); \
+                }                                                                                              \
+            }                                                                                                  \
+    }
+    PA_STORE_TILE(acc, out, true);
+    if constexpr (DS) {
+        // the branch's tile: no bias (it sits in the bias of the convolution that adds this tensor as its residual)
+        bf16_t* out2 = reinterpret_cast<bf16_t*>(p.out2);
+        PA_STORE_TILE(acc2, out2, false);
+    }
+#undef PA_STORE_TILE
 }
 
 // Ordered split-K reduction (fp32 slabs) with the fused epilogue, bf16 out.
@@ -356,10 +424,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const GemmParam
     }
 }
 
-template <int BM, int BN, int BK>
+template <int BM, int BN, int BK, bool DS = false>
 static hipError_t launch_tile_bf16(const GemmParams& p, hipStream_t s) {
     const int grid = p.tiles_m * p.tiles_n * p.splitk;
-    hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, BK>), dim3(grid), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, BK, DS>), dim3(grid), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 
@@ -395,6 +463,13 @@ hipError_t launch_igemm_bf16(const GemmParams& p_in, GemmTile tile, hipStream_t 
     const int nk = p.ktot / bk;
     if (p.splitk < 1) p.splitk = 1;
     if (p.splitk > nk) p.splitk = nk;
+    if (p.out2) {  // second 1x1 product on the centre tap (see the kernel): 3x3 taps, 64-deep k-steps, one K split
+        if (!p.wgt2 || p.taps != 9 || p.kw_taps != 3 || p.k2_steps || bk != 64 || p.splitk != 1 ||
+            (tile != TILE_128x128 && tile != TILE_128x64))
+            return hipErrorInvalidValue;
+        p.ksteps_per_split = nk;
+        return tile == TILE_128x128 ? launch_tile_bf16<128, 128, 64, true>(p, s) : launch_tile_bf16<128, 64, 64, true>(p, s);
+    }
     p.ksteps_per_split = (nk + p.splitk - 1) / p.splitk;
     p.splitk = (nk + p.ksteps_per_split - 1) / p.ksteps_per_split;
     hipError_t err;

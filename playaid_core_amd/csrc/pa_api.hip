@@ -41,6 +41,12 @@ struct ConvLayer {
     // which the 3x3 conv then adds as its residual (patchconv_bf16.hip has no second source)
     float* ds_wgt = nullptr;  // [cout][in2_c] bf16
     float* ds_out = nullptr;
+    // ... unless the block's stride-2 opener computes it on its centre tap (igemm_bf16.hip, DS): set on the OPENER
+    // (`ds_next_*` = the next layer's ds_wgt / ds_out) and on the conv that adds the result (`ds_fused`)
+    float* ds_next_wgt = nullptr;
+    float* ds_next_out = nullptr;
+    bool ds_fused = false;
+    bool ds_probe = false;  // PA_BF16_DS_FUSE=2: the opener takes the fused launch's tile and K split, the branch stays separate
     double k_alg = 0;  // algorithmic K (unpadded) for FLOP accounting
 };
 
@@ -365,7 +371,9 @@ int run_conv(pa_engine* e, const ConvLayer& L, int crop0, int ncrops, size_t sla
     p.out_img_stride = (int)out_crop;
     p.out_pad = L.out_pad;
     p.relu = L.relu;
-    if (bf_ds) {
+    if (bf_ds && L.ds_fused) {
+        p.residual = at(L.ds_out, crop0 * out_crop);  // written by the block's opener
+    } else if (bf_ds) {
         GemmParams d;
         memset(&d, 0, sizeof(d));
         const int w2 = L.in2_hw + 2;  // zero-bordered block input
@@ -402,9 +410,19 @@ int run_conv(pa_engine* e, const ConvLayer& L, int crop0, int ncrops, size_t sla
     p.splitk = splitk;
     const size_t slab_avail = e->slab_floats > slab_off ? e->slab_floats - slab_off : 0;
     if ((size_t)p.splitk * p.M * p.N > slab_avail) p.splitk = 1;
-    const double k_main = bf_ds ? L.k_alg - L.in2_c : L.k_alg;  // (the branch's own launch carries its FLOPs and bytes)
+    const bool ds_here = bf && L.ds_next_wgt;  // this launch also computes the next conv's 1x1/2 branch
+    if (ds_here) {
+        p.wgt2 = L.ds_next_wgt;
+        p.out2 = at(L.ds_next_out, crop0 * out_crop);
+    }
+    if (ds_here || (bf && L.ds_probe)) {
+        tile = (p.N % 128 == 0 && ((p.M + 127) / 128) * (p.N / 128) >= 256) ? TILE_128x128 : TILE_128x64;
+        p.splitk = 1;
+    }
+    // (the branch's FLOPs and bytes are booked where it runs: its own launch, or the opener's)
+    const double k_main = (bf_ds ? L.k_alg - L.in2_c : L.k_alg) + (ds_here ? L.cin : 0);
     const double flops = 2.0 * p.M * p.N * k_main;
-    const double bytes = (double)es * ((double)ncrops * L.in_hw * L.in_hw * L.cin + (double)p.M * p.N * ((L.residual || bf_ds) ? 2 : 1) +
+    const double bytes = (double)es * ((double)ncrops * L.in_hw * L.in_hw * L.cin + (double)p.M * p.N * ((L.residual || bf_ds || ds_here) ? 2 : 1) +
                                        (double)p.N * k_main + ((L.in2 && !bf_ds) ? (double)ncrops * L.in2_hw * L.in2_hw * L.in2_c : 0.0));
     ProfScope ps(e, s, prof_name, flops, bytes);
     // stride-1 3x3 layers: input patch resident in LDS across the nine taps (patchconv.hip);
@@ -418,7 +436,7 @@ int run_conv(pa_engine* e, const ConvLayer& L, int crop0, int ncrops, size_t sla
             // a 256-pixel tile halves the weight fill per pixel (this kernel is bound by its L2 -> LDS copies) where it
             // still leaves every CU a workgroup; PA_BF16_T256=0 for A/B runs
             static const int t256 = getenv("PA_BF16_T256") ? atoi(getenv("PA_BF16_T256")) : 1;
-            if (t256 && tile == TILE_128x128 && p.splitk == 1 && ((p.M + 255) / 256) * (p.N / 128) >= 256) tile = TILE_256x128;
+            if (t256 && !p.out2 && tile == TILE_128x128 && p.splitk == 1 && ((p.M + 255) / 256) * (p.N / 128) >= 256) tile = TILE_256x128;
             pe = launch_igemm_bf16(p, tile, s);
         }
         HIPCHK(e, pe);
@@ -862,6 +880,19 @@ int create_impl(const pa_config* cfg, const void* blob, size_t src_bytes, const 
                     rc = upload_bf16(e, &L.ds_wgt, wd);   // [co][cin]
                     if (rc) return rc;
                     ALLOC(L.ds_out, buf, true);
+                    // PA_BF16_DS_FUSE=0: the branch as its own GEMM (round 2-3), for A/B runs
+                    static const int ds_fuse = getenv("PA_BF16_DS_FUSE") ? atoi(getenv("PA_BF16_DS_FUSE")) : 1;
+                    ConvLayer& C1 = e->convs[e->convs.size() - 2];  // the block's stride-2 opener: same input, same output shape
+                    if (ds_fuse && C1.in == cur && C1.stride == 2 && C1.cout == co && C1.out_hw == hw_out && C1.out_pad == L.out_pad &&
+                        C1.chunk == cin && C1.chunk % 64 == 0 && !C1.forced) {
+                        if (ds_fuse == 2) {
+                            C1.ds_probe = true;  // (A/B: same opener launch, branch as its own GEMM -> bit-identical results)
+                        } else {
+                            C1.ds_next_wgt = L.ds_wgt;
+                            C1.ds_next_out = L.ds_out;
+                            L.ds_fused = true;
+                        }
+                    }
                 } else {
                     rc = upload(e, &L.wgt, wf);
                     if (rc) return rc;

@@ -60,6 +60,11 @@ struct GemmParams {
     // pixel m = (block * blk_rows + r) * blk_cols + c, blocks row-major over each image; a tile's patch = the
     // (blk_rows + 2) x (blk_cols + 2) input rectangles of its blocks back to back. Set by launch_conv3x3_patch_blocked.
     int32_t blk_rows, blk_cols, blk_shift_c, blk_shift_px, blk_per_row, blk_per_img, n_blocks, src_pitch;
+    // igemm_bf16.hip, stride-2 3x3 openers: a second 1x1 product off the SAME im2col rows -- the centre tap's rows are the
+    // pixels the block's 1x1/2 downsample branch reads -- wgt2 = [N][chunk] bf16, out2 addressed like out (no bias, no
+    // activation); nullptr = off
+    const float* wgt2;
+    float* out2;
     unsigned long long* clk;  // ablation builds only: in-kernel clock stamps
 };
 

@@ -223,6 +223,34 @@ def test_bf16_conv_path_against_oracle(state_dict):
     assert np.abs(lp2.cpu().numpy() - got["logp"]).max() <= 2e-2
 
 
+_BF16_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from playaid_core_amd import synth
+from playaid_core_amd.engine import Engine
+e = Engine(synth.make_state_dict(seed=1234), max_batch_frames=32, max_clip_frames=64, max_frame_height=720,
+           max_frame_width=1280, compute_dtype="bf16")
+np.save(sys.argv[1], e.infer_clip(synth.make_frames(40, 720, 1280), synth.make_boxes(40, 720, 1280))["logp"])
+e.close()
+"""
+
+
+def test_bf16_downsample_on_the_openers_centre_tap_is_bit_identical(tmp_path):
+    """igemm_bf16.hip DS: the 1x1/2 downsample branch computed on the centre tap of the block's stride-2 opener (second
+    accumulator set, second store) against the same branch as its own GEMM, the opener launched with the same tile and K
+    split (PA_BF16_DS_FUSE=2): same products in the same order, so the log-probs are BIT-IDENTICAL -- partial tiles
+    included (40 frames in backbone batches of 32 and 8). The knob is read once per process: two children."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for mode in ("2", "1"):
+        f = str(tmp_path / f"logp_{mode}.npy")
+        subprocess.run([sys.executable, "-c", _BF16_CHILD % root, f], check=True, timeout=300,
+                       env=dict(os.environ, PA_BF16_DS_FUSE=mode))
+        out[mode] = np.load(f)
+    assert np.isfinite(out["1"]).all() and np.array_equal(out["1"], out["2"])
+
+
 def test_streaming_chunks_and_feature_exchange(engine):
     """Chunked backbone + deferred head equals the one-shot clip; exported
     features re-imported into a fresh clip give the same records."""
