@@ -12,7 +12,7 @@ to split them, so that bench.py's roofline.avg_launch_ms can be checked against 
 
 bf16 (configs[2]): the conv3x3 family = every conv3x3_bf16_patch_kernel launch (the stride-1 convs) + every
 igemm_bf16_kernel launch (the stride-2 convs and the three 1x1/2 downsample GEMMs that feed the patch kernel as
-its residual): 19 launches per step; igemm_f32_kernel then only runs the fc."""
+its residual): 16 launches per step (the stride-2 openers carry the 1x1/2 branch; 19 with PA_BF16_DS_FUSE=0); igemm_f32_kernel then only runs the fc."""
 import collections, csv, json, sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
