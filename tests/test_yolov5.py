@@ -208,3 +208,32 @@ def test_detection_network_is_bitwise_repeatable():
             assert torch.equal(got, first), f"forward {it} differs from the first"
     finally:
         det.close()
+
+
+@pytest.mark.gpu
+def test_timed_forward_is_the_same_forward():
+    """``pa_detector_forward_timed`` (the measurement aid behind scripts/detect_layer_times.py) runs the same table with an
+    event between its layers: bit-identical predictions, one positive time per layer, and a refusal -- not a write past
+    the caller's array -- when ``cap`` is smaller than the table."""
+    import ctypes as C
+
+    import torch
+
+    from playaid_core_amd.yolov5 import YoloV5Detector, build_yolov5s_table
+
+    sd = synth.make_yolov5s_state_dict()
+    det = YoloV5Detector(sd, NC, NET, max_images=4)
+    try:
+        n_layers = len(build_yolov5s_table(sd, NET, NC)[0])
+        frames = torch.from_numpy(synth.make_frames(4, 720, 1280, seed=5)).cuda()
+        want = det(frames).clone()
+        pred = torch.zeros_like(want)
+        us = np.full(n_layers + 1, -1.0, np.float32)
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        args = (det._h, C.c_void_p(frames.data_ptr()), 4, 720, 1280, C.c_void_p(pred.data_ptr()), stream)
+        assert det._lib.pa_detector_forward_timed(*args, us.ctypes.data_as(C.c_void_p), n_layers) == 0
+        assert torch.equal(pred, want)
+        assert (us[:n_layers] > 0).all() and us[n_layers] == -1.0 and us[:n_layers].sum() < 1e6
+        assert det._lib.pa_detector_forward_timed(*args, us.ctypes.data_as(C.c_void_p), n_layers - 1) != 0
+    finally:
+        det.close()
