@@ -580,6 +580,12 @@ class Engine:
     def features_export(self, frame0: int, n: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         if out is None:
             out = torch.empty((n, self.F, _lib.PA_FEATURE_STRIDE), dtype=torch.float32, device=self.device)
+        elif (out.dtype != torch.float32 or out.device.type != self.device.type or not out.is_contiguous()
+              or (self.device.index is not None and out.device.index != self.device.index)
+              or out.numel() < n * self.F * _lib.PA_FEATURE_STRIDE):
+            # (the library writes n * F * PA_FEATURE_STRIDE floats through a raw pointer: a wrong buffer is a wild write)
+            raise ValueError(f"features_export: out must be a contiguous float32 tensor on {self.device} with at least "
+                             f"{n * self.F * _lib.PA_FEATURE_STRIDE} elements")
         self._check(self._lib.pa_features_export(self._h, frame0, n, _ptr(out), self._stream()))
         return out
 

@@ -192,3 +192,52 @@ def test_head_rows_to_labels_without_host_text_or_pixels(engine, state_dict):
         want = runner._results
     assert np.array_equal(got["crops_rgb"], want["crops_rgb"])
     assert np.array_equal(got["logp"], want["logp"]) and np.array_equal(got["action_id"], want["action_id"])
+
+
+def test_two_clips_in_flight_through_begin_and_finish(engine):
+    """``detector_path.begin`` / ``finish(..., device_results=True)`` -- the form bench.py's ``chain_inclusive`` keeps three
+    clips in flight with -- against the synchronous ``run_detections_to_labels``: both clips' repairs are enqueued before
+    either is finished, nothing is waited for but each clip's five words, and every result tensor (records, log-probs, crop
+    status, the repair tables) equals the one-clip-at-a-time run. Clip B loses a fighter for three frames (square-crop
+    repairs) and is shorter, so the shared crop buffer and repair scratch are reused at a different size."""
+    import torch
+
+    from playaid_core_amd import detector_path as dp
+    from playaid_core_amd import synth
+
+    h, w = 720, 1280
+
+    def clip(n, seed, lose):
+        boxes = synth.make_boxes(n, h, w, first_frame=seed)
+        pred = np.zeros((n, 64, 11), F32)
+        for i in range(n):
+            for p in range(2):
+                cx, cy, bw, bh = boxes[i, p] * np.array([w, h, w, h]) * 0.5 + np.array([0, 12, 0, 0])
+                r = np.zeros(11, F32)
+                r[:4] = [cx, cy, bw, bh]
+                r[4] = 0.9
+                r[5 + 2 + p] = 0.9
+                pred[i, 10 * p] = r
+        if lose:
+            pred[4:7, 10, 4] = 0.0
+        frames = torch.from_numpy(synth.make_frames(n, h, w, seed=seed)).cuda()
+        dets, counts = engine.detect_postprocess(pred, (384, 640), (h, w))
+        return frames, dets, counts
+
+    a, b = clip(16, 3, False), clip(11, 4, True)
+    want = [dp.run_detections_to_labels(engine, *c, jpeg_quality=95) for c in (a, b)]
+    ta, tb = dp.begin(engine, *a), dp.begin(engine, *b)
+    ra = dp.finish(engine, ta, jpeg_quality=95, device_results=True)
+    rb = dp.finish(engine, tb, jpeg_quality=95, device_results=True)
+    torch.cuda.synchronize()
+    engine.check_device_errors()
+    for got, ref, n_rep in ((ra, want[0], 0), (rb, want[1], 3)):
+        n = ref["max_frames"]
+        assert got["max_frames"] == n and int(got["info"][4]) == n_rep
+        assert np.array_equal(got["logp"].cpu().numpy(), ref["logp"])
+        assert np.array_equal(engine.decode_records(got["records"])["action_id"], ref["action_id"])
+        assert (got["crop_status"].cpu().numpy() == 0).all()
+        for k in ("labels", "pixel_frame", "pixel_box", "crop_kind"):
+            assert np.array_equal(got["cleaned"][k][:n].cpu().numpy(), ref["cleaned"][k]), k
+        if n_rep:
+            assert (got["square_crop_status"].cpu().numpy() == 0).all()

@@ -448,6 +448,13 @@ def test_indexed_backbone_rejects_frame_ids_outside_the_clip(engine):
     assert ei.value.code == _lib.PA_ERR_CAPACITY and "2 frame id" in str(ei.value)
     engine.check_device_errors()  # the counter was cleared
     assert torch.equal(engine.features_export(7, 1), before)  # nothing was written for the bad ids
+    # a caller's buffer for the export is checked before the library writes through its pointer
+    with pytest.raises(ValueError):
+        engine.features_export(0, 2, out=torch.empty((1, engine.F, 1024), dtype=torch.float32, device="cuda"))
+    with pytest.raises(ValueError):
+        engine.features_export(0, 1, out=torch.empty((1, engine.F, 1024), dtype=torch.float16, device="cuda"))
+    mine = torch.empty((2, engine.F, 1024), dtype=torch.float32, device="cuda")
+    assert engine.features_export(0, 2, out=mine) is mine and torch.equal(mine, engine.features_export(0, 2))
     assert engine.features_export(0, 2).abs().sum() > 0
     # features of a frame that is not cached in this clip cannot be exported (stale rows of an earlier clip)
     engine.clip_begin(8)
