@@ -246,8 +246,14 @@ class Engine:
                             padding: int = constants.CROP_PADDING, swap_rb: bool = False) -> torch.Tensor:
         """One ``square_crop`` per frame, everything on the device and nothing waited for: frames uint8[k,H,W,3], boxes
         float64[k,4] -> ``out`` uint8[k,128,128,3] (written in place); returns the status int32[k] (device)."""
+        if frames_dev.dim() != 4 or frames_dev.shape[3] != 3 or frames_dev.dtype != torch.uint8 or not frames_dev.is_cuda \
+                or not frames_dev.is_contiguous():
+            raise ValueError("square_crops_device: frames are a contiguous uint8[k, H, W, 3] device tensor")
         k, h, w, _ = frames_dev.shape
-        assert tuple(out.shape) == (k, 128, 128, 3) and out.is_cuda and out.is_contiguous()
+        if tuple(boxes_dev.shape) != (k, 4) or boxes_dev.dtype != torch.float64 or not boxes_dev.is_cuda:
+            raise ValueError("square_crops_device: boxes are float64[k, 4] on the device")
+        if tuple(out.shape) != (k, 128, 128, 3) or out.dtype != torch.uint8 or not out.is_cuda or not out.is_contiguous():
+            raise ValueError("square_crops_device: out is a contiguous uint8[k, 128, 128, 3] device tensor")
         status = torch.empty((k,), dtype=torch.int32, device=self.device)
         step = self.max_batch_frames
         for i0 in range(0, k, step):
@@ -397,9 +403,18 @@ class Engine:
         sf = self._dev(src_frame, torch.int32) if src_frame is not None else None
         if images is None:
             images = torch.empty(n * self.F * min(h * w, 1 << 20) * 3 + 64, dtype=torch.uint8, device=self.device)
+        elif images.dtype != torch.uint8 or not images.is_cuda or not images.is_contiguous():
+            raise ValueError("save_one_box_crops: images is a contiguous uint8 device tensor (its size is the capacity)")
         if desc is None:
             desc = torch.zeros((n * self.F, 2), dtype=torch.int64, device=self.device)
+        elif desc.dtype != torch.int64 or not desc.is_cuda or not desc.is_contiguous() or desc.numel() < n * self.F * 2:
+            raise ValueError(f"save_one_box_crops: desc is a contiguous int64[{n * self.F}, 2] device tensor")
+        if dets.dtype != torch.float32 or counts.dtype != torch.int32 or counts.numel() < n or not dets.is_contiguous():
+            raise ValueError("save_one_box_crops: dets float32[n, max_det, 6] / counts int32[n] as detect_postprocess writes them")
         di = self._dev(det_index, torch.int32) if det_index is not None else None
+        for name, t in (("det_index", di), ("src_frame", sf)):
+            if t is not None and t.numel() < n * self.F:
+                raise ValueError(f"save_one_box_crops: {name} is int32[{n}, {self.F}]")
         self._check(self._lib.pa_save_one_box_crops(self._h, _ptr(frames_dev), n_src, h, w, _ptr(dets), _ptr(counts), dets.shape[1],
                                                     _ptr(di), _ptr(sf), n, int(jpeg_quality), _ptr(images), images.numel(), _ptr(desc),
                                                     self._stream()))
