@@ -524,6 +524,21 @@ const char* pa_convnet_last_error(const pa_convnet* h);
 /* x float32[n,3,128,128] (NCHW, device) -> out: the last layer's output buffer, float32[n, out_floats_per_crop]. */
 int pa_convnet_forward(pa_convnet* h, const float* x, int32_t n, float* out, int32_t out_floats_per_crop, void* stream);
 
+/* One stride-1 3x3 convolution (padding 1) on the Winograd F(2x2, 3x3) kernel of the fp32 convolution stack
+ * (csrc/wino.hip) -- the operator the engine's ResNet-18 / the detector's Bottlenecks run their stride-1 3x3 layers on,
+ * exposed for parity tests and measurements of single layers. x: float32[n][height + 2][width + 2][in_px_stride]
+ * (device, zero border of one pixel, the first `cin` channels of every pixel are read); out:
+ * float32[n][height + 2 out_pad][width + 2 out_pad][out_px_stride] (interior written, first `cout` channels);
+ * residual: addressed like out, or NULL; act: 0 none, 1 ReLU, 2 SiLU; res_after: 1 = the residual is added after the
+ * activation. height, width multiples of 4; cin % 8 == 0; cout % 32 == 0. Filters: pa_wino_transform_weights turns
+ * BatchNorm-folded [cout][ky][kx][cin] (host) into the kernel's layout (host, pa_wino_weight_floats floats), which
+ * the caller uploads. Enqueue only. */
+size_t pa_wino_weight_floats(int32_t cin, int32_t cout);
+int pa_wino_transform_weights(const float* w_host, int32_t cin, int32_t cout, float* ug_host);
+int pa_wino_conv3x3(const float* x, const float* ug, const float* bias, const float* residual, float* out, int32_t n,
+                    int32_t height, int32_t width, int32_t cin, int32_t cout, int32_t in_px_stride, int32_t out_px_stride,
+                    int32_t out_pad, int32_t act, int32_t res_after, void* stream);
+
 /* Head of ResnetTransformerDetector (resnet_transformer_detector.py:41-93,141): Linear(in_dim, hidden_dim), the
  * enc_dim-value time encoding of the frame slot appended (d_model = hidden_dim + enc_dim, 32 per head),
  * num_layers post-norm nn.TransformerEncoderLayer (ReLU feed-forward of ff_dim), Linear(d_model, num_actions),

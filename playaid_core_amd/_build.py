@@ -23,6 +23,7 @@ SOURCES = [
     ("igemm_bf16.hip", []),
     ("patchconv.hip", []),
     ("patchconv_bf16.hip", []),
+    ("wino.hip", []),
     ("stem.hip", []),
     ("stem_pool.hip", []),
     ("misc.hip", []),

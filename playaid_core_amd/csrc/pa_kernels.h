@@ -115,6 +115,26 @@ hipError_t launch_conv3x3_patch(const GemmParams& p, int bm, hipStream_t s);
 // sides are multiples of 4; in_pad == 1; epilogue: bias, ReLU / SiLU, residual before or after the activation
 hipError_t launch_conv3x3_patch_blocked(const GemmParams& p, hipStream_t s);
 
+// stride-1 3x3 convolution as Winograd F(2x2, 3x3) on the fp32 matrix cores (wino.hip): zero-bordered NHWC input (border 1),
+// any map whose sides are multiples of 4, cin % 8 == 0, cout % 32 == 0; epilogue: bias, ReLU / SiLU, residual before or
+// after the activation. The input and output may be channel slices of wider buffers (px strides >= cin / cout).
+struct WinoParams {
+    const float* act;       // first channel of padded pixel (0, 0) of image 0
+    const float* wgt;       // wino_transform_weights' image of the filters
+    const float* bias;      // [cout] or nullptr
+    const float* residual;  // addressed like out, or nullptr
+    float* out;             // first channel of padded pixel (0, 0) of image 0
+    int32_t n_img, height, width, cin, cout;
+    int32_t in_px_stride, in_row_stride, in_img_stride;      // floats
+    int32_t out_px_stride, out_row_stride, out_img_stride, out_pad;
+    int32_t relu, res_after;  // as GemmParams
+    int32_t n_sb, sb_per_row, sb_per_img, tiles_n;  // set by the launcher
+};
+size_t wino_weight_floats(int cin, int cout);
+// w [cout][ky][kx][cin] (host) -> ug [wino_weight_floats] (host)
+void wino_transform_weights(const float* w, int cin, int cout, float* ug);
+hipError_t launch_wino3x3(const WinoParams& p, hipStream_t s);
+
 // ---------------------------------------------------------------------------
 // crop preprocessing (preprocess.hip)
 // ---------------------------------------------------------------------------

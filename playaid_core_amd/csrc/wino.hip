@@ -1,0 +1,322 @@
+// Stride-1 3x3 convolution as Winograd F(2x2, 3x3) on the fp32 matrix cores (gfx950, fp32 throughout).
+//
+// A 3x3 convolution spends 9 multiply-adds per output value and input channel; Winograd's minimal filtering form spends
+// 16 per 2x2 outputs = 4 per value: the input tile (4x4 pixels), the filter and the output tile are taken through
+//     V = B^T d B          U = G g G^T (host, fp64, once)          Y = A^T (sum_cin U . V) A
+// (Lavin & Gray's matrices; B and A hold only 0 / +-1, so both device-side transforms are additions). Between the two
+// transforms stand 16 independent products [cout x cin] x [cin x tile], one per position of the 4x4 transformed tile --
+// matrix-core work, 2.25x less of it than the direct form executes. Measured on the CPU restatement first (the whole
+// ResNet-18 of the headline with every stride-1 3x3 in this form): max |dlogp| against a float64 run 3.7e-6, the direct
+// fp32 form 3.3e-6 -- the rounding of the transforms does not show at the path's 1e-4 bar.
+//
+// Mapping. v_mfma_f32_16x16x4_f32 with the WEIGHTS as the row operand and the transformed tiles as the column operand:
+// a lane then holds, for its tile (lane & 15) and four consecutive output channels 4 (lane >> 4) .. + 3, one accumulator
+// quad per position. A wave owns 16 tiles x 32 channels x all 16 positions = 128 accumulator registers, so the OUTPUT
+// transform, bias, residual, activation and the 16-byte stores run in the lane that accumulated -- no exchange, no LDS,
+// no barrier behind the k loop. 16 tiles = four 4x4-pixel sub-blocks (2x2 tiles each, a 6x6 input patch each): any map
+// whose sides are multiples of four.
+//   workgroup = 8 waves: NCG = 2: 4 tile groups (16 sub-blocks = 256 pixels) x 2 channel groups (64 channels)
+//                        NCG = 1: 8 tile groups (32 sub-blocks = 512 pixels) x 32 channels (the 32-channel layers)
+// K loop over chunks of 8 input channels. A stage of the LDS ring holds, for one chunk,
+//   U  [16 positions][BN / 16][16 channels][8 cin]   the transformed filters (BN = 64: 32 KB), the exact image the host laid
+//                                                     out: the DMA is a straight copy (rows 8..15 of a 16-channel group
+//                                                     are rotated by four dwords so that the 32 lanes of a ds_read_b64
+//                                                     phase cover 64 distinct banks)
+//   P  [sub-block][37 pixels][8 cin]                  the raw 6x6 patches (one pad pixel per sub-block spreads the tiles'
+//                                                     pixels over the banks: two-way instead of four-way conflicts)
+// both filled by buffer_load_dwordx4 ... lds. Per chunk a lane reads its tile's 16 raw pixels (ds_read_b64: two channels),
+// transforms them (32 packed additions), and feeds 64 matrix instructions whose row operands come from U (32 ds_read_b64).
+// The raw patch is the only activation traffic: 36 pixels per 16 outputs and chunk -- the patch-resident direct kernel
+// (patchconv.hip) moves 1.4 pixels per output and chunk and nine operand reads per pixel; this one 2.25 and four.
+//
+// Summation order: chunks ascending, two channels per instruction pair, fixed by the launch geometry alone (no split, no
+// atomics): results are bitwise repeatable and do not depend on the batch size.
+#include "pa_kernels.h"
+
+#include <cstdlib>
+#include <vector>
+
+namespace pa {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+__device__ __forceinline__ void wn_blds16(__amdgpu_buffer_rsrc_t rsrc, int voff_bytes, int soff_bytes, float* lds_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_base, 16, voff_bytes, soff_bytes, 0, 0);
+}
+
+template <int NCG> struct WinoGeo {
+    static constexpr int TG = 8 / NCG;                      // tile groups = waves along the pixels
+    static constexpr int NSB = TG * 4;                      // 4x4-pixel sub-blocks per workgroup
+    static constexpr int BN = 32 * NCG;                     // output channels per workgroup
+    static constexpr int U_FLOATS = 16 * BN * 8;            // filters of one chunk
+    static constexpr int U_INSTR = U_FLOATS / 256;          // wave-wide 1 KB DMA instructions per stage
+    static constexpr int PIX = NSB * 37;                    // patch pixels (32 B each) per stage
+    static constexpr int P_INSTR = (PIX * 2 + 63) / 64;
+    static constexpr int P_FLOATS = P_INSTR * 256;
+    static constexpr int KP = (P_INSTR + 7) / 8;            // patch DMA instructions per wave (the last one not for every wave)
+};
+
+// m / d for 0 <= m < 2^24, 1 <= d < 2^16
+__device__ __forceinline__ int wn_div(int m, int d) {
+    int q = (int)((float)m * (1.0f / (float)d));
+    int r = m - q * d;
+    if (r < 0) { --q; r += d; }
+    if (r >= d) ++q;
+    return q;
+}
+
+// one chunk: raw pixels -> V (registers), 16 positions x 2 channel quads-of-16 x 2 channels
+template <int NCG>
+__device__ __forceinline__ void wino_chunk(const float* __restrict__ ul, const float* __restrict__ pl, f32x4 (&acc)[16][2], int a_off, int r_off) {
+    constexpr int GI = WinoGeo<NCG>::BN / 16;
+    f32x2 d[4][4];
+#pragma unroll
+    for (int y = 0; y < 4; ++y)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) d[y][x] = *reinterpret_cast<const f32x2*>(pl + r_off + (y * 6 + x) * 8);
+    f32x2 tt[4][4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        tt[0][x] = d[0][x] - d[2][x];
+        tt[1][x] = d[1][x] + d[2][x];
+        tt[2][x] = d[2][x] - d[1][x];
+        tt[3][x] = d[1][x] - d[3][x];
+    }
+    f32x2 v[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[4 * i + 0] = tt[i][0] - tt[i][2];
+        v[4 * i + 1] = tt[i][1] + tt[i][2];
+        v[4 * i + 2] = tt[i][2] - tt[i][1];
+        v[4 * i + 3] = tt[i][1] - tt[i][3];
+    }
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        const f32x2 a0 = *reinterpret_cast<const f32x2*>(ul + a_off + (p * GI + 0) * 128);
+        const f32x2 a1 = *reinterpret_cast<const f32x2*>(ul + a_off + (p * GI + 1) * 128);
+        acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, v[p].x, acc[p][0], 0, 0, 0);
+        acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, v[p].x, acc[p][1], 0, 0, 0);
+        acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, v[p].y, acc[p][0], 0, 0, 0);
+        acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, v[p].y, acc[p][1], 0, 0, 0);
+    }
+}
+
+template <int NCG>
+__global__ __launch_bounds__(512) void wino3x3_kernel(const WinoParams p) {
+    using G = WinoGeo<NCG>;
+    __shared__ __attribute__((aligned(16))) float u_lds0[G::U_FLOATS];
+    __shared__ __attribute__((aligned(16))) float u_lds1[G::U_FLOATS];
+    __shared__ __attribute__((aligned(16))) float p_lds0[G::P_FLOATS];
+    __shared__ __attribute__((aligned(16))) float p_lds1[G::P_FLOATS];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tg = NCG == 2 ? (wave & 3) : wave;
+    const int cg = NCG == 2 ? (wave >> 2) : 0;
+    const int t = lane & 15, kq = lane >> 4;
+
+    // XCD-aware (bijective) remap: the workgroups of an XCD are a contiguous run of (tile_m, tile_n), channel tiles fastest,
+    // so the channel tiles that read one patch meet in one L2
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
+    const int wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (b >> 3);
+    const int tile_m = wg / p.tiles_n, tile_n = wg - tile_m * p.tiles_n;
+    const int n_chunks = p.cin >> 3;
+
+    const __amdgpu_buffer_rsrc_t act_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.act), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wgt_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wgt), 0, -1, 0x00020000);
+
+    // source of this lane's 16 bytes in each of its patch DMA instructions (the same for every chunk)
+    int pvoff[G::KP];
+#pragma unroll
+    for (int k = 0; k < G::KP; ++k) {
+        const int slot = (k * 8 + wave) * 64 + lane;
+        int pi = slot >> 1;
+        int sbl = (pi * 1772) >> 16;  // pi / 37 for pi < 2048
+        int px = pi - sbl * 37;
+        px = px < 36 ? px : 35;
+        sbl = sbl < G::NSB ? sbl : G::NSB - 1;
+        int sb = tile_m * G::NSB + sbl;
+        sb = sb < p.n_sb ? sb : p.n_sb - 1;
+        const int img = wn_div(sb, p.sb_per_img);
+        const int rem = sb - img * p.sb_per_img;
+        const int sby = wn_div(rem, p.sb_per_row);
+        const int sbx = rem - sby * p.sb_per_row;
+        const int y = (px * 43) >> 8;  // px / 6 for px < 36
+        const int x = px - y * 6;
+        pvoff[k] = (img * p.in_img_stride + (4 * sby + y) * p.in_row_stride + (4 * sbx + x) * p.in_px_stride + (slot & 1) * 4) * 4;
+    }
+    const int u_soff0 = tile_n * n_chunks * G::U_FLOATS * 4;
+
+#define WN_ISSUE(UL, PL, C)                                                                                            \
+    {                                                                                                                  \
+        const int us_ = u_soff0 + (C) * (G::U_FLOATS * 4);                                                             \
+        _Pragma("unroll") for (int k_ = 0; k_ < G::U_INSTR / 8; ++k_)                                                  \
+            wn_blds16(wgt_rsrc, ((k_ * 8 + wave) * 64 + lane) * 16, us_, (UL) + (k_ * 8 + wave) * 256);                \
+        _Pragma("unroll") for (int k_ = 0; k_ < G::KP; ++k_)                                                           \
+            if (k_ * 8 + wave < G::P_INSTR) wn_blds16(act_rsrc, pvoff[k_], (C) * 32, (PL) + (k_ * 8 + wave) * 256);    \
+    }
+
+    // operand addresses inside a stage
+    const int a_off = cg * 2 * 128 + t * 8 + ((2 * kq + 4 * (t >> 3)) & 7);
+    const int sbl_own = tg * 4 + (t >> 2);
+    const int r_off = (sbl_own * 37 + ((t >> 1) & 1) * 12 + (t & 1) * 2) * 8 + 2 * kq;
+
+    f32x4 acc[16][2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    WN_ISSUE(u_lds0, p_lds0, 0);
+    for (int c = 0; c < n_chunks; c += 2) {
+        // chunk c has landed for every thread; every wave is done with the other stage
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), as an instruction hipcc's own wait bookkeeping sees
+        __builtin_amdgcn_s_barrier();
+        if (c + 1 < n_chunks) WN_ISSUE(u_lds1, p_lds1, c + 1);
+        wino_chunk<NCG>(u_lds0, p_lds0, acc, a_off, r_off);
+        if (c + 1 < n_chunks) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), as an instruction hipcc's own wait bookkeeping sees
+            __builtin_amdgcn_s_barrier();
+            if (c + 2 < n_chunks) WN_ISSUE(u_lds0, p_lds0, c + 2);
+            wino_chunk<NCG>(u_lds1, p_lds1, acc, a_off, r_off);
+        }
+    }
+#undef WN_ISSUE
+
+    // ---- output transform + epilogue, all in the accumulating lane ----------------------------------------------------
+    int sb = tile_m * G::NSB + sbl_own;
+    if (sb >= p.n_sb) return;
+    const int img = wn_div(sb, p.sb_per_img);
+    const int rem = sb - img * p.sb_per_img;
+    const int sby = wn_div(rem, p.sb_per_row);
+    const int sbx = rem - sby * p.sb_per_row;
+    const int oy0 = 4 * sby + 2 * ((t >> 1) & 1), ox0 = 4 * sbx + 2 * (t & 1);
+    const int ch0 = tile_n * G::BN + cg * 32 + 4 * kq;  // + 16 g + 0..3
+    const long o00 = (long)img * p.out_img_stride + (long)(oy0 + p.out_pad) * p.out_row_stride + (ox0 + p.out_pad) * p.out_px_stride + ch0;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const f32x4 bias4 = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + ch0 + 16 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+        // A^T m A over the 4x4 positions (p = 4 i + j)
+        f32x4 s0[4], s1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s0[j] = acc[j][g] + acc[4 + j][g] + acc[8 + j][g];
+            s1[j] = acc[4 + j][g] - acc[8 + j][g] - acc[12 + j][g];
+        }
+        f32x4 y[2][2];
+        y[0][0] = s0[0] + s0[1] + s0[2];
+        y[0][1] = s0[1] - s0[2] - s0[3];
+        y[1][0] = s1[0] + s1[1] + s1[2];
+        y[1][1] = s1[1] - s1[2] - s1[3];
+#pragma unroll
+        for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+            for (int ox = 0; ox < 2; ++ox) {
+                const long o = o00 + (long)oy * p.out_row_stride + ox * p.out_px_stride + 16 * g;
+                const f32x4 res4 = p.residual ? *reinterpret_cast<const f32x4*>(p.residual + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 v = y[oy][ox] + (p.res_after ? bias4 : bias4 + res4);
+                if (p.relu == 1) {
+                    v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+                    v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+                } else if (p.relu == 2) {
+                    v.x = silu_fast(v.x); v.y = silu_fast(v.y);
+                    v.z = silu_fast(v.z); v.w = silu_fast(v.w);
+                }
+                if (p.res_after) v += res4;
+                *reinterpret_cast<f32x4*>(p.out + o) = v;
+            }
+    }
+}
+
+}  // namespace
+
+size_t wino_weight_floats(int cin, int cout) { return (size_t)16 * cin * cout; }
+
+// [cout][ky][kx][cin] (BatchNorm folded) -> the stage images the kernel copies: [cout / BN][cin / 8][16][BN / 16][16][8]
+// with G g G^T evaluated in fp64 and rounded once
+void wino_transform_weights(const float* w, int cin, int cout, float* ug) {
+    const int bn = cout % 64 == 0 ? 64 : 32, gi_n = bn / 16, n_chunks = cin / 8;
+    static const double Gm[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci) {
+            double g[3][3], tmp[4][3], u[4][4];
+            for (int ky = 0; ky < 3; ++ky)
+                for (int kx = 0; kx < 3; ++kx) g[ky][kx] = (double)w[((size_t)co * 9 + ky * 3 + kx) * cin + ci];
+            for (int i = 0; i < 4; ++i)
+                for (int kx = 0; kx < 3; ++kx) tmp[i][kx] = Gm[i][0] * g[0][kx] + Gm[i][1] * g[1][kx] + Gm[i][2] * g[2][kx];
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) u[i][j] = tmp[i][0] * Gm[j][0] + tmp[i][1] * Gm[j][1] + tmp[i][2] * Gm[j][2];
+            const int tile_n = co / bn, gi = (co % bn) / 16, r = co % 16, c = ci / 8, cc = ci % 8;
+            for (int pp = 0; pp < 16; ++pp) {
+                const size_t idx = ((((size_t)tile_n * n_chunks + c) * 16 + pp) * gi_n + gi) * 128 + r * 8 + ((cc + 4 * (r >> 3)) & 7);
+                ug[idx] = (float)u[pp >> 2][pp & 3];
+            }
+        }
+}
+
+hipError_t launch_wino3x3(const WinoParams& p_in, hipStream_t s) {
+    WinoParams p = p_in;
+    if (!p.act || !p.wgt || !p.out || p.cin < 8 || p.cin % 8 || p.cout < 32 || p.cout % 32 || p.height < 4 || p.width < 4 || p.height % 4 ||
+        p.width % 4 || p.n_img < 1 || p.in_px_stride < p.cin || p.out_px_stride < p.cout)
+        return hipErrorInvalidValue;
+    p.sb_per_row = p.width / 4;
+    p.sb_per_img = (p.height / 4) * p.sb_per_row;
+    const long long n_sb = (long long)p.n_img * p.sb_per_img;
+    if (n_sb >= (1 << 24) || p.sb_per_img >= (1 << 16)) return hipErrorInvalidValue;
+    // byte offsets inside the buffer descriptors are 32-bit
+    if ((long long)p.n_img * p.in_img_stride * 4 >= (1ll << 31) || (long long)wino_weight_floats(p.cin, p.cout) * 4 >= (1ll << 31)) return hipErrorInvalidValue;
+    p.n_sb = (int)n_sb;
+    const int ncg = p.cout % 64 == 0 ? 2 : 1;
+    const int nsb = ncg == 2 ? 16 : 32;
+    p.tiles_n = p.cout / (32 * ncg);
+    const int tiles_m = (p.n_sb + nsb - 1) / nsb;
+    const int grid = tiles_m * p.tiles_n;
+    if (ncg == 2) hipLaunchKernelGGL((wino3x3_kernel<2>), dim3(grid), dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((wino3x3_kernel<1>), dim3(grid), dim3(512), 0, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace pa
+
+// ---- C ABI: the kernel as a single-layer operator (include/playaid_hip.h) --------------------------------------------------
+#include "../../include/playaid_hip.h"
+
+extern "C" {
+
+size_t pa_wino_weight_floats(int32_t cin, int32_t cout) {
+    if (cin < 8 || cin % 8 || cout < 32 || cout % 32) return 0;
+    return pa::wino_weight_floats(cin, cout);
+}
+
+int pa_wino_transform_weights(const float* w_host, int32_t cin, int32_t cout, float* ug_host) {
+    if (!w_host || !ug_host || cin < 8 || cin % 8 || cout < 32 || cout % 32) return PA_ERR_INVALID_ARG;
+    pa::wino_transform_weights(w_host, cin, cout, ug_host);
+    return PA_OK;
+}
+
+int pa_wino_conv3x3(const float* x, const float* ug, const float* bias, const float* residual, float* out, int32_t n, int32_t height,
+                    int32_t width, int32_t cin, int32_t cout, int32_t in_px_stride, int32_t out_px_stride, int32_t out_pad, int32_t act,
+                    int32_t res_after, void* stream) {
+    if (!x || !ug || !out || n < 1 || out_pad < 0 || act < 0 || act > 2) return PA_ERR_INVALID_ARG;
+    pa::WinoParams p{};
+    p.act = x; p.wgt = ug; p.bias = bias; p.residual = residual; p.out = out;
+    p.n_img = n; p.height = height; p.width = width; p.cin = cin; p.cout = cout;
+    p.in_px_stride = in_px_stride;
+    p.in_row_stride = (width + 2) * in_px_stride;
+    p.in_img_stride = (height + 2) * p.in_row_stride;
+    p.out_px_stride = out_px_stride;
+    p.out_row_stride = (width + 2 * out_pad) * out_px_stride;
+    p.out_img_stride = (height + 2 * out_pad) * p.out_row_stride;
+    p.out_pad = out_pad;
+    p.relu = act;
+    p.res_after = res_after;
+    const hipError_t e = pa::launch_wino3x3(p, (hipStream_t)stream);
+    return e == hipSuccess ? PA_OK : (e == hipErrorInvalidValue ? PA_ERR_INVALID_ARG : PA_ERR_HIP);
+}
+
+}  // extern "C"

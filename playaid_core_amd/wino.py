@@ -1,0 +1,49 @@
+"""One stride-1 3x3 convolution on the Winograd F(2x2, 3x3) kernel (``csrc/wino.hip``, ``pa_wino_*``).
+
+The engine's ResNet-18 (``playaid/models/cnn_action_detector.py:16,32``: torchvision ``resnet18``'s stride-1 3x3
+convolutions) and the detector's Bottlenecks run on this kernel inside the library; this module exposes it as a
+single-layer operator for parity tests and measurements. No CPU fallback: it needs the HIP library and a GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def transform_weights(w_oihw: np.ndarray) -> np.ndarray:
+    """[cout, cin, 3, 3] (BatchNorm already folded) -> the kernel's filter layout (float32, host)."""
+    lib = _lib.load()
+    w = np.ascontiguousarray(np.asarray(w_oihw, dtype=np.float32).transpose(0, 2, 3, 1))  # [cout][ky][kx][cin]
+    cout, cin = w.shape[0], w.shape[3]
+    n = lib.pa_wino_weight_floats(cin, cout)
+    if n == 0:
+        raise ValueError("cin must be a multiple of 8, cout a multiple of 32")
+    ug = np.empty(n, dtype=np.float32)
+    rc = lib.pa_wino_transform_weights(w.ctypes.data_as(C.c_void_p), cin, cout, ug.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise ValueError(f"pa_wino_transform_weights: {rc}")
+    return ug
+
+
+def conv3x3(x_pad: torch.Tensor, ug: torch.Tensor, cin: int, cout: int, bias=None, residual=None, out=None, out_pad: int = 1,
+            act: int = 0, res_after: bool = False, out_px_stride: int = None) -> torch.Tensor:
+    """x_pad float32[n, H + 2, W + 2, C >= cin] (device, zero border) -> out float32[n, H + 2 out_pad, W + 2 out_pad, C'] (interior
+    written, border untouched). Enqueues on the current stream."""
+    lib = _lib.load()
+    if x_pad.dtype != torch.float32 or not x_pad.is_cuda or not x_pad.is_contiguous() or x_pad.dim() != 4:
+        raise ValueError("x_pad: contiguous float32[n, H + 2, W + 2, C] on the device")
+    n, hp, wp, cs = x_pad.shape
+    h, w = hp - 2, wp - 2
+    ops = out_px_stride or cout
+    if out is None:
+        out = torch.zeros((n, h + 2 * out_pad, w + 2 * out_pad, ops), dtype=torch.float32, device=x_pad.device)
+    ptr = lambda t_: C.c_void_p(t_.data_ptr()) if t_ is not None else C.c_void_p(0)
+    rc = lib.pa_wino_conv3x3(ptr(x_pad), ptr(ug), ptr(bias), ptr(residual), ptr(out), n, h, w, cin, cout, cs, out.shape[3], out_pad,
+                             int(act), int(bool(res_after)), C.c_void_p(torch.cuda.current_stream(x_pad.device).cuda_stream))
+    if rc:
+        raise ValueError(f"pa_wino_conv3x3: status {rc}")
+    return out
