@@ -29,6 +29,7 @@ struct ConvLayer {
     float* out = nullptr;
     float* residual = nullptr;
     float* wgt = nullptr;   // device [cout][taps*chunk]
+    float* wino_wgt = nullptr;  // fp32 stride-1 3x3 layers run as Winograd F(2x2, 3x3): the filters in wino.hip's layout, else nullptr
     float* bias = nullptr;  // device [cout]
     int relu = 1;
     GemmTile tile = TILE_128x64;
@@ -440,6 +441,15 @@ int run_conv(pa_engine* e, const ConvLayer& L, int crop0, int ncrops, size_t sla
             pe = launch_igemm_bf16(p, tile, s);
         }
         HIPCHK(e, pe);
+    } else if (L.wino_wgt && !p.act2) {
+        WinoParams q;
+        memset(&q, 0, sizeof(q));
+        q.act = p.act; q.wgt = L.wino_wgt; q.bias = p.bias; q.residual = p.residual; q.out = p.out;
+        q.n_img = ncrops; q.height = L.out_hw; q.width = L.out_hw; q.cin = L.cin; q.cout = L.cout;
+        q.in_px_stride = p.in_px_stride; q.in_row_stride = p.in_row_stride; q.in_img_stride = p.in_img_stride;
+        q.out_px_stride = p.out_px_stride; q.out_row_stride = p.out_row_stride; q.out_img_stride = p.out_img_stride; q.out_pad = p.out_pad;
+        q.relu = p.relu;
+        HIPCHK(e, launch_wino3x3(q, s));
     } else if (use_patch && L.kh == 3 && L.stride == 1) {
         int bm = tile == TILE_64x64 || tile == TILE_64x64_K64 ? 64 : 128;
         const int howo = L.out_hw * L.out_hw, in_w2 = L.out_hw + 2;
@@ -771,7 +781,8 @@ int create_impl(const pa_config* cfg, const void* blob, size_t src_bytes, const 
     // ---- layer table + weights --------------------------------------------
     // arena capacity: the folded tensors are the blob's plus zero padding (stem K 147 -> 224, fc and
     // Conv1d 1000 -> 1024) and 256-byte alignment per tensor; 1.25x + 1 MiB covers every (S, A)
-    e->arena_cap = pa_weight_blob_bytes(S, A) / 4 * 5 + (1u << 20);
+    // (+ 16 / 9 of the 3x3 filters once more: the Winograd layout of the fp32 stride-1 3x3 layers, kept beside the direct one)
+    e->arena_cap = pa_weight_blob_bytes(S, A) / 4 * 13 + (1u << 20);
     {
         void* ar = nullptr;
         HIPCHK(e, hipMalloc(&ar, e->arena_cap));
@@ -817,6 +828,15 @@ int create_impl(const pa_config* cfg, const void* blob, size_t src_bytes, const 
         } else {
             r2 = (e->bf16 && k == 3) ? upload_bf16(e, &L.wgt, w) : upload(e, &L.wgt, w);
             if (r2) return r2;
+            // Winograd F(2x2, 3x3) for the fp32 stride-1 3x3 layers it is faster on (wino.hip; measured per shape at 128 crops:
+            // 32 x 32 x 64 and 16 x 16 x 128 maps). PA_WINO=0: none (A/B), 2: every stride-1 3x3 layer without a fused second source
+            static const int wino_mode = getenv("PA_WINO") ? atoi(getenv("PA_WINO")) : 1;
+            if (!e->bf16 && k == 3 && stride == 1 && wino_mode && (wino_mode >= 2 || L.out_hw >= 16) && L.out_hw % 4 == 0) {
+                std::vector<float> ug(wino_weight_floats(cin, cout), 0.f);
+                if (!br.dry) wino_transform_weights(w.data(), cin, cout, ug.data());
+                r2 = upload(e, &L.wino_wgt, ug);
+                if (r2) return r2;
+            }
             if (e->bf16 && k == 7 && (r2 = upload_bf16(e, &e->stem_wgt_bf16, w))) return r2;
             r2 = upload(e, &L.bias, b);
             if (r2) return r2;

@@ -40,6 +40,8 @@ namespace pa {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) float lds_f;
+typedef __attribute__((address_space(3))) const volatile f32x2 lds_cv2;  // an LDS read hipcc may not merge with its neighbour
 
 namespace {
 
@@ -53,11 +55,17 @@ template <int NCG> struct WinoGeo {
     static constexpr int BN = 32 * NCG;                     // output channels per workgroup
     static constexpr int U_FLOATS = 16 * BN * 8;            // filters of one chunk
     static constexpr int U_INSTR = U_FLOATS / 256;          // wave-wide 1 KB DMA instructions per stage
-    static constexpr int PIX = NSB * 37;                    // patch pixels (32 B each) per stage
-    static constexpr int P_INSTR = (PIX * 2 + 63) / 64;
-    static constexpr int P_FLOATS = P_INSTR * 256;
-    static constexpr int KP = (P_INSTR + 7) / 8;            // patch DMA instructions per wave (the last one not for every wave)
+    // patch stage: two planes (channels 0-3 / 4-7 of the chunk) of 16-byte pixel slots; a tile group's four 6x6 sub-blocks
+    // start at slots 0 / 40 / 81 / 121 of its 160, which puts the 16 tiles of a wave on 16 distinct slots mod 16 for every
+    // (dy, dx): the 32 lanes of a ds_read_b64 phase (two channel pairs of one plane) then cover all 64 banks
+    static constexpr int TG_SLOTS = 160;
+    static constexpr int PLANE_SLOTS = TG * TG_SLOTS;
+    static constexpr int P_INSTR = 2 * PLANE_SLOTS / 64;    // 20 | 40
+    static constexpr int P_FLOATS = 2 * PLANE_SLOTS * 4;
+    static constexpr int KP = P_INSTR / 8;                  // patch DMA instructions per wave: 2.5 | 5
 };
+
+__device__ __forceinline__ int wn_sb_base(int s) { return s == 0 ? 0 : (s == 1 ? 40 : (s == 2 ? 81 : 121)); }
 
 // m / d for 0 <= m < 2^24, 1 <= d < 2^16
 __device__ __forceinline__ int wn_div(int m, int d) {
@@ -69,14 +77,27 @@ __device__ __forceinline__ int wn_div(int m, int d) {
 }
 
 // one chunk: raw pixels -> V (registers), 16 positions x 2 channel quads-of-16 x 2 channels
-template <int NCG>
-__device__ __forceinline__ void wino_chunk(const float* __restrict__ ul, const float* __restrict__ pl, f32x4 (&acc)[16][2], int a_off, int r_off) {
+// ABL (timing experiments, PA_WINO_ABL; results wrong when != 0): 1 no DMA behind the first chunk, 2 no matrix instructions,
+// 4 no raw reads / input transform
+template <int NCG, int ABL>
+__device__ __forceinline__ void wino_chunk(const lds_f* ul, const lds_f* pl, f32x4 (&acc)[16][2], int a_off, int r_off) {
     constexpr int GI = WinoGeo<NCG>::BN / 16;
     f32x2 d[4][4];
 #pragma unroll
     for (int y = 0; y < 4; ++y)
 #pragma unroll
-        for (int x = 0; x < 4; ++x) d[y][x] = *reinterpret_cast<const f32x2*>(pl + r_off + (y * 6 + x) * 8);
+        for (int x = 0; x < 4; ++x)
+            d[y][x] = (ABL & 4) ? f32x2{(float)r_off, 1.f} : *(lds_cv2*)(pl + r_off + (y * 6 + x) * 4);
+    // row operands: three positions ahead of the matrix instructions that consume them
+    constexpr int AHEAD = 3;
+    f32x2 a[16][2];
+#define WN_LOAD_A(P)                                                       \
+    {                                                                      \
+        a[P][0] = *(lds_cv2*)(ul + a_off + ((P) * GI + 0) * 128);          \
+        a[P][1] = *(lds_cv2*)(ul + a_off + ((P) * GI + 1) * 128);          \
+    }
+#pragma unroll
+    for (int p = 0; p < AHEAD; ++p) WN_LOAD_A(p);
     f32x2 tt[4][4];
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
@@ -95,16 +116,23 @@ __device__ __forceinline__ void wino_chunk(const float* __restrict__ ul, const f
     }
 #pragma unroll
     for (int p = 0; p < 16; ++p) {
-        const f32x2 a0 = *reinterpret_cast<const f32x2*>(ul + a_off + (p * GI + 0) * 128);
-        const f32x2 a1 = *reinterpret_cast<const f32x2*>(ul + a_off + (p * GI + 1) * 128);
-        acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, v[p].x, acc[p][0], 0, 0, 0);
-        acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, v[p].x, acc[p][1], 0, 0, 0);
-        acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, v[p].y, acc[p][0], 0, 0, 0);
-        acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, v[p].y, acc[p][1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (p + AHEAD < 16) WN_LOAD_A(p + AHEAD);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ABL & 2) {
+            acc[p][0].x += a[p][0].x * v[p].x + a[p][0].y * v[p].y;
+            acc[p][1].x += a[p][1].x * v[p].x + a[p][1].y * v[p].y;
+            continue;
+        }
+        acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p][0].x, v[p].x, acc[p][0], 0, 0, 0);
+        acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p][1].x, v[p].x, acc[p][1], 0, 0, 0);
+        acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p][0].y, v[p].y, acc[p][0], 0, 0, 0);
+        acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p][1].y, v[p].y, acc[p][1], 0, 0, 0);
     }
+#undef WN_LOAD_A
 }
 
-template <int NCG>
+template <int NCG, int ABL>
 __global__ __launch_bounds__(512) void wino3x3_kernel(const WinoParams p) {
     using G = WinoGeo<NCG>;
     __shared__ __attribute__((aligned(16))) float u_lds0[G::U_FLOATS];
@@ -130,24 +158,28 @@ __global__ __launch_bounds__(512) void wino3x3_kernel(const WinoParams p) {
     const __amdgpu_buffer_rsrc_t wgt_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wgt), 0, -1, 0x00020000);
 
     // source of this lane's 16 bytes in each of its patch DMA instructions (the same for every chunk)
-    int pvoff[G::KP];
+    constexpr int KPI = (G::P_INSTR + 7) / 8;
+    int pvoff[KPI];
 #pragma unroll
-    for (int k = 0; k < G::KP; ++k) {
+    for (int k = 0; k < KPI; ++k) {
         const int slot = (k * 8 + wave) * 64 + lane;
-        int pi = slot >> 1;
-        int sbl = (pi * 1772) >> 16;  // pi / 37 for pi < 2048
-        int px = pi - sbl * 37;
-        px = px < 36 ? px : 35;
-        sbl = sbl < G::NSB ? sbl : G::NSB - 1;
-        int sb = tile_m * G::NSB + sbl;
+        const int h = slot >= G::PLANE_SLOTS ? 1 : 0;
+        const int pi = slot - h * G::PLANE_SLOTS;
+        int tgi = pi / G::TG_SLOTS;
+        tgi = tgi < G::TG ? tgi : G::TG - 1;
+        const int rem = pi - tgi * G::TG_SLOTS;
+        const int s4 = rem >= 121 ? 3 : (rem >= 81 ? 2 : (rem >= 40 ? 1 : 0));
+        int px = rem - wn_sb_base(s4);
+        px = px < 36 ? px : 35;  // (pad slots: any valid pixel)
+        int sb = tile_m * G::NSB + tgi * 4 + s4;
         sb = sb < p.n_sb ? sb : p.n_sb - 1;
         const int img = wn_div(sb, p.sb_per_img);
-        const int rem = sb - img * p.sb_per_img;
-        const int sby = wn_div(rem, p.sb_per_row);
-        const int sbx = rem - sby * p.sb_per_row;
-        const int y = (px * 43) >> 8;  // px / 6 for px < 36
+        const int rem2 = sb - img * p.sb_per_img;
+        const int sby = wn_div(rem2, p.sb_per_row);
+        const int sbx = rem2 - sby * p.sb_per_row;
+        const int y = px / 6;
         const int x = px - y * 6;
-        pvoff[k] = (img * p.in_img_stride + (4 * sby + y) * p.in_row_stride + (4 * sbx + x) * p.in_px_stride + (slot & 1) * 4) * 4;
+        pvoff[k] = (img * p.in_img_stride + (4 * sby + y) * p.in_row_stride + (4 * sbx + x) * p.in_px_stride + h * 4) * 4;
     }
     const int u_soff0 = tile_n * n_chunks * G::U_FLOATS * 4;
 
@@ -156,14 +188,14 @@ __global__ __launch_bounds__(512) void wino3x3_kernel(const WinoParams p) {
         const int us_ = u_soff0 + (C) * (G::U_FLOATS * 4);                                                             \
         _Pragma("unroll") for (int k_ = 0; k_ < G::U_INSTR / 8; ++k_)                                                  \
             wn_blds16(wgt_rsrc, ((k_ * 8 + wave) * 64 + lane) * 16, us_, (UL) + (k_ * 8 + wave) * 256);                \
-        _Pragma("unroll") for (int k_ = 0; k_ < G::KP; ++k_)                                                           \
+        _Pragma("unroll") for (int k_ = 0; k_ < KPI; ++k_)                                                             \
             if (k_ * 8 + wave < G::P_INSTR) wn_blds16(act_rsrc, pvoff[k_], (C) * 32, (PL) + (k_ * 8 + wave) * 256);    \
     }
 
     // operand addresses inside a stage
     const int a_off = cg * 2 * 128 + t * 8 + ((2 * kq + 4 * (t >> 3)) & 7);
     const int sbl_own = tg * 4 + (t >> 2);
-    const int r_off = (sbl_own * 37 + ((t >> 1) & 1) * 12 + (t & 1) * 2) * 8 + 2 * kq;
+    const int r_off = (kq >> 1) * (G::PLANE_SLOTS * 4) + (tg * G::TG_SLOTS + wn_sb_base(t >> 2) + ((t >> 1) & 1) * 12 + (t & 1) * 2) * 4 + (kq & 1) * 2;
 
     f32x4 acc[16][2];
 #pragma unroll
@@ -177,13 +209,13 @@ __global__ __launch_bounds__(512) void wino3x3_kernel(const WinoParams p) {
         // chunk c has landed for every thread; every wave is done with the other stage
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), as an instruction hipcc's own wait bookkeeping sees
         __builtin_amdgcn_s_barrier();
-        if (c + 1 < n_chunks) WN_ISSUE(u_lds1, p_lds1, c + 1);
-        wino_chunk<NCG>(u_lds0, p_lds0, acc, a_off, r_off);
+        if (c + 1 < n_chunks && !(ABL & 1)) WN_ISSUE(u_lds1, p_lds1, c + 1);
+        wino_chunk<NCG, ABL>((const lds_f*)u_lds0, (const lds_f*)p_lds0, acc, a_off, r_off);
         if (c + 1 < n_chunks) {
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), as an instruction hipcc's own wait bookkeeping sees
             __builtin_amdgcn_s_barrier();
-            if (c + 2 < n_chunks) WN_ISSUE(u_lds0, p_lds0, c + 2);
-            wino_chunk<NCG>(u_lds1, p_lds1, acc, a_off, r_off);
+            if (c + 2 < n_chunks && !(ABL & 1)) WN_ISSUE(u_lds0, p_lds0, c + 2);
+            wino_chunk<NCG, ABL>((const lds_f*)u_lds1, (const lds_f*)p_lds1, acc, a_off, r_off);
         }
     }
 #undef WN_ISSUE
@@ -276,8 +308,20 @@ hipError_t launch_wino3x3(const WinoParams& p_in, hipStream_t s) {
     p.tiles_n = p.cout / (32 * ncg);
     const int tiles_m = (p.n_sb + nsb - 1) / nsb;
     const int grid = tiles_m * p.tiles_n;
-    if (ncg == 2) hipLaunchKernelGGL((wino3x3_kernel<2>), dim3(grid), dim3(512), 0, s, p);
-    else hipLaunchKernelGGL((wino3x3_kernel<1>), dim3(grid), dim3(512), 0, s, p);
+    static const int abl = getenv("PA_WINO_ABL") ? atoi(getenv("PA_WINO_ABL")) : 0;
+#define WN_LAUNCH(ABL_)                                                                                  \
+    if (ncg == 2) hipLaunchKernelGGL((wino3x3_kernel<2, ABL_>), dim3(grid), dim3(512), 0, s, p);        \
+    else hipLaunchKernelGGL((wino3x3_kernel<1, ABL_>), dim3(grid), dim3(512), 0, s, p)
+    switch (abl) {
+        case 1: WN_LAUNCH(1); break;
+        case 2: WN_LAUNCH(2); break;
+        case 3: WN_LAUNCH(3); break;
+        case 4: WN_LAUNCH(4); break;
+        case 6: WN_LAUNCH(6); break;
+        case 7: WN_LAUNCH(7); break;
+        default: WN_LAUNCH(0);
+    }
+#undef WN_LAUNCH
     return hipGetLastError();
 }
 

@@ -323,6 +323,8 @@ struct pa_detector {
     std::vector<size_t> buf_floats;
     float* weights = nullptr;
     size_t n_weights = 0;
+    float* wino_weights = nullptr;      // the stride-1 3x3 layers' filters in the Winograd kernel's layout (wino.hip)
+    std::vector<long long> wino_off;    // per layer: float offset into wino_weights, -1 = the layer runs in its direct form
     float* x0 = nullptr;       // letter-boxed input [max_images][net_h + 4][net_w + 4][4]
     float* anchors = nullptr;  // device copy of the decode layers' anchors [n_decode][8]
     std::string last_error;
@@ -335,6 +337,7 @@ const char* pa_detector_last_error(const pa_detector* h) { return h ? h->last_er
 void pa_detector_destroy(pa_detector* h) {
     if (!h) return;
     (void)hipFree(h->weights);
+    (void)hipFree(h->wino_weights);
     (void)hipFree(h->x0);
     (void)hipFree(h->anchors);
     for (float* b : h->bufs) (void)hipFree(b);
@@ -410,6 +413,28 @@ int pa_detector_create(int32_t device, const pa_net_layer* layers, int32_t n_lay
     h->n_weights = n_weights;
     if (!chk(hipMalloc(&h->weights, n_weights * sizeof(float)), "hipMalloc weights")) return PA_ERR_HIP;
     if (!chk(hipMemcpy(h->weights, weights_host, n_weights * sizeof(float), hipMemcpyHostToDevice), "upload weights")) return PA_ERR_HIP;
+    {
+        // stride-1 3x3 convolutions on maps whose sides are multiples of four run as Winograd F(2x2, 3x3) (wino.hip: 4 / 9 of
+        // the direct form's multiply-adds, the same fp32 matrix instructions); their filters are transformed here, once, in
+        // fp64. PA_DET_WINO=0 keeps the direct patch-resident kernel (A/B)
+        static const int use_wino = getenv("PA_DET_WINO") ? atoi(getenv("PA_DET_WINO")) : 1;
+        h->wino_off.assign(n_layers, -1);
+        size_t total = 0;
+        for (int i = 0; i < n_layers; ++i) {
+            const pa_net_layer& L = h->layers[i];
+            if (use_wino && L.kind == 0 && L.ksize == 3 && L.stride == 1 && L.in_pad == 1 && L.in_h % 4 == 0 && L.in_w % 4 == 0 && L.cin % 8 == 0) {
+                h->wino_off[i] = (long long)total;
+                total += pa::wino_weight_floats(L.cin, L.cout);
+            }
+        }
+        if (total) {
+            std::vector<float> ug(total);
+            for (int i = 0; i < n_layers; ++i)
+                if (h->wino_off[i] >= 0) pa::wino_transform_weights(weights_host + h->layers[i].w_off, h->layers[i].cin, h->layers[i].cout, ug.data() + h->wino_off[i]);
+            if (!chk(hipMalloc(&h->wino_weights, total * sizeof(float)), "hipMalloc Winograd filters")) return PA_ERR_HIP;
+            if (!chk(hipMemcpy(h->wino_weights, ug.data(), total * sizeof(float), hipMemcpyHostToDevice), "upload Winograd filters")) return PA_ERR_HIP;
+        }
+    }
     h->bufs.assign(n_bufs, nullptr);
     h->buf_floats.assign(buf_floats_per_image, buf_floats_per_image + n_bufs);
     for (int b = 0; b < n_bufs; ++b) {
@@ -578,7 +603,17 @@ static int detector_run(pa_detector* h, const uint8_t* frames, int32_t n, int32_
         static const int use_pgemm = getenv("PA_DET_PGEMM") ? atoi(getenv("PA_DET_PGEMM")) : 1;  // 0: the one-tile-per-workgroup engine (A/B)
         static const int use_patch = getenv("PA_DET_PATCH") ? atoi(getenv("PA_DET_PATCH")) : 1;  // 0: im2col for the 3x3 convolutions (A/B)
         pe = hipErrorInvalidValue;
-        if (use_patch && L.ksize == 3 && L.stride == 1 && L.in_pad == 1)
+        if (h->wino_off[li] >= 0) {
+            pa::WinoParams q;
+            memset(&q, 0, sizeof(q));
+            q.act = p.act; q.wgt = h->wino_weights + h->wino_off[li]; q.bias = p.bias; q.residual = p.residual; q.out = p.out;
+            q.n_img = n; q.height = L.in_h; q.width = L.in_w; q.cin = L.cin; q.cout = L.cout;
+            q.in_px_stride = p.in_px_stride; q.in_row_stride = p.in_row_stride; q.in_img_stride = p.in_img_stride;
+            q.out_px_stride = p.out_px_stride; q.out_row_stride = p.out_row_stride; q.out_img_stride = p.out_img_stride; q.out_pad = p.out_pad;
+            q.relu = p.relu; q.res_after = p.res_after;
+            pe = pa::launch_wino3x3(q, s);
+        }
+        if (pe == hipErrorInvalidValue && use_patch && L.ksize == 3 && L.stride == 1 && L.in_pad == 1)
             pe = pa::launch_conv3x3_patch_blocked(p, s);  // input patch resident in LDS across the nine taps (patchconv.hip)
         if (pe != hipErrorInvalidValue) {
         } else if ((use_pgemm || p.N % 64) && !p.residual) {

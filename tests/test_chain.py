@@ -46,7 +46,7 @@ def test_chain_from_mjpeg_bytes_to_labels(engine, state_dict):
         got = pred.cpu().numpy()
         e_box, e_score = np.abs(got[..., :4] - want[..., :4]).max(), np.abs(got[..., 4:] - want[..., 4:]).max()
         print(f"chain: network rows vs oracle: boxes {e_box:.2e} px, scores {e_score:.2e}")
-        assert e_box <= 2e-2 and e_score <= 1e-4
+        assert e_box <= 1e-4 * 384 and e_score <= 1e-4  # 1e-4 of the network input's shorter side (tests/test_yolov5.py)
         # 3. Seeded random-init weights detect nothing a runner could use, so BOTH sides get the same candidate rows written
         # over the first six rows of their own network output: the clip's true fighter boxes as a trained detector would
         # report them (three near-duplicates each), fighter 1 lost in frames 6-8. Everything the network itself emits stays
