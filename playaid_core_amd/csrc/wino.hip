@@ -33,6 +33,7 @@
 // atomics): results are bitwise repeatable and do not depend on the batch size.
 #include "pa_kernels.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -45,12 +46,27 @@ typedef __attribute__((address_space(3))) const volatile f32x2 lds_cv2;  // an L
 
 namespace {
 
-__device__ __forceinline__ void wn_blds16(__amdgpu_buffer_rsrc_t rsrc, int voff_bytes, int soff_bytes, float* lds_base) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_base, 16, voff_bytes, soff_bytes, 0, 0);
+// 16-byte global -> LDS DMA (buffer_load_dwordx4 ... offen lds): LDS destination = M0 + lane * 16, source = descriptor base +
+// voff + soff bytes. As inline assembly, not the builtin: hipcc's wait insertion then knows nothing of these copies, and the
+// kernel's own counted s_waitcnt vmcnt(N) in front of its barriers are the only waits for them. With the builtin it tracked
+// them as LDS stores and, losing precision over the chunk loop's back edge, drained vmcnt to 0 in front of the first operand
+// read of every third chunk -- behind copies issued a quarter of a chunk earlier.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 wn_rsrc(const void* base) {
+    const unsigned long long a = (unsigned long long)base;
+    return i32x4{__builtin_amdgcn_readfirstlane((int)(unsigned)a), __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff), -1, 0x00020000};
+}
+__device__ __forceinline__ void wn_blds16(i32x4 rsrc, int voff_bytes, int soff_bytes, float* lds_base) {
+    const unsigned lds_addr = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)lds_base;
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                 :
+                 : "v"(voff_bytes), "s"(rsrc), "s"(soff_bytes), "s"(lds_addr)
+                 : "memory");
 }
 
-template <int NCG> struct WinoGeo {
-    static constexpr int TG = 8 / NCG;                      // tile groups = waves along the pixels
+template <int TGN, int NCG> struct WinoGeo {
+    static constexpr int TG = TGN;                          // tile groups = waves along the pixels
+    static constexpr int NW = TGN * NCG;                    // waves per workgroup
     static constexpr int NSB = TG * 4;                      // 4x4-pixel sub-blocks per workgroup
     static constexpr int BN = 32 * NCG;                     // output channels per workgroup
     static constexpr int U_FLOATS = 16 * BN * 8;            // filters of one chunk
@@ -62,7 +78,6 @@ template <int NCG> struct WinoGeo {
     static constexpr int PLANE_SLOTS = TG * TG_SLOTS;
     static constexpr int P_INSTR = 2 * PLANE_SLOTS / 64;    // 20 | 40
     static constexpr int P_FLOATS = 2 * PLANE_SLOTS * 4;
-    static constexpr int KP = P_INSTR / 8;                  // patch DMA instructions per wave: 2.5 | 5
 };
 
 __device__ __forceinline__ int wn_sb_base(int s) { return s == 0 ? 0 : (s == 1 ? 40 : (s == 2 ? 81 : 121)); }
@@ -77,11 +92,17 @@ __device__ __forceinline__ int wn_div(int m, int d) {
 }
 
 // one chunk: raw pixels -> V (registers), 16 positions x 2 channel quads-of-16 x 2 channels
-// ABL (timing experiments, PA_WINO_ABL; results wrong when != 0): 1 no DMA behind the first chunk, 2 no matrix instructions,
-// 4 no raw reads / input transform
-template <int NCG, int ABL>
-__device__ __forceinline__ void wino_chunk(const lds_f* ul, const lds_f* pl, f32x4 (&acc)[16][2], int a_off, int r_off) {
-    constexpr int GI = WinoGeo<NCG>::BN / 16;
+// ABL (timing experiments, PA_WINO_ABL; results wrong when != 0): 1 no DMA behind the prologue's, 2 no matrix instructions,
+// 4 no raw reads / input transform, 8 timeline stamps (results right)
+//
+// One chunk: the lane's 16 raw pixels -> V (registers), then 16 positions x 2 channel groups x 2 channels of matrix
+// instructions, the row operands read three positions ahead. ISSUE: the DMA instructions of a later chunk are handed out
+// between the positions (issue(k), k = 0 .. KD - 1) instead of in one burst behind the barrier: eight waves issuing ~50 KB of
+// LDS-DMA at once kept every wave in its address / texture queue for ~1400 cycles per chunk before its first LDS read
+// (per-wave stamps, profiles/r05_wino_stamps_*.txt).
+template <int GI, int ABL, int KD, bool ISSUE, typename IssueFn>
+__device__ __forceinline__ void wino_chunk(const lds_f* ul, const lds_f* pl, f32x4 (&acc)[16][2], int a_off, int r_off, IssueFn issue,
+                                           unsigned long long* stamp) {
     f32x2 d[4][4];
 #pragma unroll
     for (int y = 0; y < 4; ++y)
@@ -89,6 +110,8 @@ __device__ __forceinline__ void wino_chunk(const lds_f* ul, const lds_f* pl, f32
         for (int x = 0; x < 4; ++x)
             d[y][x] = (ABL & 4) ? f32x2{(float)r_off, 1.f} : *(lds_cv2*)(pl + r_off + (y * 6 + x) * 4);
     // row operands: three positions ahead of the matrix instructions that consume them
+    // (volatile reads: hipcc would merge a pair into ds_read2st64_b64, which the LDS serves in 16-lane groups over 32 banks --
+    // four-way conflicts on this image and half the rate of two ds_read_b64 even without)
     constexpr int AHEAD = 3;
     f32x2 a[16][2];
 #define WN_LOAD_A(P)                                                       \
@@ -114,10 +137,21 @@ __device__ __forceinline__ void wino_chunk(const lds_f* ul, const lds_f* pl, f32
         v[4 * i + 2] = tt[i][2] - tt[i][1];
         v[4 * i + 3] = tt[i][1] - tt[i][3];
     }
+    if (ABL & 8) {  // (stamp build: when the transformed tile is complete)
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 0" ::"v"(v[0].x), "v"(v[5].y), "v"(v[10].x), "v"(v[15].y));
+        if (stamp) *stamp = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int p = 0; p < 16; ++p) {
         __builtin_amdgcn_sched_barrier(0);
         if (p + AHEAD < 16) WN_LOAD_A(p + AHEAD);
+        if (ISSUE) {
+#pragma unroll
+            for (int k = 0; k < KD; ++k)
+                if ((k * 14) / KD == p) issue(k);
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (ABL & 2) {
             acc[p][0].x += a[p][0].x * v[p].x + a[p][0].y * v[p].y;
@@ -132,18 +166,33 @@ __device__ __forceinline__ void wino_chunk(const lds_f* ul, const lds_f* pl, f32
 #undef WN_LOAD_A
 }
 
-template <int NCG, int ABL>
-__global__ __launch_bounds__(512) void wino3x3_kernel(const WinoParams p) {
-    using G = WinoGeo<NCG>;
+template <int N> __device__ __forceinline__ void wn_wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is six bits");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// NST: stages of the LDS ring (3 where they fit: the DMA of chunk c + 2 is issued during chunk c, so the wait in front of a
+// barrier is for copies issued a whole chunk earlier)
+template <int TGN, int NCG, int NST, int ABL>
+__global__ __launch_bounds__(64 * TGN * NCG) void wino3x3_kernel(const WinoParams p) {
+    using G = WinoGeo<TGN, NCG>;
+    constexpr int NW = G::NW;
+    constexpr int KU = G::U_INSTR / NW;               // filter DMA instructions per wave and chunk
+    constexpr int KPI = (G::P_INSTR + NW - 1) / NW;   // patch DMA instructions per wave and chunk
+    constexpr int KD = KU + KPI;
+    constexpr int D = NST - 1;                        // chunks a DMA is issued ahead of its use
+    static_assert(G::U_INSTR % NW == 0 && NST >= 2 && NST <= 3, "");
     __shared__ __attribute__((aligned(16))) float u_lds0[G::U_FLOATS];
     __shared__ __attribute__((aligned(16))) float u_lds1[G::U_FLOATS];
+    __shared__ __attribute__((aligned(16))) float u_lds2[NST == 3 ? G::U_FLOATS : 4];
     __shared__ __attribute__((aligned(16))) float p_lds0[G::P_FLOATS];
     __shared__ __attribute__((aligned(16))) float p_lds1[G::P_FLOATS];
+    __shared__ __attribute__((aligned(16))) float p_lds2[NST == 3 ? G::P_FLOATS : 4];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tg = NCG == 2 ? (wave & 3) : wave;
-    const int cg = NCG == 2 ? (wave >> 2) : 0;
+    const int tg = wave % TGN;
+    const int cg = wave / TGN;
     const int t = lane & 15, kq = lane >> 4;
 
     // XCD-aware (bijective) remap: the workgroups of an XCD are a contiguous run of (tile_m, tile_n), channel tiles fastest,
@@ -154,15 +203,34 @@ __global__ __launch_bounds__(512) void wino3x3_kernel(const WinoParams p) {
     const int tile_m = wg / p.tiles_n, tile_n = wg - tile_m * p.tiles_n;
     const int n_chunks = p.cin >> 3;
 
-    const __amdgpu_buffer_rsrc_t act_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.act), 0, -1, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wgt_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wgt), 0, -1, 0x00020000);
+    unsigned long long* const clk = (ABL & 8) && p.clk && lane == 0 ? p.clk + ((size_t)blockIdx.x * NW + wave) * 64 : nullptr;
+    if ((ABL & 8) && clk) clk[0] = __builtin_amdgcn_s_memtime();
+#define WN_STAMP(K) if ((ABL & 8) && clk && (K) < 63) clk[K] = __builtin_amdgcn_s_memtime()
 
-    // source of this lane's 16 bytes in each of its patch DMA instructions (the same for every chunk)
-    constexpr int KPI = (G::P_INSTR + 7) / 8;
-    int pvoff[KPI];
+    const i32x4 act_rsrc = wn_rsrc(p.act), wgt_rsrc = wn_rsrc(p.wgt);
+    const int u_soff0 = tile_n * n_chunks * G::U_FLOATS * 4;
+    // DMA instruction K (0 .. KD - 1) of chunk C into stage (UL, PL): first the wave's share of the filter image (a straight
+    // copy), then of the patch. Patch instructions past the stage's last (P_INSTR is not always a multiple of the wave count)
+    // repeat the wave's previous one -- the same bytes to the same place -- so that every wave issues KD per chunk and one
+    // counted wait serves all.
+    int pvoff[KPI], pdst[KPI];
+#define WN_ISSUE_U(UL, C, K) wn_blds16(wgt_rsrc, (((K) * NW + wave) * 64 + lane) * 16, u_soff0 + (C) * (G::U_FLOATS * 4), (UL) + ((K) * NW + wave) * 256)
+#define WN_ISSUE_P(PL, C, J) wn_blds16(act_rsrc, pvoff[J], (C) * 32, (PL) + pdst[J])
+#define WN_ISSUE_ALL(UL, PL, C)                                                                  \
+    {                                                                                            \
+        _Pragma("unroll") for (int k_ = 0; k_ < KU; ++k_) WN_ISSUE_U(UL, C, k_);                 \
+        _Pragma("unroll") for (int k_ = 0; k_ < KPI; ++k_) WN_ISSUE_P(PL, C, k_);                \
+    }
+    // the first chunk's filters need no address work: on their way before anything else
+#pragma unroll
+    for (int k = 0; k < KU; ++k) WN_ISSUE_U(u_lds0, 0, k);
+
 #pragma unroll
     for (int k = 0; k < KPI; ++k) {
-        const int slot = (k * 8 + wave) * 64 + lane;
+        int idx = k * NW + wave;
+        idx = idx < G::P_INSTR ? idx : idx - NW;
+        pdst[k] = idx * 256;
+        const int slot = idx * 64 + lane;
         const int h = slot >= G::PLANE_SLOTS ? 1 : 0;
         const int pi = slot - h * G::PLANE_SLOTS;
         int tgi = pi / G::TG_SLOTS;
@@ -181,21 +249,30 @@ __global__ __launch_bounds__(512) void wino3x3_kernel(const WinoParams p) {
         const int x = px - y * 6;
         pvoff[k] = (img * p.in_img_stride + (4 * sby + y) * p.in_row_stride + (4 * sbx + x) * p.in_px_stride + h * 4) * 4;
     }
-    const int u_soff0 = tile_n * n_chunks * G::U_FLOATS * 4;
-
-#define WN_ISSUE(UL, PL, C)                                                                                            \
-    {                                                                                                                  \
-        const int us_ = u_soff0 + (C) * (G::U_FLOATS * 4);                                                             \
-        _Pragma("unroll") for (int k_ = 0; k_ < G::U_INSTR / 8; ++k_)                                                  \
-            wn_blds16(wgt_rsrc, ((k_ * 8 + wave) * 64 + lane) * 16, us_, (UL) + (k_ * 8 + wave) * 256);                \
-        _Pragma("unroll") for (int k_ = 0; k_ < KPI; ++k_)                                                             \
-            if (k_ * 8 + wave < G::P_INSTR) wn_blds16(act_rsrc, pvoff[k_], (C) * 32, (PL) + (k_ * 8 + wave) * 256);    \
-    }
+#pragma unroll
+    for (int k = 0; k < KPI; ++k) WN_ISSUE_P(p_lds0, 0, k);
+    if (D == 2 && n_chunks > 1) WN_ISSUE_ALL(u_lds1, p_lds1, 1);
 
     // operand addresses inside a stage
     const int a_off = cg * 2 * 128 + t * 8 + ((2 * kq + 4 * (t >> 3)) & 7);
     const int sbl_own = tg * 4 + (t >> 2);
     const int r_off = (kq >> 1) * (G::PLANE_SLOTS * 4) + (tg * G::TG_SLOTS + wn_sb_base(t >> 2) + ((t >> 1) & 1) * 12 + (t & 1) * 2) * 4 + (kq & 1) * 2;
+
+    // where this lane's outputs go (its tile's 2 x 2 pixels, channels ch0 + 16 g + 0..3)
+    const int sb_own = tile_m * G::NSB + sbl_own;
+    const bool own = sb_own < p.n_sb;
+    long o00;
+    {
+        const int sbc = own ? sb_own : p.n_sb - 1;
+        const int img = wn_div(sbc, p.sb_per_img);
+        const int rem = sbc - img * p.sb_per_img;
+        const int sby = wn_div(rem, p.sb_per_row);
+        const int sbx = rem - sby * p.sb_per_row;
+        const int oy0 = 4 * sby + 2 * ((t >> 1) & 1), ox0 = 4 * sbx + 2 * (t & 1);
+        o00 = (long)img * p.out_img_stride + (long)(oy0 + p.out_pad) * p.out_row_stride + (ox0 + p.out_pad) * p.out_px_stride +
+              tile_n * G::BN + cg * 32 + 4 * kq;
+    }
+    const int ch0 = tile_n * G::BN + cg * 32 + 4 * kq;
 
     f32x4 acc[16][2];
 #pragma unroll
@@ -203,33 +280,47 @@ __global__ __launch_bounds__(512) void wino3x3_kernel(const WinoParams p) {
         acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
         acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // chunk 0 landed (the copies of chunk 1, if any, stay in flight)
+    if (D == 2 && n_chunks > 1) wn_wait_vmcnt<KD>(); else wn_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
 
-    WN_ISSUE(u_lds0, p_lds0, 0);
-    for (int c = 0; c < n_chunks; c += 2) {
-        // chunk c has landed for every thread; every wave is done with the other stage
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), as an instruction hipcc's own wait bookkeeping sees
-        __builtin_amdgcn_s_barrier();
-        if (c + 1 < n_chunks && !(ABL & 1)) WN_ISSUE(u_lds1, p_lds1, c + 1);
-        wino_chunk<NCG, ABL>((const lds_f*)u_lds0, (const lds_f*)p_lds0, acc, a_off, r_off);
-        if (c + 1 < n_chunks) {
-            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), as an instruction hipcc's own wait bookkeeping sees
-            __builtin_amdgcn_s_barrier();
-            if (c + 2 < n_chunks && !(ABL & 1)) WN_ISSUE(u_lds0, p_lds0, c + 2);
-            wino_chunk<NCG, ABL>((const lds_f*)u_lds1, (const lds_f*)p_lds1, acc, a_off, r_off);
+    float* const ust[3] = {u_lds0, u_lds1, u_lds2};
+    float* const pst[3] = {p_lds0, p_lds1, p_lds2};
+    for (int c0 = 0; c0 < n_chunks; c0 += NST) {
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            const int c = c0 + st;
+            if (c >= n_chunks) break;
+            WN_STAMP(1 + 3 * c);
+            float* const ut = ust[(st + D) % NST];
+            float* const pt = pst[(st + D) % NST];
+            const bool more = c + D < n_chunks && !(ABL & 1);
+            // (one copy of the chunk body with a wave-uniform branch around each DMA instruction: two copies -- with and without
+            // the issue -- made hipcc spill ~400 registers at the join)
+            auto issue = [&](int k) {
+                if (!more) return;
+                if (k < KU) { WN_ISSUE_U(ut, c + D, k); } else { WN_ISSUE_P(pt, c + D, k - KU); }
+            };
+            unsigned long long* const sp = (ABL & 8) && clk && 2 + 3 * c < 63 ? clk + 2 + 3 * c : nullptr;
+            wino_chunk<G::BN / 16, ABL, KD, true>((const lds_f*)ust[st], (const lds_f*)pst[st], acc, a_off, r_off, issue, sp);
+            WN_STAMP(3 + 3 * c);
+            if (c + 1 < n_chunks) {
+                // chunk c + 1 has landed for this thread (what was issued behind it stays in flight); behind the barrier it has
+                // for every thread, and every wave is done with the stage the next chunk's issue overwrites
+                if (D == 2 && more) wn_wait_vmcnt<KD>(); else wn_wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+            }
         }
     }
-#undef WN_ISSUE
+#undef WN_ISSUE_U
+#undef WN_ISSUE_P
+#undef WN_ISSUE_ALL
 
     // ---- output transform + epilogue, all in the accumulating lane ----------------------------------------------------
-    int sb = tile_m * G::NSB + sbl_own;
-    if (sb >= p.n_sb) return;
-    const int img = wn_div(sb, p.sb_per_img);
-    const int rem = sb - img * p.sb_per_img;
-    const int sby = wn_div(rem, p.sb_per_row);
-    const int sbx = rem - sby * p.sb_per_row;
-    const int oy0 = 4 * sby + 2 * ((t >> 1) & 1), ox0 = 4 * sbx + 2 * (t & 1);
-    const int ch0 = tile_n * G::BN + cg * 32 + 4 * kq;  // + 16 g + 0..3
-    const long o00 = (long)img * p.out_img_stride + (long)(oy0 + p.out_pad) * p.out_row_stride + (ox0 + p.out_pad) * p.out_px_stride + ch0;
+    if (!own) {
+        if ((ABL & 8) && clk) clk[63] = __builtin_amdgcn_s_memtime();
+        return;
+    }
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const f32x4 bias4 = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + ch0 + 16 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -250,8 +341,8 @@ __global__ __launch_bounds__(512) void wino3x3_kernel(const WinoParams p) {
 #pragma unroll
             for (int ox = 0; ox < 2; ++ox) {
                 const long o = o00 + (long)oy * p.out_row_stride + ox * p.out_px_stride + 16 * g;
-                const f32x4 res4 = p.residual ? *reinterpret_cast<const f32x4*>(p.residual + o) : f32x4{0.f, 0.f, 0.f, 0.f};
-                f32x4 v = y[oy][ox] + (p.res_after ? bias4 : bias4 + res4);
+                const f32x4 r4 = p.residual ? *reinterpret_cast<const f32x4*>(p.residual + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 v = y[oy][ox] + (p.res_after ? bias4 : bias4 + r4);
                 if (p.relu == 1) {
                     v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
                     v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
@@ -259,10 +350,12 @@ __global__ __launch_bounds__(512) void wino3x3_kernel(const WinoParams p) {
                     v.x = silu_fast(v.x); v.y = silu_fast(v.y);
                     v.z = silu_fast(v.z); v.w = silu_fast(v.w);
                 }
-                if (p.res_after) v += res4;
+                if (p.res_after) v += r4;
                 *reinterpret_cast<f32x4*>(p.out + o) = v;
             }
     }
+    if ((ABL & 8) && clk) clk[63] = __builtin_amdgcn_s_memtime();
+#undef WN_STAMP
 }
 
 }  // namespace
@@ -271,8 +364,15 @@ size_t wino_weight_floats(int cin, int cout) { return (size_t)16 * cin * cout; }
 
 // [cout][ky][kx][cin] (BatchNorm folded) -> the stage images the kernel copies: [cout / BN][cin / 8][16][BN / 16][16][8]
 // with G g G^T evaluated in fp64 and rounded once
+// output channels per workgroup (= per filter stage image): 64 where the layer has them, unless PA_WINO_BN=32 asks for the
+// four-wave, 32-channel workgroup everywhere (two per CU; an A/B knob read once per process, so filters and launches agree)
+int wino_bn(int cout) {
+    static const int force = getenv("PA_WINO_BN") ? atoi(getenv("PA_WINO_BN")) : 0;
+    return (cout % 64 == 0 && force != 32) ? 64 : 32;
+}
+
 void wino_transform_weights(const float* w, int cin, int cout, float* ug) {
-    const int bn = cout % 64 == 0 ? 64 : 32, gi_n = bn / 16, n_chunks = cin / 8;
+    const int bn = wino_bn(cout), gi_n = bn / 16, n_chunks = cin / 8;
     static const double Gm[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
     for (int co = 0; co < cout; ++co)
         for (int ci = 0; ci < cin; ++ci) {
@@ -303,22 +403,53 @@ hipError_t launch_wino3x3(const WinoParams& p_in, hipStream_t s) {
     // byte offsets inside the buffer descriptors are 32-bit
     if ((long long)p.n_img * p.in_img_stride * 4 >= (1ll << 31) || (long long)wino_weight_floats(p.cin, p.cout) * 4 >= (1ll << 31)) return hipErrorInvalidValue;
     p.n_sb = (int)n_sb;
-    const int ncg = p.cout % 64 == 0 ? 2 : 1;
-    const int nsb = ncg == 2 ? 16 : 32;
-    p.tiles_n = p.cout / (32 * ncg);
+    const int bn = wino_bn(p.cout);
+    static const int small_wg = getenv("PA_WINO_BN") && atoi(getenv("PA_WINO_BN")) == 32;
+    const int nsb = bn == 64 ? 16 : (small_wg ? 16 : 32);
+    p.tiles_n = p.cout / bn;
     const int tiles_m = (p.n_sb + nsb - 1) / nsb;
     const int grid = tiles_m * p.tiles_n;
     static const int abl = getenv("PA_WINO_ABL") ? atoi(getenv("PA_WINO_ABL")) : 0;
-#define WN_LAUNCH(ABL_)                                                                                  \
-    if (ncg == 2) hipLaunchKernelGGL((wino3x3_kernel<2, ABL_>), dim3(grid), dim3(512), 0, s, p);        \
-    else hipLaunchKernelGGL((wino3x3_kernel<1, ABL_>), dim3(grid), dim3(512), 0, s, p)
+    static const int nst = getenv("PA_WINO_STAGES") ? atoi(getenv("PA_WINO_STAGES")) : 2;  // 3: a three-stage ring (A/B: 62.3 against 61.5 us on layer 1, 95.2 against 92.1 on the 24 x 40 map -- the prologue then waits behind two chunks of copies)
+#define WN_LAUNCH(ABL_)                                                                                        \
+    if (bn == 64 && nst == 3) hipLaunchKernelGGL((wino3x3_kernel<4, 2, 3, ABL_>), dim3(grid), dim3(512), 0, s, p);    \
+    else if (bn == 64) hipLaunchKernelGGL((wino3x3_kernel<4, 2, 2, ABL_>), dim3(grid), dim3(512), 0, s, p);           \
+    else if (small_wg) hipLaunchKernelGGL((wino3x3_kernel<4, 1, 2, ABL_>), dim3(grid), dim3(256), 0, s, p);           \
+    else hipLaunchKernelGGL((wino3x3_kernel<8, 1, 2, ABL_>), dim3(grid), dim3(512), 0, s, p)
     switch (abl) {
         case 1: WN_LAUNCH(1); break;
         case 2: WN_LAUNCH(2); break;
         case 3: WN_LAUNCH(3); break;
-        case 4: WN_LAUNCH(4); break;
-        case 6: WN_LAUNCH(6); break;
         case 7: WN_LAUNCH(7); break;
+        case 8: {
+            // timeline stamps of one launch (the PA_WINO_STAMP_CALL-th) -> PA_WINO_STAMP_FILE: header {grid, waves, cin, n_sb}, then
+            // [grid][waves][64] s_memtime values (scripts/wino_stamps.py)
+            static int calls = 0;
+            static unsigned long long* dev = nullptr;
+            const char* sf = getenv("PA_WINO_STAMP_FILE");
+            const int nw = bn == 64 ? 8 : (small_wg ? 4 : 8);
+            const bool now = sf && calls++ == (getenv("PA_WINO_STAMP_CALL") ? atoi(getenv("PA_WINO_STAMP_CALL")) : 0);
+            const size_t words = (size_t)grid * nw * 64;
+            if (now) {
+                if (dev) (void)hipFree(dev);
+                if (hipMalloc(&dev, words * 8) != hipSuccess) return hipErrorOutOfMemory;
+                (void)hipMemset(dev, 0, words * 8);
+                p.clk = dev;
+            }
+            WN_LAUNCH(8);
+            if (now) {
+                (void)hipStreamSynchronize(s);
+                std::vector<unsigned long long> hst(words);
+                (void)hipMemcpy(hst.data(), dev, words * 8, hipMemcpyDeviceToHost);
+                if (FILE* f = fopen(sf, "wb")) {
+                    const int hdr[4] = {grid, nw, p.cin, p.n_sb};
+                    fwrite(hdr, 4, 4, f);
+                    fwrite(hst.data(), 8, words, f);
+                    fclose(f);
+                }
+            }
+            break;
+        }
         default: WN_LAUNCH(0);
     }
 #undef WN_LAUNCH
