@@ -262,6 +262,27 @@ int pa_clean_detections(pa_engine* e, const float* dets, const int32_t* counts, 
                         double* labels, int32_t* pixel_frame, double* pixel_box, int32_t* crop_kind, float* crop_row, int32_t* info4,
                         void* stream);
 
+/* What the crop hand-off needs from pa_clean_detections' tables, worked out on the device (one launch instead of a dozen
+ * generic element-wise / sort launches between the repair and the crops): det_index / src_own int32[n_labels][F] = the
+ * det_index / src_frame arguments of pa_save_one_box_crops for the entries of kind 1 (-1 / 0 elsewhere; rows behind
+ * max_frames count as "no crop"); the square_crop repairs (kind 2, rows < max_frames) compacted in entry order:
+ * rep_entry int32[] = their (frame * F + fighter) entries, rep_boxes float64[][4], rep_src int32[] = source frames --
+ * each with room for n_labels * F entries, padded with copies of the first repair to a whole number of F (the shape
+ * pa_square_crops_src cuts); words5 int32[5] = info4 followed by the number of repairs (the five words a host waits
+ * for). Enqueue only. */
+int pa_detector_plan(pa_engine* e, const int32_t* pixel_frame, const double* pixel_box, const int32_t* crop_kind, const int32_t* info4,
+                     int32_t n_labels, int32_t* det_index, int32_t* src_own, int32_t* rep_entry, double* rep_boxes, int32_t* rep_src,
+                     int32_t* words5, void* stream);
+/* The clip's crop-image descriptors once pa_save_one_box_crops has packed every chunk of `step_frames` frames into a region
+ * of `region_bytes` of its own (descriptor offsets relative to the region): kind-1 entries move by their chunk's region,
+ * the n_rep repairs' 128 x 128 x 3 images sit back to back from byte `rep_base`. desc[n_frames][F]. Enqueue only. */
+int pa_detector_plan_desc(pa_engine* e, pa_crop_image* desc, const int32_t* crop_kind, int32_t n_frames, int32_t step_frames,
+                          long long region_bytes, const int32_t* rep_entry, int32_t n_rep, long long rep_base, void* stream);
+/* pa_square_crops with every crop cut from the frame src_frame names (int32[n][F], device; frames uint8[n_src,H,W,3]):
+ * the square_crop repairs of clean_yolo_crops, whose pixels come from VideoCapture position j (ai_runner.py:404-418). */
+int pa_square_crops_src(pa_engine* e, const uint8_t* frames, int32_t n_src, int32_t height, int32_t width, const double* boxes,
+                        const int32_t* src_frame, int32_t n, int32_t padding, int32_t swap_rb, uint8_t* crops, int32_t* status, void* stream);
+
 /* Replaces the crop half of the same subprocess (`--save-crop`, ai_runner.py:208) and the cv2.imread that reads each
  * crop back (:445-446): per (frame, fighter) YOLOv5 v7.0's utils/plots.py::save_one_box -- the label row's pixel box ->
  * xyxy2xywh -> wh * 1.02 + 10 -> xywh2xyxy -> .long() -> clip_boxes -> im[y1:y2, x1:x2] (float32 like torch) -- and, for

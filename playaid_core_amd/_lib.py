@@ -161,6 +161,9 @@ SYMBOLS = [
     ("pa_convnet_destroy", None, [_P]),
     ("pa_convnet_last_error", C.c_char_p, [_P]),
     ("pa_convnet_forward", C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P]),
+    ("pa_detector_plan", C.c_int, [_P] * 5 + [C.c_int32] + [_P] * 7),
+    ("pa_detector_plan_desc", C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_longlong, _P, C.c_int32, C.c_longlong, _P]),
+    ("pa_square_crops_src", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     ("pa_wino_weight_floats", C.c_size_t, [C.c_int32, C.c_int32]),
     ("pa_wino_transform_weights", C.c_int, [_P, C.c_int32, C.c_int32, _P]),
     ("pa_wino_conv3x3", C.c_int, [_P, _P, _P, _P, _P] + [C.c_int32] * 10 + [_P]),

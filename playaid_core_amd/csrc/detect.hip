@@ -205,6 +205,12 @@ __global__ void clean_labels_kernel(const CleanParams p) {
     }
     __syncthreads();
     const int maxf = maxf_sh;
+    // rows behind the last labelled frame hold "no crop": callers count crop kinds over the whole table, and the table may be
+    // recycled memory (an earlier clip's kinds)
+    for (int i = maxf * F + f; i < n * F; i += blockDim.x) {
+        p.pixel_frame[i] = -1;
+        p.crop_kind[i] = 0;
+    }
     if (f >= F) return;
     const int cid = p.class_ids[f];
     auto fail = [&](int code, int frame) {
@@ -312,6 +318,98 @@ hipError_t launch_clean_labels(const CleanParams& p, hipStream_t s) {
     const int total = p.n_labels * p.max_det * 6;
     hipLaunchKernelGGL(g6_rows_kernel, dim3((total + 255) / 256), dim3(256), 0, s, p.dets, p.g6v, total);
     hipLaunchKernelGGL(clean_labels_kernel, dim3(1), dim3(64), 0, s, p);
+    return hipGetLastError();
+}
+
+
+// ---- what the crop hand-off needs from the repaired table (detector_path.py), on the device ---------------------------------
+//
+// The tables clean_labels_kernel wrote decide three launches: which detection each (frame, fighter) entry's save_one_box crop
+// is cut from, which entries are square_crop repairs (their boxes and source frames, in entry order) and how many there are.
+// PyTorch's generic kernels did this with ~12 launches per clip (where / full_like / argsort / gathers / arange); it is one
+// workgroup's worth of work.
+namespace {
+
+// det_index / src_own: the save_one_box inputs (entries of kind 1). rep_*: the entries of kind 2, compacted in ascending entry
+// order and padded with copies of the first to a whole number of frames (pa_square_crops_src cuts F crops per "frame").
+// words5 = info4 + the number of repairs.
+__global__ __launch_bounds__(256) void detector_plan_kernel(const int32_t* __restrict__ pixel_frame, const double* __restrict__ pixel_box,
+                                                            const int32_t* __restrict__ crop_kind, const int32_t* __restrict__ info4, int n_labels, int F,
+                                                            int32_t* __restrict__ det_index, int32_t* __restrict__ src_own, int32_t* __restrict__ rep_entry,
+                                                            double* __restrict__ rep_boxes, int32_t* __restrict__ rep_src, int32_t* __restrict__ words5) {
+    __shared__ int wave_cnt[4];
+    __shared__ int base_sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int maxf = info4[0];
+    const int total = n_labels * F;
+    if (tid == 0) base_sh = 0;
+    __syncthreads();
+    for (int e0 = 0; e0 < total; e0 += 256) {
+        const int e = e0 + tid;
+        int kind = 0;
+        if (e < total) {
+            const int row = e / F;
+            kind = row < maxf ? crop_kind[e] : 0;
+            det_index[e] = kind == 1 ? e - row * F : -1;
+            src_own[e] = kind == 1 ? pixel_frame[e] : 0;
+        }
+        const unsigned long long m = __ballot(kind == 2);
+        if (lane == 0) wave_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = base_sh;
+        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+        if (kind == 2) {
+            const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+            rep_entry[pos] = e;
+            rep_src[pos] = pixel_frame[e];
+            for (int k = 0; k < 4; ++k) rep_boxes[(size_t)pos * 4 + k] = pixel_box[(size_t)e * 4 + k];
+        }
+        __syncthreads();
+        if (tid == 0) base_sh += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+    const int n_rep = base_sh;
+    const int padded = ((n_rep + F - 1) / F) * F;
+    for (int pos = n_rep + tid; pos < padded; pos += 256) {  // (n_rep > 0 here)
+        rep_entry[pos] = -1;
+        rep_src[pos] = rep_src[0];
+        for (int k = 0; k < 4; ++k) rep_boxes[(size_t)pos * 4 + k] = rep_boxes[k];
+    }
+    if (tid < 4) words5[tid] = info4[tid];
+    if (tid == 4) words5[4] = n_rep;
+}
+
+// the descriptors of a clip's crop images once every chunk of frames has packed its own region: the detector's crops move by
+// their chunk's region, the repairs' 128 x 128 images sit back to back from `rep_base`
+__global__ __launch_bounds__(256) void detector_desc_kernel(CropImageDesc* __restrict__ desc, const int32_t* __restrict__ crop_kind, int n_entries, int F,
+                                                            int step_frames, long long region, const int32_t* __restrict__ rep_entry, int n_rep,
+                                                            long long rep_base) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_entries && crop_kind[i] == 1) desc[i].offset += (long long)((i / F) / step_frames) * region;
+    if (i < n_rep) {
+        CropImageDesc d;
+        d.offset = rep_base + (long long)i * (128 * 128 * 3);
+        d.height = 128;
+        d.width = 128;
+        desc[rep_entry[i]] = d;
+    }
+}
+
+}  // namespace
+
+hipError_t launch_detector_plan(const int32_t* pixel_frame, const double* pixel_box, const int32_t* crop_kind, const int32_t* info4, int n_labels, int F,
+                                int32_t* det_index, int32_t* src_own, int32_t* rep_entry, double* rep_boxes, int32_t* rep_src, int32_t* words5,
+                                hipStream_t s) {
+    hipLaunchKernelGGL(detector_plan_kernel, dim3(1), dim3(256), 0, s, pixel_frame, pixel_box, crop_kind, info4, n_labels, F, det_index, src_own,
+                       rep_entry, rep_boxes, rep_src, words5);
+    return hipGetLastError();
+}
+
+hipError_t launch_detector_desc(CropImageDesc* desc, const int32_t* crop_kind, int n_entries, int F, int step_frames, long long region,
+                                const int32_t* rep_entry, int n_rep, long long rep_base, hipStream_t s) {
+    const int n = n_entries > n_rep ? n_entries : n_rep;
+    hipLaunchKernelGGL(detector_desc_kernel, dim3((n + 255) / 256), dim3(256), 0, s, desc, crop_kind, n_entries, F, step_frames, region, rep_entry,
+                       n_rep, rep_base);
     return hipGetLastError();
 }
 

@@ -139,14 +139,18 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict_
 // sixteen in flight per thread) and simply re-reads a granule whose tag is not t yet: arrival and payload are the same 8 bytes, so
 // nothing has to be ordered against anything (MI355X_MICROARCH.md, "allgather": ~3 us for this size). Two buffers suffice: who
 // writes h(t + 1) has read all of h(t), which nobody could write before everybody had read h(t - 1). hseq gets the same
-// values by plain stores for the next layer / the decoder (visible at the end of the launch). The launch is COOPERATIVE (the
-// runtime refuses a grid that cannot be co-resident); a granule that does not arrive within 20 ms sets *err: the decoder then
-// writes NaN rows, pa_lstm_last_status reports it once and the handle falls back to one launch per step.
+// values by plain stores for the next layer / the decoder (visible at the end of the launch). The grid must be CO-RESIDENT
+// (every workgroup waits for every other's granules): the host launches it only when the device holds H / U such workgroups at
+// once (hipOccupancyMaxActiveBlocksPerMultiprocessor x compute units) -- an ordinary launch; round 4 used
+// hipLaunchCooperativeKernel for that check alone (no grid-wide sync is used), and the runtime's cooperative queue turned out
+// to be what aborted at process exit under rocprofv3 (profiles/README.md, round 5). A granule that does not arrive within
+// 20 ms sets *err: the decoder then writes NaN rows, pa_lstm_last_status reports it once and the handle falls back to one
+// launch per step. force_timeout (PA_LSTM_FORCE_TIMEOUT=1, tests): workgroup 0 withholds its granules of step 0.
 template <int U>
 __global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict__ pre_all, const float* __restrict__ w_hh,
                                                          const float* __restrict__ b_hh, float* __restrict__ hseq, int L, int N, int H,
                                                          unsigned long long* __restrict__ gran, int* __restrict__ err,
-                                                         unsigned long long* __restrict__ dbg) {
+                                                         unsigned long long* __restrict__ dbg, int force_timeout) {
     constexpr int R = 4 * U, P = 256 / R, KQ = 128 / P;
     unsigned long long d_sweep = 0, d_prod = 0, d_gate = 0, d_t = 0;  // PA_LSTM_STAMP=1: where a step's time goes (100 MHz ticks)  // rows, lanes per row, float4 pieces per lane (H <= 512)
     extern __shared__ float sm[];
@@ -244,6 +248,7 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict
                 c_reg = cn;
                 const float hv = og * tanhf(cn);
                 hseq[(size_t)t * nh + n * H + j] = hv;
+                if (!(force_timeout && blockIdx.x == 0 && t == 0))
                 __hip_atomic_store(gran + (size_t)(t & 1) * nh + n * H + j, ((unsigned long long)(unsigned)(t + 1) << 32) | __float_as_uint(hv),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -336,6 +341,9 @@ struct pa_lstm {
     unsigned long long* gran = nullptr;   // [2][LSTM_NMAX][512] h granules {value, tag} of the layer in flight
     unsigned long long* dbg = nullptr;    // PA_LSTM_STAMP=1: in-kernel clock sums of the last layer launch
     int* sync_host = nullptr;             // pinned copy of the error words
+    hipEvent_t sync_ev = nullptr;         // behind the last forward's copies into sync_host: the host reads the words only once it is done
+    bool sync_pending = false;            // a forward has been enqueued since the words were last read
+    int occ_blocks = -1, occ_key = -1;    // co-resident lstm_layer_kernel workgroups the device holds for batch * 16 + U == occ_key
     bool persistent = true;               // one launch per layer (lstm_layer_kernel); false after a barrier timeout
     std::string last_error;
 };
@@ -403,14 +411,21 @@ int pa_lstm_create(int32_t device, int32_t input_dim, int32_t hidden_dim, int32_
     if (getenv("PA_LSTM_STAMP") && !chk(hipMalloc(&h->dbg, 4 * sizeof(unsigned long long)), "hipMalloc stamps")) return PA_ERR_HIP;
     if (!chk(hipHostMalloc(&h->sync_host, 2 * 8 * sizeof(int)), "hipHostMalloc")) return PA_ERR_HIP;
     memset(h->sync_host, 0, 2 * 8 * sizeof(int));
+    if (!chk(hipEventCreateWithFlags(&h->sync_ev, hipEventDisableTiming), "hipEventCreate")) return PA_ERR_HIP;
     // one launch per layer needs H / U workgroups co-resident (U = 2 above 256 hidden units): PA_LSTM_STEPS=1 forces the
-    // per-step kernels (A/B); a cooperative launch the runtime refuses switches to them by itself
+    // per-step kernels (A/B); a grid the device cannot hold at once switches to them by itself (pa_lstm_forward)
     if (getenv("PA_LSTM_STEPS")) h->persistent = false;
     return PA_OK;
 }
 
+// The error words of the forwards enqueued so far: waits for the copies behind the last forward (so: for that forward) before
+// reading the pinned words -- a status query is a synchronisation point of the handle's last stream.
 int pa_lstm_last_status(pa_lstm* h) {
     if (!h) return PA_ERR_INVALID_ARG;
+    if (h->sync_pending && h->sync_ev) {
+        (void)hipEventSynchronize(h->sync_ev);
+        h->sync_pending = false;
+    }
     bool failed = false;
     for (int l = 0; l < h->layers; ++l)
         if (h->sync_host && h->sync_host[2 * l + 1]) failed = true;
@@ -433,6 +448,11 @@ void pa_lstm_destroy(pa_lstm* h) {
     (void)hipFree(h->sync_words);
     (void)hipFree(h->gran);
     (void)hipFree(h->dbg);
+    // (the pinned words may still be the target of a copy in flight: wait for it before they go)
+    if (h->sync_ev) {
+        if (h->sync_pending) (void)hipEventSynchronize(h->sync_ev);
+        (void)hipEventDestroy(h->sync_ev);
+    }
     if (h->sync_host) (void)hipHostFree(h->sync_host);
     delete h;
 }
@@ -453,7 +473,11 @@ int pa_lstm_forward(pa_lstm* h, const float* x, int32_t ld, int32_t seq_len, int
         const int in_ld = l == 0 ? ld : H, K = l == 0 ? h->in_dim : H;
         (void)pa::launch_linear_f32(in, in_ld, h->w_ih[l], h->b_ih[l], h->pre, 4 * H, M, 4 * H, K, 0, s);
         float* hs = h->hseq[l & 1];
-        if (h->persistent && h->sync_host[2 * l + 1]) h->persistent = false;  // (a timeout the caller has not asked about yet)
+        // (a timeout of an EARLIER forward the caller has not asked about yet -- read only once that forward's copies are done)
+        if (h->persistent && l == 0 && h->sync_pending && hipEventQuery(h->sync_ev) == hipSuccess) {
+            for (int q = 0; q < h->layers; ++q)
+                if (h->sync_host[2 * q + 1]) h->persistent = false;
+        }
         if (h->persistent) {
             // all time steps of the layer in one cooperative launch
             static const int u_env = getenv("PA_LSTM_UNITS") ? atoi(getenv("PA_LSTM_UNITS")) : 0;   // tuning: hidden units per workgroup
@@ -464,13 +488,27 @@ int pa_lstm_forward(pa_lstm* h, const float* x, int32_t ld, int32_t seq_len, int
             int a_L = seq_len, a_N = batch, a_H = H;
             unsigned long long* a_gran = h->gran; int* a_err = h->sync_words + 2 * l + 1;
             unsigned long long* a_dbg = h->dbg;
-            void* args[] = {&a_pre, &a_w, &a_b, &hs, &a_L, &a_N, &a_H, &a_gran, &a_err, &a_dbg};
+            static const int force_to = getenv("PA_LSTM_FORCE_TIMEOUT") ? atoi(getenv("PA_LSTM_FORCE_TIMEOUT")) : 0;
+            int a_force = force_to;
+            void* args[] = {&a_pre, &a_w, &a_b, &hs, &a_L, &a_N, &a_H, &a_gran, &a_err, &a_dbg, &a_force};
             (void)hipMemsetAsync(h->gran, 0, (size_t)2 * batch * H * sizeof(unsigned long long), s);   // tag 0 = not written
             const void* fn = U == 8   ? reinterpret_cast<const void*>(&pa::lstm_layer_kernel<8>)
                              : U == 4 ? reinterpret_cast<const void*>(&pa::lstm_layer_kernel<4>)
                              : U == 2 ? reinterpret_cast<const void*>(&pa::lstm_layer_kernel<2>)
                                       : reinterpret_cast<const void*>(&pa::lstm_layer_kernel<1>);
-            const hipError_t ce = hipLaunchCooperativeKernel(fn, dim3(H / U), dim3(256), args, (unsigned)lds, s);
+            // an ordinary launch, behind the check a cooperative launch would make: the device must hold the grid at once (the
+            // kernel only needs co-residency, not the runtime's grid sync; the cooperative QUEUE the runtime creates for
+            // hipLaunchCooperativeKernel was the one thing the rnn workload had that the others did not when it aborted
+            // inside exit() under rocprofv3)
+            if (h->occ_key != batch * 16 + U) {  // (the kernel's LDS grows with the batch)
+                h->occ_key = batch * 16 + U;
+                int per_cu = 0, cus = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds) != hipSuccess) per_cu = 0;
+                if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess) cus = 0;
+                (void)hipGetLastError();
+                h->occ_blocks = per_cu * cus;
+            }
+            const hipError_t ce = H / U <= h->occ_blocks ? hipLaunchKernel(fn, dim3(H / U), dim3(256), args, lds, s) : hipErrorCooperativeLaunchTooLarge;
             if (ce == hipSuccess) {
                 (void)hipMemcpyAsync(h->sync_host + 2 * l, h->sync_words + 2 * l, 2 * sizeof(int), hipMemcpyDeviceToHost, s);
                 continue;
@@ -486,6 +524,8 @@ int pa_lstm_forward(pa_lstm* h, const float* x, int32_t ld, int32_t seq_len, int
                        h->actions, h->sync_words, h->layers);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return bad(PA_ERR_HIP, hipGetErrorString(e));
+    (void)hipEventRecord(h->sync_ev, s);
+    h->sync_pending = true;
     if (h->dbg) {   // (measurement aid: synchronises)
         unsigned long long d[4];
         (void)hipStreamSynchronize(s);

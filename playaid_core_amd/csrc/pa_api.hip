@@ -777,6 +777,10 @@ int create_impl(const pa_config* cfg, const void* blob, size_t src_bytes, const 
     ALLOC(e->gather, (size_t)NC * S, true);
     ALLOC(e->status_tmp, (size_t)NC, true);
     ALLOC(e->dev_errors, 4, true);
+    // scratch of pa_clean_detections, sized for the longest clip and the widest detection table (max_det <= 8): the enqueue-only
+    // call never allocates for a table the engine was made for (a longer one still grows it, behind a device synchronisation)
+    e->clean_g6_cap = (size_t)cfg->max_clip_frames * 8 * 6;
+    ALLOC(e->clean_g6, e->clean_g6_cap, false);
 
     // ---- layer table + weights --------------------------------------------
     // arena capacity: the folded tensors are the blob's plus zero padding (stem K 147 -> 224, fc and
@@ -1076,7 +1080,6 @@ void pa_destroy(pa_engine* e) {
     if (e->side) (void)hipStreamDestroy(e->side);
     if (e->gate_flag) (void)hipHostFree(e->gate_flag);
     for (void* p : e->allocs) (void)hipFree(p);
-    (void)hipFree(e->clean_g6);
     delete e;
 }
 
@@ -1412,16 +1415,46 @@ int pa_clean_detections(pa_engine* e, const float* dets, const int32_t* counts, 
     for (int i = 0; i < 4; ++i) p.class_ids[i] = e->cfg.fighter_class_ids[i];
     p.lab = labels; p.pixel_frame = pixel_frame; p.pixel_box = pixel_box; p.crop_kind = crop_kind; p.crop_row = crop_row; p.info = info4;
     const size_t need = (size_t)n_labels * max_det * 6;
-    if (need > e->clean_g6_cap) {  // (first call, or a longer clip than any before: the old scratch may still be read by a call in flight)
+    if (need > e->clean_g6_cap) {  // (a table longer than max_clip_frames x 8 detections: the old scratch may still be read by a call in flight)
         HIPCHK(e, hipDeviceSynchronize());
-        (void)hipFree(e->clean_g6);
-        e->clean_g6 = nullptr; e->clean_g6_cap = 0;
-        HIPCHK(e, hipMalloc(&e->clean_g6, need * sizeof(double)));
+        double* grown = nullptr;
+        HIPCHK(e, hipMalloc(&grown, need * sizeof(double)));
+        e->allocs.push_back(grown);  // (the scratch it replaces stays in the engine's list and is freed with it)
+        e->clean_g6 = grown;
         e->clean_g6_cap = need;
     }
     p.g6v = e->clean_g6;
     HIPCHK(e, pa::launch_clean_labels(p, (hipStream_t)stream));
     return PA_OK;
+}
+
+int pa_detector_plan(pa_engine* e, const int32_t* pixel_frame, const double* pixel_box, const int32_t* crop_kind, const int32_t* info4,
+                     int32_t n_labels, int32_t* det_index, int32_t* src_own, int32_t* rep_entry, double* rep_boxes, int32_t* rep_src,
+                     int32_t* words5, void* stream) {
+    if (!e || !pixel_frame || !pixel_box || !crop_kind || !info4 || !det_index || !src_own || !rep_entry || !rep_boxes || !rep_src || !words5 ||
+        n_labels < 1)
+        return fail(e, PA_ERR_INVALID_ARG, "pa_detector_plan: bad argument");
+    HIPCHK(e, pa::launch_detector_plan(pixel_frame, pixel_box, crop_kind, info4, n_labels, e->cfg.num_fighters, det_index, src_own, rep_entry,
+                                       rep_boxes, rep_src, words5, (hipStream_t)stream));
+    return PA_OK;
+}
+
+int pa_detector_plan_desc(pa_engine* e, pa_crop_image* desc, const int32_t* crop_kind, int32_t n_frames, int32_t step_frames,
+                          long long region_bytes, const int32_t* rep_entry, int32_t n_rep, long long rep_base, void* stream) {
+    if (!e || !desc || !crop_kind || n_frames < 1 || step_frames < 1 || region_bytes < 0 || n_rep < 0 || (n_rep && !rep_entry) || rep_base < 0)
+        return fail(e, PA_ERR_INVALID_ARG, "pa_detector_plan_desc: bad argument");
+    HIPCHK(e, pa::launch_detector_desc(reinterpret_cast<pa::CropImageDesc*>(desc), crop_kind, n_frames * e->cfg.num_fighters, e->cfg.num_fighters,
+                                       step_frames, region_bytes, rep_entry, n_rep, rep_base, (hipStream_t)stream));
+    return PA_OK;
+}
+
+int pa_square_crops_src(pa_engine* e, const uint8_t* frames, int32_t n_src, int32_t height, int32_t width, const double* boxes,
+                        const int32_t* src_frame, int32_t n, int32_t padding, int32_t swap_rb, uint8_t* crops, int32_t* status, void* stream) {
+    if (!e || !frames || !boxes || !src_frame || !crops || n < 1 || n_src < 1 || height < 1 || width < 1 || padding < 0)
+        return fail(e, PA_ERR_INVALID_ARG, "pa_square_crops_src: bad argument");
+    if (n > e->cfg.max_batch_frames || height > e->cfg.max_frame_height || width > e->cfg.max_frame_width)
+        return fail(e, PA_ERR_CAPACITY, "pa_square_crops_src: crops exceed engine capacity");
+    return run_preprocess(e, frames, n, height, width, boxes, padding, swap_rb, crops, nullptr, status, (hipStream_t)stream, src_frame, n_src);
 }
 
 int pa_save_one_box_crops(pa_engine* e, const uint8_t* frames, int32_t n_src, int32_t height, int32_t width, const float* dets,

@@ -265,6 +265,13 @@ struct CleanParams {
     double* g6v;            // scratch [n_labels][max_det][6]: every row value through the label file's '%g' (filled by the launcher's first kernel)
 };
 hipError_t launch_clean_labels(const CleanParams& p, hipStream_t s);
+struct CropImageDesc;
+// what the crop hand-off needs from the repaired table, and the clip's crop-image descriptors (detect.hip; pa_detector_plan*)
+hipError_t launch_detector_plan(const int32_t* pixel_frame, const double* pixel_box, const int32_t* crop_kind, const int32_t* info4, int n_labels, int F,
+                                int32_t* det_index, int32_t* src_own, int32_t* rep_entry, double* rep_boxes, int32_t* rep_src, int32_t* words5,
+                                hipStream_t s);
+hipError_t launch_detector_desc(CropImageDesc* desc, const int32_t* crop_kind, int n_entries, int F, int step_frames, long long region,
+                                const int32_t* rep_entry, int n_rep, long long rep_base, hipStream_t s);
 
 // YOLOv5 save_one_box crops + their 4:4:4 JPEG write / read (savebox.hip)
 struct SaveBoxRect { int32_t x1, y1, w, h; };

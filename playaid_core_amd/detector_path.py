@@ -13,7 +13,10 @@ table ``pa_detect_postprocess`` wrote:
 
 ONE small thing comes back to the host in the middle: five words -- the repair's ``info`` (last labelled frame, the
 reference's assertions as error codes) and the number of repaired entries -- because the clip's length decides every later
-launch. ``begin`` enqueues the repair and that copy, ``finish`` waits for the five words and enqueues the rest; pixels,
+launch. What the later launches need from the repaired table (which detection each crop is cut from, the repairs' boxes and
+source frames in entry order, the crop images' descriptors) is worked out on the device by two small kernels
+(``pa_detector_plan``, ``pa_detector_plan_desc``), not by a dozen generic tensor launches. ``begin`` enqueues the repair, the
+plan and that copy, ``finish`` waits for the five words and enqueues the rest; pixels,
 boxes, crop images and descriptors never leave the device, nothing else synchronises (``finish(..., device_results=True)``
 does not even wait for the results), so a caller can put the next clip's detector under this clip's wait.
 """
@@ -37,21 +40,25 @@ _REPAIR_ERRORS = {
 
 
 class Ticket:
-    """A clip between ``begin`` and ``finish``: the repair tables (device), the five host words and the event behind them."""
+    """A clip between ``begin`` and ``finish``: the repair tables and the plan (device), the five host words and the event
+    behind them."""
 
-    def __init__(self, frames_dev, tab, words, event):
-        self.frames_dev, self.tab, self.words, self.event = frames_dev, tab, words, event
+    def __init__(self, frames_dev, tab, plan, words, event):
+        self.frames_dev, self.tab, self.plan, self.words, self.event = frames_dev, tab, plan, words, event
 
 
 def begin(engine, frames_dev: torch.Tensor, dets: torch.Tensor, counts: torch.Tensor) -> Ticket:
-    """Enqueue the label repair (``pa_clean_detections``) and the copy of its five host words on the current stream."""
+    """Enqueue the label repair (``pa_clean_detections``), the plan of the crop hand-off (``pa_detector_plan``: only rows below
+    the repair's max_frames count -- the tables behind them may be recycled memory) and the copy of the five host words on
+    the current stream. Successive ``begin`` calls of one engine belong on one stream (the repair's scratch is the engine's)."""
+    n_rows = dets.shape[0]
     tab = engine.clean_detections(dets, counts, frames_dev.shape[0])
-    words_dev = torch.cat([tab["info"], (tab["crop_kind"] == 2).sum().to(torch.int32).reshape(1)])
+    plan = engine.detector_plan(tab, n_rows)
     words = torch.empty(5, dtype=torch.int32).pin_memory()
-    words.copy_(words_dev, non_blocking=True)
+    words.copy_(plan["words"], non_blocking=True)
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(engine.device))
-    return Ticket(frames_dev, tab, words, ev)
+    return Ticket(frames_dev, tab, plan, words, ev)
 
 
 def _crop_buffer(engine, nbytes: int) -> torch.Tensor:
@@ -74,46 +81,37 @@ def finish(engine, t: Ticket, jpeg_quality: int = 95, want_crops: bool = False, 
     n, n_rep = int(info[0]), int(info[4])
     if n < 2:
         raise ValueError("no detections in any label")
-    dev, F, tab, frames_dev = engine.device, engine.F, t.tab, t.frames_dev
+    dev, F, tab, plan, frames_dev = engine.device, engine.F, t.tab, t.plan, t.frames_dev
     h, w = frames_dev.shape[1], frames_dev.shape[2]
-    kind = tab["crop_kind"][:n]
-    src = tab["pixel_frame"][:n]
-    slot = torch.arange(F, dtype=torch.int32, device=dev)[None, :].expand(n, F)
-    det_index = torch.where(kind == 1, slot, torch.full_like(slot, -1)).contiguous()
-    src_own = torch.where(kind == 1, src, torch.zeros_like(src)).contiguous()
-    row_counts = torch.full((n,), F, dtype=torch.int32, device=dev)
     step = engine.max_batch_frames
+    rc = getattr(engine, "_detector_row_counts", None)
+    if rc is None or rc.numel() < n:
+        rc = engine._detector_row_counts = torch.full((max(n, engine.max_clip_frames),), F, dtype=torch.int32, device=dev)
     # every chunk of frames packs its crop images into a region of its own (the offsets inside a region are the kernel's
     # prefix sums), so no chunk has to know where the one before it ended
     region = step * F * min(h * w, 1 << 20) * 3 + 64
     n_chunks = (n + step - 1) // step
-    sq_bytes = n_rep * 128 * 128 * 3
+    k_rep = (n_rep + F - 1) // F * F  # the repairs are cut F at a time (pa_square_crops_src); the plan padded their list
+    sq_bytes = k_rep * 128 * 128 * 3
     images = _crop_buffer(engine, n_chunks * region + sq_bytes + 64)
     desc = torch.zeros((n * F, 2), dtype=torch.int64, device=dev)
     for k, f0 in enumerate(range(0, n, step)):
         cnt = min(step, n - f0)
-        d = desc[f0 * F:(f0 + cnt) * F]
-        engine.save_one_box_crops(frames_dev, tab["crop_row"][f0:f0 + cnt].contiguous(), row_counts[f0:f0 + cnt],
-                                  det_index=det_index[f0:f0 + cnt], jpeg_quality=jpeg_quality, src_frame=src_own[f0:f0 + cnt],
-                                  images=images[k * region:(k + 1) * region], desc=d)
-        if k:
-            d[:, 0] += k * region
+        engine.save_one_box_crops(frames_dev, tab["crop_row"][f0:f0 + cnt], rc[f0:f0 + cnt], det_index=plan["det_index"][f0:f0 + cnt],
+                                  jpeg_quality=jpeg_quality, src_frame=plan["src_own"][f0:f0 + cnt], images=images[k * region:(k + 1) * region],
+                                  desc=desc[f0 * F:(f0 + cnt) * F])
     sq_status = None
+    base = n_chunks * region
     if n_rep:
-        # the square_crop repairs, n_rep of them: their (frame, fighter) entries come out of a stable sort (no host round
-        # trip: the count is already here), their pixels are cut on the device into the tail of the same buffer
-        e = torch.argsort((kind != 2).reshape(-1).to(torch.int8), stable=True)[:n_rep]
-        boxes = tab["pixel_box"][:n].reshape(-1, 4)[e]
-        fr = frames_dev[src.reshape(-1)[e].long()]
-        base = n_chunks * region
-        sq = images[base:base + sq_bytes].view(n_rep, 128, 128, 3)
+        # the square_crop repairs: their entries, boxes and source frames came out of the plan in entry order; their pixels are
+        # cut on the device into the tail of the same buffer
         engine.set_crop_jpeg_quality(jpeg_quality)
         try:
-            sq_status = engine.square_crops_device(fr, boxes, sq, padding=engine.cfg.crop_padding)
+            sq_status = engine.square_crops_src_device(frames_dev, plan["rep_boxes"], plan["rep_src"], k_rep, images[base:base + sq_bytes],
+                                                       padding=engine.cfg.crop_padding)[:n_rep]
         finally:
             engine.set_crop_jpeg_quality(0)
-        desc[e, 0] = base + torch.arange(n_rep, device=dev, dtype=torch.int64) * (128 * 128 * 3)
-        desc[e, 1] = (128 << 32) | 128
+    engine.detector_plan_desc(desc, tab["crop_kind"], n, step, region, plan["rep_entry"], n_rep, base)
     out = engine.infer_clip_from_packed_crop_images(images, desc, n, want_crops=want_crops, device_results=device_results)
     out["max_frames"] = n
     if device_results:
@@ -124,7 +122,7 @@ def finish(engine, t: Ticket, jpeg_quality: int = 95, want_crops: bool = False, 
     if sq_status is not None:
         st = sq_status.cpu().numpy()
         if (st != 0).any():
-            bad = int(torch.div(e[int(np.nonzero(st)[0][0])], F, rounding_mode="floor"))
+            bad = int(plan["rep_entry"][int(np.nonzero(st)[0][0])]) // F
             raise AssertionError(f"Failed to get square crop from frame {bad + 1}")  # ai_runner.py:418
     out["cleaned"] = {k: (v[:n].cpu().numpy() if k != "info" else info[:4]) for k, v in tab.items()}
     return out

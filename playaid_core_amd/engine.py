@@ -391,6 +391,56 @@ class Engine:
                                                   _ptr(out["crop_row"]), _ptr(out["info"]), self._stream()))
         return out
 
+    def detector_plan(self, tab, n_rows: int):
+        """The crop hand-off's inputs from ``clean_detections``' tables, one launch (``pa_detector_plan``) -> dict of device
+        tensors: det_index / src_own int32[n_rows, F] (``save_one_box_crops``' arguments), rep_entry / rep_src int32[n_rows * F],
+        rep_boxes float64[n_rows * F, 4] (the square-crop repairs in entry order, padded to a whole number of F) and words
+        int32[5] (``info`` + the number of repairs)."""
+        dev, F = self.device, self.F
+        out = {
+            "det_index": torch.empty((n_rows, F), dtype=torch.int32, device=dev),
+            "src_own": torch.empty((n_rows, F), dtype=torch.int32, device=dev),
+            "rep_entry": torch.empty((n_rows * F,), dtype=torch.int32, device=dev),
+            "rep_boxes": torch.empty((n_rows * F, 4), dtype=torch.float64, device=dev),
+            "rep_src": torch.empty((n_rows * F,), dtype=torch.int32, device=dev),
+            "words": torch.empty((5,), dtype=torch.int32, device=dev),
+        }
+        self._check(self._lib.pa_detector_plan(self._h, _ptr(tab["pixel_frame"]), _ptr(tab["pixel_box"]), _ptr(tab["crop_kind"]), _ptr(tab["info"]),
+                                               n_rows, _ptr(out["det_index"]), _ptr(out["src_own"]), _ptr(out["rep_entry"]), _ptr(out["rep_boxes"]),
+                                               _ptr(out["rep_src"]), _ptr(out["words"]), self._stream()))
+        return out
+
+    def detector_plan_desc(self, desc: torch.Tensor, crop_kind: torch.Tensor, n_frames: int, step_frames: int, region_bytes: int,
+                           rep_entry: torch.Tensor, n_rep: int, rep_base: int):
+        """Descriptors of a clip's crop images after the per-chunk packing (``pa_detector_plan_desc``), in place."""
+        if desc.dtype != torch.int64 or not desc.is_cuda or not desc.is_contiguous() or desc.numel() < n_frames * self.F * 2:
+            raise ValueError(f"detector_plan_desc: desc is a contiguous int64[{n_frames * self.F}, 2] device tensor")
+        if crop_kind.dtype != torch.int32 or crop_kind.numel() < n_frames * self.F or rep_entry.numel() < n_rep:
+            raise ValueError("detector_plan_desc: tables shorter than the clip")
+        self._check(self._lib.pa_detector_plan_desc(self._h, _ptr(desc), _ptr(crop_kind), n_frames, step_frames, int(region_bytes), _ptr(rep_entry),
+                                                    n_rep, int(rep_base), self._stream()))
+
+    def square_crops_src_device(self, frames_dev: torch.Tensor, boxes_dev: torch.Tensor, src_dev: torch.Tensor, k: int, out: torch.Tensor,
+                                padding: int = constants.CROP_PADDING, swap_rb: bool = False) -> torch.Tensor:
+        """``k`` square crops (k a multiple of F), crop i cut from ``frames_dev[src_dev[i]]`` with ``boxes_dev[i]`` (float64[k, 4], int32[k],
+        device) -> ``out`` uint8[k, 128, 128, 3] written in place; returns the status int32[k] (device). Nothing is waited for."""
+        if frames_dev.dim() != 4 or frames_dev.shape[3] != 3 or frames_dev.dtype != torch.uint8 or not frames_dev.is_cuda \
+                or not frames_dev.is_contiguous():
+            raise ValueError("square_crops_src_device: frames are a contiguous uint8[n, H, W, 3] device tensor")
+        n_src, h, w, _ = frames_dev.shape
+        F = self.F
+        if k < F or k % F or boxes_dev.dtype != torch.float64 or boxes_dev.numel() < k * 4 or src_dev.dtype != torch.int32 or src_dev.numel() < k:
+            raise ValueError("square_crops_src_device: k is a multiple of the fighter count; boxes float64[k, 4], src int32[k]")
+        if out.dtype != torch.uint8 or not out.is_cuda or not out.is_contiguous() or out.numel() < k * 128 * 128 * 3:
+            raise ValueError("square_crops_src_device: out is a contiguous uint8[k, 128, 128, 3] device tensor")
+        status = torch.empty((k,), dtype=torch.int32, device=self.device)
+        step = self.max_batch_frames * F
+        for i0 in range(0, k, step):
+            cnt = min(step, k - i0)
+            self._check(self._lib.pa_square_crops_src(self._h, _ptr(frames_dev), n_src, h, w, _ptr(boxes_dev[i0:]), _ptr(src_dev[i0:]), cnt // F,
+                                                      padding, int(swap_rb), _ptr(out.view(-1)[i0 * 49152:]), _ptr(status[i0:]), self._stream()))
+        return status
+
     def save_one_box_crops(self, frames_dev: torch.Tensor, dets: torch.Tensor, counts: torch.Tensor, det_index=None,
                            jpeg_quality: int = 95, images: torch.Tensor = None, desc: torch.Tensor = None, src_frame=None):
         """``detect.py --save-crop`` + ``cv2.imread`` of every crop (``ai_runner.py:208,445-446``) on the device: frames

@@ -51,3 +51,33 @@ def test_main_launches_children_before_any_gpu_call(monkeypatch):
     else:
         raise AssertionError("main() returned instead of exiting with the child's code")
     assert called["a"] == (["--gpus", "2", "--steps", "1", "--warmup", "0"], 2)
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_driver_scale_command_shape_on_two_ranks():
+    """The command the driver's SCALE tier runs -- ``python3 bench.py --gpus N ...`` with no launcher around it -- as a FRESH child
+    process (never an exec of a process that touched the GPU): bench.py starts its own two ranks, both on the box's one GPU
+    over gloo (RCCL needs one GPU per rank), shards one 256-frame clip, exchanges the halo features and prints ONE JSON line. The
+    nearest thing to an 8-GPU rehearsal this pool allows; no scaling claim -- none can be measured on one GPU."""
+    import json
+    import subprocess
+
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--clip-frames", "256", "--steps", "1",
+           "--warmup", "0", "--no-cpu-baseline", "--no-pcie", "--no-decode"]
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 1 and d["warmup"] == 0 and d["higher_is_better"] is True
+    assert d["metric"].startswith("1080p frames/sec") and d["unit"] == "frames/s" and d["value"] > 0 and d["ms_per_step"] > 0
+    assert d["config"]["exchange"]["halo_rows_sent_rank0"] > 0, "two ranks of one clip must exchange halo features"
+    assert d["config"]["workload"] and d["scaling"] in ("strong", "weak")
+    # (rank 0 asserts that every record of the clip arrived and every log-probability is finite before it prints the line:
+    # bench.py, "sanity: results are finite and complete" -- a non-finite label fails the child, not this parse)

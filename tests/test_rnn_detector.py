@@ -86,3 +86,60 @@ def test_rnn_detector_matches_oracle():
             model(_inputs(10, 7))   # 70 rows > max_rows
     finally:
         model.close()
+
+
+@pytest.mark.gpu
+def test_lstm_barrier_timeout_is_reported_once_and_the_handle_recovers():
+    """The failure path of the per-layer LSTM kernel (``csrc/lstm.hip``), driven by the debug knob ``PA_LSTM_FORCE_TIMEOUT=1`` (one
+    workgroup withholds its granules of step 0, so every other one gives up after 20 ms): that call's log-probabilities are NaN,
+    ``check()`` raises ONCE with the status ``pa_lstm_last_status`` reports (read only behind the forward's own copies), and
+    the handle then launches one kernel per time step -- results equal to a handle made with ``PA_LSTM_STEPS=1``. Runs in a
+    child process: both knobs are read once per process."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    code = r"""
+import json, sys
+import numpy as np, torch
+sys.path.insert(0, %r)
+from playaid_core_amd import synth
+from playaid_core_amd.engine import EngineError
+from playaid_core_amd.rnn_action_detector import RNNActionDetector
+actions = [f"a{i}" for i in range(63)]
+sd = synth.make_rnn_state_dict(seed=4321, num_actions=63)
+rng = np.random.default_rng(5)
+x = torch.from_numpy(rng.integers(0, 256, (2, 7, 3, 128, 128)).astype(np.float32) / 255)
+m = RNNActionDetector("byleth", actions, state_dict=sd, max_rows=64).eval()
+out = {}
+try:
+    first = m(x.cuda())          # device input: enqueued only, nothing raised here
+    torch.cuda.synchronize()
+    out["first_nan"] = bool(torch.isnan(first).all())
+    try:
+        m.check(); out["raised"] = False
+    except EngineError as e:
+        out["raised"] = True; out["msg"] = str(e)
+    try:
+        m.check(); out["raised_twice"] = False
+    except EngineError:
+        out["raised_twice"] = True
+    out["second"] = m(x).numpy().tolist()   # per-step launches from here on
+finally:
+    m.close()
+print("RESULT" + json.dumps(out))
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(env_extra):
+        env = dict(os.environ, **env_extra)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1][6:])
+
+    forced = run({"PA_LSTM_FORCE_TIMEOUT": "1"})
+    assert forced["first_nan"], "the timed-out call must return NaN rows, not stale or partial numbers"
+    assert forced["raised"] and "timed out" in forced["msg"] and not forced["raised_twice"]
+    steps = run({"PA_LSTM_STEPS": "1"})
+    assert not steps["raised"] and not steps["first_nan"]
+    assert np.array_equal(np.asarray(forced["second"]), np.asarray(steps["second"]))

@@ -170,6 +170,17 @@ def test_detection_network_full_batch_of_configs1():
     sd = synth.make_yolov5s_state_dict()
     det = YoloV5Detector(sd, NC, NET, max_images=n)
     try:
+        # configs[1] itself: 64 x 1080p frames (the 3:1 letterbox), every row against the oracle (in chunks of 8)
+        frames = synth.make_frames(n, 1080, 1920, seed=4)
+        got = det(frames)
+        torch.cuda.synchronize()
+        got = got.cpu().numpy()
+        x = torch.from_numpy(np.stack([oy.letterbox(f, NET) for f in frames]))
+        want = np.concatenate([oy.forward(x[i:i + 8], sd, NC).numpy() for i in range(0, n, 8)])
+        e_box, e_score = np.abs(got[..., :4] - want[..., :4]).max(), np.abs(got[..., 4:] - want[..., 4:]).max()
+        print(f"64 x 1080p batch: boxes {e_box:.2e} px, scores {e_score:.2e}")
+        assert e_score <= 1e-4 and e_box <= BOX_TOL_PX
+        del frames, x, want
         frames = synth.make_frames(n, 720, 1280, seed=3)
         got = det(frames)
         torch.cuda.synchronize()
