@@ -128,7 +128,7 @@ struct WinoParams {
     int32_t in_px_stride, in_row_stride, in_img_stride;      // floats
     int32_t out_px_stride, out_row_stride, out_img_stride, out_pad;
     int32_t relu, res_after;  // as GemmParams
-    int32_t n_sb, sb_per_row, sb_per_img, tiles_n;  // set by the launcher
+    int32_t n_sb, sb_per_row, sb_per_img, tiles_n, tiles_m;  // set by the launcher
     unsigned long long* clk;  // stamp launches only (PA_WINO_ABL=8)
 };
 size_t wino_weight_floats(int cin, int cout);

@@ -1,5 +1,5 @@
 """Per-layer times of the Winograd 3x3 kernel at the shapes of the headline's ResNet-18 (128 crops) and of the detector
-(64 x 1080p frames): HIP events on the current stream, median of 20 after 5 warm-ups. Prints algorithmic (direct-form)
+(64 x 1080p frames): HIP events on the current stream around 20 back-to-back launches, median of 5 after 5 warm-ups. Prints algorithmic (direct-form)
 GFLOP, time, effective TFLOP/s (algorithmic / time) and executed TFLOP/s (4 / 9 of that)."""
 import os
 import sys
@@ -22,14 +22,17 @@ for name, n, h, w, cin, cout in SHAPES:
     out = torch.zeros((n, h + 2, w + 2, cout), device=dev)
     for _ in range(5):
         wino.conv3x3(xp, ug, cin, cout, out=out, act=1)
+    # 20 launches back to back between two events, five times: a launch's own time in a stream that is kept busy (a single
+    # launch between two events with the host in between reads 5-10 us longer: the queue runs dry in front of it)
     ts = []
-    for _ in range(20):
+    for _ in range(5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        wino.conv3x3(xp, ug, cin, cout, out=out, act=1)
+        for _ in range(20):
+            wino.conv3x3(xp, ug, cin, cout, out=out, act=1)
         e1.record()
         e1.synchronize()
-        ts.append(e0.elapsed_time(e1) * 1e3)
+        ts.append(e0.elapsed_time(e1) * 1e3 / 20)
     us = float(np.median(ts))
     gf = 2.0 * n * h * w * cin * cout * 9 / 1e9
     print(f"{name:18s} n={n:3d} {h:3d}x{w:3d} cin {cin:3d} cout {cout:3d}  {gf:6.2f} GF  {us:7.1f} us  {gf / us * 1e3:6.1f} TF effective  {gf / us * 1e3 * 4 / 9:6.1f} TF executed", flush=True)
