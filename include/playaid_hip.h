@@ -553,12 +553,15 @@ int pa_convnet_forward(pa_convnet* h, const float* x, int32_t n, float* out, int
  * residual: addressed like out, or NULL; act: 0 none, 1 ReLU, 2 SiLU; res_after: 1 = the residual is added after the
  * activation. height, width multiples of 4; cin % 8 == 0; cout % 32 == 0. Filters: pa_wino_transform_weights turns
  * BatchNorm-folded [cout][ky][kx][cin] (host) into the kernel's layout (host, pa_wino_weight_floats floats), which
- * the caller uploads. Enqueue only. */
+ * the caller uploads. `bn` = output channels per workgroup (64 | 32), part of that layout and of the launch:
+ * pa_wino_channels_per_workgroup gives the value the engine would pick for a layer of `cout` channels launched over
+ * `sub_blocks` = n * height / 4 * width / 4 sub-blocks (32 when 64-channel workgroups would not fill the chip). Enqueue only. */
 size_t pa_wino_weight_floats(int32_t cin, int32_t cout);
-int pa_wino_transform_weights(const float* w_host, int32_t cin, int32_t cout, float* ug_host);
+int pa_wino_channels_per_workgroup(int32_t cout, int64_t sub_blocks);
+int pa_wino_transform_weights(const float* w_host, int32_t cin, int32_t cout, int32_t bn, float* ug_host);
 int pa_wino_conv3x3(const float* x, const float* ug, const float* bias, const float* residual, float* out, int32_t n,
-                    int32_t height, int32_t width, int32_t cin, int32_t cout, int32_t in_px_stride, int32_t out_px_stride,
-                    int32_t out_pad, int32_t act, int32_t res_after, void* stream);
+                    int32_t height, int32_t width, int32_t cin, int32_t cout, int32_t bn, int32_t in_px_stride,
+                    int32_t out_px_stride, int32_t out_pad, int32_t act, int32_t res_after, void* stream);
 
 /* Head of ResnetTransformerDetector (resnet_transformer_detector.py:41-93,141): Linear(in_dim, hidden_dim), the
  * enc_dim-value time encoding of the frame slot appended (d_model = hidden_dim + enc_dim, 32 per head),

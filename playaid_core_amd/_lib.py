@@ -165,8 +165,9 @@ SYMBOLS = [
     ("pa_detector_plan_desc", C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_longlong, _P, C.c_int32, C.c_longlong, _P]),
     ("pa_square_crops_src", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     ("pa_wino_weight_floats", C.c_size_t, [C.c_int32, C.c_int32]),
-    ("pa_wino_transform_weights", C.c_int, [_P, C.c_int32, C.c_int32, _P]),
-    ("pa_wino_conv3x3", C.c_int, [_P, _P, _P, _P, _P] + [C.c_int32] * 10 + [_P]),
+    ("pa_wino_channels_per_workgroup", C.c_int, [C.c_int32, C.c_int64]),
+    ("pa_wino_transform_weights", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P]),
+    ("pa_wino_conv3x3", C.c_int, [_P, _P, _P, _P, _P] + [C.c_int32] * 11 + [_P]),
     ("pa_crop_resize_width", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, _P, C.c_int32,
                                        C.POINTER(C.c_int32), _P]),
     ("pa_encoder_blob_bytes", C.c_size_t, [C.c_int32] * 7),

@@ -30,6 +30,7 @@ struct ConvLayer {
     float* residual = nullptr;
     float* wgt = nullptr;   // device [cout][taps*chunk]
     float* wino_wgt = nullptr;  // fp32 stride-1 3x3 layers run as Winograd F(2x2, 3x3): the filters in wino.hip's layout, else nullptr
+    int wino_bn = 0;            // ... laid out for workgroups of this many output channels (wino_pick_bn at the full batch)
     float* bias = nullptr;  // device [cout]
     int relu = 1;
     GemmTile tile = TILE_128x64;
@@ -343,6 +344,7 @@ int run_conv(pa_engine* e, const ConvLayer& L, int crop0, int ncrops, size_t sla
     const size_t out_crop = (size_t)out_w * out_w * L.cout;
     const bool bf = e->bf16 && L.kh == 3;  // bf16 conv path: the 3x3 stack (buffers addressed in 2-byte elements)
     const bool bf_ds = bf && L.in2 && L.ds_wgt;  // downsample branch as its own GEMM, added as the residual
+    const bool f32_ds = !bf && L.in2 && L.ds_wgt && L.wino_wgt;  // the same for the fp32 Winograd form of the layer
     const size_t es = bf ? 2 : 4;
     auto at = [es](float* base, size_t elems) { return reinterpret_cast<float*>(reinterpret_cast<char*>(base) + elems * es); };
     p.act = at(L.in, crop0 * in_crop);
@@ -394,6 +396,29 @@ int run_conv(pa_engine* e, const ConvLayer& L, int crop0, int ncrops, size_t sla
                      2.0 * ((double)ncrops * L.in2_hw * L.in2_hw * L.in2_c / (L.in2_stride * L.in2_stride) + (double)d.M * d.N + (double)d.N * L.in2_c));
         HIPCHK(e, launch_igemm_bf16(d, TILE_128x64, s));  // (128x128 / 256x128 tiles measured 2-7 us slower here)
         p.residual = d.out;
+    } else if (f32_ds) {
+        GemmParams d;
+        memset(&d, 0, sizeof(d));
+        const int w2 = L.in2_hw + 2;  // zero-bordered block input
+        d.act = L.in2 + (size_t)crop0 * w2 * w2 * L.in2_c;
+        d.wgt = L.ds_wgt;
+        d.out = L.ds_out + crop0 * out_crop;
+        d.slab = p.slab;
+        d.M = p.M; d.N = p.N;
+        d.taps = 1; d.kw_taps = 1; d.chunk = L.in2_c; d.ktot = L.in2_c;
+        d.howo = p.howo; d.wo = p.wo;
+        d.in_px_stride = L.in2_c; d.in_row_stride = w2 * L.in2_c; d.in_img_stride = w2 * w2 * L.in2_c;
+        d.stride = L.in2_stride; d.off_y = 1; d.off_x = 1;
+        d.out_px_stride = p.out_px_stride; d.out_row_stride = p.out_row_stride; d.out_img_stride = p.out_img_stride;
+        d.out_pad = p.out_pad;
+        d.relu = 0; d.splitk = 1;
+        ProfScope ps(e, s, prof_name, 2.0 * d.M * d.N * L.in2_c,
+                     4.0 * ((double)ncrops * L.in2_hw * L.in2_hw * L.in2_c / (L.in2_stride * L.in2_stride) + (double)d.M * d.N + (double)d.N * L.in2_c));
+        GemmTile dt;
+        int dsk;
+        choose_tile(d.M, d.N, L.in2_c / 32, &dt, &dsk);
+        HIPCHK(e, launch_igemm(d, dt, s));
+        p.residual = d.out;
     } else if (L.in2) {
         const int w2 = L.in2_hw + 2;  // zero-bordered block input
         p.act2 = at(L.in2, (size_t)crop0 * w2 * w2 * L.in2_c);
@@ -421,10 +446,10 @@ int run_conv(pa_engine* e, const ConvLayer& L, int crop0, int ncrops, size_t sla
         p.splitk = 1;
     }
     // (the branch's FLOPs and bytes are booked where it runs: its own launch, or the opener's)
-    const double k_main = (bf_ds ? L.k_alg - L.in2_c : L.k_alg) + (ds_here ? L.cin : 0);
+    const double k_main = ((bf_ds || f32_ds) ? L.k_alg - L.in2_c : L.k_alg) + (ds_here ? L.cin : 0);
     const double flops = 2.0 * p.M * p.N * k_main;
-    const double bytes = (double)es * ((double)ncrops * L.in_hw * L.in_hw * L.cin + (double)p.M * p.N * ((L.residual || bf_ds || ds_here) ? 2 : 1) +
-                                       (double)p.N * k_main + ((L.in2 && !bf_ds) ? (double)ncrops * L.in2_hw * L.in2_hw * L.in2_c : 0.0));
+    const double bytes = (double)es * ((double)ncrops * L.in_hw * L.in_hw * L.cin + (double)p.M * p.N * ((L.residual || bf_ds || f32_ds || ds_here) ? 2 : 1) +
+                                       (double)p.N * k_main + ((L.in2 && !bf_ds && !f32_ds) ? (double)ncrops * L.in2_hw * L.in2_hw * L.in2_c : 0.0));
     ProfScope ps(e, s, prof_name, flops, bytes);
     // stride-1 3x3 layers: input patch resident in LDS across the nine taps (patchconv.hip);
     // PA_PATCH=0 keeps the generic im2col engine for A/B runs
@@ -445,7 +470,7 @@ int run_conv(pa_engine* e, const ConvLayer& L, int crop0, int ncrops, size_t sla
         WinoParams q;
         memset(&q, 0, sizeof(q));
         q.act = p.act; q.wgt = L.wino_wgt; q.bias = p.bias; q.residual = p.residual; q.out = p.out;
-        q.n_img = ncrops; q.height = L.out_hw; q.width = L.out_hw; q.cin = L.cin; q.cout = L.cout;
+        q.n_img = ncrops; q.height = L.out_hw; q.width = L.out_hw; q.cin = L.cin; q.cout = L.cout; q.bn = L.wino_bn;
         q.in_px_stride = p.in_px_stride; q.in_row_stride = p.in_row_stride; q.in_img_stride = p.in_img_stride;
         q.out_px_stride = p.out_px_stride; q.out_row_stride = p.out_row_stride; q.out_img_stride = p.out_img_stride; q.out_pad = p.out_pad;
         q.relu = p.relu;
@@ -832,12 +857,14 @@ int create_impl(const pa_config* cfg, const void* blob, size_t src_bytes, const 
         } else {
             r2 = (e->bf16 && k == 3) ? upload_bf16(e, &L.wgt, w) : upload(e, &L.wgt, w);
             if (r2) return r2;
-            // Winograd F(2x2, 3x3) for the fp32 stride-1 3x3 layers it is faster on (wino.hip; measured per shape at 128 crops:
-            // 32 x 32 x 64 and 16 x 16 x 128 maps). PA_WINO=0: none (A/B), 2: every stride-1 3x3 layer without a fused second source
+            // Winograd F(2x2, 3x3) for the fp32 stride-1 3x3 layers it is faster on (wino.hip; measured per layer at 128 crops,
+            // profiles/r05_resnet_layer_times_wino_options.txt: layers 1-3; layer 4's 4 x 4 maps stay on the direct kernel, 84 against
+            // 117-160 us). PA_WINO=0: none (A/B), 2: every stride-1 3x3 layer
             static const int wino_mode = getenv("PA_WINO") ? atoi(getenv("PA_WINO")) : 1;
-            if (!e->bf16 && k == 3 && stride == 1 && wino_mode && (wino_mode >= 2 || L.out_hw >= 16) && L.out_hw % 4 == 0) {
+            if (!e->bf16 && k == 3 && stride == 1 && wino_mode && (wino_mode >= 2 || L.out_hw >= 8) && L.out_hw % 4 == 0) {
+                L.wino_bn = wino_pick_bn(cout, (long long)NC * (L.out_hw / 4) * (L.out_hw / 4));
                 std::vector<float> ug(wino_weight_floats(cin, cout), 0.f);
-                if (!br.dry) wino_transform_weights(w.data(), cin, cout, ug.data());
+                if (!br.dry) wino_transform_weights(w.data(), cin, cout, L.wino_bn, ug.data());
                 r2 = upload(e, &L.wino_wgt, ug);
                 if (r2) return r2;
             }
@@ -920,6 +947,21 @@ int create_impl(const pa_config* cfg, const void* blob, size_t src_bytes, const 
                 } else {
                     rc = upload(e, &L.wgt, wf);
                     if (rc) return rc;
+                    // the same layer in Winograd form: the 3x3 alone on wino.hip, the 1x1/2 branch as a small GEMM of its own whose
+                    // result the 3x3 adds as its residual (PA_WINO >= 1 and the map sizes the kernel is faster on; else the fused
+                    // implicit GEMM above)
+                    static const int wino_mode = getenv("PA_WINO") ? atoi(getenv("PA_WINO")) : 1;
+                    static const int wino_ds = getenv("PA_WINO_DS") ? atoi(getenv("PA_WINO_DS")) : 1;
+                    if (wino_mode && wino_ds && (wino_mode >= 2 || hw_out >= 8) && hw_out % 4 == 0) {
+                        L.wino_bn = wino_pick_bn(co, (long long)NC * (hw_out / 4) * (hw_out / 4));
+                        std::vector<float> ug(wino_weight_floats(co, co), 0.f);
+                        if (!br.dry) wino_transform_weights(keep_w.data(), co, co, L.wino_bn, ug.data());
+                        rc = upload(e, &L.wino_wgt, ug);
+                        if (rc) return rc;
+                        rc = upload(e, &L.ds_wgt, wd);   // [co][cin] fp32
+                        if (rc) return rc;
+                        ALLOC(L.ds_out, buf, true);
+                    }
                 }
                 rc = upload(e, &L.bias, bf);
                 if (rc) return rc;

@@ -125,16 +125,17 @@ struct WinoParams {
     const float* residual;  // addressed like out, or nullptr
     float* out;             // first channel of padded pixel (0, 0) of image 0
     int32_t n_img, height, width, cin, cout;
+    int32_t bn;             // output channels per workgroup the filters were laid out for (wino_pick_bn: 64 | 32)
     int32_t in_px_stride, in_row_stride, in_img_stride;      // floats
     int32_t out_px_stride, out_row_stride, out_img_stride, out_pad;
     int32_t relu, res_after;  // as GemmParams
-    int32_t n_sb, sb_per_row, sb_per_img, tiles_n, tiles_m;  // set by the launcher
+    int32_t n_sb, sb_per_row, sb_per_img, tiles_n;  // set by the launcher
     unsigned long long* clk;  // stamp launches only (PA_WINO_ABL=8)
 };
 size_t wino_weight_floats(int cin, int cout);
-int wino_bn(int cout);  // output channels per workgroup = per stage image of the filter layout (64 | 32)
+int wino_pick_bn(int cout, long long n_sb);  // output channels per workgroup = per stage image of the filter layout (64 | 32)
 // w [cout][ky][kx][cin] (host) -> ug [wino_weight_floats] (host)
-void wino_transform_weights(const float* w, int cin, int cout, float* ug);
+void wino_transform_weights(const float* w, int cin, int cout, int bn, float* ug);
 hipError_t launch_wino3x3(const WinoParams& p, hipStream_t s);
 
 // ---------------------------------------------------------------------------

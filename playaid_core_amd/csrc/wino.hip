@@ -29,6 +29,14 @@
 // The raw patch is the only activation traffic: 36 pixels per 16 outputs and chunk -- the patch-resident direct kernel
 // (patchconv.hip) moves 1.4 pixels per output and chunk and nine operand reads per pixel; this one 2.25 and four.
 //
+// Built, measured and taken out again (bit-identical results, no gain; DESIGN.md section 5.1c, profiles/r05_wino_*): a
+// PERSISTENT form -- one workgroup per CU over all its tiles, its two wave groups half a chunk apart (one transforms while the
+// other multiplies), copies running on across tiles, a three-stage ring -- 56.9 against 57.1 us on layer 1, 51.8 against 48.8
+// on layer 2; both row operands of a wave in one ds_read_b128; read-ahead depths 2 and 5. Per-wave stamps put an iteration of
+// the chunk loop at 5190 cycles in EVERY form, against 4096 cycles of matrix-pipe time (v_mfma_f32_16x16x4_f32 issues every
+// 32 cycles by itself: scripts/micro/mfma_f32_rate.hip); the operand reads, the copies and the transform each add their own
+// time to a matrix-only skeleton instead of hiding under it (profiles/r05_wino_ablations_b2b.txt).
+//
 // Summation order: chunks ascending, two channels per instruction pair, fixed by the launch geometry alone (no split, no
 // atomics): results are bitwise repeatable and do not depend on the batch size.
 #include "pa_kernels.h"
@@ -40,16 +48,12 @@
 namespace pa {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-#ifndef WN_A128
-#define WN_A128 0   // 1: a lane's row operands of both 16-channel groups of its wave in one ds_read_b128 (filter image [p][cg][r][kq][g][2])
-#endif
 #ifndef WN_AHEAD
-#define WN_AHEAD 3   // positions the row-operand reads run ahead of their matrix instructions
+#define WN_AHEAD 3   // positions the row-operand reads run ahead of their matrix instructions (2 and 5 measure the same: profiles/r05_wino_operand_read_variants.txt)
 #endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) float lds_f;
-typedef __attribute__((address_space(3))) const volatile f32x2 lds_cv2;
-typedef __attribute__((address_space(3))) const volatile f32x4 lds_cv4;  // an LDS read hipcc may not merge with its neighbour
+typedef __attribute__((address_space(3))) const volatile f32x2 lds_cv2;  // an LDS read hipcc may not merge with its neighbour
 
 namespace {
 
@@ -121,14 +125,6 @@ __device__ __forceinline__ void wino_chunk(const lds_f* ul, const lds_f* pl, f32
     // four-way conflicts on this image and half the rate of two ds_read_b64 even without)
     constexpr int AHEAD = WN_AHEAD;
     f32x2 a[16][2];
-#if WN_A128
-#define WN_LOAD_A(P)                                                       \
-    {                                                                      \
-        const f32x4 q_ = *(lds_cv4*)(ul + a_off + (P) * GI * 128);         \
-        a[P][0] = f32x2{q_.x, q_.y};                                       \
-        a[P][1] = f32x2{q_.z, q_.w};                                       \
-    }
-#else
 #define WN_LOAD_A(P)                                                       \
     {                                                                      \
         if (ABL & 16) { a[P][0] = f32x2{(float)a_off, 0.5f}; a[P][1] = f32x2{0.25f, (float)(P)}; } else {  \
@@ -136,7 +132,6 @@ __device__ __forceinline__ void wino_chunk(const lds_f* ul, const lds_f* pl, f32
         a[P][1] = *(lds_cv2*)(ul + a_off + ((P) * GI + 1) * 128);          \
         }                                                                  \
     }
-#endif
 #pragma unroll
     for (int p = 0; p < AHEAD; ++p) WN_LOAD_A(p);
     f32x2 tt[4][4];
@@ -272,7 +267,7 @@ __global__ __launch_bounds__(64 * TGN * NCG) void wino3x3_kernel(const WinoParam
     if (D == 2 && n_chunks > 1) WN_ISSUE_ALL(u_lds1, p_lds1, 1);
 
     // operand addresses inside a stage
-    const int a_off = WN_A128 ? cg * 2 * 128 + t * 16 + kq * 4 : cg * 2 * 128 + t * 8 + ((2 * kq + 4 * (t >> 3)) & 7);
+    const int a_off = cg * 2 * 128 + t * 8 + ((2 * kq + 4 * (t >> 3)) & 7);
     const int sbl_own = tg * 4 + (t >> 2);
     const int r_off = (kq >> 1) * (G::PLANE_SLOTS * 4) + (tg * G::TG_SLOTS + wn_sb_base(t >> 2) + ((t >> 1) & 1) * 12 + (t & 1) * 2) * 4 + (kq & 1) * 2;
 
@@ -386,324 +381,27 @@ __global__ __launch_bounds__(64 * TGN * NCG) void wino3x3_kernel(const WinoParam
 }
 
 
-// ---- the persistent form (64-channel workgroups) ---------------------------------------------------------------------------
-//
-// Per-wave stamps of the kernel above (profiles/r05_wino_stamps_*.txt) put a workgroup's life at: prologue 3500-8400 cycles
-// (entry -> first chunk landed), per chunk ~490 (raw reads + input transform, both waves of a SIMD at once: the matrix pipe idle)
-// + ~3700 (matrix phase) + ~950 (drain, barrier), epilogue ~5700 (output transform: vector work, the matrix pipe idle again), and
-// the launch ~25 % longer than its workgroups' lives (one workgroup per CU: nothing of the next round runs under the last one's
-// tail). This form keeps ONE workgroup per CU alive over all its tiles and lets its two wave groups run half a chunk apart:
-//   * group A (waves 0-3, channels 0-31 of the tile) runs chunk w as  transform(w) -> matrix(w);
-//     group B (waves 4-7, channels 32-63) as  matrix(w - 1) -> transform(w): on every SIMD one wave's transform (and, at a tile's
-//     end, its output transform + stores) runs under the other's matrix instructions. One barrier per chunk as before; a stage
-//     is read by B one chunk after A, hence a THREE-stage ring with copies still issued one chunk ahead;
-//   * the chunk sequence runs on across tiles (w = tile ordinal x chunks + chunk): the first chunks of the next tile are on their
-//     way while this tile's last chunks multiply, so only a workgroup's first tile pays a prologue;
-//   * a wave's stores (8 per tile) are younger than the copies it must wait for in front of the next barrier: that one wait is
-//     vmcnt(8), every other vmcnt(0).
-// Same arithmetic in the same order as the kernel above: results are bit-identical to it.
-template <int ABL>
-__device__ __forceinline__ void wn_transform(const lds_f* pl, int r_off, f32x2 (&v)[16]) {
-    f32x2 d[4][4];
-#pragma unroll
-    for (int y = 0; y < 4; ++y)
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
-            d[y][x] = (ABL & 4) ? f32x2{(float)r_off, 1.f} : *(lds_cv2*)(pl + r_off + (y * 6 + x) * 4);
-    f32x2 tt[4][4];
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {
-        tt[0][x] = d[0][x] - d[2][x];
-        tt[1][x] = d[1][x] + d[2][x];
-        tt[2][x] = d[2][x] - d[1][x];
-        tt[3][x] = d[1][x] - d[3][x];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        v[4 * i + 0] = tt[i][0] - tt[i][2];
-        v[4 * i + 1] = tt[i][1] + tt[i][2];
-        v[4 * i + 2] = tt[i][2] - tt[i][1];
-        v[4 * i + 3] = tt[i][1] - tt[i][3];
-    }
-}
-
-template <int GI, int ABL, int KD, typename IssueFn>
-__device__ __forceinline__ void wn_matrix(const lds_f* ul, int a_off, const f32x2 (&v)[16], f32x4 (&acc)[16][2], IssueFn issue) {
-    constexpr int AHEAD = WN_AHEAD;
-    f32x2 a[16][2];
-#if WN_A128
-#define WN_LOAD_A(P)                                                       \
-    {                                                                      \
-        const f32x4 q_ = *(lds_cv4*)(ul + a_off + (P) * GI * 128);         \
-        a[P][0] = f32x2{q_.x, q_.y};                                       \
-        a[P][1] = f32x2{q_.z, q_.w};                                       \
-    }
-#else
-#define WN_LOAD_A(P)                                                       \
-    {                                                                      \
-        if (ABL & 16) { a[P][0] = f32x2{(float)a_off, 0.5f}; a[P][1] = f32x2{0.25f, (float)(P)}; } else {  \
-        a[P][0] = *(lds_cv2*)(ul + a_off + ((P) * GI + 0) * 128);          \
-        a[P][1] = *(lds_cv2*)(ul + a_off + ((P) * GI + 1) * 128);          \
-        }                                                                  \
-    }
-#endif
-#pragma unroll
-    for (int p = 0; p < AHEAD; ++p) WN_LOAD_A(p);
-#pragma unroll
-    for (int p = 0; p < 16; ++p) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (p + AHEAD < 16) WN_LOAD_A(p + AHEAD);
-#pragma unroll
-        for (int k = 0; k < KD; ++k)
-            if ((k * 14) / KD == p) issue(k);
-        __builtin_amdgcn_sched_barrier(0);
-        if (ABL & 2) {
-            acc[p][0].x += a[p][0].x * v[p].x + a[p][0].y * v[p].y;
-            acc[p][1].x += a[p][1].x * v[p].x + a[p][1].y * v[p].y;
-            continue;
-        }
-        acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p][0].x, v[p].x, acc[p][0], 0, 0, 0);
-        acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p][1].x, v[p].x, acc[p][1], 0, 0, 0);
-        acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p][0].y, v[p].y, acc[p][0], 0, 0, 0);
-        acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p][1].y, v[p].y, acc[p][1], 0, 0, 0);
-    }
-#undef WN_LOAD_A
-}
-
-// output transform + bias / residual / activation + stores of one tile's accumulators, then the accumulators cleared.
-// Returns whether the wave issued its 8 stores (any of its four sub-blocks inside the launch).
-__device__ __forceinline__ bool wn_epilogue(const WinoParams& p, f32x4 (&acc)[16][2], int tile_m, int tile_n, int tg, int cg, int t, int kq) {
-    const int sb_own = tile_m * 16 + tg * 4 + (t >> 2);
-    const bool own = sb_own < p.n_sb;
-    const bool wave_valid = tile_m * 16 + tg * 4 < p.n_sb;
-    if (own) {
-        const int img = wn_div(sb_own, p.sb_per_img);
-        const int rem = sb_own - img * p.sb_per_img;
-        const int sby = wn_div(rem, p.sb_per_row);
-        const int sbx = rem - sby * p.sb_per_row;
-        const int oy0 = 4 * sby + 2 * ((t >> 1) & 1), ox0 = 4 * sbx + 2 * (t & 1);
-        const int ch0 = tile_n * 64 + cg * 32 + 4 * kq;
-        const long o00 = (long)img * p.out_img_stride + (long)(oy0 + p.out_pad) * p.out_row_stride + (ox0 + p.out_pad) * p.out_px_stride + ch0;
-        f32x4 res4[2][2][2];
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                res4[g][i >> 1][i & 1] = p.residual ? *reinterpret_cast<const f32x4*>(p.residual + o00 + (long)(i >> 1) * p.out_row_stride + (i & 1) * p.out_px_stride + 16 * g)
-                                                   : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const f32x4 bias4 = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + ch0 + 16 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
-            f32x4 s0[4], s1[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                s0[j] = acc[j][g] + acc[4 + j][g] + acc[8 + j][g];
-                s1[j] = acc[4 + j][g] - acc[8 + j][g] - acc[12 + j][g];
-            }
-            f32x4 y[2][2];
-            y[0][0] = s0[0] + s0[1] + s0[2];
-            y[0][1] = s0[1] - s0[2] - s0[3];
-            y[1][0] = s1[0] + s1[1] + s1[2];
-            y[1][1] = s1[1] - s1[2] - s1[3];
-#pragma unroll
-            for (int oy = 0; oy < 2; ++oy)
-#pragma unroll
-                for (int ox = 0; ox < 2; ++ox) {
-                    const long o = o00 + (long)oy * p.out_row_stride + ox * p.out_px_stride + 16 * g;
-                    const f32x4 r4 = res4[g][oy][ox];
-                    f32x4 v = y[oy][ox] + (p.res_after ? bias4 : bias4 + r4);
-                    if (p.relu == 1) {
-                        v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
-                        v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
-                    } else if (p.relu == 2) {
-                        v.x = silu_fast(v.x); v.y = silu_fast(v.y);
-                        v.z = silu_fast(v.z); v.w = silu_fast(v.w);
-                    }
-                    if (p.res_after) v += r4;
-                    *reinterpret_cast<f32x4*>(p.out + o) = v;
-                }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-        acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    return wave_valid;
-}
-
-template <int ABL>
-__global__ __launch_bounds__(512) void wino3x3_p_kernel(const WinoParams p) {
-    using G = WinoGeo<4, 2>;
-    constexpr int NW = 8, KU = G::U_INSTR / NW, KPI = (G::P_INSTR + NW - 1) / NW, KD = KU + KPI;
-    constexpr int SF = G::U_FLOATS + G::P_FLOATS;   // floats per stage: filters, then the patch planes
-    __shared__ __attribute__((aligned(16))) float ring[3 * SF];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tg = wave & 3, grp = wave >> 2;   // grp = channel group = which half-chunk phase the wave runs in
-    const int t = lane & 15, kq = lane >> 4;
-    const int nwg = gridDim.x, b = blockIdx.x;
-    const int q = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
-    const int wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (b >> 3);
-    const int n_chunks = p.cin >> 3;
-    const int n_tiles = p.tiles_m * p.tiles_n;
-    const int nt = (n_tiles - wg + nwg - 1) / nwg;   // this workgroup's tiles: wg, wg + nwg, ... (>= 1: the grid is no larger than the tile count)
-    const int W = nt * n_chunks;
-
-    // stamp build (ABL & 8): lane 0 of every wave: [0] entry, [1 + w] behind the barrier that ends its iteration w, [62] in front of
-    // its last epilogue, [63] exit
-    unsigned long long* const clk = (ABL & 8) && p.clk && lane == 0 ? p.clk + ((size_t)blockIdx.x * NW + wave) * 64 : nullptr;
-    if ((ABL & 8) && clk) clk[0] = __builtin_amdgcn_s_memtime();
-#define WN_PSTAMP(K) if ((ABL & 8) && clk && (K) < 62) clk[K] = __builtin_amdgcn_s_memtime()
-    const i32x4 act_rsrc = wn_rsrc(p.act), wgt_rsrc = wn_rsrc(p.wgt);
-    const unsigned ring_addr = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)ring;
-
-    // the tile whose chunks are being ISSUED: this lane's patch sources and the tile's filter image
-    int pvoff[KPI], pdst[KPI], u_soff0 = 0;
-#pragma unroll
-    for (int k = 0; k < KPI; ++k) {
-        int idx = k * NW + wave;
-        idx = idx < G::P_INSTR ? idx : idx - NW;
-        pdst[k] = idx * 256;
-    }
-    auto set_issue_tile = [&](int ordinal) {
-        const int tl = wg + ordinal * nwg;
-        const int tile_m = tl / p.tiles_n, tile_n = tl - tile_m * p.tiles_n;
-        u_soff0 = tile_n * n_chunks * (G::U_FLOATS * 4);
-#pragma unroll
-        for (int k = 0; k < KPI; ++k) {
-            const int slot = (pdst[k] >> 2) + lane;   // pdst = idx * 256 floats = idx * 64 slots
-            const int h = slot >= G::PLANE_SLOTS ? 1 : 0;
-            const int pi = slot - h * G::PLANE_SLOTS;
-            int tgi = pi / G::TG_SLOTS;
-            tgi = tgi < G::TG ? tgi : G::TG - 1;
-            const int rem = pi - tgi * G::TG_SLOTS;
-            const int s4 = rem >= 121 ? 3 : (rem >= 81 ? 2 : (rem >= 40 ? 1 : 0));
-            int px = rem - wn_sb_base(s4);
-            px = px < 36 ? px : 35;
-            int sb = tile_m * G::NSB + tgi * 4 + s4;
-            sb = sb < p.n_sb ? sb : p.n_sb - 1;
-            const int img = wn_div(sb, p.sb_per_img);
-            const int rem2 = sb - img * p.sb_per_img;
-            const int sby = wn_div(rem2, p.sb_per_row);
-            const int sbx = rem2 - sby * p.sb_per_row;
-            const int y = px / 6;
-            const int x = px - y * 6;
-            pvoff[k] = (img * p.in_img_stride + (4 * sby + y) * p.in_row_stride + (4 * sbx + x) * p.in_px_stride + h * 4) * 4;
-        }
-    };
-    // DMA instruction k (0 .. KD - 1) of channel chunk c of the issue tile into ring stage st
-    auto issue_piece = [&](int k, int st, int c) {
-        const unsigned base = ring_addr + (unsigned)st * (SF * 4);
-        if (k < KU) {
-            const unsigned lds_addr = base + ((k * NW + wave) * 256) * 4;
-            asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
-                         :: "v"(((k * NW + wave) * 64 + lane) * 16), "s"(wgt_rsrc), "s"(u_soff0 + c * (G::U_FLOATS * 4)), "s"(lds_addr) : "memory");
-        } else {
-            const unsigned lds_addr = base + (G::U_FLOATS + pdst[k - KU]) * 4;
-            asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
-                         :: "v"(pvoff[k - KU]), "s"(act_rsrc), "s"(c * 32), "s"(lds_addr) : "memory");
-        }
-    };
-
-    // operand addresses inside a stage
-    const int a_off = WN_A128 ? grp * 2 * 128 + t * 16 + kq * 4 : grp * 2 * 128 + t * 8 + ((2 * kq + 4 * (t >> 3)) & 7);
-    const int r_off = G::U_FLOATS + (kq >> 1) * (G::PLANE_SLOTS * 4) + (tg * G::TG_SLOTS + wn_sb_base(t >> 2) + ((t >> 1) & 1) * 12 + (t & 1) * 2) * 4 + (kq & 1) * 2;
-    const lds_f* const ring3 = (const lds_f*)ring;
-
-    f32x4 acc[16][2];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-        acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-
-    // prologue: the first chunk of the first tile, in one burst
-    set_issue_tile(0);
-#pragma unroll
-    for (int k = 0; k < KD; ++k) issue_piece(k, 0, 0);
-    int i_ord = n_chunks > 1 ? 0 : 1, i_c = n_chunks > 1 ? 1 : 0;   // the next chunk to issue: (tile ordinal, channel chunk)
-    wn_wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-
-    // the tile whose chunks are being COMPUTED
-    int c_ord = 0, c_c = 0;
-    auto finish_tile = [&]() -> bool {
-        const int tl = wg + c_ord * nwg;
-        const int tile_m = tl / p.tiles_n, tile_n = tl - tile_m * p.tiles_n;
-        return wn_epilogue(p, acc, tile_m, tile_n, tg, grp, t, kq);
-    };
-    f32x2 v[16];
-    if (grp == 0) {
-        int s = 0;
-        for (int w = 0; w < W; ++w) {
-            const bool more = w + 1 < W && !(ABL & 1);
-            if (more && i_c == 0) set_issue_tile(i_ord);
-            const int st = s == 2 ? 0 : s + 1;
-            const int ic = i_c;
-            wn_transform<ABL>(ring3 + s * SF, r_off, v);
-            wn_matrix<4, ABL, KD>(ring3 + s * SF, a_off, v, acc, [&](int k) { if (more) issue_piece(k, st, ic); });
-            if (more) { if (++i_c == n_chunks) { i_c = 0; ++i_ord; } }
-            bool stored = false;
-            if (c_c == n_chunks - 1) { stored = finish_tile(); c_c = 0; ++c_ord; } else ++c_c;
-            if (stored) wn_wait_vmcnt<8>(); else wn_wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-            WN_PSTAMP(1 + w);
-            s = st;
-        }
-    } else {
-        // chunk 0: the transform only; its copies of chunk 1 in one burst (no matrix phase to spread them over)
-        wn_transform<ABL>(ring3, r_off, v);
-        if (W > 1 && !(ABL & 1)) {
-            if (i_c == 0) set_issue_tile(i_ord);
-#pragma unroll
-            for (int k = 0; k < KD; ++k) issue_piece(k, 1, i_c);
-            if (++i_c == n_chunks) { i_c = 0; ++i_ord; }
-        }
-        wn_wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        WN_PSTAMP(1);
-        int s = 1, sp = 0;   // stages of chunk w and of chunk w - 1
-        for (int w = 1; w < W; ++w) {
-            const bool more = w + 1 < W && !(ABL & 1);
-            if (more && i_c == 0) set_issue_tile(i_ord);
-            const int st = s == 2 ? 0 : s + 1;
-            const int ic = i_c;
-            wn_matrix<4, ABL, KD>(ring3 + sp * SF, a_off, v, acc, [&](int k) { if (more) issue_piece(k, st, ic); });
-            if (more) { if (++i_c == n_chunks) { i_c = 0; ++i_ord; } }
-            bool stored = false;
-            if (c_c == n_chunks - 1) { stored = finish_tile(); c_c = 0; ++c_ord; } else ++c_c;
-            wn_transform<ABL>(ring3 + s * SF, r_off, v);
-            if (stored) wn_wait_vmcnt<8>(); else wn_wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-            WN_PSTAMP(1 + w);
-            sp = s;
-            s = st;
-        }
-        wn_matrix<4, ABL, KD>(ring3 + sp * SF, a_off, v, acc, [&](int) {});
-        if ((ABL & 8) && clk) clk[62] = __builtin_amdgcn_s_memtime();
-        (void)finish_tile();
-    }
-    if ((ABL & 8) && clk) clk[63] = __builtin_amdgcn_s_memtime();
-#undef WN_PSTAMP
-}
-
 }  // namespace
 
 size_t wino_weight_floats(int cin, int cout) { return (size_t)16 * cin * cout; }
 
 // [cout][ky][kx][cin] (BatchNorm folded) -> the stage images the kernel copies: [cout / BN][cin / 8][16][BN / 16][16][8]
 // with G g G^T evaluated in fp64 and rounded once
-// output channels per workgroup (= per filter stage image): 64 where the layer has them, unless PA_WINO_BN=32 asks for the
-// four-wave, 32-channel workgroup everywhere (two per CU; an A/B knob read once per process, so filters and launches agree)
-int wino_bn(int cout) {
+// Output channels per workgroup (= per stage image of the filter layout) for a layer of `cout` channels and `n_sb` 4x4-pixel
+// sub-blocks per launch: 64 (eight waves: 4 tile groups x 2 channel groups) where that fills the chip; 32 -- four waves, two
+// workgroups per CU -- where 64-channel workgroups would leave CUs idle (ResNet-18's layer 3 at 128 crops: 128 workgroups of 64
+// channels take 81 us, 256 of 32 channels 65; the detector's 12 x 20 map at 64 frames has 240 and keeps 64: 83 against 121 us)
+// and for layers of 32 channels (eight tile groups). PA_WINO_BN=32|64 forces it (A/B).
+int wino_pick_bn(int cout, long long n_sb) {
     static const int force = getenv("PA_WINO_BN") ? atoi(getenv("PA_WINO_BN")) : 0;
-    return (cout % 64 == 0 && force != 32) ? 64 : 32;
+    if (cout % 64) return 32;
+    if (force == 32 || force == 64) return force;
+    const long long wg64 = ((n_sb + 15) / 16) * (cout / 64);
+    return wg64 < 192 ? 32 : 64;
 }
 
-void wino_transform_weights(const float* w, int cin, int cout, float* ug) {
-    const int bn = wino_bn(cout), gi_n = bn / 16, n_chunks = cin / 8;
+void wino_transform_weights(const float* w, int cin, int cout, int bn, float* ug) {
+    const int gi_n = bn / 16, n_chunks = cin / 8;
     static const double Gm[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
     for (int co = 0; co < cout; ++co)
         for (int ci = 0; ci < cin; ++ci) {
@@ -716,9 +414,7 @@ void wino_transform_weights(const float* w, int cin, int cout, float* ug) {
                 for (int j = 0; j < 4; ++j) u[i][j] = tmp[i][0] * Gm[j][0] + tmp[i][1] * Gm[j][1] + tmp[i][2] * Gm[j][2];
             const int tile_n = co / bn, gi = (co % bn) / 16, r = co % 16, c = ci / 8, cc = ci % 8;
             for (int pp = 0; pp < 16; ++pp) {
-                // (WN_A128: a wave's two 16-channel groups side by side, [pair of groups][r][kq][g][2 cin]: 16 contiguous bytes per lane)
-                const size_t idx = WN_A128 ? ((((size_t)tile_n * n_chunks + c) * 16 + pp) * gi_n + (gi & ~1)) * 128 + r * 16 + (cc >> 1) * 4 + (gi & 1) * 2 + (cc & 1)
-                                           : ((((size_t)tile_n * n_chunks + c) * 16 + pp) * gi_n + gi) * 128 + r * 8 + ((cc + 4 * (r >> 3)) & 7);
+                const size_t idx = ((((size_t)tile_n * n_chunks + c) * 16 + pp) * gi_n + gi) * 128 + r * 8 + ((cc + 4 * (r >> 3)) & 7);
                 ug[idx] = (float)u[pp >> 2][pp & 3];
             }
         }
@@ -736,59 +432,13 @@ hipError_t launch_wino3x3(const WinoParams& p_in, hipStream_t s) {
     // byte offsets inside the buffer descriptors are 32-bit
     if ((long long)p.n_img * p.in_img_stride * 4 >= (1ll << 31) || (long long)wino_weight_floats(p.cin, p.cout) * 4 >= (1ll << 31)) return hipErrorInvalidValue;
     p.n_sb = (int)n_sb;
-    const int bn = wino_bn(p.cout);
-    static const int small_wg = getenv("PA_WINO_BN") && atoi(getenv("PA_WINO_BN")) == 32;
+    const int bn = p.bn;
+    if ((bn != 32 && bn != 64) || p.cout % bn) return hipErrorInvalidValue;
+    const bool small_wg = bn == 32 && p.cout % 64 == 0;   // four-wave workgroups (layers that also have the 64-channel form)
     const int nsb = bn == 64 ? 16 : (small_wg ? 16 : 32);
     p.tiles_n = p.cout / bn;
     const int tiles_m = (p.n_sb + nsb - 1) / nsb;
-    p.tiles_m = tiles_m;
     const int grid = tiles_m * p.tiles_n;
-    // 64-channel workgroups: the persistent, half-chunk-skewed form (one workgroup per CU over all its tiles); PA_WINO_PERSIST=0
-    // keeps one workgroup per tile (A/B)
-    static const int persist = getenv("PA_WINO_PERSIST") ? atoi(getenv("PA_WINO_PERSIST")) : 1;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-        n_cu = cus;
-    }
-    if (bn == 64 && persist) {
-        const int pgrid = grid < n_cu ? grid : n_cu;
-        static const int pabl = getenv("PA_WINO_ABL") ? atoi(getenv("PA_WINO_ABL")) : 0;
-        switch (pabl) {
-            case 1: hipLaunchKernelGGL((wino3x3_p_kernel<1>), dim3(pgrid), dim3(512), 0, s, p); break;
-            case 2: hipLaunchKernelGGL((wino3x3_p_kernel<2>), dim3(pgrid), dim3(512), 0, s, p); break;
-            case 3: hipLaunchKernelGGL((wino3x3_p_kernel<3>), dim3(pgrid), dim3(512), 0, s, p); break;
-            case 8: {
-                static int calls = 0;
-                static unsigned long long* dev = nullptr;
-                const char* sf = getenv("PA_WINO_STAMP_FILE");
-                const bool now = sf && calls++ == (getenv("PA_WINO_STAMP_CALL") ? atoi(getenv("PA_WINO_STAMP_CALL")) : 0);
-                const size_t words = (size_t)pgrid * 8 * 64;
-                if (now) {
-                    if (dev) (void)hipFree(dev);
-                    if (hipMalloc(&dev, words * 8) != hipSuccess) return hipErrorOutOfMemory;
-                    (void)hipMemset(dev, 0, words * 8);
-                    p.clk = dev;
-                }
-                hipLaunchKernelGGL((wino3x3_p_kernel<8>), dim3(pgrid), dim3(512), 0, s, p);
-                if (now) {
-                    (void)hipStreamSynchronize(s);
-                    std::vector<unsigned long long> hst(words);
-                    (void)hipMemcpy(hst.data(), dev, words * 8, hipMemcpyDeviceToHost);
-                    if (FILE* f = fopen(sf, "wb")) {
-                        const int hdr[4] = {pgrid, 8, p.cin, -grid};   // (negative last word: the persistent kernel's stamp layout, grid = tiles)
-                        fwrite(hdr, 4, 4, f);
-                        fwrite(hst.data(), 8, words, f);
-                        fclose(f);
-                    }
-                }
-                break;
-            }
-            default: hipLaunchKernelGGL((wino3x3_p_kernel<0>), dim3(pgrid), dim3(512), 0, s, p);
-        }
-        return hipGetLastError();
-    }
     static const int abl = getenv("PA_WINO_ABL") ? atoi(getenv("PA_WINO_ABL")) : 0;
     static const int nst = getenv("PA_WINO_STAGES") ? atoi(getenv("PA_WINO_STAGES")) : 2;  // 3: a three-stage ring (A/B: 62.3 against 61.5 us on layer 1, 95.2 against 92.1 on the 24 x 40 map -- the prologue then waits behind two chunks of copies)
 #define WN_LAUNCH(ABL_)                                                                                        \
@@ -852,19 +502,24 @@ size_t pa_wino_weight_floats(int32_t cin, int32_t cout) {
     return pa::wino_weight_floats(cin, cout);
 }
 
-int pa_wino_transform_weights(const float* w_host, int32_t cin, int32_t cout, float* ug_host) {
-    if (!w_host || !ug_host || cin < 8 || cin % 8 || cout < 32 || cout % 32) return PA_ERR_INVALID_ARG;
-    pa::wino_transform_weights(w_host, cin, cout, ug_host);
+int pa_wino_channels_per_workgroup(int32_t cout, int64_t sub_blocks) {
+    if (cout < 32 || cout % 32 || sub_blocks < 1) return 0;
+    return pa::wino_pick_bn(cout, sub_blocks);
+}
+
+int pa_wino_transform_weights(const float* w_host, int32_t cin, int32_t cout, int32_t bn, float* ug_host) {
+    if (!w_host || !ug_host || cin < 8 || cin % 8 || cout < 32 || cout % 32 || (bn != 32 && bn != 64) || cout % bn) return PA_ERR_INVALID_ARG;
+    pa::wino_transform_weights(w_host, cin, cout, bn, ug_host);
     return PA_OK;
 }
 
 int pa_wino_conv3x3(const float* x, const float* ug, const float* bias, const float* residual, float* out, int32_t n, int32_t height,
-                    int32_t width, int32_t cin, int32_t cout, int32_t in_px_stride, int32_t out_px_stride, int32_t out_pad, int32_t act,
+                    int32_t width, int32_t cin, int32_t cout, int32_t bn, int32_t in_px_stride, int32_t out_px_stride, int32_t out_pad, int32_t act,
                     int32_t res_after, void* stream) {
     if (!x || !ug || !out || n < 1 || out_pad < 0 || act < 0 || act > 2) return PA_ERR_INVALID_ARG;
     pa::WinoParams p{};
     p.act = x; p.wgt = ug; p.bias = bias; p.residual = residual; p.out = out;
-    p.n_img = n; p.height = height; p.width = width; p.cin = cin; p.cout = cout;
+    p.n_img = n; p.height = height; p.width = width; p.cin = cin; p.cout = cout; p.bn = bn;
     p.in_px_stride = in_px_stride;
     p.in_row_stride = (width + 2) * in_px_stride;
     p.in_img_stride = (height + 2) * p.in_row_stride;

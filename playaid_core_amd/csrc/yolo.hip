@@ -325,6 +325,7 @@ struct pa_detector {
     size_t n_weights = 0;
     float* wino_weights = nullptr;      // the stride-1 3x3 layers' filters in the Winograd kernel's layout (wino.hip)
     std::vector<long long> wino_off;    // per layer: float offset into wino_weights, -1 = the layer runs in its direct form
+    std::vector<int> wino_bn;           // per layer: output channels per workgroup its filters were laid out for
     float* x0 = nullptr;       // letter-boxed input [max_images][net_h + 4][net_w + 4][4]
     float* anchors = nullptr;  // device copy of the decode layers' anchors [n_decode][8]
     std::string last_error;
@@ -419,18 +420,20 @@ int pa_detector_create(int32_t device, const pa_net_layer* layers, int32_t n_lay
         // fp64. PA_DET_WINO=0 keeps the direct patch-resident kernel (A/B)
         static const int use_wino = getenv("PA_DET_WINO") ? atoi(getenv("PA_DET_WINO")) : 1;
         h->wino_off.assign(n_layers, -1);
+        h->wino_bn.assign(n_layers, 0);
         size_t total = 0;
         for (int i = 0; i < n_layers; ++i) {
             const pa_net_layer& L = h->layers[i];
             if (use_wino && L.kind == 0 && L.ksize == 3 && L.stride == 1 && L.in_pad == 1 && L.in_h % 4 == 0 && L.in_w % 4 == 0 && L.cin % 8 == 0) {
                 h->wino_off[i] = (long long)total;
+                h->wino_bn[i] = pa::wino_pick_bn(L.cout, (long long)max_images * (L.in_h / 4) * (L.in_w / 4));
                 total += pa::wino_weight_floats(L.cin, L.cout);
             }
         }
         if (total) {
             std::vector<float> ug(total);
             for (int i = 0; i < n_layers; ++i)
-                if (h->wino_off[i] >= 0) pa::wino_transform_weights(weights_host + h->layers[i].w_off, h->layers[i].cin, h->layers[i].cout, ug.data() + h->wino_off[i]);
+                if (h->wino_off[i] >= 0) pa::wino_transform_weights(weights_host + h->layers[i].w_off, h->layers[i].cin, h->layers[i].cout, h->wino_bn[i], ug.data() + h->wino_off[i]);
             if (!chk(hipMalloc(&h->wino_weights, total * sizeof(float)), "hipMalloc Winograd filters")) return PA_ERR_HIP;
             if (!chk(hipMemcpy(h->wino_weights, ug.data(), total * sizeof(float), hipMemcpyHostToDevice), "upload Winograd filters")) return PA_ERR_HIP;
         }
@@ -607,7 +610,7 @@ static int detector_run(pa_detector* h, const uint8_t* frames, int32_t n, int32_
             pa::WinoParams q;
             memset(&q, 0, sizeof(q));
             q.act = p.act; q.wgt = h->wino_weights + h->wino_off[li]; q.bias = p.bias; q.residual = p.residual; q.out = p.out;
-            q.n_img = n; q.height = L.in_h; q.width = L.in_w; q.cin = L.cin; q.cout = L.cout;
+            q.n_img = n; q.height = L.in_h; q.width = L.in_w; q.cin = L.cin; q.cout = L.cout; q.bn = h->wino_bn[li];
             q.in_px_stride = p.in_px_stride; q.in_row_stride = p.in_row_stride; q.in_img_stride = p.in_img_stride;
             q.out_px_stride = p.out_px_stride; q.out_row_stride = p.out_row_stride; q.out_img_stride = p.out_img_stride; q.out_pad = p.out_pad;
             q.relu = p.relu; q.res_after = p.res_after;

@@ -14,23 +14,34 @@ import torch
 from . import _lib
 
 
-def transform_weights(w_oihw: np.ndarray) -> np.ndarray:
-    """[cout, cin, 3, 3] (BatchNorm already folded) -> the kernel's filter layout (float32, host)."""
+def channels_per_workgroup(cout: int, sub_blocks: int) -> int:
+    """The workgroup width (64 | 32 output channels) the engine picks for a layer launched over ``sub_blocks`` 4x4-pixel
+    sub-blocks (``n * H / 4 * W / 4``): part of the filter layout and of the launch."""
+    bn = _lib.load().pa_wino_channels_per_workgroup(cout, sub_blocks)
+    if bn == 0:
+        raise ValueError("cout must be a multiple of 32")
+    return bn
+
+
+def transform_weights(w_oihw: np.ndarray, bn: int = 0) -> np.ndarray:
+    """[cout, cin, 3, 3] (BatchNorm already folded) -> the kernel's filter layout (float32, host) for workgroups of ``bn`` output
+    channels (0: 64 where the layer has them)."""
     lib = _lib.load()
     w = np.ascontiguousarray(np.asarray(w_oihw, dtype=np.float32).transpose(0, 2, 3, 1))  # [cout][ky][kx][cin]
     cout, cin = w.shape[0], w.shape[3]
     n = lib.pa_wino_weight_floats(cin, cout)
     if n == 0:
         raise ValueError("cin must be a multiple of 8, cout a multiple of 32")
+    bn = bn or (64 if cout % 64 == 0 else 32)
     ug = np.empty(n, dtype=np.float32)
-    rc = lib.pa_wino_transform_weights(w.ctypes.data_as(C.c_void_p), cin, cout, ug.ctypes.data_as(C.c_void_p))
+    rc = lib.pa_wino_transform_weights(w.ctypes.data_as(C.c_void_p), cin, cout, bn, ug.ctypes.data_as(C.c_void_p))
     if rc:
         raise ValueError(f"pa_wino_transform_weights: {rc}")
     return ug
 
 
 def conv3x3(x_pad: torch.Tensor, ug: torch.Tensor, cin: int, cout: int, bias=None, residual=None, out=None, out_pad: int = 1,
-            act: int = 0, res_after: bool = False, out_px_stride: int = None) -> torch.Tensor:
+            act: int = 0, res_after: bool = False, out_px_stride: int = None, bn: int = 0) -> torch.Tensor:
     """x_pad float32[n, H + 2, W + 2, C >= cin] (device, zero border) -> out float32[n, H + 2 out_pad, W + 2 out_pad, C'] (interior
     written, border untouched). Enqueues on the current stream."""
     lib = _lib.load()
@@ -42,7 +53,7 @@ def conv3x3(x_pad: torch.Tensor, ug: torch.Tensor, cin: int, cout: int, bias=Non
     if out is None:
         out = torch.zeros((n, h + 2 * out_pad, w + 2 * out_pad, ops), dtype=torch.float32, device=x_pad.device)
     ptr = lambda t_: C.c_void_p(t_.data_ptr()) if t_ is not None else C.c_void_p(0)
-    rc = lib.pa_wino_conv3x3(ptr(x_pad), ptr(ug), ptr(bias), ptr(residual), ptr(out), n, h, w, cin, cout, cs, out.shape[3], out_pad,
+    rc = lib.pa_wino_conv3x3(ptr(x_pad), ptr(ug), ptr(bias), ptr(residual), ptr(out), n, h, w, cin, cout, bn or (64 if cout % 64 == 0 else 32), cs, out.shape[3], out_pad,
                              int(act), int(bool(res_after)), C.c_void_p(torch.cuda.current_stream(x_pad.device).cuda_stream))
     if rc:
         raise ValueError(f"pa_wino_conv3x3: status {rc}")

@@ -28,19 +28,6 @@ raw = open(os.environ["PA_WINO_STAMP_FILE"], "rb").read()
 grid, nw, cin_, n_sb = np.frombuffer(raw[:16], dtype=np.int32)
 st = np.frombuffer(raw[16:], dtype=np.uint64).reshape(grid, nw, 64).astype(np.int64)
 nch = cin_ // 8
-if n_sb < 0:
-    # the persistent kernel: [0] entry, [1 + w] behind the barrier ending iteration w, [62] before group B's last epilogue, [63] exit
-    tiles = -n_sb
-    per = (tiles + grid - 1) // grid
-    W = per * nch
-    print(f"persistent kernel: {grid} workgroups, {tiles} tiles, {nch} chunks per tile, up to {W} iterations; s_memtime ticks / 100")
-    full = st[st[..., 1 + min(W, 60) - 1].min(axis=1) > 0] if W <= 60 else st
-    for name, sl in (("group A (waves 0-3)", slice(0, 4)), ("group B (waves 4-7)", slice(4, 8))):
-        g = full[:, sl]
-        its = np.diff(g[..., 1:1 + min(W, 60)], axis=-1)
-        print(f"{name}: entry -> first barrier {np.median(g[..., 1] - g[..., 0]) / 100:.2f}; iterations (median) " + " ".join(f"{x / 100:.2f}" for x in np.median(its, axis=(0, 1))))
-        print(f"   lifetime median {np.median(g[..., 63] - g[..., 0]) / 100:.2f}, last barrier -> exit {np.median(g[..., 63] - g[..., min(W, 60)]) / 100:.2f}")
-    sys.exit(0)
 t0 = st[..., 0].min()
 print(f"shape n={n} {h}x{w} cin {cin} cout {cout}: grid {grid}, {nw} waves, {nch} chunks; values below are s_memtime ticks / 100 (shader clock: 100 ticks = ~42 ns at 2.4 GHz)")
 life = st[..., 63] - st[..., 0]

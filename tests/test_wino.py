@@ -23,9 +23,11 @@ def test_weight_transform_layout():
     rng = np.random.default_rng(3)
     for cin, cout in ((8, 32), (16, 64), (24, 96), (64, 128)):
         w = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32)
-        ug = wino.transform_weights(w)
-        u = _ref_transform(w).astype(np.float32)
         bn = 64 if cout % 64 == 0 else 32
+        if (cin, cout) == (64, 128):
+            bn = 32   # the four-wave form of a layer that also has the 64-channel one
+        ug = wino.transform_weights(w, bn=bn)
+        u = _ref_transform(w).astype(np.float32)
         gi_n, n_chunks = bn // 16, cin // 8
         img = ug.reshape(cout // bn, n_chunks, 16, gi_n, 16, 8)
         for co in rng.integers(0, cout, 12):
@@ -42,10 +44,12 @@ def test_transform_rejects_bad_shapes():
     lib = _lib.load()
     assert lib.pa_wino_weight_floats(12, 64) == 0 and lib.pa_wino_weight_floats(8, 48) == 0
     buf = np.zeros(16, dtype=np.float32)
-    assert lib.pa_wino_transform_weights(buf.ctypes.data_as(ctypes.c_void_p), 12, 64, buf.ctypes.data_as(ctypes.c_void_p)) != 0
+    assert lib.pa_wino_transform_weights(buf.ctypes.data_as(ctypes.c_void_p), 12, 64, 64, buf.ctypes.data_as(ctypes.c_void_p)) != 0
+    assert lib.pa_wino_transform_weights(buf.ctypes.data_as(ctypes.c_void_p), 8, 32, 64, buf.ctypes.data_as(ctypes.c_void_p)) != 0   # 32 channels, 64-wide workgroups
+    assert lib.pa_wino_transform_weights(buf.ctypes.data_as(ctypes.c_void_p), 8, 64, 48, buf.ctypes.data_as(ctypes.c_void_p)) != 0
 
 
-def _case(n, h, w, cin, cout, seed, act=0, residual=False, res_after=False, in_extra=0, out_extra=0, out_pad=1):
+def _case(n, h, w, cin, cout, seed, act=0, residual=False, res_after=False, in_extra=0, out_extra=0, out_pad=1, bn=0):
     from playaid_core_amd import wino
 
     rng = np.random.default_rng(seed)
@@ -64,9 +68,9 @@ def _case(n, h, w, cin, cout, seed, act=0, residual=False, res_after=False, in_e
     if residual:
         resp = torch.zeros_like(out)
         resp[:, out_pad:out_pad + h, out_pad:out_pad + w, :cout] = torch.from_numpy(res).permute(0, 2, 3, 1)
-    ug = torch.from_numpy(wino.transform_weights(wt)).to(dev)
+    ug = torch.from_numpy(wino.transform_weights(wt, bn=bn)).to(dev)
     got = wino.conv3x3(xp.to(dev), ug, cin, cout, bias=torch.from_numpy(b).to(dev), residual=resp.to(dev) if residual else None,
-                       out=out.to(dev), out_pad=out_pad, act=act, res_after=res_after).cpu()
+                       out=out.to(dev), out_pad=out_pad, act=act, res_after=res_after, bn=bn).cpu()
     ref = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(), torch.from_numpy(b).double(), padding=1)
     if residual and not res_after:
         ref = ref + torch.from_numpy(res).double()
@@ -101,6 +105,27 @@ def test_wino_conv_matches_conv2d(shape):
     n, h, w, cin, cout = shape
     err = _case(n, h, w, cin, cout, seed=h * 131 + cin)
     assert err <= 2e-5, (shape, err)
+
+
+def test_workgroup_width_rule():
+    """64-channel workgroups where they fill the chip, 32-channel ones where they would leave CUs idle (host-side rule)."""
+    from playaid_core_amd import wino
+
+    assert wino.channels_per_workgroup(64, 128 * 64) == 64       # ResNet-18 layer 1 at 128 crops: 512 workgroups
+    assert wino.channels_per_workgroup(256, 128 * 4) == 32       # layer 3: 128 workgroups of 64 channels -> 256 of 32
+    assert wino.channels_per_workgroup(256, 64 * 15) == 64       # the detector's 12 x 20 map at 64 frames: 240 workgroups
+    assert wino.channels_per_workgroup(32, 64 * 24 * 40) == 32   # a 32-channel layer has no 64-channel form
+    with pytest.raises(ValueError):
+        wino.channels_per_workgroup(48, 100)
+
+
+@pytest.mark.gpu
+def test_wino_conv_four_wave_workgroups():
+    """The 32-channel, four-wave workgroup form on layers that also have the 64-channel one (what the engine picks for small
+    launches): same results to the same bar, partial last workgroup included."""
+    assert _case(7, 8, 8, 256, 256, 11, bn=32) <= 2e-5
+    assert _case(3, 16, 16, 128, 128, 12, act=1, residual=True, bn=32) <= 2e-5
+    assert _case(1, 12, 20, 64, 64, 13, act=2, residual=True, res_after=True, bn=32) <= 2e-5
 
 
 @pytest.mark.gpu
