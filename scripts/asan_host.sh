@@ -4,13 +4,13 @@
 # marker parser + table builder of mjpeg.hip -- run against the no-GPU tests (argument validation, weight-blob sizes,
 # header probe on truncated and corrupted files). Device code is compiled WITHOUT instrumentation (-fno-gpu-sanitize):
 # GPU AddressSanitizer needs XNACK, which this pool does not offer. CPU box only; never run this on the GPU box.
-#   usage: scripts/asan_host.sh [log]        (log defaults to profiles/r03_asan_host.log)
+#   usage: scripts/asan_host.sh [log]        (log defaults to profiles/r05_asan_host.log)
 set -eu
 R=$(cd "$(dirname "$0")/.." && pwd)
-LOG=${1:-$R/profiles/r03_asan_host.log}
+LOG=${1:-$R/profiles/r05_asan_host.log}
 B=$R/build/asan
 mkdir -p $B
-SRC="igemm igemm_bf16 patchconv patchconv_bf16 stem stem_pool misc preprocess detect lstm convnet transformer jpeg mjpeg savebox yolo pa_api"
+SRC="igemm pigemm igemm_bf16 patchconv patchconv_bf16 wino stem stem_pool misc preprocess detect lstm convnet transformer jpeg mjpeg savebox yolo pa_api"
 for s in $SRC; do
   extra=""
   case $s in preprocess|detect|jpeg|savebox|yolo) extra="-ffp-contract=off";; esac

@@ -184,3 +184,80 @@ def test_jpeg_header_probe_on_the_host(lib):
             bad[k] = int(rng.integers(0, 256))
         rc, _, _ = probe(bytes(bad))
         assert rc in (0, _lib.PA_ERR_INVALID_ARG)
+
+
+def test_round5_host_planners_reject_bad_tables_and_stay_in_bounds(lib):
+    """Host-side planning code added in rounds 4-5, driven without a GPU (and under ASan / UBSan by scripts/asan_host.sh):
+    ``pa_detector_create``'s layer-table validation with truncated / inconsistent tables, ``pa_detector_forward_timed`` with a
+    short result buffer, the Winograd filter transform writing exactly its ``pa_wino_weight_floats`` floats for every layout, and
+    the argument checks of the round's new entries."""
+    import numpy as np
+
+    from playaid_core_amd import _lib, synth
+    from playaid_core_amd.yolov5 import build_yolov5s_table
+
+    layers, bufs, weights, rows = build_yolov5s_table(synth.make_yolov5s_state_dict(), (384, 640), 6)
+
+    def create(mutate=None, n_layers=None, n_weights=None, bufs_=None, net=(384, 640), nc=6, max_images=2):
+        arr = (_lib.pa_net_layer * len(layers))(*layers)
+        arr = (_lib.pa_net_layer * len(layers)).from_buffer_copy(bytes(arr))   # a private copy: the table object is reused
+        if mutate:
+            mutate(arr)
+        b = list(bufs_ if bufs_ is not None else bufs)
+        w = np.ascontiguousarray(weights[: n_weights if n_weights is not None else len(weights)], dtype=np.float32)
+        hh = ctypes.c_void_p(0)
+        rc = lib.pa_detector_create(0, arr, n_layers if n_layers is not None else len(layers), (ctypes.c_int64 * len(b))(*b), len(b),
+                                    w.ctypes.data_as(ctypes.c_void_p), w.size, max_images, net[0], net[1], nc, ctypes.byref(hh))
+        msg = lib.pa_detector_last_error(hh).decode() if hh else ""
+        return rc, msg, hh
+
+    def gone(hh):
+        if hh:
+            lib.pa_detector_destroy(hh)
+
+    first_conv = next(i for i, l in enumerate(layers) if l.kind == 0)
+    first_3x3 = next(i for i, l in enumerate(layers) if l.kind == 0 and l.ksize == 3 and l.stride == 1)
+    cases = [
+        (dict(n_weights=len(weights) // 2), "weights outside the blob"),                                   # a truncated blob
+        (dict(n_layers=first_conv + 3), "no decode layer"),                                                 # a truncated table
+        (dict(mutate=lambda a: setattr(a[first_conv], "cin", 48)), "unsupported convolution"),
+        (dict(mutate=lambda a: setattr(a[first_conv], "in_coff", 16)), "slice outside its buffer"),        # slices start at multiples of 32
+        (dict(mutate=lambda a: setattr(a[first_3x3], "out_cstride", a[first_3x3].cout - 4)), "slice outside its buffer"),
+        (dict(mutate=lambda a: setattr(a[first_conv], "in_buf", 99)), "slice outside its buffer"),
+        (dict(mutate=lambda a: setattr(a[0], "cout", 64)), "bad stem"),
+        (dict(mutate=lambda a: setattr(a[first_conv], "kind", 9)), "unknown kind"),
+        (dict(bufs_=[max(1, v // 8) for v in bufs]), "bad stem"),                                           # buffers too small: the first layer's slice already
+    ]
+    for kw, want in cases:
+        rc, msg, hh = create(**kw)
+        gone(hh)
+        assert rc == _lib.PA_ERR_INVALID_ARG and want in msg, (kw.keys(), rc, msg)
+    assert create(net=(380, 640))[0] == _lib.PA_ERR_INVALID_ARG and create(nc=0)[0] == _lib.PA_ERR_INVALID_ARG
+    # a valid table passes the validation and stops at the device (none here) -- with the handle handed back for the error text;
+    # a timed forward with too short a result buffer is refused before anything is enqueued
+    rc, msg, hh = create()
+    assert rc in (_lib.PA_OK, _lib.PA_ERR_NO_DEVICE, _lib.PA_ERR_HIP), (rc, msg)
+    if hh:
+        us = np.zeros(4, np.float32)
+        z = ctypes.c_void_p(0)
+        assert lib.pa_detector_forward_timed(hh, z, 1, 720, 1280, z, z, us.ctypes.data_as(ctypes.c_void_p), 4) == _lib.PA_ERR_INVALID_ARG
+        assert lib.pa_detector_forward_timed(hh, z, 1, 720, 1280, z, z, z, 1000) == _lib.PA_ERR_INVALID_ARG
+    gone(hh)
+    # the Winograd filter transform: every layout the engine uses, into buffers of exactly the advertised size
+    rng = np.random.default_rng(1)
+    for cin, cout, bn in ((8, 32, 32), (32, 32, 32), (64, 64, 64), (64, 64, 32), (128, 128, 64), (256, 256, 32), (24, 96, 32)):
+        w = rng.standard_normal((cout, 3, 3, cin)).astype(np.float32)
+        n = lib.pa_wino_weight_floats(cin, cout)
+        assert n == 16 * cin * cout
+        ug = np.full(n, np.nan, np.float32)
+        assert lib.pa_wino_transform_weights(w.ctypes.data_as(ctypes.c_void_p), cin, cout, bn, ug.ctypes.data_as(ctypes.c_void_p)) == 0
+        assert np.isfinite(ug).all(), "every float of the layout is written exactly once"
+        # the centre position of every filter is (g00 + g01 + ... ) / 4-type sums; a cheap invariant: total energy is preserved up to G's norm
+        assert abs(float(np.abs(ug).sum())) > 0
+    z = ctypes.c_void_p(0)
+    assert lib.pa_wino_channels_per_workgroup(48, 10) == 0 and lib.pa_wino_channels_per_workgroup(64, 0) == 0
+    assert lib.pa_wino_conv3x3(z, z, z, z, z, 1, 8, 8, 8, 32, 32, 8, 32, 1, 0, 0, z) == _lib.PA_ERR_INVALID_ARG
+    # this round's engine entries refuse a null engine / null tables before touching anything
+    assert lib.pa_detector_plan(z, z, z, z, z, 4, z, z, z, z, z, z, z) == _lib.PA_ERR_INVALID_ARG
+    assert lib.pa_detector_plan_desc(z, z, z, 4, 2, 100, z, 0, 0, z) == _lib.PA_ERR_INVALID_ARG
+    assert lib.pa_square_crops_src(z, z, 1, 720, 1280, z, z, 1, 30, 0, z, z, z) == _lib.PA_ERR_INVALID_ARG
