@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PA_ABI_VERSION 8
+#define PA_ABI_VERSION 9
 #define PA_WEIGHT_MAGIC 0x31574150 /* "PAW1" */
 #define PA_LSTM_MAGIC 0x314c4150   /* "PAL1" */
 #define PA_ENCODER_MAGIC 0x31454150 /* "PAE1" */
@@ -101,8 +101,10 @@ typedef struct pa_kernel_stat {
     char name[48];
     int32_t launches;
     float total_ms;     /* sum of HIP-event durations on the engine's stream */
-    double flops;       /* algorithmic FLOPs summed over those launches */
+    double flops;       /* algorithmic FLOPs summed over those launches (a convolution: 2 x outputs x k x k x cin) */
     double bytes;       /* algorithmic (compulsory) HBM bytes summed over those launches */
+    double flops_executed; /* multiply-adds the matrix cores actually ran, x 2: equal to `flops` except for launches of the
+                              Winograd F(2x2, 3x3) kernel, which execute 4 / 9 of their layer's direct-form count (ABI 9) */
 } pa_kernel_stat;
 
 /* ---- lifetime ----------------------------------------------------------- */

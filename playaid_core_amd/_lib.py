@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # PA_LIB_PATH: load a differently built library (e.g. the ablation build used by scripts/)
 LIB_PATH = os.environ.get("PA_LIB_PATH") or os.path.join(HERE, "libplayaid_hip.so")
 
-PA_ABI_VERSION = 8
+PA_ABI_VERSION = 9
 PA_DTYPE_F32 = 0
 PA_DTYPE_BF16 = 1
 PA_WEIGHT_MAGIC = 0x31574150
@@ -94,6 +94,7 @@ class pa_kernel_stat(C.Structure):
         ("total_ms", C.c_float),
         ("flops", C.c_double),
         ("bytes", C.c_double),
+        ("flops_executed", C.c_double),
     ]
 
 

@@ -56,6 +56,7 @@ struct ProfEntry {
     int name_id;
     hipEvent_t start, stop;
     double flops, bytes;
+    double flops_executed;  // = flops unless the launch runs an algorithm that executes fewer (Winograd: 4 / 9)
 };
 
 }  // namespace
@@ -313,10 +314,12 @@ struct ProfScope {
     hipStream_t s;
     ProfEntry ent;
     bool on;
-    ProfScope(pa_engine* e_, hipStream_t s_, const char* name, double flops, double bytes) : e(e_), s(s_), on(e_->profiling) {
+    ProfScope(pa_engine* e_, hipStream_t s_, const char* name, double flops, double bytes, double executed = -1.0)
+        : e(e_), s(s_), on(e_->profiling) {
         if (!on) return;
         ent.name_id = prof_name_id(e, name);
         ent.flops = flops;
+        ent.flops_executed = executed >= 0.0 ? executed : flops;
         ent.bytes = bytes;
         ent.start = get_event(e);
         ent.stop = get_event(e);
@@ -450,7 +453,8 @@ int run_conv(pa_engine* e, const ConvLayer& L, int crop0, int ncrops, size_t sla
     const double flops = 2.0 * p.M * p.N * k_main;
     const double bytes = (double)es * ((double)ncrops * L.in_hw * L.in_hw * L.cin + (double)p.M * p.N * ((L.residual || bf_ds || f32_ds || ds_here) ? 2 : 1) +
                                        (double)p.N * k_main + ((L.in2 && !bf_ds && !f32_ds) ? (double)ncrops * L.in2_hw * L.in2_hw * L.in2_c : 0.0));
-    ProfScope ps(e, s, prof_name, flops, bytes);
+    const bool as_wino = !bf && L.wino_wgt && !p.act2;
+    ProfScope ps(e, s, prof_name, flops, bytes, as_wino ? flops * 4.0 / 9.0 : flops);
     // stride-1 3x3 layers: input patch resident in LDS across the nine taps (patchconv.hip);
     // PA_PATCH=0 keeps the generic im2col engine for A/B runs
     static const int use_patch = getenv("PA_PATCH") ? atoi(getenv("PA_PATCH")) : 1;
@@ -1674,6 +1678,7 @@ int pa_profile_read(pa_engine* e, pa_kernel_stat* stats, int32_t max_stats, int3
         acc[p.name_id].total_ms += ms;
         acc[p.name_id].flops += p.flops;
         acc[p.name_id].bytes += p.bytes;
+        acc[p.name_id].flops_executed += p.flops_executed;
         e->event_pool.push_back(p.start);
         e->event_pool.push_back(p.stop);
     }

@@ -211,6 +211,11 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const GemmParams p) {
                     v.z = silu_fast(v.z); v.w = silu_fast(v.w);
                 }
                 // (rows past M of a partial last tile were computed on clamped addresses and are dropped)
+                // INVARIANT the counted waits rely on: a wave whose rows are all past M issues NO stores here (hipcc branches
+                // around them), so its vmcnt(NLD + k * NST) would under-wait if another k-step of this workgroup followed. None
+                // does: a workgroup walks its tiles in ASCENDING order (t_lo + lm, + LM, ...) and only the launch's last tile
+                // (tiles_m - 1) can be partial, so a partial tile is always the last thing its workgroup computes. Any other
+                // tile order must first make the store count independent of the predicate (launch_pgemm checks the premise).
                 if (m < p.M) *reinterpret_cast<f32x4*>(p.out + o_px + 8 * gq) = v;
             }
         }
@@ -248,6 +253,8 @@ hipError_t launch_pgemm(const GemmParams& p_in, int bm, hipStream_t s) {
         (void)plan(bm, &lm);
     }
     p.tiles_m = (p.M + bm - 1) / bm;
+    // the premise of the kernel's counted waits (see its store loop): every tile but the last is full
+    if ((long long)(p.tiles_m - 1) * bm >= p.M || (long long)p.tiles_m * bm < p.M) return hipErrorInvalidValue;
     const int per = lm * p.tiles_n;
     const int grid = per * 8;
     if (bn == 32) hipLaunchKernelGGL((pgemm_kernel<128, 32>), dim3(grid), dim3(256), 0, s, p);

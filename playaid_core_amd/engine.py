@@ -673,6 +673,7 @@ class Engine:
                 "total_ms": arr[i].total_ms,
                 "flops": arr[i].flops,
                 "bytes": arr[i].bytes,
+                "flops_executed": arr[i].flops_executed,
             }
             for i in range(n.value)
         ]

@@ -50,7 +50,7 @@ def test_struct_layouts_match_header():
 
     assert ctypes.sizeof(_lib.pa_record) == 16
     assert ctypes.sizeof(_lib.pa_config) == 16 * 4
-    assert ctypes.sizeof(_lib.pa_kernel_stat) == 72
+    assert ctypes.sizeof(_lib.pa_kernel_stat) == 80
 
 
 def test_create_rejects_bad_arguments_without_gpu(lib):
