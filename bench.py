@@ -45,8 +45,8 @@ from playaid_core_amd.parallel import ClipLanes, FrameParallelClip, broadcast_en
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, = fp32 vector peak
 PEAK_HBM_GBS = 8000.0
-TRAFFIC_FILES = {"f32": "r05_traffic.json", "bf16": "r05_cfg2_bf16_traffic.json"}
-TRAFFIC_FALLBACK = {"f32": "r04_traffic.json", "bf16": "r04_cfg2_bf16_traffic.json"}
+TRAFFIC_FILES = {"f32": "r05_traffic.json", "bf16": "r04_cfg2_bf16_traffic.json"}  # (the bf16 conv path is round 4's: its counter passes were not repeated)
+TRAFFIC_FALLBACK = {"f32": "r04_traffic.json", "bf16": "r01_cfg2_bf16_traffic.json"}
 
 
 def _pmc_traffic(kernel_name, dtype, frames, height, width):
