@@ -32,7 +32,8 @@
 // Built, measured and taken out again (bit-identical results, no gain; DESIGN.md section 5.1c, profiles/r05_wino_*): a
 // PERSISTENT form -- one workgroup per CU over all its tiles, its two wave groups half a chunk apart (one transforms while the
 // other multiplies), copies running on across tiles, a three-stage ring -- 56.9 against 57.1 us on layer 1, 51.8 against 48.8
-// on layer 2; both row operands of a wave in one ds_read_b128; read-ahead depths 2 and 5. Per-wave stamps put an iteration of
+// on layer 2 (the same with the older wave group multiplying first: 57.3 / 50.4); both row operands of a wave in one
+// ds_read_b128; read-ahead depths 2 and 5. Per-wave stamps put an iteration of
 // the chunk loop at 5190 cycles in EVERY form, against 4096 cycles of matrix-pipe time (v_mfma_f32_16x16x4_f32 issues every
 // 32 cycles by itself: scripts/micro/mfma_f32_rate.hip); the operand reads, the copies and the transform each add their own
 // time to a matrix-only skeleton instead of hiding under it (profiles/r05_wino_ablations_b2b.txt).

@@ -30,7 +30,7 @@ for r in rows:
         else:
             ig.append(dur)
     elif name.startswith("pa::") or " pa::" in name:
-        fam[name.split("(")[0].replace("void ", "").replace("pa::", "")].append(dur)
+        fam[name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("pa::", "")].append(dur)
 dtype = sys.argv[3] if len(sys.argv) > 3 else "f32"
 per = 6 if dtype == "f32" else (4 if dtype == "f32-direct" else 1)
 assert len(ig) % per == 0, len(ig)
