@@ -12,6 +12,7 @@
 // Nothing here is specific to ResNet-50; the table in playaid_core_amd/resnet_transformer_detector.py is.
 #include "pa_kernels.h"
 #include "../../include/playaid_hip.h"
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -45,6 +46,9 @@ struct pa_convnet {
     std::vector<size_t> buf_floats;  // per crop
     float* weights = nullptr;
     size_t n_weights = 0;
+    float* wino_weights = nullptr;      // the stride-1 3x3 layers' filters in the Winograd kernel's layout (wino.hip)
+    std::vector<long long> wino_off;    // per layer: float offset into wino_weights, -1 = direct form
+    std::vector<int> wino_bn;           // per layer: output channels per workgroup its filters were laid out for
     float* x0 = nullptr;  // [max_crops][134][134][4] model input of the stem
     std::string last_error;
 };
@@ -130,6 +134,29 @@ int pa_convnet_create(int32_t device, const pa_conv_desc* descs, int32_t n_descs
     h->n_weights = n_weights;
     if (!chk(hipMalloc(&h->weights, n_weights * sizeof(float)), "hipMalloc weights")) return PA_ERR_HIP;
     if (!chk(hipMemcpy(h->weights, weights_host, n_weights * sizeof(float), hipMemcpyHostToDevice), "upload weights")) return PA_ERR_HIP;
+    {
+        // stride-1 3x3 convolutions on maps of 8 x 8 and larger run as Winograd F(2x2, 3x3) (wino.hip, as in the engine's
+        // ResNet-18: the 4 x 4 maps stay on the direct kernel); PA_CONVNET_WINO=0 keeps the direct form (A/B)
+        static const int use_wino = getenv("PA_CONVNET_WINO") ? atoi(getenv("PA_CONVNET_WINO")) : 1;
+        h->wino_off.assign(n_descs, -1);
+        h->wino_bn.assign(n_descs, 0);
+        size_t total = 0;
+        for (int i = 0; i < n_descs; ++i) {
+            const pa_conv_desc& d = h->descs[i];
+            if (use_wino && d.kind == 0 && d.ksize == 3 && d.stride == 1 && d.in_pad == 1 && d.in_hw >= 8 && d.in_hw % 4 == 0 && d.cin % 8 == 0) {
+                h->wino_off[i] = (long long)total;
+                h->wino_bn[i] = pa::wino_pick_bn(d.cout, (long long)max_crops * (d.in_hw / 4) * (d.in_hw / 4));
+                total += pa::wino_weight_floats(d.cin, d.cout);
+            }
+        }
+        if (total) {
+            std::vector<float> ug(total);
+            for (int i = 0; i < n_descs; ++i)
+                if (h->wino_off[i] >= 0) pa::wino_transform_weights(weights_host + h->descs[i].w_off, h->descs[i].cin, h->descs[i].cout, h->wino_bn[i], ug.data() + h->wino_off[i]);
+            if (!chk(hipMalloc(&h->wino_weights, total * sizeof(float)), "hipMalloc Winograd filters")) return PA_ERR_HIP;
+            if (!chk(hipMemcpy(h->wino_weights, ug.data(), total * sizeof(float), hipMemcpyHostToDevice), "upload Winograd filters")) return PA_ERR_HIP;
+        }
+    }
     h->bufs.assign(n_bufs, nullptr);
     h->buf_floats.assign(buf_floats_per_crop, buf_floats_per_crop + n_bufs);
     for (int b = 0; b < n_bufs; ++b) {
@@ -147,6 +174,7 @@ int pa_convnet_create(int32_t device, const pa_conv_desc* descs, int32_t n_descs
 void pa_convnet_destroy(pa_convnet* h) {
     if (!h) return;
     (void)hipFree(h->weights);
+    (void)hipFree(h->wino_weights);
     (void)hipFree(h->x0);
     for (float* b : h->bufs) (void)hipFree(b);
     delete h;
@@ -216,7 +244,17 @@ int pa_convnet_forward(pa_convnet* h, const float* x, int32_t n, float* out, int
         const long long t128 = (long long)((p.M + 127) / 128) * (p.N / 64);
         const pa::GemmTile tile = (p.N % 128 == 0 && t128 / 2 >= 512) ? pa::TILE_128x128 : (t128 >= 512 ? pa::TILE_128x64 : pa::TILE_64x64);
         hipError_t pe = hipErrorInvalidValue;
-        if (d.ksize == 3 && d.stride == 1 && d.in_pad == 1) pe = pa::launch_conv3x3_patch(p, tile == pa::TILE_64x64 ? 64 : 128, s);
+        if (h->wino_off[li] >= 0) {
+            pa::WinoParams q;
+            memset(&q, 0, sizeof(q));
+            q.act = p.act; q.wgt = h->wino_weights + h->wino_off[li]; q.bias = p.bias; q.residual = p.residual; q.out = p.out;
+            q.n_img = n; q.height = d.in_hw; q.width = d.in_hw; q.cin = d.cin; q.cout = d.cout; q.bn = h->wino_bn[li];
+            q.in_px_stride = p.in_px_stride; q.in_row_stride = p.in_row_stride; q.in_img_stride = p.in_img_stride;
+            q.out_px_stride = p.out_px_stride; q.out_row_stride = p.out_row_stride; q.out_img_stride = p.out_img_stride; q.out_pad = p.out_pad;
+            q.relu = p.relu;
+            pe = pa::launch_wino3x3(q, s);
+        }
+        if (pe == hipErrorInvalidValue && d.ksize == 3 && d.stride == 1 && d.in_pad == 1) pe = pa::launch_conv3x3_patch(p, tile == pa::TILE_64x64 ? 64 : 128, s);
         if (pe == hipErrorInvalidValue) pe = pa::launch_igemm(p, tile, s);
         if (pe != hipSuccess) return cn_fail(h, PA_ERR_HIP, "layer " + std::to_string(li) + ": " + hipGetErrorString(pe));
     }
