@@ -146,21 +146,37 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict_
 // to be what aborted at process exit under rocprofv3 (profiles/README.md, round 5). A granule that does not arrive within
 // 20 ms sets *err: the decoder then writes NaN rows, pa_lstm_last_status reports it once and the handle falls back to one
 // launch per step. force_timeout (PA_LSTM_FORCE_TIMEOUT=1, tests): workgroup 0 withholds its granules of step 0.
-template <int U>
+// MF (U == 4 only, H % 64 == 0): the recurrent product W_hh[16 rows of this workgroup][H] x h(t-1)[H][N <= 16] on the fp32 matrix cores --
+// ONE v_mfma_f32_16x16x4_f32 tile (rows = the workgroup's 4 gates x 4 units, columns = the batch), K = H split over the four waves
+// (H / 16 instructions each: 32 at H = 512), the four partial tiles summed by the gate threads. The row operand (a lane's 32
+// weights) stays in registers for the whole launch as before; the column operand comes from the h tile in LDS with eight
+// ds_read_b128 per step (row pitch H + 8 floats: the 16 lanes of a read phase cover 64 distinct banks). The vector form did these
+// 16 x 16 x 512 multiply-adds as 512 dependent fmaf per thread plus four shuffle rounds: 4.6 us of a step's 8.6; this one ~0.9.
+// fp32 throughout (the instruction is an fmaf chain); the summation order differs from the vector form's.
+template <int U, bool MF = false>
 __global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict__ pre_all, const float* __restrict__ w_hh,
                                                          const float* __restrict__ b_hh, float* __restrict__ hseq, int L, int N, int H,
                                                          unsigned long long* __restrict__ gran, int* __restrict__ err,
                                                          unsigned long long* __restrict__ dbg, int force_timeout) {
     constexpr int R = 4 * U, P = 256 / R, KQ = 128 / P;
     unsigned long long d_sweep = 0, d_prod = 0, d_gate = 0, d_t = 0;  // PA_LSTM_STAMP=1: where a step's time goes (100 MHz ticks)  // rows, lanes per row, float4 pieces per lane (H <= 512)
+    static_assert(!MF || U == 4, "the matrix-core product is one 16-row tile");
     extern __shared__ float sm[];
-    float* hs = sm;                              // [N][H]
-    float* gs = hs + (size_t)N * H;              // [R][LSTM_NMAX]
+    float* hs = sm;                              // [N][HP], HP = H (+ 8 with MF)
+    const int HP = MF ? H + 8 : H;
+    const int hshift = (H & (H - 1)) == 0 ? __ffs(H) - 1 : -1;
+    float* gs = hs + (size_t)N * HP;             // [R][LSTM_NMAX]; MF: [4 waves][R][LSTM_NMAX] partial tiles
     const int j0 = blockIdx.x * U;
     const int row = threadIdx.x / P, part = threadIdx.x % P;   // row = gate * U + unit
     const int hq = H >> 2, nh = N * H;
     float4 wreg[KQ];
-    {
+    // MF: lane (r = lane & 15, kq = lane >> 4) of wave w holds W[row r][k], k = w * (H / 4) + 16 j + 4 kq + i for j < H / 64, i < 4
+    const int mf_lane = threadIdx.x & 63, mf_wave = threadIdx.x >> 6, mf_r = mf_lane & 15, mf_kq = mf_lane >> 4;
+    if (MF) {
+        const float* wr = w_hh + (size_t)((mf_r / U) * H + j0 + (mf_r % U)) * H + mf_wave * (H >> 2) + 4 * mf_kq;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) wreg[q] = q < (H >> 6) ? *reinterpret_cast<const float4*>(wr + 16 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
         const float4* wr = reinterpret_cast<const float4*>(w_hh + (size_t)((row / U) * H + j0 + (row % U)) * H);
 #pragma unroll
         for (int q = 0; q < KQ; ++q) wreg[q] = q * P + part < hq ? wr[q * P + part] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -188,7 +204,8 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict
 #pragma unroll
                     for (int k = 0; k < 16; ++k)
                         if ((pending & (1u << k)) && (unsigned)(v[k] >> 32) == (unsigned)t) {
-                            hs[base + k * 256] = __uint_as_float((unsigned)v[k]);
+                            const int gi = base + k * 256;   // granule n * H + j -> the h tile's row n (pitch HP)
+                            hs[MF ? gi + (hshift >= 0 ? gi >> hshift : gi / H) * 8 : gi] = __uint_as_float((unsigned)v[k]);
                             pending &= ~(1u << k);
                         }
                     if (pending) {
@@ -203,33 +220,56 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict
             }
             if (__syncthreads_or(failed)) return;
             if (dbg) { const unsigned long long n_ = wall_clock64(); d_sweep += n_ - d_t; d_t = n_; }
-            float acc[LSTM_NMAX];
+            if (MF) {
+                typedef float mf4 __attribute__((ext_vector_type(4)));
+                mf4 d4 = mf4{0.f, 0.f, 0.f, 0.f};
+                const int nn = mf_r < N ? mf_r : N - 1;   // (columns past the batch read a valid row; their results are never used)
+                const float* hb = hs + (size_t)nn * HP + mf_wave * (H >> 2) + 4 * mf_kq;
 #pragma unroll
-            for (int n = 0; n < LSTM_NMAX; ++n) acc[n] = 0.f;
-#pragma unroll
-            for (int q = 0; q < KQ; ++q) {
-                const int k4 = q * P + part;  // consecutive lanes read consecutive 16-byte pieces of h: no bank conflicts
-                if (k4 < hq) {
-                    const float4 w = wreg[q];
-#pragma unroll
-                    for (int n = 0; n < LSTM_NMAX; ++n)
-                        if (n < N) {
-                            const float4 hv = reinterpret_cast<const float4*>(hs + (size_t)n * H)[k4];
-                            acc[n] = fmaf(w.x, hv.x, acc[n]);
-                            acc[n] = fmaf(w.y, hv.y, acc[n]);
-                            acc[n] = fmaf(w.z, hv.z, acc[n]);
-                            acc[n] = fmaf(w.w, hv.w, acc[n]);
-                        }
+                for (int q = 0; q < KQ; ++q)
+                    if (q < (H >> 6)) {
+                        const float4 hv = *reinterpret_cast<const float4*>(hb + 16 * q);
+                        const float4 w = wreg[q];
+                        d4 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, hv.x, d4, 0, 0, 0);
+                        d4 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, hv.y, d4, 0, 0, 0);
+                        d4 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, hv.z, d4, 0, 0, 0);
+                        d4 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, hv.w, d4, 0, 0, 0);
+                    }
+                // this wave's partial tile: rows 4 kq + i, column lane & 15
+                float* gp = gs + mf_wave * (R * LSTM_NMAX);
+                gp[(4 * mf_kq + 0) * LSTM_NMAX + mf_r] = d4.x;
+                gp[(4 * mf_kq + 1) * LSTM_NMAX + mf_r] = d4.y;
+                gp[(4 * mf_kq + 2) * LSTM_NMAX + mf_r] = d4.z;
+                gp[(4 * mf_kq + 3) * LSTM_NMAX + mf_r] = d4.w;
+            } else {
+                float acc[LSTM_NMAX];
+    #pragma unroll
+                for (int n = 0; n < LSTM_NMAX; ++n) acc[n] = 0.f;
+    #pragma unroll
+                for (int q = 0; q < KQ; ++q) {
+                    const int k4 = q * P + part;  // consecutive lanes read consecutive 16-byte pieces of h: no bank conflicts
+                    if (k4 < hq) {
+                        const float4 w = wreg[q];
+    #pragma unroll
+                        for (int n = 0; n < LSTM_NMAX; ++n)
+                            if (n < N) {
+                                const float4 hv = reinterpret_cast<const float4*>(hs + (size_t)n * H)[k4];
+                                acc[n] = fmaf(w.x, hv.x, acc[n]);
+                                acc[n] = fmaf(w.y, hv.y, acc[n]);
+                                acc[n] = fmaf(w.z, hv.z, acc[n]);
+                                acc[n] = fmaf(w.w, hv.w, acc[n]);
+                            }
+                    }
                 }
+    #pragma unroll
+                for (int n = 0; n < LSTM_NMAX; ++n)
+                    if (n < N) {
+                        float v = acc[n];
+    #pragma unroll
+                        for (int d = 1; d < P; d <<= 1) v += __shfl_xor(v, d, 64);
+                        if (part == 0) gs[row * LSTM_NMAX + n] = v;
+                    }
             }
-#pragma unroll
-            for (int n = 0; n < LSTM_NMAX; ++n)
-                if (n < N) {
-                    float v = acc[n];
-#pragma unroll
-                    for (int d = 1; d < P; d <<= 1) v += __shfl_xor(v, d, 64);
-                    if (part == 0) gs[row * LSTM_NMAX + n] = v;
-                }
             __syncthreads();
             if (dbg) { const unsigned long long n_ = wall_clock64(); d_prod += n_ - d_t; d_t = n_; }
         }
@@ -240,7 +280,13 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict
                 float g4[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const float rec = (t > 0 ? gs[(g * U + u) * LSTM_NMAX + n] : 0.f) + b_hh[g * H + j];
+                    float rsum = 0.f;
+                    if (t > 0) {
+                        rsum = gs[(g * U + u) * LSTM_NMAX + n];
+                        if (MF) rsum = ((rsum + gs[R * LSTM_NMAX + (g * U + u) * LSTM_NMAX + n]) + gs[2 * R * LSTM_NMAX + (g * U + u) * LSTM_NMAX + n]) +
+                                       gs[3 * R * LSTM_NMAX + (g * U + u) * LSTM_NMAX + n];
+                    }
+                    const float rec = rsum + b_hh[g * H + j];
                     g4[g] = pre[(size_t)n * 4 * H + g * H + j] + rec;
                 }
                 const float ig = sigmoidf(g4[0]), fg = sigmoidf(g4[1]), gg = tanhf(g4[2]), og = sigmoidf(g4[3]);
@@ -483,7 +529,11 @@ int pa_lstm_forward(pa_lstm* h, const float* x, int32_t ld, int32_t seq_len, int
             static const int u_env = getenv("PA_LSTM_UNITS") ? atoi(getenv("PA_LSTM_UNITS")) : 0;   // tuning: hidden units per workgroup
             int U = u_env == 1 || u_env == 2 || u_env == 4 || u_env == 8 ? u_env : pa::LSTM_UNITS_DEFAULT;
             while (U > 1 && H % U) U >>= 1;
-            const size_t lds = ((size_t)batch * H + (size_t)4 * U * pa::LSTM_NMAX) * sizeof(float);
+            // the recurrent product on the matrix cores where its tile shape fits (PA_LSTM_MFMA=0: the vector form, A/B)
+            static const int mfma_env = getenv("PA_LSTM_MFMA") ? atoi(getenv("PA_LSTM_MFMA")) : 1;
+            const bool mf = mfma_env && U == 4 && H % 64 == 0;
+            const size_t lds = mf ? ((size_t)batch * (H + 8) + (size_t)4 * 4 * U * pa::LSTM_NMAX) * sizeof(float)
+                                  : ((size_t)batch * H + (size_t)4 * U * pa::LSTM_NMAX) * sizeof(float);
             const float* a_pre = h->pre; const float* a_w = h->w_hh[l]; const float* a_b = h->b_hh[l];
             int a_L = seq_len, a_N = batch, a_H = H;
             unsigned long long* a_gran = h->gran; int* a_err = h->sync_words + 2 * l + 1;
@@ -493,6 +543,7 @@ int pa_lstm_forward(pa_lstm* h, const float* x, int32_t ld, int32_t seq_len, int
             void* args[] = {&a_pre, &a_w, &a_b, &hs, &a_L, &a_N, &a_H, &a_gran, &a_err, &a_dbg, &a_force};
             (void)hipMemsetAsync(h->gran, 0, (size_t)2 * batch * H * sizeof(unsigned long long), s);   // tag 0 = not written
             const void* fn = U == 8   ? reinterpret_cast<const void*>(&pa::lstm_layer_kernel<8>)
+                             : mf     ? reinterpret_cast<const void*>(&pa::lstm_layer_kernel<4, true>)
                              : U == 4 ? reinterpret_cast<const void*>(&pa::lstm_layer_kernel<4>)
                              : U == 2 ? reinterpret_cast<const void*>(&pa::lstm_layer_kernel<2>)
                                       : reinterpret_cast<const void*>(&pa::lstm_layer_kernel<1>);
@@ -500,8 +551,8 @@ int pa_lstm_forward(pa_lstm* h, const float* x, int32_t ld, int32_t seq_len, int
             // kernel only needs co-residency, not the runtime's grid sync; the cooperative QUEUE the runtime creates for
             // hipLaunchCooperativeKernel was the one thing the rnn workload had that the others did not when it aborted
             // inside exit() under rocprofv3)
-            if (h->occ_key != batch * 16 + U) {  // (the kernel's LDS grows with the batch)
-                h->occ_key = batch * 16 + U;
+            if (h->occ_key != batch * 32 + U * 2 + (mf ? 1 : 0)) {  // (the kernel's LDS grows with the batch)
+                h->occ_key = batch * 32 + U * 2 + (mf ? 1 : 0);
                 int per_cu = 0, cus = 0;
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds) != hipSuccess) per_cu = 0;
                 if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess) cus = 0;
