@@ -88,7 +88,8 @@ template <int W, int WAVES> struct PatchGeom {
     static_assert(BAND ? (PXT % W == 0 && HW % PXT == 0) : (PXT % HW == 0), "tile must be whole rows / whole images");
 };
 
-constexpr int WSTAGE_BYTES = 3 * 64 * 64;  // three taps x 64 output channels x 32 bf16
+template <int CN> constexpr int WSTAGE_BYTES_OF = 3 * (32 * CN) * 64;  // three taps x 32 CN output channels x 32 bf16
+constexpr int WSTAGE_BYTES = WSTAGE_BYTES_OF<2>;
 constexpr int NSTG = 3;                    // weight ring depth
 
 }  // namespace
@@ -107,9 +108,18 @@ constexpr int NSTG = 3;                    // weight ring depth
 // LDS ONCE per workgroup and stay there, [chunk][tap][64 channels][64 B]; only activation patches stream, the
 // stage ring, its copies, counted waits and per-stage barriers disappear (one barrier per chunk = 72 matrix
 // instructions per wave), and a 512-pixel tile amortises the halo rows. These layers are HBM-bound.
-template <int W, int WAVES, bool WRES>
+//
+// CN (round 5): 32-channel blocks per wave. CN = 2 is the kernel of rounds 2-4 (a wave = 64 pixels x 64 channels). CN = 4 makes a
+// workgroup 64 WAVES pixels x 128 channels SHARING ONE PATCH -- the prototype round 4's verdict asked for: the patch crosses L2 ->
+// LDS once per 128 channels instead of once per 64, the weight stage (24 KB) is shared by eight waves, 48 matrix instructions per
+// wave and barrier. It holds 128 accumulator registers, so bias and residual are fetched in the epilogue, not ahead.
+template <int W, int WAVES, bool WRES, int CN = 2>
 __global__ __launch_bounds__(64 * WAVES) void conv3x3_bf16_patch_kernel(const GemmParams p) {
     using G = PatchGeom<W, WAVES>;
+    static_assert(CN == 2 || (CN == 4 && !WRES), "");
+    constexpr int BN = 32 * CN;                       // output channels per workgroup
+    constexpr int TAPB = BN * 64;                     // bytes of one tap of a weight stage (BN rows x 64 B)
+    constexpr int WSTAGE_BYTES = WSTAGE_BYTES_OF<CN>;
     constexpr int WRES_BYTES = 2 * 9 * 4096;  // two 32-channel chunks x nine taps x (64 rows x 64 B)
     constexpr int LDS_BYTES = 2 * G::PATCH_BYTES + (WRES ? WRES_BYTES : NSTG * WSTAGE_BYTES);
     __shared__ __attribute__((aligned(1024))) uint8_t lds[LDS_BYTES];
@@ -156,7 +166,8 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_bf16_patch_kernel(const Ge
     // jobs w, w + WAVES, ...; every wave issues the same NUMBER of copies per stage (the counted vmcnt
     // waits rely on it), surplus slots repeat the list's last piece.
     constexpr int HALF = WRES ? G::NPIECE : (G::NPIECE + 1) / 2;   // WRES: the whole next patch in the ky = 0 stage
-    constexpr int NWJ = WRES ? 0 : 12;                              // weight pieces per stage
+    constexpr int NGRP = 2 * CN;                                    // groups of 16 output channels per tap
+    constexpr int NWJ = WRES ? 0 : 3 * NGRP;                        // weight pieces per stage
     constexpr int CNT_P = (NWJ + HALF + WAVES - 1) / WAVES;  // copies per wave in a stage that also moves patch pieces
     constexpr int CNT_W = (NWJ + WAVES - 1) / WAVES;         // ... in the ky = 2 stage
     static_assert(CNT_P <= 12, "extend wait_vmcnt");
@@ -182,7 +193,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_bf16_patch_kernel(const Ge
             pvoff[h][i] = job >= NWJ ? patch_voff(q) : 0;
         }
     // weight piece job: tap kx = job >> 2, output channels 16 (job & 3) + (lane >> 2), slot (lane & 3) ^ ((n >> 2) & 3)
-    const int wvoff_base = (tile_n * 64 + (lane >> 2)) * p.ktot * 2;
+    const int wvoff_base = (tile_n * BN + (lane >> 2)) * p.ktot * 2;
 
     // copies of weight stage (chunk CH, tap row KY) into ring slot SLOT, plus -- WITH_PATCH -- half HALF_IDX of the
     // patch at byte offset PSOFF of the activation buffer into patch buffer PB
@@ -194,7 +205,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_bf16_patch_kernel(const Ge
             const int last_ = (WITH_PATCH) ? NWJ + HALF - 1 : NWJ - 1;                                               \
             job_ = job_ < last_ ? job_ : last_;                                                                      \
             if (job_ < NWJ) {                                                                                        \
-                const int kx_ = job_ >> 2, grp_ = job_ & 3;                                                          \
+                const int kx_ = job_ / NGRP, grp_ = job_ - kx_ * NGRP;                                               \
                 const int n_ = 16 * grp_ + (lane >> 2);                                                              \
                 const int voff_ = wvoff_base + 16 * grp_ * p.ktot * 2 + (((lane & 3) ^ ((n_ >> 2) & 3)) << 4);       \
                 dma16(wgt_rs, voff_, (((KY) * 3 + kx_) * C + (CH) * 32) * 2, wring + (SLOT) * WSTAGE_BYTES + job_ * 1024); \
@@ -219,7 +230,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_bf16_patch_kernel(const Ge
         prow[pi] = oy;
         pcol[pi] = ox;
         obase[pi] = img * p.out_img_stride + (oy + p.out_pad) * p.out_row_stride + (ox + p.out_pad) * p.out_px_stride +
-                    tile_n * 64 + 8 * lh;
+                    tile_n * BN + 8 * lh;
     }
     // output offset of tile t's first pixel
     auto out_origin = [&](int t) -> int {
@@ -227,35 +238,37 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_bf16_patch_kernel(const Ge
                        : t * G::IMGS * p.out_img_stride;
     };
     // weight fragment of channel block ci: row n = 32 ci + lr of the stage, slot (2 kg + lh) ^ ((n >> 2) & 3)
-    int wbase[2][2];
+    int wbase[CN][2];
 #pragma unroll
-    for (int ci = 0; ci < 2; ++ci)
+    for (int ci = 0; ci < CN; ++ci)
 #pragma unroll
         for (int kg = 0; kg < 2; ++kg) {
             const int n = 32 * ci + lr;
             wbase[ci][kg] = n * 64 + (((2 * kg + lh) ^ ((n >> 2) & 3)) << 4);
         }
     // bias of this lane's 4 x 8 output channels (channel column fixed for the workgroup)
-    float bias8[2][2][8];
+    constexpr int CB = CN == 2 ? 2 : 1;   // (CN = 4: fetched in the epilogue)
+    float bias8[CB][2][8];
 #pragma unroll
-    for (int ci = 0; ci < 2; ++ci)
+    for (int ci = 0; ci < CB; ++ci)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const float* bp = p.bias + tile_n * 64 + 32 * ci + 16 * j + 8 * lh;
+            if (CN != 2) break;
+            const float* bp = p.bias + tile_n * BN + 32 * ci + 16 * j + 8 * lh;
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
             bias8[ci][j][0] = b0.x; bias8[ci][j][1] = b0.y; bias8[ci][j][2] = b0.z; bias8[ci][j][3] = b0.w;
             bias8[ci][j][4] = b1.x; bias8[ci][j][5] = b1.y; bias8[ci][j][6] = b1.z; bias8[ci][j][7] = b1.w;
         }
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][CN];
 #pragma unroll
     for (int pi = 0; pi < 2; ++pi)
 #pragma unroll
-        for (int ci = 0; ci < 2; ++ci)
+        for (int ci = 0; ci < CN; ++ci)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[pi][ci][e] = 0.f;
 
-    u32x4 fa[2][2], fw[2][2];  // [set][pi | ci]
+    u32x4 fa[2][2], fw[2][CN];  // [set][pi | ci]
 #define BP_LOAD(SET, PATCH, WST, KY, KX, KG)                                                                         \
     {                                                                                                                \
         _Pragma("unroll") for (int pi_ = 0; pi_ < 2; ++pi_) {                                                        \
@@ -263,13 +276,13 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_bf16_patch_kernel(const Ge
             fa[SET][pi_] = *reinterpret_cast<const u32x4*>((PATCH) + pbase[pi_] + ((KY) * G::PITCH + (KX)) * 64 +    \
                                                            (((2 * (KG) + lh) ^ key_) << 4));                         \
         }                                                                                                            \
-        _Pragma("unroll") for (int ci_ = 0; ci_ < 2; ++ci_)                                                          \
-            fw[SET][ci_] = *reinterpret_cast<const u32x4*>((WST) + (KX) * 4096 + wbase[ci_][KG]);                    \
+        _Pragma("unroll") for (int ci_ = 0; ci_ < CN; ++ci_)                                                         \
+            fw[SET][ci_] = *reinterpret_cast<const u32x4*>((WST) + (KX) * (WRES ? 4096 : TAPB) + wbase[ci_][KG]);    \
     }
 #define BP_MFMA(SET)                                                                                                 \
     {                                                                                                                \
         _Pragma("unroll") for (int pi_ = 0; pi_ < 2; ++pi_)                                                          \
-            _Pragma("unroll") for (int ci_ = 0; ci_ < 2; ++ci_)                                                      \
+            _Pragma("unroll") for (int ci_ = 0; ci_ < CN; ++ci_)                                                     \
                 acc[pi_][ci_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[SET][ci_]),    \
                                                                         __builtin_bit_cast(bf16x8, fa[SET][pi_]),    \
                                                                         acc[pi_][ci_], 0, 0, 0);                     \
@@ -288,8 +301,8 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_bf16_patch_kernel(const Ge
                 dma16(wgt_rs, voff, (tap * C + chn * 32) * 2, wring + j * 1024);
             }
         } else {
-            for (int job = wave; job < 12; job += WAVES) {
-                const int kx = job >> 2, grp_ = job & 3;
+            for (int job = wave; job < NWJ; job += WAVES) {
+                const int kx = job / NGRP, grp_ = job - kx * NGRP;
                 const int n = 16 * grp_ + (lane >> 2);
                 const int voff = wvoff_base + 16 * grp_ * p.ktot * 2 + (((lane & 3) ^ ((n >> 2) & 3)) << 4);
                 dma16(wgt_rs, voff, ((0 * 3 + kx) * C) * 2, wring + 0 * WSTAGE_BYTES + job * 1024);
@@ -303,7 +316,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_bf16_patch_kernel(const Ge
 
     // ---- main loop over (tile, chunk); the three tap rows unrolled (ring slot of a stage is its ky) -----
     int pb = 0;  // patch buffer of the current chunk
-    u32x4 res[2][2][2];
+    u32x4 res[2][CB][2];
     for (int tk = 0; tk < tile_cnt; ++tk) {
         const int tile = tile_first + tk;
         const int ps_tile = patch_origin(tile);
@@ -326,14 +339,14 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_bf16_patch_kernel(const Ge
     {                                                                                                                \
         const int oo_ = out_origin(tile);                                                                            \
         _Pragma("unroll") for (int pi = 0; pi < 2; ++pi)                                                             \
-            _Pragma("unroll") for (int ci = 0; ci < 2; ++ci)                                                         \
+            _Pragma("unroll") for (int ci = 0; ci < CB; ++ci)                                                        \
                 _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                        \
                     res[pi][ci][j] = *reinterpret_cast<const u32x4*>(residual + oo_ + obase[pi] + 32 * ci + 16 * j); \
     }
                 // residual of this tile. Ring kernel: requested in the tile's last stage BEFORE that stage's copies, so
                 // that the stage's counted wait also covers it (vmcnt is in order). WRES: one wait per chunk, so it is
                 // requested at the start of the tile's last chunk, behind the patch copies, a whole chunk ahead.
-                if (!WRES && last_ch && ky == 2 && residual) BP_RESIDUAL();
+                if (!WRES && CN == 2 && last_ch && ky == 2 && residual) BP_RESIDUAL();
                 if constexpr (WRES) {
                     if (ky == 0) {
                         BP_ISSUE(0, 0, 0, true, 0, ps_next, pb_next);  // (only patch jobs exist)
@@ -403,7 +416,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_bf16_patch_kernel(const Ge
         for (int pi = 0; pi < 2; ++pi) {
             const bool valid = tile * G::PXT + wave * 64 + pi * 32 + lr < p.M;
 #pragma unroll
-            for (int ci = 0; ci < 2; ++ci)
+            for (int ci = 0; ci < CN; ++ci)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     float vv[8];
@@ -417,12 +430,22 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_bf16_patch_kernel(const Ge
                         vv[4 + i] = __uint_as_float(r[1]);  // lh = 0: partner's X (16j+4+i) | lh = 1: own Y (16j + 12 + i)
                     }
                     u32x4 rv = {0u, 0u, 0u, 0u};
-                    if (residual) rv = res[pi][ci][j];
+                    float bb[8];
+                    if constexpr (CN == 2) {
+                        if (residual) rv = res[pi][ci][j];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) bb[k] = bias8[ci][j][k];
+                    } else {
+                        if (residual && valid) rv = *reinterpret_cast<const u32x4*>(residual + oo + obase[pi] + 32 * ci + 16 * j);
+                        const float* bp = p.bias + tile_n * BN + 32 * ci + 16 * j + 8 * lh;
+                        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+                        bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
+                    }
                     uint32_t pk[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        float a0 = vv[2 * k] + bias8[ci][j][2 * k] + __uint_as_float(rv[k] << 16);
-                        float a1 = vv[2 * k + 1] + bias8[ci][j][2 * k + 1] + __uint_as_float(rv[k] & 0xffff0000u);
+                        float a0 = vv[2 * k] + bb[2 * k] + __uint_as_float(rv[k] << 16);
+                        float a1 = vv[2 * k + 1] + bb[2 * k + 1] + __uint_as_float(rv[k] & 0xffff0000u);
                         if (p.relu) {
                             a0 = a0 > 0.f ? a0 : 0.f;
                             a1 = a1 > 0.f ? a1 : 0.f;
@@ -464,6 +487,19 @@ hipError_t launch_conv3x3_bf16_patch(const GemmParams& p_in, hipStream_t s) {
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidValue;
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    // PA_BF16_WIDE=1 (prototype, 16-wide maps with N % 128 == 0 only): eight waves over 512 pixels x 128 channels sharing one patch
+    static const int wide = getenv("PA_BF16_WIDE") ? atoi(getenv("PA_BF16_WIDE")) : 0;
+    if (wide && W == 16 && p.N % 128 == 0) {
+        using G_ = PatchGeom<16, 8>;
+        p.tiles_n = p.N / 128;
+        p.tiles_m = (p.M + G_::PXT - 1) / G_::PXT;
+        int slots_ = n_cu / p.tiles_n;
+        slots_ = slots_ > 0 ? slots_ : 1;
+        p.tiles_per_img = (p.tiles_m + slots_ - 1) / slots_;
+        const int groups_ = (p.tiles_m + p.tiles_per_img - 1) / p.tiles_per_img;
+        hipLaunchKernelGGL((conv3x3_bf16_patch_kernel<16, 8, false, 4>), dim3(groups_ * p.tiles_n), dim3(512), 0, s, p);
+        return hipGetLastError();
     }
     p.tiles_n = p.N / 64;
     // persistent workgroups: WGPC per CU (what the LDS image allows), each a run of consecutive pixel tiles
