@@ -426,6 +426,12 @@ hipError_t launch_wino3x3(const WinoParams& p_in, hipStream_t s) {
     if (!p.act || !p.wgt || !p.out || p.cin < 8 || p.cin % 8 || p.cout < 32 || p.cout % 32 || p.height < 4 || p.width < 4 || p.height % 4 ||
         p.width % 4 || p.n_img < 1 || p.in_px_stride < p.cin || p.out_px_stride < p.cout)
         return hipErrorInvalidValue;
+    // every access is 16 bytes wide (LDS-DMA of four channels, dwordx4 stores / residual / bias loads): pixel pitches in whole
+    // groups of four floats, every base 16-byte aligned
+    auto mis = [](const void* q) { return (reinterpret_cast<unsigned long long>(q) & 15ull) != 0; };
+    if (p.in_px_stride % 4 || p.out_px_stride % 4 || p.in_row_stride % 4 || p.in_img_stride % 4 || p.out_row_stride % 4 || p.out_img_stride % 4 ||
+        mis(p.act) || mis(p.wgt) || mis(p.out) || (p.bias && mis(p.bias)) || (p.residual && mis(p.residual)))
+        return hipErrorInvalidValue;
     p.sb_per_row = p.width / 4;
     p.sb_per_img = (p.height / 4) * p.sb_per_row;
     const long long n_sb = (long long)p.n_img * p.sb_per_img;

@@ -257,6 +257,13 @@ def test_round5_host_planners_reject_bad_tables_and_stay_in_bounds(lib):
     z = ctypes.c_void_p(0)
     assert lib.pa_wino_channels_per_workgroup(48, 10) == 0 and lib.pa_wino_channels_per_workgroup(64, 0) == 0
     assert lib.pa_wino_conv3x3(z, z, z, z, z, 1, 8, 8, 8, 32, 32, 8, 32, 1, 0, 0, z) == _lib.PA_ERR_INVALID_ARG
+    # (host-side checks of the launcher, reached with non-null but never dereferenced addresses: pixel pitches that are not whole
+    # groups of four floats, bases that are not 16-byte aligned, a workgroup width the layer does not have)
+    a16, a4 = ctypes.c_void_p(4096), ctypes.c_void_p(4100)
+    assert lib.pa_wino_conv3x3(a16, a16, z, z, a16, 1, 8, 8, 8, 32, 32, 10, 32, 1, 0, 0, z) == _lib.PA_ERR_INVALID_ARG
+    assert lib.pa_wino_conv3x3(a4, a16, z, z, a16, 1, 8, 8, 8, 32, 32, 8, 32, 1, 0, 0, z) == _lib.PA_ERR_INVALID_ARG
+    assert lib.pa_wino_conv3x3(a16, a16, z, z, a16, 1, 8, 8, 8, 32, 64, 8, 32, 1, 0, 0, z) == _lib.PA_ERR_INVALID_ARG
+    assert lib.pa_wino_conv3x3(a16, a16, z, z, a16, 1, 6, 8, 8, 32, 32, 8, 32, 1, 0, 0, z) == _lib.PA_ERR_INVALID_ARG
     # this round's engine entries refuse a null engine / null tables before touching anything
     assert lib.pa_detector_plan(z, z, z, z, z, 4, z, z, z, z, z, z, z) == _lib.PA_ERR_INVALID_ARG
     assert lib.pa_detector_plan_desc(z, z, z, 4, 2, 100, z, 0, 0, z) == _lib.PA_ERR_INVALID_ARG
