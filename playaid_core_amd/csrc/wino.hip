@@ -36,7 +36,9 @@
 // ds_read_b128; read-ahead depths 2 and 5. Per-wave stamps put an iteration of
 // the chunk loop at 5190 cycles in EVERY form, against 4096 cycles of matrix-pipe time (v_mfma_f32_16x16x4_f32 issues every
 // 32 cycles by itself: scripts/micro/mfma_f32_rate.hip); the operand reads, the copies and the transform each add their own
-// time to a matrix-only skeleton instead of hiding under it (profiles/r05_wino_ablations_b2b.txt).
+// time to a matrix-only skeleton instead of hiding under it (profiles/r05_wino_ablations_b2b.txt): SQ_VALU_MFMA_COEXEC_CYCLES is 0
+// (profiles/r05_wino_pmc_coexec.txt) -- the fp32-input matrix instruction executes on the vector lanes, so every packed addition
+// of the transform and every LDS return takes its cycles from the matrix pipe.
 //
 // Summation order: chunks ascending, two channels per instruction pair, fixed by the launch geometry alone (no split, no
 // atomics): results are bitwise repeatable and do not depend on the batch size.
