@@ -259,7 +259,10 @@ int pa_detector_forward_timed(pa_detector* h, const uint8_t* frames, int32_t n, 
  * crop_kind int32[n_labels][F]: 1 the detector's own crop (save_one_box of crop_row), 2 a square_crop repair, 0 none;
  * crop_row float32[n_labels][F][6]; info4 int32[4] = max_frames (number of the last non-empty label), error code
  * (0 ok; 1 duplicate detections of a class never seen before, ai_runner.py:343; 2 a gap before a fighter's first
- * detection, :375-378; 3 a fighter without any detection), the label number it happened at, duplicates resolved. */
+ * detection, :375-378; 3 a fighter without any detection), the label number it happened at, duplicates resolved. Rows
+ * behind max_frames of pixel_frame / crop_kind are written as "no crop" (-1 / 0) whatever the caller's memory held. Enqueue
+ * only; the call uses ONE scratch per engine (sized at pa_create for max_clip_frames x 8 detections; a longer table grows it
+ * behind a device synchronisation), so the calls of one engine belong on one stream, or on streams the caller orders. */
 int pa_clean_detections(pa_engine* e, const float* dets, const int32_t* counts, int32_t n_labels, int32_t max_det, int32_t n_decoded_frames,
                         double* labels, int32_t* pixel_frame, double* pixel_box, int32_t* crop_kind, float* crop_row, int32_t* info4,
                         void* stream);
