@@ -51,6 +51,11 @@ struct GemmParams {
     int32_t* splitk_used;
     int32_t skip_w;         // 1: k % 4 == 3 always meets a zero weight (stem channel pad): those MFMAs are skipped
     int32_t tiles_m, tiles_n;
+    // persistent GEMM (pigemm.hip), filled by its launcher: workgroups per XCD, output rows per image, ceil(2^32 / howo) and
+    // ceil(2^32 / wo) for the scalar divisions, how often 31 consecutive pixels can wrap a row / that many rows an image
+    // (beside tiles_m / tiles_n: the kernel's first scalar loads fetch them together)
+    int32_t pg_per, pg_ho, pg_nwx, pg_nwy;
+    uint32_t pg_magic_howo, pg_magic_wo;
     // patch-resident 3x3 kernel (patchconv.hip), filled by its launcher: pixels per LDS patch buffer,
     // input row pitch and image size in pixels, tile -> first patch pixel, pixels in the whole buffer
     int32_t patch_slots, patch_pitch, img_px, tiles_per_img, p0_img, p0_row, total_px;
@@ -74,7 +79,7 @@ enum GemmTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x64 = 2, TILE_128x64_K
 
 hipError_t launch_igemm(const GemmParams& p, GemmTile tile, hipStream_t s);
 // persistent form of the same engine for short tiles (pigemm.hip): conv mode, no residual / second source / split-K;
-// bm = 128 | 64, 64 output channels per tile; results bit-identical to launch_igemm
+// bm = 128 | 64, 64 output channels per tile; results equal to launch_igemm up to where the bias enters the sum
 hipError_t launch_pgemm(const GemmParams& p, int bm, hipStream_t s);
 // bf16 activations / weights (uint16_t storage behind the float* fields, every count in elements),
 // f32 accumulate on v_mfma_f32_32x32x16_bf16; conv mode only (igemm_bf16.hip)

@@ -59,11 +59,14 @@ __global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restric
             const int a0 = sat((1.f - fx) * 2048.f), a1 = sat(fx * 2048.f);
             const int b0 = sat((1.f - fy) * 2048.f), b1 = sat(fy * 2048.f);
             const int sx1 = sx + 1 < W ? sx + 1 : sx, sy1 = sy + 1 < H ? sy + 1 : sy;
+            // (a tap whose coefficient is zero is not fetched: at an exact 3:1 reduction -- 1080p to 640 x 360 -- the sample
+            // point falls on a source pixel, b1 = a1 = 0, and two of three source rows are never read)
             const uint8_t* r0 = f + (size_t)sy * W * 3;
-            const uint8_t* r1 = f + (size_t)sy1 * W * 3;
+            const uint8_t* r1 = f + (size_t)(b1 ? sy1 : sy) * W * 3;
+            const int sxb = a1 ? sx1 : sx;
             for (int c = 0; c < 3; ++c) {
-                const int S0 = r0[sx * 3 + c] * a0 + r0[sx1 * 3 + c] * a1;
-                const int S1 = r1[sx * 3 + c] * a0 + r1[sx1 * 3 + c] * a1;
+                const int S0 = r0[sx * 3 + c] * a0 + r0[sxb * 3 + c] * a1;
+                const int S1 = r1[sx * 3 + c] * a0 + r1[sxb * 3 + c] * a1;
                 int v = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;
                 v = v < 0 ? 0 : (v > 255 ? 255 : v);
                 rgb[2 - c] = v;
@@ -179,30 +182,25 @@ __global__ __launch_bounds__(256) void upsample2_kernel(const float* __restrict_
 }
 
 // models/yolo.py Detect.forward (inference): y = sigmoid(conv out); xy = (y * 2 + grid) * stride with grid = index - 0.5;
-// wh = (y * 2)^2 * anchor; rows of one scale in (anchor, y, x) order at row0. One thread per output VALUE: consecutive
-// threads write consecutive floats of pred and read runs of `no` consecutive channels.
-__global__ __launch_bounds__(256) void detect_decode_kernel(const float* __restrict__ in, SliceGeom gi, int n, int na, int no, float stride,
+// wh = (y * 2)^2 * anchor; rows of one scale in (anchor, y, x) order at row0. blockIdx.y = image x anchor, one thread per
+// output VALUE of that slab: consecutive threads write consecutive floats of pred and read runs of `no` consecutive channels
+// (32-bit index arithmetic: the slab of one image and anchor has h * w * no < 2^31 values).
+__global__ __launch_bounds__(256) void detect_decode_kernel(const float* __restrict__ in, SliceGeom gi, int na, int no, float stride,
                                                             const float* __restrict__ anchors_px, float* __restrict__ pred, int rows_total,
                                                             int row0) {
-    const long long total = (long long)n * na * gi.h * gi.w * no;
-    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
-        long long r = t;
-        const int k = (int)(r % no);
-        r /= no;
-        const int x = (int)(r % gi.w);
-        r /= gi.w;
-        const int y = (int)(r % gi.h);
-        r /= gi.h;
-        const int a = (int)(r % na), img = (int)(r / na);
-        const float v = in[px_off(gi, img, y, x) + a * no + k];
-        const float s = 1.f / (1.f + expf(-v));
-        float val = s;
-        if (k == 0) val = (s * 2.f + ((float)x - 0.5f)) * stride;
-        else if (k == 1) val = (s * 2.f + ((float)y - 0.5f)) * stride;
-        else if (k == 2) val = (s * 2.f) * (s * 2.f) * anchors_px[a * 2];
-        else if (k == 3) val = (s * 2.f) * (s * 2.f) * anchors_px[a * 2 + 1];
-        pred[((size_t)img * rows_total + row0 + ((size_t)a * gi.h + y) * gi.w + x) * no + k] = val;
-    }
+    const unsigned t = blockIdx.x * 256u + threadIdx.x, hw = gi.h * gi.w;
+    if (t >= hw * (unsigned)no) return;
+    const int img = blockIdx.y / na, a = blockIdx.y - img * na;
+    const unsigned pix = t / (unsigned)no, k = t - pix * no;
+    const int y = pix / (unsigned)gi.w, x = pix - y * gi.w;
+    const float v = in[px_off(gi, img, y, x) + a * no + k];
+    const float s = 1.f / (1.f + expf(-v));
+    float val = s;
+    if (k == 0) val = (s * 2.f + ((float)x - 0.5f)) * stride;
+    else if (k == 1) val = (s * 2.f + ((float)y - 0.5f)) * stride;
+    else if (k == 2) val = (s * 2.f) * (s * 2.f) * anchors_px[a * 2];
+    else if (k == 3) val = (s * 2.f) * (s * 2.f) * anchors_px[a * 2 + 1];
+    pred[((size_t)img * rows_total + row0 + (size_t)a * hw) * no + t] = val;
 }
 
 // The 6x6 / 2 stem (models/yolov5s.yaml layer 0: Conv(3, 32, 6, 2, 2) + BatchNorm + SiLU) as a direct convolution on the
@@ -563,9 +561,8 @@ static int detector_run(pa_detector* h, const uint8_t* frames, int32_t n, int32_
         }
         if (L.kind == 6) {
             pa::SliceGeom gi = {L.in_h, L.in_w, L.in_pad, L.in_cstride, L.in_coff};
-            const long long total = (long long)n * 3 * L.in_h * L.in_w;
-            hipLaunchKernelGGL(pa::detect_decode_kernel, dim3(pa::grid_for(total)), dim3(256), 0, s, h->bufs[L.in_buf], gi, n, 3, no, L.aux[0],
-                               h->anchors + (size_t)di * 8, pred, h->rows, row0);
+            hipLaunchKernelGGL(pa::detect_decode_kernel, dim3((L.in_h * L.in_w * no + 255) / 256, n * 3), dim3(256), 0, s, h->bufs[L.in_buf], gi, 3, no,
+                               L.aux[0], h->anchors + (size_t)di * 8, pred, h->rows, row0);
             DT_HIP(hipGetLastError());
             row0 += 3 * L.in_h * L.in_w;
             ++di;
