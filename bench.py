@@ -915,7 +915,7 @@ def main():
                     "unit": "TFLOP/s",
                     "frac": round(tf / PEAK_FP32_MATRIX_TFLOPS, 4),
                     "achieved_is": "ALGORITHMIC FLOP/s: the family's direct-form count (2 x outputs x 9 x cin per 3x3 convolution, SURVEY.md 8d) over its "
-                                   "HIP-event time -- what the contract asks for. Ten of its eighteen launches (sixteen convolutions + the two 1x1/2 branch GEMMs of layers 2-3) run as Winograd F(2x2, 3x3) "
+                                   "HIP-event time -- what the contract asks for. Thirteen of its nineteen launches (sixteen convolutions + the three 1x1/2 branch GEMMs of layers 2-4) run as Winograd F(2x2, 3x3) "
                                    "(csrc/wino.hip) and execute 4/9 of their direct-form multiply-adds, so this figure may pass the chip's peak; "
                                    "`executed_*` is what the matrix cores ran",
                     "executed_tflops": round(tf_exec, 3),

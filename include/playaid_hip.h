@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PA_ABI_VERSION 9
+#define PA_ABI_VERSION 10
 #define PA_WEIGHT_MAGIC 0x31574150 /* "PAW1" */
 #define PA_LSTM_MAGIC 0x314c4150   /* "PAL1" */
 #define PA_ENCODER_MAGIC 0x31454150 /* "PAE1" */
@@ -567,6 +567,17 @@ int pa_wino_transform_weights(const float* w_host, int32_t cin, int32_t cout, in
 int pa_wino_conv3x3(const float* x, const float* ug, const float* bias, const float* residual, float* out, int32_t n,
                     int32_t height, int32_t width, int32_t cin, int32_t cout, int32_t bn, int32_t in_px_stride,
                     int32_t out_px_stride, int32_t out_pad, int32_t act, int32_t res_after, void* stream);
+/* The same launch with split-K scratch (ABI 10): where the layer's tiles alone would leave CUs without a workgroup (few pixels,
+ * many channels: ResNet-18's 8 x 8 and 4 x 4 maps) the launcher lets 2 / 4 / 8 workgroups share a tile, each summing a run of
+ * input-channel chunks; their partial output tiles meet in `slab` and the last workgroup to arrive adds them IN SPLIT ORDER
+ * (results do not depend on arrival order) and runs the epilogue. slab: device scratch of slab_floats floats (16 MB covers
+ * every launch: 256 x 512 x 32 floats); tickets: int32[n_tickets] on the device, ZERO before the first launch -- the kernel
+ * leaves them zero; a launch with more tiles than tickets, or too small a slab, runs unsplit. Launches that share the scratch
+ * belong on one stream. */
+int pa_wino_conv3x3_splitk(const float* x, const float* ug, const float* bias, const float* residual, float* out, int32_t n,
+                           int32_t height, int32_t width, int32_t cin, int32_t cout, int32_t bn, int32_t in_px_stride, int32_t out_px_stride,
+                           int32_t out_pad, int32_t act, int32_t res_after, float* slab, size_t slab_floats, int32_t* tickets,
+                           int32_t n_tickets, void* stream);
 
 /* Head of ResnetTransformerDetector (resnet_transformer_detector.py:41-93,141): Linear(in_dim, hidden_dim), the
  * enc_dim-value time encoding of the frame slot appended (d_model = hidden_dim + enc_dim, 32 per head),

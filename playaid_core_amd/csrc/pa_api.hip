@@ -17,6 +17,8 @@ using namespace pa;
 
 namespace {
 
+constexpr int WINO_TICKETS = 4096;   // tiles of one Winograd launch that may use split K (more: no split)
+
 struct ConvLayer {
     std::string name;
     int cin, cout, kh, kw, stride;  // logical conv
@@ -100,6 +102,7 @@ struct pa_engine {
     int gather_key[4] = {-1, -1, -1, -1}; // (f0, cnt, clip_frames, sub_frames) the table in `gather` was built for; -1 = none (other users of the buffer reset it)
     float* slab = nullptr;
     size_t slab_floats = 0;
+    float* wino_tickets = nullptr;  // int32[2][WINO_TICKETS], zero between launches: split-K tickets of the Winograd kernel, one set per half batch
     std::vector<ConvLayer> convs;  // stem + 19 convs
     ConvLayer fc;
     float* stem_wgt_bf16 = nullptr;  // bf16 path: the folded stem weights [64][224] as bf16
@@ -478,6 +481,12 @@ int run_conv(pa_engine* e, const ConvLayer& L, int crop0, int ncrops, size_t sla
         q.in_px_stride = p.in_px_stride; q.in_row_stride = p.in_row_stride; q.in_img_stride = p.in_img_stride;
         q.out_px_stride = p.out_px_stride; q.out_row_stride = p.out_row_stride; q.out_img_stride = p.out_img_stride; q.out_pad = p.out_pad;
         q.relu = p.relu;
+        if (e->wino_tickets && e->slab) {   // split-K scratch: this half batch's region
+            q.slab = e->slab + slab_off;
+            q.slab_floats = e->slab_floats > slab_off ? std::min(e->slab_floats - slab_off, e->slab_floats / 2) : 0;
+            q.tickets = reinterpret_cast<int32_t*>(e->wino_tickets) + (slab_off ? WINO_TICKETS : 0);
+            q.tickets_cap = WINO_TICKETS;
+        }
         HIPCHK(e, launch_wino3x3(q, s));
     } else if (use_patch && L.kh == 3 && L.stride == 1) {
         int bm = tile == TILE_64x64 || tile == TILE_64x64_K64 ? 64 : 128;
@@ -861,12 +870,14 @@ int create_impl(const pa_config* cfg, const void* blob, size_t src_bytes, const 
         } else {
             r2 = (e->bf16 && k == 3) ? upload_bf16(e, &L.wgt, w) : upload(e, &L.wgt, w);
             if (r2) return r2;
-            // Winograd F(2x2, 3x3) for the fp32 stride-1 3x3 layers it is faster on (wino.hip; measured per layer at 128 crops,
-            // profiles/r05_resnet_layer_times_wino_options.txt: layers 1-3; layer 4's 4 x 4 maps stay on the direct kernel, 84 against
-            // 117-160 us). PA_WINO=0: none (A/B), 2: every stride-1 3x3 layer
+            // Winograd F(2x2, 3x3) for the fp32 stride-1 3x3 layers (wino.hip; measured per layer at 128 crops,
+            // profiles/r05_resnet_layer_times_wino_options.txt). Layer 4's 4 x 4 maps -- 64 tiles at 128 crops -- were slower there
+            // than on the direct kernel (117-160 against 84 us) until the kernel learnt to split K. PA_WINO=0: none (A/B);
+            // PA_WINO_MIN_HW=8: layers 1-3 only (A/B)
             static const int wino_mode = getenv("PA_WINO") ? atoi(getenv("PA_WINO")) : 1;
-            if (!e->bf16 && k == 3 && stride == 1 && wino_mode && (wino_mode >= 2 || L.out_hw >= 8) && L.out_hw % 4 == 0) {
-                L.wino_bn = wino_pick_bn(cout, (long long)NC * (L.out_hw / 4) * (L.out_hw / 4));
+            static const int wino_min_hw = getenv("PA_WINO_MIN_HW") ? atoi(getenv("PA_WINO_MIN_HW")) : 4;
+            if (!e->bf16 && k == 3 && stride == 1 && wino_mode && L.out_hw >= wino_min_hw && L.out_hw % 4 == 0) {
+                L.wino_bn = wino_pick_bn(cout, (long long)NC * (L.out_hw / 4) * (L.out_hw / 4), cin);
                 std::vector<float> ug(wino_weight_floats(cin, cout), 0.f);
                 if (!br.dry) wino_transform_weights(w.data(), cin, cout, L.wino_bn, ug.data());
                 r2 = upload(e, &L.wino_wgt, ug);
@@ -956,8 +967,9 @@ int create_impl(const pa_config* cfg, const void* blob, size_t src_bytes, const 
                     // implicit GEMM above)
                     static const int wino_mode = getenv("PA_WINO") ? atoi(getenv("PA_WINO")) : 1;
                     static const int wino_ds = getenv("PA_WINO_DS") ? atoi(getenv("PA_WINO_DS")) : 1;
-                    if (wino_mode && wino_ds && (wino_mode >= 2 || hw_out >= 8) && hw_out % 4 == 0) {
-                        L.wino_bn = wino_pick_bn(co, (long long)NC * (hw_out / 4) * (hw_out / 4));
+                    static const int wino_min_hw = getenv("PA_WINO_MIN_HW") ? atoi(getenv("PA_WINO_MIN_HW")) : 4;
+                    if (wino_mode && wino_ds && hw_out >= wino_min_hw && hw_out % 4 == 0) {
+                        L.wino_bn = wino_pick_bn(co, (long long)NC * (hw_out / 4) * (hw_out / 4), co);
                         std::vector<float> ug(wino_weight_floats(co, co), 0.f);
                         if (!br.dry) wino_transform_weights(keep_w.data(), co, co, L.wino_bn, ug.data());
                         rc = upload(e, &L.wino_wgt, ug);
@@ -1060,6 +1072,14 @@ int create_impl(const pa_config* cfg, const void* blob, size_t src_bytes, const 
             if (L.splitk > 1) need = std::max(need, (size_t)L.splitk * NC * L.out_hw * L.out_hw * L.cout);
         if (e->fc.splitk > 1) need = std::max(need, (size_t)e->fc.splitk * NC * PA_FEATURE_STRIDE);
         if (e->head_splitk > 1) need = std::max(need, (size_t)e->head_splitk * NC * 512);
+        // the Winograd kernel's split-K scratch (wino.hip): at most one launch's worth of partial output tiles -- a grid of 256
+        // eight-wave (512 four-wave) workgroups x 32 floats per thread -- and a ticket per tile
+        bool any_wino = false;
+        for (const ConvLayer& L : e->convs) any_wino = any_wino || L.wino_wgt;
+        if (any_wino) {
+            need = std::max(need, (size_t)256 * 512 * 32);
+            ALLOC(e->wino_tickets, (size_t)2 * WINO_TICKETS, true);
+        }
         need *= 2;  // one region per interleaved half batch
         e->slab_floats = need;
         ALLOC(e->slab, need, false);

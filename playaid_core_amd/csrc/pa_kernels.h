@@ -136,9 +136,18 @@ struct WinoParams {
     int32_t relu, res_after;  // as GemmParams
     int32_t n_sb, sb_per_row, sb_per_img, tiles_n;  // set by the launcher
     unsigned long long* clk;  // stamp launches only (PA_WINO_ABL=8)
+    // split K (optional; the launcher turns it on for layers whose tiles do not fill the chip): scratch for the partial output
+    // tiles -- slab_floats floats -- and one ticket per tile, tickets_cap of them, ZERO before the first launch (the kernel
+    // leaves them zero); ksplit is set by the launcher
+    float* slab;
+    size_t slab_floats;
+    int32_t* tickets;
+    int32_t tickets_cap, ksplit;
 };
 size_t wino_weight_floats(int cin, int cout);
-int wino_pick_bn(int cout, long long n_sb);  // output channels per workgroup = per stage image of the filter layout (64 | 32)
+// output channels per workgroup = per stage image of the filter layout (64 | 32); cin_split > 0: the caller launches with split-K
+// scratch (WinoParams::slab, tickets) and the layer has that many input channels
+int wino_pick_bn(int cout, long long n_sb, int cin_split = 0);
 // w [cout][ky][kx][cin] (host) -> ug [wino_weight_floats] (host)
 void wino_transform_weights(const float* w, int cin, int cout, int bn, float* ug);
 hipError_t launch_wino3x3(const WinoParams& p, hipStream_t s);

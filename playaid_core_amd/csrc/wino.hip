@@ -189,8 +189,9 @@ template <int N> __device__ __forceinline__ void wn_wait_vmcnt() {
 
 // NST: stages of the LDS ring (3 where they fit: the DMA of chunk c + 2 is issued during chunk c, so the wait in front of a
 // barrier is for copies issued a whole chunk earlier)
+// (four-wave workgroups: two per CU -- without the bound hipcc spreads the kernel over 330 registers and one fits)
 template <int TGN, int NCG, int NST, int ABL>
-__global__ __launch_bounds__(64 * TGN * NCG) void wino3x3_kernel(const WinoParams p) {
+__global__ __launch_bounds__(64 * TGN * NCG, TGN * NCG == 4 ? 2 : 1) void wino3x3_kernel(const WinoParams p) {
     using G = WinoGeo<TGN, NCG>;
     constexpr int NW = G::NW;
     constexpr int KU = G::U_INSTR / NW;               // filter DMA instructions per wave and chunk
@@ -216,15 +217,20 @@ __global__ __launch_bounds__(64 * TGN * NCG) void wino3x3_kernel(const WinoParam
     const int nwg = gridDim.x, b = blockIdx.x;
     const int q = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
     const int wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (b >> 3);
-    const int tile_m = wg / p.tiles_n, tile_n = wg - tile_m * p.tiles_n;
-    const int n_chunks = p.cin >> 3;
+    // split K (p.ksplit > 1; layers with too few tiles to fill the chip): ksplit consecutive workgroups share a tile, each sums
+    // its run of n_chunks channel chunks; the partial OUTPUT tiles meet in the epilogue (the output transform is linear)
+    const int ks = p.ksplit > 1 ? wg % p.ksplit : 0;
+    const int wgt_ = p.ksplit > 1 ? wg / p.ksplit : wg;
+    const int tile_m = wgt_ / p.tiles_n, tile_n = wgt_ - tile_m * p.tiles_n;
+    const int n_chunks = (p.cin >> 3) / (p.ksplit > 1 ? p.ksplit : 1);
+    const int chunk0 = ks * n_chunks;
 
     unsigned long long* const clk = (ABL & 8) && p.clk && lane == 0 ? p.clk + ((size_t)blockIdx.x * NW + wave) * 64 : nullptr;
     if ((ABL & 8) && clk) clk[0] = __builtin_amdgcn_s_memtime();
 #define WN_STAMP(K) if ((ABL & 8) && clk && (K) < 63) clk[K] = __builtin_amdgcn_s_memtime()
 
     const i32x4 act_rsrc = wn_rsrc(p.act), wgt_rsrc = wn_rsrc(p.wgt);
-    const int u_soff0 = tile_n * n_chunks * G::U_FLOATS * 4;
+    const int u_soff0 = (tile_n * (p.cin >> 3) + chunk0) * G::U_FLOATS * 4;
     // DMA instruction K (0 .. KD - 1) of chunk C into stage (UL, PL): first the wave's share of the filter image (a straight
     // copy), then of the patch. Patch instructions past the stage's last (P_INSTR is not always a multiple of the wave count)
     // repeat the wave's previous one -- the same bytes to the same place -- so that every wave issues KD per chunk and one
@@ -263,7 +269,7 @@ __global__ __launch_bounds__(64 * TGN * NCG) void wino3x3_kernel(const WinoParam
         const int sbx = rem2 - sby * p.sb_per_row;
         const int y = px / 6;
         const int x = px - y * 6;
-        pvoff[k] = (img * p.in_img_stride + (4 * sby + y) * p.in_row_stride + (4 * sbx + x) * p.in_px_stride + h * 4) * 4;
+        pvoff[k] = (img * p.in_img_stride + (4 * sby + y) * p.in_row_stride + (4 * sbx + x) * p.in_px_stride + h * 4 + chunk0 * 8) * 4;
     }
 #pragma unroll
     for (int k = 0; k < KPI; ++k) WN_ISSUE_P(p_lds0, 0, k);
@@ -333,6 +339,65 @@ __global__ __launch_bounds__(64 * TGN * NCG) void wino3x3_kernel(const WinoParam
 #undef WN_ISSUE_ALL
 
     // ---- output transform + epilogue, all in the accumulating lane ----------------------------------------------------
+    // A^T m A over the 4x4 positions (p = 4 i + j): y[g][oy][ox] = the lane's 2 x 2 pixels x channels ch0 + 16 g + 0..3
+    f32x4 y[2][2][2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        f32x4 s0[4], s1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s0[j] = acc[j][g] + acc[4 + j][g] + acc[8 + j][g];
+            s1[j] = acc[4 + j][g] - acc[8 + j][g] - acc[12 + j][g];
+        }
+        y[g][0][0] = s0[0] + s0[1] + s0[2];
+        y[g][0][1] = s0[1] - s0[2] - s0[3];
+        y[g][1][0] = s1[0] + s1[1] + s1[2];
+        y[g][1][1] = s1[1] - s1[2] - s1[3];
+    }
+    if (p.ksplit > 1) {
+        // Every split writes its partial tile to slab[tile][split][value e][thread] (each store instruction 256 contiguous bytes)
+        // with agent-scope stores (write-through: the splits of a tile may sit on different XCDs, whose L2s do not see each
+        // other), waits for them, and draws a ticket; the LAST to arrive sums the ksplit partials IN SPLIT ORDER -- its own from
+        // the slab as well, so the result does not depend on who was last -- and runs the epilogue.
+        constexpr int NT = 64 * TGN * NCG;
+        float* const mine = p.slab + ((size_t)wgt_ * p.ksplit + ks) * (32 * NT) + tid;
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    __hip_atomic_store(mine + ((g * 4 + i) * 4 + e) * NT, y[g][i >> 1][i & 1][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __shared__ int last_s;
+        __syncthreads();
+        if (tid == 0) {
+            const int ticket = __hip_atomic_fetch_add(p.tickets + wgt_, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last_s = ticket == p.ksplit - 1;
+            if (last_s) __hip_atomic_store(p.tickets + wgt_, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        }
+        __syncthreads();
+        if (!last_s) {
+            if ((ABL & 8) && clk) clk[63] = __builtin_amdgcn_s_memtime();
+            return;
+        }
+        const float* const all = p.slab + (size_t)wgt_ * p.ksplit * (32 * NT) + tid;
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[g][i >> 1][i & 1][e] = 0.f;
+        for (int k = 0; k < p.ksplit; ++k) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        y[g][i >> 1][i & 1][e] += __hip_atomic_load(all + (size_t)k * (32 * NT) + ((g * 4 + i) * 4 + e) * NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     if (!own) {
         if ((ABL & 8) && clk) clk[63] = __builtin_amdgcn_s_memtime();
         return;
@@ -349,25 +414,13 @@ __global__ __launch_bounds__(64 * TGN * NCG) void wino3x3_kernel(const WinoParam
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const f32x4 bias4 = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + ch0 + 16 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
-        // A^T m A over the 4x4 positions (p = 4 i + j)
-        f32x4 s0[4], s1[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            s0[j] = acc[j][g] + acc[4 + j][g] + acc[8 + j][g];
-            s1[j] = acc[4 + j][g] - acc[8 + j][g] - acc[12 + j][g];
-        }
-        f32x4 y[2][2];
-        y[0][0] = s0[0] + s0[1] + s0[2];
-        y[0][1] = s0[1] - s0[2] - s0[3];
-        y[1][0] = s1[0] + s1[1] + s1[2];
-        y[1][1] = s1[1] - s1[2] - s1[3];
 #pragma unroll
         for (int oy = 0; oy < 2; ++oy)
 #pragma unroll
             for (int ox = 0; ox < 2; ++ox) {
                 const long o = o00 + (long)oy * p.out_row_stride + ox * p.out_px_stride + 16 * g;
                 const f32x4 r4 = res4[g][oy][ox];
-                f32x4 v = y[oy][ox] + (p.res_after ? bias4 : bias4 + r4);
+                f32x4 v = y[g][oy][ox] + (p.res_after ? bias4 : bias4 + r4);
                 if (p.relu == 1) {
                     v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
                     v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
@@ -395,11 +448,16 @@ size_t wino_weight_floats(int cin, int cout) { return (size_t)16 * cin * cout; }
 // workgroups per CU -- where 64-channel workgroups would leave CUs idle (ResNet-18's layer 3 at 128 crops: 128 workgroups of 64
 // channels take 81 us, 256 of 32 channels 65; the detector's 12 x 20 map at 64 frames has 240 and keeps 64: 83 against 121 us)
 // and for layers of 32 channels (eight tile groups). PA_WINO_BN=32|64 forces it (A/B).
-int wino_pick_bn(int cout, long long n_sb) {
+int wino_pick_bn(int cout, long long n_sb, int cin_split) {
     static const int force = getenv("PA_WINO_BN") ? atoi(getenv("PA_WINO_BN")) : 0;
     if (cout % 64) return 32;
     if (force == 32 || force == 64) return force;
-    const long long wg64 = ((n_sb + 15) / 16) * (cout / 64);
+    long long wg64 = ((n_sb + 15) / 16) * (cout / 64);
+    // a caller with split-K scratch (cin_split = the layer's input channels): the launcher multiplies the grid by up to the
+    // largest power of two that leaves eight chunks per split -- 64-channel workgroups x 4 beat 32-channel ones x 4 on
+    // ResNet-18's layers 3 / 4 (52-54 against 55 us, 56 against 61 us at 128 crops)
+    if (cin_split > 0)
+        for (int k2 = 2; k2 <= 8 && (cin_split / 8) % k2 == 0 && (cin_split / 8) / k2 >= 8 && wg64 * 2 <= 256; k2 *= 2) wg64 *= 2;
     return wg64 < 192 ? 32 : 64;
 }
 
@@ -447,7 +505,22 @@ hipError_t launch_wino3x3(const WinoParams& p_in, hipStream_t s) {
     const int nsb = bn == 64 ? 16 : (small_wg ? 16 : 32);
     p.tiles_n = p.cout / bn;
     const int tiles_m = (p.n_sb + nsb - 1) / nsb;
-    const int grid = tiles_m * p.tiles_n;
+    // split K where the tiles alone leave CUs without a workgroup (ResNet-18's layers 3 and 4 at 128 crops: 256 four-wave / 64
+    // eight-wave workgroups): the largest power of two that keeps >= 8 chunks per split and the grid within one workgroup of
+    // eight waves (two of four) per CU; needs the caller's scratch (slab, tickets). PA_WINO_KS=1 turns it off, n forces n.
+    static const int ks_force = getenv("PA_WINO_KS") ? atoi(getenv("PA_WINO_KS")) : 0;
+    const int n_tiles = tiles_m * p.tiles_n, threads = (bn == 64 || !small_wg) ? 512 : 256;
+    int ks = 1;
+    if (p.slab && p.tickets && n_tiles <= p.tickets_cap) {
+        const int target = threads == 512 ? 256 : 512;
+        for (int k2 = 2; k2 <= 8; k2 *= 2)
+            if ((p.cin / 8) % k2 == 0 && (p.cin / 8) / k2 >= 8 && n_tiles * k2 <= target && (size_t)n_tiles * k2 * 32 * threads <= p.slab_floats &&
+                (ks_force == 0 || k2 <= ks_force))
+                ks = k2;
+        if (ks_force == 1) ks = 1;
+    }
+    p.ksplit = ks;
+    const int grid = n_tiles * ks;
     static const int abl = getenv("PA_WINO_ABL") ? atoi(getenv("PA_WINO_ABL")) : 0;
     static const int nst = getenv("PA_WINO_STAGES") ? atoi(getenv("PA_WINO_STAGES")) : 2;  // 3: a three-stage ring (A/B: 62.3 against 61.5 us on layer 1, 95.2 against 92.1 on the 24 x 40 map -- the prologue then waits behind two chunks of copies)
 #define WN_LAUNCH(ABL_)                                                                                        \
@@ -513,7 +586,7 @@ size_t pa_wino_weight_floats(int32_t cin, int32_t cout) {
 
 int pa_wino_channels_per_workgroup(int32_t cout, int64_t sub_blocks) {
     if (cout < 32 || cout % 32 || sub_blocks < 1) return 0;
-    return pa::wino_pick_bn(cout, sub_blocks);
+    return pa::wino_pick_bn(cout, sub_blocks, 0);
 }
 
 int pa_wino_transform_weights(const float* w_host, int32_t cin, int32_t cout, int32_t bn, float* ug_host) {
@@ -522,11 +595,12 @@ int pa_wino_transform_weights(const float* w_host, int32_t cin, int32_t cout, in
     return PA_OK;
 }
 
-int pa_wino_conv3x3(const float* x, const float* ug, const float* bias, const float* residual, float* out, int32_t n, int32_t height,
-                    int32_t width, int32_t cin, int32_t cout, int32_t bn, int32_t in_px_stride, int32_t out_px_stride, int32_t out_pad, int32_t act,
-                    int32_t res_after, void* stream) {
+static int wino_conv3x3_impl(const float* x, const float* ug, const float* bias, const float* residual, float* out, int32_t n, int32_t height,
+                             int32_t width, int32_t cin, int32_t cout, int32_t bn, int32_t in_px_stride, int32_t out_px_stride, int32_t out_pad,
+                             int32_t act, int32_t res_after, float* slab, size_t slab_floats, int32_t* tickets, int32_t n_tickets, void* stream) {
     if (!x || !ug || !out || n < 1 || out_pad < 0 || act < 0 || act > 2) return PA_ERR_INVALID_ARG;
     pa::WinoParams p{};
+    p.slab = slab; p.slab_floats = slab_floats; p.tickets = tickets; p.tickets_cap = n_tickets;
     p.act = x; p.wgt = ug; p.bias = bias; p.residual = residual; p.out = out;
     p.n_img = n; p.height = height; p.width = width; p.cin = cin; p.cout = cout; p.bn = bn;
     p.in_px_stride = in_px_stride;
@@ -540,6 +614,21 @@ int pa_wino_conv3x3(const float* x, const float* ug, const float* bias, const fl
     p.res_after = res_after;
     const hipError_t e = pa::launch_wino3x3(p, (hipStream_t)stream);
     return e == hipSuccess ? PA_OK : (e == hipErrorInvalidValue ? PA_ERR_INVALID_ARG : PA_ERR_HIP);
+}
+
+int pa_wino_conv3x3(const float* x, const float* ug, const float* bias, const float* residual, float* out, int32_t n, int32_t height,
+                    int32_t width, int32_t cin, int32_t cout, int32_t bn, int32_t in_px_stride, int32_t out_px_stride, int32_t out_pad, int32_t act,
+                    int32_t res_after, void* stream) {
+    return wino_conv3x3_impl(x, ug, bias, residual, out, n, height, width, cin, cout, bn, in_px_stride, out_px_stride, out_pad, act, res_after, nullptr, 0,
+                             nullptr, 0, stream);
+}
+
+int pa_wino_conv3x3_splitk(const float* x, const float* ug, const float* bias, const float* residual, float* out, int32_t n, int32_t height,
+                           int32_t width, int32_t cin, int32_t cout, int32_t bn, int32_t in_px_stride, int32_t out_px_stride, int32_t out_pad,
+                           int32_t act, int32_t res_after, float* slab, size_t slab_floats, int32_t* tickets, int32_t n_tickets, void* stream) {
+    if (!slab || !tickets || n_tickets < 1 || (reinterpret_cast<unsigned long long>(slab) & 15ull)) return PA_ERR_INVALID_ARG;
+    return wino_conv3x3_impl(x, ug, bias, residual, out, n, height, width, cin, cout, bn, in_px_stride, out_px_stride, out_pad, act, res_after, slab,
+                             slab_floats, tickets, n_tickets, stream);
 }
 
 }  // extern "C"

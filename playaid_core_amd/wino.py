@@ -40,10 +40,20 @@ def transform_weights(w_oihw: np.ndarray, bn: int = 0) -> np.ndarray:
     return ug
 
 
+class SplitKScratch:
+    """Device scratch of ``pa_wino_conv3x3_splitk``: the slab the partial output tiles meet in (16 MB covers every launch) and the
+    tickets (zero between launches). Launches that share one belong on one stream."""
+
+    def __init__(self, device="cuda:0", slab_floats: int = 256 * 512 * 32, n_tickets: int = 4096):
+        self.slab = torch.empty(slab_floats, dtype=torch.float32, device=device)
+        self.tickets = torch.zeros(n_tickets, dtype=torch.int32, device=device)
+
+
 def conv3x3(x_pad: torch.Tensor, ug: torch.Tensor, cin: int, cout: int, bias=None, residual=None, out=None, out_pad: int = 1,
-            act: int = 0, res_after: bool = False, out_px_stride: int = None, bn: int = 0) -> torch.Tensor:
+            act: int = 0, res_after: bool = False, out_px_stride: int = None, bn: int = 0, split_k: SplitKScratch = None) -> torch.Tensor:
     """x_pad float32[n, H + 2, W + 2, C >= cin] (device, zero border) -> out float32[n, H + 2 out_pad, W + 2 out_pad, C'] (interior
-    written, border untouched). Enqueues on the current stream."""
+    written, border untouched). Enqueues on the current stream. ``split_k``: scratch that lets the launcher split the input
+    channels over several workgroups per tile where the tiles alone would not fill the chip."""
     lib = _lib.load()
     if x_pad.dtype != torch.float32 or not x_pad.is_cuda or not x_pad.is_contiguous() or x_pad.dim() != 4:
         raise ValueError("x_pad: contiguous float32[n, H + 2, W + 2, C] on the device")
@@ -53,8 +63,13 @@ def conv3x3(x_pad: torch.Tensor, ug: torch.Tensor, cin: int, cout: int, bias=Non
     if out is None:
         out = torch.zeros((n, h + 2 * out_pad, w + 2 * out_pad, ops), dtype=torch.float32, device=x_pad.device)
     ptr = lambda t_: C.c_void_p(t_.data_ptr()) if t_ is not None else C.c_void_p(0)
-    rc = lib.pa_wino_conv3x3(ptr(x_pad), ptr(ug), ptr(bias), ptr(residual), ptr(out), n, h, w, cin, cout, bn or (64 if cout % 64 == 0 else 32), cs, out.shape[3], out_pad,
-                             int(act), int(bool(res_after)), C.c_void_p(torch.cuda.current_stream(x_pad.device).cuda_stream))
+    stream = C.c_void_p(torch.cuda.current_stream(x_pad.device).cuda_stream)
+    args = (ptr(x_pad), ptr(ug), ptr(bias), ptr(residual), ptr(out), n, h, w, cin, cout, bn or (64 if cout % 64 == 0 else 32), cs, out.shape[3], out_pad,
+            int(act), int(bool(res_after)))
+    if split_k is None:
+        rc = lib.pa_wino_conv3x3(*args, stream)
+    else:
+        rc = lib.pa_wino_conv3x3_splitk(*args, ptr(split_k.slab), split_k.slab.numel(), ptr(split_k.tickets), split_k.tickets.numel(), stream)
     if rc:
         raise ValueError(f"pa_wino_conv3x3: status {rc}")
     return out

@@ -7,8 +7,8 @@
 Units: both counters are in KiB. On gfx950 FETCH_SIZE reports half the bytes of a wide
 coalesced read stream (guide, section HBM), so it is doubled; WRITE_SIZE is taken as is.
 fp32: the family = every wino3x3_kernel and conv3x3_patch_kernel launch (thirteen stride-1 convs per step) plus
-the first five of each six non-gather igemm_f32_kernel launches (the stride-2 convs and the two 1x1/2 branch GEMMs of
-the Winograd block-0 layers; the sixth is the fc): 18 per step. bf16: every conv3x3_bf16_patch_kernel and igemm_bf16_kernel launch (16 per step; 19 with PA_BF16_DS_FUSE=0)."""
+the first six of each seven non-gather igemm_f32_kernel launches (the stride-2 convs and the three 1x1/2 branch GEMMs of
+the Winograd block-0 layers; the seventh is the fc): 19 per step. bf16: every conv3x3_bf16_patch_kernel and igemm_bf16_kernel launch (16 per step; 19 with PA_BF16_DS_FUSE=0)."""
 import collections, csv, glob, json, sys
 
 
@@ -26,10 +26,10 @@ def conv3x3_values(disp, dtype):
         return [v for (name, v) in disp if "igemm_bf16_kernel" in name or "conv3x3_bf16_patch_kernel" in name]
     vals = [v for (name, v) in disp if "conv3x3_patch_kernel" in name or "wino3x3_kernel" in name]
     ig = [v for (name, v) in disp if "igemm_f32_kernel" in name and ", true," not in name]
-    per_step = 5 + 1  # the three stride-2 convs and the two 1x1/2 branch GEMMs, then the fc
+    per_step = 6 + 1  # the three stride-2 convs and the three 1x1/2 branch GEMMs, then the fc
     assert len(ig) % per_step == 0, (len(ig), per_step)
     for s in range(len(ig) // per_step):
-        vals += ig[s * per_step:s * per_step + 5]
+        vals += ig[s * per_step:s * per_step + per_step - 1]
     return vals
 
 
@@ -49,7 +49,7 @@ out = {
     "fetch_bytes_per_launch": round(fetch),
     "write_bytes_per_launch": round(write),
     "traffic_bytes_per_launch": round(fetch + write),
-    "note": "FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, KiB -> bytes, mean over the conv3x3-family launches of each step (18 in fp32, 16 in bf16)",
+    "note": "FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, KiB -> bytes, mean over the conv3x3-family launches of each step (19 in fp32, 16 in bf16)",
 }
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 print(json.dumps(out))

@@ -2,13 +2,13 @@
 """Average duration per kernel FAMILY from a rocprofv3 --kernel-trace CSV of bench.py.
 
 rocprofv3 --stats groups by kernel symbol. The conv3x3 family of bench.py's `roofline` is served
-by three symbols (round 5): wino3x3_kernel<...> (the ten stride-1 3x3 convs of layers 1-3, Winograd),
-conv3x3_patch_kernel<...> (layer 4's three) and igemm_f32_kernel<...> (the three stride-2 convs and the
-two 1x1/2 branch GEMMs of layers 2-3, whose 3x3 runs as Winograd), and igemm_f32_kernel also runs the fc. The
-non-gather igemm launches of a bench step come in a fixed order (layer2.0.conv1, layer2.0 branch, layer3.0.conv1,
-layer3.0 branch, layer4.0.conv1, fc; the gather-mode Conv1d is a different instantiation), which this script uses
-to split them, so that bench.py's roofline.avg_launch_ms can be checked against the profiler: 18 launches per step
-(PA_WINO=0: 16, four non-gather igemm launches per step -- pass `f32-direct`).
+by two symbols (round 5): wino3x3_kernel<...> (the thirteen stride-1 3x3 convs, Winograd; conv3x3_patch_kernel<...> under
+PA_WINO=0 / PA_WINO_MIN_HW=8) and igemm_f32_kernel<...> (the three stride-2 convs and the three 1x1/2 branch GEMMs of layers
+2-4, whose 3x3 runs as Winograd), and igemm_f32_kernel also runs the fc. The non-gather igemm launches of a bench step come in
+a fixed order (layer2.0.conv1, layer2.0 branch, layer3.0.conv1, layer3.0 branch, layer4.0.conv1, layer4.0 branch, fc; the
+gather-mode Conv1d is a different instantiation), which this script uses to split them, so that bench.py's
+roofline.avg_launch_ms can be checked against the profiler: 19 launches per step (PA_WINO=0: 16, four non-gather igemm
+launches per step -- pass `f32-direct`; PA_WINO_MIN_HW=8, the set of early round 5: 18, six -- pass `f32-wino8`).
 
   python scripts/rocprof_families.py <dir>/<host>/<pid>_kernel_trace.csv out.json [f32|bf16]
 
@@ -32,7 +32,7 @@ for r in rows:
     elif name.startswith("pa::") or " pa::" in name:
         fam[name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("pa::", "")].append(dur)
 dtype = sys.argv[3] if len(sys.argv) > 3 else "f32"
-per = 6 if dtype == "f32" else (4 if dtype == "f32-direct" else 1)
+per = 7 if dtype == "f32" else (6 if dtype == "f32-wino8" else (4 if dtype == "f32-direct" else 1))
 assert len(ig) % per == 0, len(ig)
 for s in range(len(ig) // per):
     step = ig[s * per:(s + 1) * per]

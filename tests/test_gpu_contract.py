@@ -319,10 +319,10 @@ def test_profile_rows(engine):
     names = {r["name"] for r in rows}
     assert {"preprocess_crops", "igemm_conv3x3", "stem_conv7x7_pool", "head_mlp_logsoftmax"} <= names
     conv = next(r for r in rows if r["name"] == "igemm_conv3x3")
-    # sixteen convolutions + the two 1x1/2 branch GEMMs of layers 2-3 (whose 3x3 runs as Winograd since round 5); ten of the
-    # launches execute 4/9 of their algorithmic multiply-adds
-    assert conv["launches"] == 18 and conv["total_ms"] > 0 and conv["flops"] > 1e9
-    assert 0.55 * conv["flops"] < conv["flops_executed"] < 0.70 * conv["flops"]
+    # sixteen convolutions + the three 1x1/2 branch GEMMs of layers 2-4 (whose 3x3 runs as Winograd since round 5); thirteen of
+    # the launches execute 4/9 of their algorithmic multiply-adds
+    assert conv["launches"] == 19 and conv["total_ms"] > 0 and conv["flops"] > 1e9
+    assert 0.45 * conv["flops"] < conv["flops_executed"] < 0.60 * conv["flops"]
 
 
 def test_two_stream_pipeline_equals_serial(engine):

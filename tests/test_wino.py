@@ -49,7 +49,7 @@ def test_transform_rejects_bad_shapes():
     assert lib.pa_wino_transform_weights(buf.ctypes.data_as(ctypes.c_void_p), 8, 64, 48, buf.ctypes.data_as(ctypes.c_void_p)) != 0
 
 
-def _case(n, h, w, cin, cout, seed, act=0, residual=False, res_after=False, in_extra=0, out_extra=0, out_pad=1, bn=0):
+def _case(n, h, w, cin, cout, seed, act=0, residual=False, res_after=False, in_extra=0, out_extra=0, out_pad=1, bn=0, split_k=None):
     from playaid_core_amd import wino
 
     rng = np.random.default_rng(seed)
@@ -70,7 +70,7 @@ def _case(n, h, w, cin, cout, seed, act=0, residual=False, res_after=False, in_e
         resp[:, out_pad:out_pad + h, out_pad:out_pad + w, :cout] = torch.from_numpy(res).permute(0, 2, 3, 1)
     ug = torch.from_numpy(wino.transform_weights(wt, bn=bn)).to(dev)
     got = wino.conv3x3(xp.to(dev), ug, cin, cout, bias=torch.from_numpy(b).to(dev), residual=resp.to(dev) if residual else None,
-                       out=out.to(dev), out_pad=out_pad, act=act, res_after=res_after, bn=bn).cpu()
+                       out=out.to(dev), out_pad=out_pad, act=act, res_after=res_after, bn=bn, split_k=split_k).cpu()
     ref = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(), torch.from_numpy(b).double(), padding=1)
     if residual and not res_after:
         ref = ref + torch.from_numpy(res).double()
@@ -115,6 +115,7 @@ def test_workgroup_width_rule():
     assert wino.channels_per_workgroup(256, 128 * 4) == 32       # layer 3: 128 workgroups of 64 channels -> 256 of 32
     assert wino.channels_per_workgroup(256, 64 * 15) == 64       # the detector's 12 x 20 map at 64 frames: 240 workgroups
     assert wino.channels_per_workgroup(32, 64 * 24 * 40) == 32   # a 32-channel layer has no 64-channel form
+    # (the engine, which launches with split-K scratch, keeps 64-channel workgroups on layers 3 / 4 and splits the input channels)
     with pytest.raises(ValueError):
         wino.channels_per_workgroup(48, 100)
 
@@ -155,3 +156,35 @@ def test_wino_conv_is_bitwise_repeatable_and_batch_independent():
     assert torch.equal(a, b)
     one = wino.conv3x3(xd[2:3].contiguous(), ug, c, c).cpu()
     assert torch.equal(one[0], a[2]), "an image's result must not depend on the batch around it"
+
+
+@pytest.mark.gpu
+def test_wino_conv_split_k():
+    """Few tiles, many channels (ResNet-18's layers 3 and 4 at 128 crops): several workgroups per tile, each over a run of input
+    channels, the partial tiles summed in split order by the last to arrive. Same bar as the unsplit launch, the tickets back at
+    zero, bitwise repeatable (arrival order must not matter), epilogues and partial tiles included."""
+    from playaid_core_amd import wino
+
+    dev = torch.device("cuda:0")
+    sk = wino.SplitKScratch(dev)
+    assert _case(128, 4, 4, 512, 512, 21, act=1, residual=True, split_k=sk) <= 2e-5          # layer 4: 64 tiles x 4 splits
+    assert _case(128, 4, 4, 512, 512, 22, act=1, bn=32, split_k=sk) <= 2e-5                  # ... as 128 four-wave tiles x 4
+    assert _case(37, 8, 8, 256, 256, 23, act=1, residual=True, split_k=sk) <= 2e-5           # layer 3 shape, partial last tile
+    assert _case(9, 4, 4, 512, 512, 24, act=2, residual=True, res_after=True, out_extra=32, split_k=sk) <= 2e-5   # 8 splits of 8 chunks
+    assert _case(2, 16, 16, 64, 64, 25, split_k=sk) <= 2e-5                                  # 8 chunks: too few to split
+    assert int(sk.tickets.abs().sum()) == 0
+    rng = np.random.default_rng(5)
+    n, h, w, c = 128, 4, 4, 512
+    xp = torch.zeros((n, h + 2, w + 2, c))
+    xp[:, 1:-1, 1:-1] = torch.from_numpy(rng.standard_normal((n, h, w, c)).astype(np.float32))
+    wt = (rng.standard_normal((c, c, 3, 3)) / 60).astype(np.float32)
+    ug = torch.from_numpy(wino.transform_weights(wt)).to(dev)
+    xd = xp.to(dev)
+    first = wino.conv3x3(xd, ug, c, c, split_k=sk).cpu()
+    for _ in range(20):
+        assert torch.equal(wino.conv3x3(xd, ug, c, c, split_k=sk).cpu(), first)
+    plain = wino.conv3x3(xd, ug, c, c).cpu()
+    assert float((plain - first).abs().max()) <= 2e-5 * float(plain.abs().max())   # (a different summation order, not a different sum)
+    # a scratch too small for any split, or with too few tickets, runs the unsplit launch
+    tiny = wino.SplitKScratch(dev, slab_floats=1024, n_tickets=4)
+    assert torch.equal(wino.conv3x3(xd, ug, c, c, split_k=tiny).cpu(), plain)
