@@ -15,8 +15,10 @@
 // transform, bias, residual, activation and the 16-byte stores run in the lane that accumulated -- no exchange, no LDS,
 // no barrier behind the k loop. 16 tiles = four 4x4-pixel sub-blocks (2x2 tiles each, a 6x6 input patch each): any map
 // whose sides are multiples of four.
-//   workgroup = 8 waves: NCG = 2: 4 tile groups (16 sub-blocks = 256 pixels) x 2 channel groups (64 channels)
-//                        NCG = 1: 8 tile groups (32 sub-blocks = 512 pixels) x 32 channels (the 32-channel layers)
+//   workgroup = 8 waves: 4 tile groups (16 sub-blocks = 256 pixels) x 2 channel groups (64 channels), one to a CU
+//            or 4 waves: 4 tile groups x 32 channels, two to a CU: 32-channel layers, and layers too small for the first form
+//               (8 waves as 8 tile groups x 32 channels: the first shape of the 32-channel layers, kept behind PA_WINO_SMALL32=0)
+//   Where even that leaves CUs without work the launcher splits K (ksplit workgroups per tile, see the epilogue).
 // K loop over chunks of 8 input channels. A stage of the LDS ring holds, for one chunk,
 //   U  [16 positions][BN / 16][16 channels][8 cin]   the transformed filters (BN = 64: 32 KB), the exact image the host laid
 //                                                     out: the DMA is a straight copy (rows 8..15 of a 16-channel group
@@ -447,7 +449,7 @@ size_t wino_weight_floats(int cin, int cout) { return (size_t)16 * cin * cout; }
 // sub-blocks per launch: 64 (eight waves: 4 tile groups x 2 channel groups) where that fills the chip; 32 -- four waves, two
 // workgroups per CU -- where 64-channel workgroups would leave CUs idle (ResNet-18's layer 3 at 128 crops: 128 workgroups of 64
 // channels take 81 us, 256 of 32 channels 65; the detector's 12 x 20 map at 64 frames has 240 and keeps 64: 83 against 121 us)
-// and for layers of 32 channels (eight tile groups). PA_WINO_BN=32|64 forces it (A/B).
+// and for layers of 32 channels. PA_WINO_BN=32|64 forces it (A/B).
 int wino_pick_bn(int cout, long long n_sb, int cin_split) {
     static const int force = getenv("PA_WINO_BN") ? atoi(getenv("PA_WINO_BN")) : 0;
     if (cout % 64) return 32;
@@ -501,7 +503,11 @@ hipError_t launch_wino3x3(const WinoParams& p_in, hipStream_t s) {
     p.n_sb = (int)n_sb;
     const int bn = p.bn;
     if ((bn != 32 && bn != 64) || p.cout % bn) return hipErrorInvalidValue;
-    const bool small_wg = bn == 32 && p.cout % 64 == 0;   // four-wave workgroups (layers that also have the 64-channel form)
+    // 32-channel workgroups are four waves (four tile groups), two to a CU: the detector's 32-channel Bottleneck (four chunks per
+    // tile, its prologue and epilogue as long as its chunks) 154 -> 138 us against the eight-wave form, one to a CU
+    // (PA_WINO_SMALL32=0: that form, A/B)
+    static const int small32 = getenv("PA_WINO_SMALL32") ? atoi(getenv("PA_WINO_SMALL32")) : 1;
+    const bool small_wg = bn == 32 && (p.cout % 64 == 0 || small32);
     const int nsb = bn == 64 ? 16 : (small_wg ? 16 : 32);
     p.tiles_n = p.cout / bn;
     const int tiles_m = (p.n_sb + nsb - 1) / nsb;

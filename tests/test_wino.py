@@ -98,7 +98,7 @@ def _case(n, h, w, cin, cout, seed, act=0, residual=False, res_after=False, in_e
     (2, 24, 40, 128, 128),    # detector P4
     (1, 12, 20, 256, 256),    # detector P5: 15 sub-blocks, one partial workgroup
     (2, 48, 80, 64, 64),
-    (1, 96, 160, 32, 32),     # the 32-channel Bottleneck: 8 tile groups x 32 channels
+    (1, 96, 160, 32, 32),     # the 32-channel Bottleneck: four-wave workgroups of 32 channels
     (1, 4, 4, 8, 32),
 ])
 def test_wino_conv_matches_conv2d(shape):
