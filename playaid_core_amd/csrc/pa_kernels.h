@@ -143,6 +143,7 @@ struct WinoParams {
     size_t slab_floats;
     int32_t* tickets;
     int32_t tickets_cap, ksplit;
+    int32_t xcd_split;      // set by the launcher: workgroup -> (tile, split) so that an XCD owns one K range and one group of channel tiles
 };
 size_t wino_weight_floats(int cin, int cout);
 // output channels per workgroup = per stage image of the filter layout (64 | 32); cin_split > 0: the caller launches with split-K

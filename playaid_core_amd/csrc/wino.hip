@@ -221,8 +221,19 @@ __global__ __launch_bounds__(64 * TGN * NCG, TGN * NCG == 4 ? 2 : 1) void wino3x
     const int wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (b >> 3);
     // split K (p.ksplit > 1; layers with too few tiles to fill the chip): ksplit consecutive workgroups share a tile, each sums
     // its run of n_chunks channel chunks; the partial OUTPUT tiles meet in the epilogue (the output transform is linear)
-    const int ks = p.ksplit > 1 ? wg % p.ksplit : 0;
-    const int wgt_ = p.ksplit > 1 ? wg / p.ksplit : wg;
+    int ks = p.ksplit > 1 ? wg % p.ksplit : 0;
+    int wgt_ = p.ksplit > 1 ? wg / p.ksplit : wg;
+    if (p.xcd_split) {
+        // A/B form (PA_WINO_XCD_SPLIT=1; off): the 8 XCDs as ksplit K-ranges x (8 / ksplit) groups of channel tiles, so that every
+        // filter byte is fetched into ONE L2 and a patch byte into 8 / ksplit of them -- in launch order all eight XCDs read
+        // every filter (134 MB per layer-4 launch at 128 crops). Measured SLOWER (layer 3: 52.5 -> 58.1 us, layer 4: 58.0 -> 60.7;
+        // profiles/r05_wino_splitk_xcd_mapping.txt): in launch order the splits of a tile are neighbours in one XCD and their
+        // partial tiles meet in that XCD's L2; here they cross the fabric.
+        const int groups = 8 / p.ksplit, tn_per = p.tiles_n / groups, local = b >> 3;
+        ks = xcd % p.ksplit;
+        const int tm = local / tn_per;
+        wgt_ = tm * p.tiles_n + (xcd / p.ksplit) * tn_per + (local - tm * tn_per);
+    }
     const int tile_m = wgt_ / p.tiles_n, tile_n = wgt_ - tile_m * p.tiles_n;
     const int n_chunks = (p.cin >> 3) / (p.ksplit > 1 ? p.ksplit : 1);
     const int chunk0 = ks * n_chunks;
@@ -527,6 +538,8 @@ hipError_t launch_wino3x3(const WinoParams& p_in, hipStream_t s) {
     }
     p.ksplit = ks;
     const int grid = n_tiles * ks;
+    static const int xcd_split = getenv("PA_WINO_XCD_SPLIT") ? atoi(getenv("PA_WINO_XCD_SPLIT")) : 0;   // 1: XCD-partitioned splits (A/B)
+    p.xcd_split = xcd_split && ks > 1 && 8 % ks == 0 && p.tiles_n % (8 / ks) == 0 && grid % 8 == 0;
     static const int abl = getenv("PA_WINO_ABL") ? atoi(getenv("PA_WINO_ABL")) : 0;
     static const int nst = getenv("PA_WINO_STAGES") ? atoi(getenv("PA_WINO_STAGES")) : 2;  // 3: a three-stage ring (A/B: 62.3 against 61.5 us on layer 1, 95.2 against 92.1 on the 24 x 40 map -- the prologue then waits behind two chunks of copies)
 #define WN_LAUNCH(ABL_)                                                                                        \
