@@ -31,7 +31,8 @@ namespace {
 // copyMakeBorder(114), BGR -> RGB, / 255. out: [n][net_h + 4][net_w + 4][4] fp32 with a 2-pixel ZERO border (the stem's
 // padding) and channel 3 = 0.
 __global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restrict__ frames, int n, int H, int W, int new_h, int new_w,
-                                                        int top, int left, int net_h, int net_w, float* __restrict__ out) {
+                                                        int top, int left, int net_h, int net_w, double scale_x, double scale_y,
+                                                        float* __restrict__ out) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), img = blockIdx.z;
     if (x >= net_w || y >= net_h) return;
     int rgb[3] = {114, 114, 114};
@@ -43,8 +44,7 @@ __global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restric
             rgb[0] = s[2]; rgb[1] = s[1]; rgb[2] = s[0];
         } else {
             // resize.cpp: fx = (dx + 0.5) * scale - 0.5 in float, sx = cvFloor(fx), clamped; cbuf = saturate_cast<short>(f * 2048)
-            const double inv_x = (double)new_w / W, inv_y = (double)new_h / H;
-            const double scale_x = 1.0 / inv_x, scale_y = 1.0 / inv_y;
+            // (scale_x = 1.0 / ((double)new_w / W), scale_y likewise: computed once on the host, in double as OpenCV does)
             float fx = (float)((dx + 0.5) * scale_x - 0.5);
             int sx = (int)floorf(fx);
             fx -= sx;
@@ -59,15 +59,21 @@ __global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restric
             const int a0 = sat((1.f - fx) * 2048.f), a1 = sat(fx * 2048.f);
             const int b0 = sat((1.f - fy) * 2048.f), b1 = sat(fy * 2048.f);
             const int sx1 = sx + 1 < W ? sx + 1 : sx, sy1 = sy + 1 < H ? sy + 1 : sy;
-            // (a tap whose coefficient is zero is not fetched: at an exact 3:1 reduction -- 1080p to 640 x 360 -- the sample
-            // point falls on a source pixel, b1 = a1 = 0, and two of three source rows are never read)
+            // A tap whose coefficient is zero is not fetched: at an exact 3:1 reduction -- 1080p to 640 x 360 -- the sample point
+            // falls on a source pixel, a1 = b1 = 0 for every thread, and three byte loads remain of twelve.
             const uint8_t* r0 = f + (size_t)sy * W * 3;
-            const uint8_t* r1 = f + (size_t)(b1 ? sy1 : sy) * W * 3;
-            const int sxb = a1 ? sx1 : sx;
+            const uint8_t* r1 = f + (size_t)sy1 * W * 3;
+            int S0[3], S1[3] = {0, 0, 0};
+            for (int c = 0; c < 3; ++c) S0[c] = r0[sx * 3 + c] * a0;
+            if (a1)
+                for (int c = 0; c < 3; ++c) S0[c] += r0[sx1 * 3 + c] * a1;
+            if (b1) {
+                for (int c = 0; c < 3; ++c) S1[c] = r1[sx * 3 + c] * a0;
+                if (a1)
+                    for (int c = 0; c < 3; ++c) S1[c] += r1[sx1 * 3 + c] * a1;
+            }
             for (int c = 0; c < 3; ++c) {
-                const int S0 = r0[sx * 3 + c] * a0 + r0[sxb * 3 + c] * a1;
-                const int S1 = r1[sx * 3 + c] * a0 + r1[sxb * 3 + c] * a1;
-                int v = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;
+                int v = (((b0 * (S0[c] >> 4)) >> 16) + ((b1 * (S1[c] >> 4)) >> 16) + 2) >> 2;
                 v = v < 0 ? 0 : (v > 255 ? 255 : v);
                 rgb[2 - c] = v;
             }
@@ -488,8 +494,9 @@ static int detector_run(pa_detector* h, const uint8_t* frames, int32_t n, int32_
     if (new_w > h->net_w || new_h > h->net_h || new_w < 1 || new_h < 1) return fail(PA_ERR_INVALID_ARG, "pa_detector_forward: frame does not fit the network input");
     const double dw = (h->net_w - new_w) / 2.0, dh = (h->net_h - new_h) / 2.0;
     const int top = (int)lrint(dh - 0.1), left = (int)lrint(dw - 0.1);
+    const double lb_scale_x = 1.0 / ((double)new_w / width), lb_scale_y = 1.0 / ((double)new_h / height);   // cv2.resize's inv_scale, inverted
     hipLaunchKernelGGL(pa::letterbox_kernel, dim3((h->net_w + 63) / 64, (h->net_h + 3) / 4, n), dim3(256), 0, s, frames, n, height, width, new_h,
-                       new_w, top, left, h->net_h, h->net_w, h->x0);
+                       new_w, top, left, h->net_h, h->net_w, lb_scale_x, lb_scale_y, h->x0);
     DT_HIP(hipGetLastError());
     const int no = 5 + h->nc;
     int row0 = 0, di = 0;
