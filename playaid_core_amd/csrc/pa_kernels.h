@@ -56,6 +56,10 @@ struct GemmParams {
     // (beside tiles_m / tiles_n: the kernel's first scalar loads fetch them together)
     int32_t pg_per, pg_ho, pg_nwx, pg_nwy;
     uint32_t pg_magic_howo, pg_magic_wo;
+    // persistent GEMM only: a second, nearest-neighbour x2 up-sampled copy of the output (first channel of the slice's padded pixel
+    // (0, 0) of image 0; strides in floats of the UP-SAMPLED buffer; nullptr = none)
+    float* up_out;
+    int32_t up_img_stride, up_row_stride, up_px_stride, up_pad;
     // patch-resident 3x3 kernel (patchconv.hip), filled by its launcher: pixels per LDS patch buffer,
     // input row pitch and image size in pixels, tile -> first patch pixel, pixels in the whole buffer
     int32_t patch_slots, patch_pitch, img_px, tiles_per_img, p0_img, p0_row, total_px;

@@ -50,7 +50,8 @@ __device__ __forceinline__ int pg_sdiv(int n, int d, unsigned magic, int& rem) {
     return q;
 }
 
-template <int N> __device__ __forceinline__ void pg_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// (vmcnt is six bits: a count past 63 waits at 63 -- for more than it must, never for less)
+template <int N> __device__ __forceinline__ void pg_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N > 63 ? 63 : N) : "memory"); }
 
 }  // namespace
 
@@ -65,7 +66,10 @@ template <int N> __device__ __forceinline__ void pg_wait_vm() { asm volatile("s_
 //   * a k-step's copies differ from the tile's first in a scalar byte offset only (buffer_load's soffset);
 //   * the LDS read addresses of a k-step are eight adds in one burst (a burst costs about what a lone instruction does);
 //   * SiLU on register pairs (v_pk_mul / v_pk_add around the two transcendentals).
-template <int BM, int BN = 64, bool SILU = true, bool STAMP = false>
+// UP: the tile is ALSO written nearest-neighbour up-sampled by two into a second buffer (p.up_out: every output pixel to the 2 x 2
+// pixels it becomes) -- YOLOv5's nn.Upsample behind model.10 / model.14 as four more stores of the producer instead of a pass
+// of its own over HBM.
+template <int BM, int BN = 64, bool SILU = true, bool STAMP = false, bool UP = false>
 __global__ __launch_bounds__(256, 2) void pgemm_kernel(const GemmParams p) {
     // STAMP (scripts/pgemm_stamps.py): s_memtime per wave at entry [0], after the prologue [1], per tile t < 15 at 2 + 4 t:
     // tile start, first barrier passed, last matrix instruction issued, stores issued; exit [63]
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const GemmParams p) {
     constexpr int MI = BM / WM / 32;
     constexpr int A_ROWS = BM / 32, B_ROWS = BN / 32;
     constexpr int NLD = A_ROWS + B_ROWS;  // LDS-DMA wave instructions per k-step
-    constexpr int NST = MI * 4;           // store wave instructions per tile
+    constexpr int NST = MI * 4 * (UP ? 5 : 1);   // store wave instructions per tile
     constexpr int STAGE = (BM + BN) * 32;
     __shared__ __attribute__((aligned(16))) float lds[3 * STAGE];
 
@@ -164,26 +168,32 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const GemmParams p) {
     const int out_wrap_y = p.out_img_stride - p.pg_ho * p.out_row_stride;
     int out_lane = lr * p.out_px_stride + p.out_pad * (p.out_row_stride + p.out_px_stride) + ch0;
     asm volatile("" : "+v"(out_lane));
-    auto out_offset = [&](int m_base) {
+    // offset of this lane's pixel of the 32-pixel run at m_base in a buffer whose pixel (img, oy, ox) sits at img * is + oy * rs + ox * ps
+    auto pix_offset = [&](int m_base, int is, int rs, int ps, int wrap_x, int wrap_y, int lane_const) {
         int rem, ox_b;
         const int img_b = pg_sdiv(m_base, p.howo, p.pg_magic_howo, rem);
         int oy = pg_sdiv(rem, p.wo, p.pg_magic_wo, ox_b);
-        int off = img_b * p.out_img_stride + oy * p.out_row_stride + ox_b * p.out_px_stride + out_lane;
+        int off = img_b * is + oy * rs + ox_b * ps + lane_const;
         int ox = ox_b + lr;
         for (int w = 0; w < nwx; ++w) {
             const bool c = ox >= p.wo;
             ox -= c ? p.wo : 0;
-            off += c ? out_wrap_x : 0;
+            off += c ? wrap_x : 0;
             oy += c ? 1 : 0;
         }
         for (int w = 0; w < nwy; ++w) {
             const bool c = oy >= p.pg_ho;
             oy -= c ? p.pg_ho : 0;
-            off += c ? out_wrap_y : 0;
+            off += c ? wrap_y : 0;
         }
         return off;
     };
-
+    auto out_offset = [&](int m_base) { return pix_offset(m_base, p.out_img_stride, p.out_row_stride, p.out_px_stride, out_wrap_x, out_wrap_y, out_lane); };
+    // the up-sampled copy: pixel (oy, ox) -> (2 oy, 2 ox) .. (2 oy + 1, 2 ox + 1): the same walk with doubled row and pixel strides
+    const int up_rs = 2 * p.up_row_stride, up_ps = 2 * p.up_px_stride;
+    const int up_wrap_x = up_rs - p.wo * up_ps, up_wrap_y = p.up_img_stride - p.pg_ho * up_rs;
+    int up_lane = lr * up_ps + p.up_pad * (p.up_row_stride + p.up_px_stride) + ch0;
+    asm volatile("" : "+v"(up_lane));
     // issue cursor: tile, its row offsets, (ky, kx, kc) of its next k-step
     int i_tile = t_lo + lm, i_ks = 0, i_ky = 0, i_kx = 0, i_kc = 0;
     int a_off[A_ROWS];   // bytes
@@ -330,6 +340,7 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const GemmParams p) {
             const int m_base = tile_m * BM + wm * (BM / WM) + mi * 32;
             float* o_px = p.out + out_offset(m_base);
             const bool live = m_base + lr < p.M;
+            f32x4 out4[4];
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 f32x2 lo = f32x2{acc[mi][4 * gq], acc[mi][4 * gq + 1]}, hi = f32x2{acc[mi][4 * gq + 2], acc[mi][4 * gq + 3]};   // (bias inside)
@@ -350,6 +361,16 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const GemmParams p) {
                 // (tiles_m - 1) can be partial, so a partial tile is always the last thing its workgroup computes. Any other
                 // tile order must first make the store count independent of the predicate (launch_pgemm checks the premise).
                 if (live) *reinterpret_cast<f32x4*>(o_px + 8 * gq) = f32x4{lo.x, lo.y, hi.x, hi.y};
+                if (UP) { out4[gq] = f32x4{lo.x, lo.y, hi.x, hi.y}; }
+            }
+            if (UP && live) {   // (a launch with an up-sampled copy has no partial tile followed by a k-step either: same invariant)
+                float* u_px = p.up_out + pix_offset(m_base, p.up_img_stride, up_rs, up_ps, up_wrap_x, up_wrap_y, up_lane);
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    float* u = u_px + (q4 >> 1) * p.up_row_stride + (q4 & 1) * p.up_px_stride;
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) *reinterpret_cast<f32x4*>(u + 8 * gq) = out4[gq];
+                }
             }
         }
         if (t < 15) stamp(5 + 4 * t);
@@ -430,9 +451,12 @@ hipError_t launch_pgemm(const GemmParams& p_in, int bm, hipStream_t s) {
     }
 #define PA_PG_LAUNCH(BM_, BN_)                                                                               \
     do {                                                                                                     \
-        if (silu) hipLaunchKernelGGL((pgemm_kernel<BM_, BN_, true>), dim3(grid), dim3(256), 0, s, p);        \
+        if (p.up_out) hipLaunchKernelGGL((pgemm_kernel<BM_, BN_, true, false, true>), dim3(grid), dim3(256), 0, s, p); \
+        else if (silu) hipLaunchKernelGGL((pgemm_kernel<BM_, BN_, true>), dim3(grid), dim3(256), 0, s, p);   \
         else hipLaunchKernelGGL((pgemm_kernel<BM_, BN_, false>), dim3(grid), dim3(256), 0, s, p);            \
     } while (0)
+    if (p.up_out && (!silu || p.up_px_stride % 4 || p.up_row_stride % 4 || p.up_img_stride % 4 || (reinterpret_cast<unsigned long long>(p.up_out) & 15ull)))
+        return hipErrorInvalidValue;   // (the up-sampled copy exists for SiLU layers only)
     if (bn == 32) PA_PG_LAUNCH(128, 32);
     else if (bm == 128) PA_PG_LAUNCH(128, 64);
     else PA_PG_LAUNCH(64, 64);
