@@ -147,7 +147,7 @@ struct WinoParams {
     size_t slab_floats;
     int32_t* tickets;
     int32_t tickets_cap, ksplit;
-    int32_t xcd_split;      // set by the launcher: workgroup -> (tile, split) so that an XCD owns one K range and one group of channel tiles
+    int32_t tiles_m, xcd_gm, xcd_gn;   // set by the launcher: pixel tiles; the 8 XCDs as a gm x gn grid over (pixel, channel) tiles, 0 = launch order
 };
 size_t wino_weight_floats(int cin, int cout);
 // output channels per workgroup = per stage image of the filter layout (64 | 32); cin_split > 0: the caller launches with split-K

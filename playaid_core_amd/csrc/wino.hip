@@ -221,18 +221,19 @@ __global__ __launch_bounds__(64 * TGN * NCG, TGN * NCG == 4 ? 2 : 1) void wino3x
     const int wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (b >> 3);
     // split K (p.ksplit > 1; layers with too few tiles to fill the chip): ksplit consecutive workgroups share a tile, each sums
     // its run of n_chunks channel chunks; the partial OUTPUT tiles meet in the epilogue (the output transform is linear)
-    int ks = p.ksplit > 1 ? wg % p.ksplit : 0;
-    int wgt_ = p.ksplit > 1 ? wg / p.ksplit : wg;
-    if (p.xcd_split) {
-        // A/B form (PA_WINO_XCD_SPLIT=1; off): the 8 XCDs as ksplit K-ranges x (8 / ksplit) groups of channel tiles, so that every
-        // filter byte is fetched into ONE L2 and a patch byte into 8 / ksplit of them -- in launch order all eight XCDs read
-        // every filter (134 MB per layer-4 launch at 128 crops). Measured SLOWER (layer 3: 52.5 -> 58.1 us, layer 4: 58.0 -> 60.7;
-        // profiles/r05_wino_splitk_xcd_mapping.txt): in launch order the splits of a tile are neighbours in one XCD and their
-        // partial tiles meet in that XCD's L2; here they cross the fabric.
-        const int groups = 8 / p.ksplit, tn_per = p.tiles_n / groups, local = b >> 3;
-        ks = xcd % p.ksplit;
-        const int tm = local / tn_per;
-        wgt_ = tm * p.tiles_n + (xcd / p.ksplit) * tn_per + (local - tm * tn_per);
+    const int ksn = p.ksplit > 1 ? p.ksplit : 1;
+    int ks = wg % ksn;
+    int wgt_ = wg / ksn;
+    if (p.xcd_gn) {
+        // The 8 XCDs as a grid of xcd_gm x xcd_gn over (pixel tiles, channel tiles): an XCD's L2 then fetches 1 / xcd_gn of the
+        // filters and 1 / xcd_gm of the patches (in launch order it fetches ALL filters on a layer with few pixel tiles -- 134 MB
+        // per layer-4 launch of ResNet-18 at 128 crops). The splits of a tile stay neighbours inside one XCD, channel tiles fastest.
+        const int tm_per = p.tiles_m / p.xcd_gm, tn_per = p.tiles_n / p.xcd_gn, local = b >> 3;
+        const int xm = xcd / p.xcd_gn, xn = xcd - xm * p.xcd_gn;
+        ks = local % ksn;
+        const int r = local / ksn;
+        const int tm_l = r / tn_per;
+        wgt_ = (xm * tm_per + tm_l) * p.tiles_n + xn * tn_per + (r - tm_l * tn_per);
     }
     const int tile_m = wgt_ / p.tiles_n, tile_n = wgt_ - tile_m * p.tiles_n;
     const int n_chunks = (p.cin >> 3) / (p.ksplit > 1 ? p.ksplit : 1);
@@ -538,8 +539,25 @@ hipError_t launch_wino3x3(const WinoParams& p_in, hipStream_t s) {
     }
     p.ksplit = ks;
     const int grid = n_tiles * ks;
-    static const int xcd_split = getenv("PA_WINO_XCD_SPLIT") ? atoi(getenv("PA_WINO_XCD_SPLIT")) : 0;   // 1: XCD-partitioned splits (A/B)
-    p.xcd_split = xcd_split && ks > 1 && 8 % ks == 0 && p.tiles_n % (8 / ks) == 0 && grid % 8 == 0;
+    // XCD grid (see the kernel): the (gm, gn) with gm x gn = 8 that divides the tile counts and fetches least -- filters x gm +
+    // patches x gn -- if that is under 0.8 of what launch order fetches (filters x min(8, tiles_m ...) is its worst case: all
+    // eight). PA_WINO_XCD_GRID=0: launch order always (A/B).
+    static const int xcd_grid = getenv("PA_WINO_XCD_GRID") ? atoi(getenv("PA_WINO_XCD_GRID")) : 1;
+    p.tiles_m = tiles_m;
+    p.xcd_gm = p.xcd_gn = 0;
+    if (xcd_grid && grid % 8 == 0) {
+        const double wb = (double)wino_weight_floats(p.cin, p.cout) * 4.0, pb = (double)p.n_sb * 36.0 * p.cin * 4.0;
+        // launch order: an XCD holds grid / 8 consecutive (tile, split) pairs = n_tiles / 8 consecutive tiles, channel tiles fastest
+        const double per_xcd_tiles = n_tiles / 8.0;
+        const double order_w = wb * 8.0 * std::min(1.0, per_xcd_tiles / p.tiles_n), order_p = pb * std::max(1.0, p.tiles_n / per_xcd_tiles);
+        double best = 0.8 * (order_w + order_p);
+        for (int gm = 1; gm <= 8; gm *= 2) {
+            const int gn = 8 / gm;
+            if (tiles_m % gm || p.tiles_n % gn) continue;
+            const double t = wb * gm + pb * gn;
+            if (t < best) { best = t; p.xcd_gm = gm; p.xcd_gn = gn; }
+        }
+    }
     static const int abl = getenv("PA_WINO_ABL") ? atoi(getenv("PA_WINO_ABL")) : 0;
     static const int nst = getenv("PA_WINO_STAGES") ? atoi(getenv("PA_WINO_STAGES")) : 2;  // 3: a three-stage ring (A/B: 62.3 against 61.5 us on layer 1, 95.2 against 92.1 on the 24 x 40 map -- the prologue then waits behind two chunks of copies)
 #define WN_LAUNCH(ABL_)                                                                                        \
