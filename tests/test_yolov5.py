@@ -129,11 +129,12 @@ def test_detection_network_batches_and_small_frames():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("net", [(320, 320), (352, 608)])
+@pytest.mark.parametrize("net", [(320, 320), (352, 608), (64, 96)])
 def test_detection_network_other_network_inputs(net):
     """Network inputs other than 384 x 640: the map sizes decide which kernel form a layer takes (round 4) -- 8 x 16, 8 x 8 or
     4 x 4 blocks on the patch-resident kernel, the im2col engine where no block divides the map (10 x 10, 38-wide), partial
-    row / column blocks in the direct stem, partial pixel tiles in the persistent GEMM -- and every form must equal the oracle."""
+    row / column blocks in the direct stem, partial pixel tiles in the persistent GEMM -- and every form must equal the oracle.
+    64 x 96 (maps down to 2 x 3): the persistent GEMM's lanes fold up to eleven row wraps and six image wraps into a run of 32 pixels."""
     import torch
 
     from oracle import yolov5 as oy
