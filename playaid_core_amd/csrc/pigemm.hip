@@ -59,8 +59,9 @@ template <int N> __device__ __forceinline__ void pg_wait_vm() { asm volatile("s_
 // padding), three LDS stages of (BM + BN) rows x 32 floats.
 //
 // What a tile costs besides its matrix instructions is vector-ALU time -- scripts/micro/mfma_f32_mix.hip: next to a stream of
-// v_mfma_f32_32x32x2_f32 an LDS read is free, a lone vector instruction costs ~12 cycles of the SIMD, a transcendental 16, an
-// integer multiply as much -- so the bookkeeping is kept off the vector unit:
+// v_mfma_f32_32x32x2_f32 an LDS read is free, a lone vector instruction costs ~12 cycles of the SIMD, a transcendental 16 (and
+// v_mul_lo_u32, which the per-lane divisions were made of, is a quarter-rate instruction too) -- so the bookkeeping is kept off
+// the vector unit:
 //   * pixel index -> (image, row, column) of the tile's FIRST pixel on the scalar unit (pg_sdiv); a lane adds its pixel's
 //     distance and folds the row / image wraps in with compares and selects (no multiply, no division per lane);
 //   * a k-step's copies differ from the tile's first in a scalar byte offset only (buffer_load's soffset);
