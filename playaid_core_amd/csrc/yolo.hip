@@ -535,7 +535,8 @@ static int detector_run(pa_detector* h, const uint8_t* frames, int32_t n, int32_
             static const int fuse = getenv("PA_DET_SPPF") ? atoi(getenv("PA_DET_SPPF")) : 1;  // 0: three launches (A/B)
             const int hw = L.in_h * L.in_w;
             if (fuse && chained(L, L2) && chained(L2, L3) && L.out_buf == L.in_buf && L.cin % 16 == 0 && hw <= 480) {
-                const int cg = hw <= 240 ? 16 : 8;   // four float arrays of the map x cg channels in <= 60 KB of LDS
+                static const int cg_force = getenv("PA_DET_SPPF_CG") ? atoi(getenv("PA_DET_SPPF_CG")) : 0;   // A/B
+                const int cg = cg_force ? cg_force : (hw <= 240 ? 16 : 8);   // four float arrays of the map x cg channels in <= 60 KB of LDS
                 pa::SliceGeom gi = {L.in_h, L.in_w, L.in_pad, L.in_cstride, L.in_coff};
                 pa::SliceGeom g1 = {L.in_h, L.in_w, L.out_pad, L.out_cstride, L.out_coff};
                 pa::SliceGeom g2 = {L.in_h, L.in_w, L2.out_pad, L2.out_cstride, L2.out_coff};
