@@ -497,12 +497,14 @@ int run_conv(pa_engine* e, const ConvLayer& L, int crop0, int ncrops, size_t sla
         if (pe == hipErrorInvalidValue) pe = launch_igemm(p, tile, s);  // geometry the patch kernel does not cover
         HIPCHK(e, pe);
     } else {
-        // A/B knob (PA_S2_PGEMM=1): stride-2 3x3 convolutions that need no split-K on the persistent form of the engine (pigemm.hip;
-        // same k order, bit-identical). Measured at configs[1]: 48.39 k against 48.53 k frames/s -- one tile per workgroup slot here, nothing
-        // for persistence to win; off by default
-        static const int use_pgemm = getenv("PA_S2_PGEMM") ? atoi(getenv("PA_S2_PGEMM")) : 0;
+        // Stride-2 3x3 convolutions that need no split-K run on the persistent form of the engine (pigemm.hip) with 64-row tiles:
+        // two tiles per workgroup slot, so the second tile's first operands arrive under the first one's matrix instructions
+        // (one 128-row tile per slot, round 4's A/B, gained nothing: 48.39 k against 48.53 k frames/s). At 128 crops: 50.3 / 50.2 /
+        // 54.0 -> 48.8 / 46.6 / 52.7 us for the three openers. Same k order as igemm.hip; the bias is the value pgemm's accumulators start
+        // from and igemm's last addition: results agree to that rounding. PA_S2_PGEMM=0: igemm.hip (A/B), 1: pgemm's own choice of tile height
+        static const int use_pgemm = getenv("PA_S2_PGEMM") ? atoi(getenv("PA_S2_PGEMM")) : 2;
         hipError_t pe = hipErrorInvalidValue;
-        if (use_pgemm && L.kh == 3 && L.stride == 2 && !p.act2 && !p.residual && p.splitk <= 1 && !p.gather) pe = launch_pgemm(p, 0, s);
+        if (use_pgemm && L.kh == 3 && L.stride == 2 && !p.act2 && !p.residual && p.splitk <= 1 && !p.gather) pe = launch_pgemm(p, use_pgemm == 2 ? 64 : 0, s);
         if (pe == hipErrorInvalidValue) pe = launch_igemm(p, tile, s);
         HIPCHK(e, pe);
     }

@@ -21,8 +21,8 @@ if dtype == "bf16":
     conv = [d for d in ds if "igemm_bf16_kernel" in d["name"] or "conv3x3_bf16_patch_kernel" in d["name"]]
 else:
     ig = [d for d in ds if "igemm_f32_kernel" in d["name"] and ", true," not in d["name"]]
-    assert len(ig) % 7 == 0, len(ig)   # per step: three stride-2 convs, three 1x1/2 branch GEMMs, the fc
-    conv = [d for d in ds if "conv3x3_patch_kernel" in d["name"] or "wino3x3_kernel" in d["name"]] + [d for s in range(len(ig) // 7) for d in ig[s * 7:s * 7 + 6]]
+    assert len(ig) % 5 == 0, len(ig)   # per step: layer 4's opener + three 1x1/2 branch GEMMs, then the fc (layers 2 / 3's openers are pgemm_kernel launches)
+    conv = [d for d in ds if "conv3x3_patch_kernel" in d["name"] or "wino3x3_kernel" in d["name"] or "pgemm_kernel" in d["name"]] + [d for s in range(len(ig) // 5) for d in ig[s * 5:s * 5 + 4]]
 n = len(conv)
 mean = lambda k: sum(d.get(k, 0.0) for d in conv) / n
 gui = mean("GRBM_GUI_ACTIVE") / 8.0  # the counter comes back summed over the 8 XCDs

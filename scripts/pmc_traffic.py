@@ -6,9 +6,9 @@
 
 Units: both counters are in KiB. On gfx950 FETCH_SIZE reports half the bytes of a wide
 coalesced read stream (guide, section HBM), so it is doubled; WRITE_SIZE is taken as is.
-fp32: the family = every wino3x3_kernel and conv3x3_patch_kernel launch (thirteen stride-1 convs per step) plus
-the first six of each seven non-gather igemm_f32_kernel launches (the stride-2 convs and the three 1x1/2 branch GEMMs of
-the Winograd block-0 layers; the seventh is the fc): 19 per step. bf16: every conv3x3_bf16_patch_kernel and igemm_bf16_kernel launch (16 per step; 19 with PA_BF16_DS_FUSE=0)."""
+fp32: the family = every wino3x3_kernel / conv3x3_patch_kernel launch (thirteen stride-1 convs per step), every pgemm_kernel
+launch (the stride-2 openers of layers 2 and 3) plus the first four of each five non-gather igemm_f32_kernel launches (layer 4's opener,
+which splits K, and the 1x1/2 branch GEMMs of the Winograd block-0 layers; the fifth is the fc): 19 per step. bf16: every conv3x3_bf16_patch_kernel and igemm_bf16_kernel launch (16 per step; 19 with PA_BF16_DS_FUSE=0)."""
 import collections, csv, glob, json, sys
 
 
@@ -24,9 +24,9 @@ def dispatches(path, counter):
 def conv3x3_values(disp, dtype):
     if dtype == "bf16":  # 16 launches per step: patch kernels and the stride-2 openers (which carry the 1x1/2 downsample branch)
         return [v for (name, v) in disp if "igemm_bf16_kernel" in name or "conv3x3_bf16_patch_kernel" in name]
-    vals = [v for (name, v) in disp if "conv3x3_patch_kernel" in name or "wino3x3_kernel" in name]
+    vals = [v for (name, v) in disp if "conv3x3_patch_kernel" in name or "wino3x3_kernel" in name or "pgemm_kernel" in name]
     ig = [v for (name, v) in disp if "igemm_f32_kernel" in name and ", true," not in name]
-    per_step = 6 + 1  # the three stride-2 convs and the three 1x1/2 branch GEMMs, then the fc
+    per_step = 4 + 1  # two 1x1/2 branch GEMMs, layer 4's opener, its branch GEMM, then the fc
     assert len(ig) % per_step == 0, (len(ig), per_step)
     for s in range(len(ig) // per_step):
         vals += ig[s * per_step:s * per_step + per_step - 1]
