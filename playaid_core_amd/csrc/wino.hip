@@ -310,6 +310,18 @@ __global__ __launch_bounds__(64 * TGN * NCG, TGN * NCG == 4 ? 2 : 1) void wino3x
     }
     const int ch0 = tile_n * G::BN + cg * 32 + 4 * kq;
 
+    // The epilogue's bias is fetched HERE, behind the first chunk's copies (its round trip runs under theirs; the wait for the first
+    // chunk, which follows, covers it) and pinned in registers for the life of the kernel: in front of the output transform it was
+    // a round trip of its own per tile (every stride-1 3x3 of ResNet-18: -1.5 us). The residual stays in the epilogue: fetched here
+    // as well it made the detector's in-place Bottlenecks 3-5 us slower (all workgroups of a round asking for it at once, in
+    // front of their first chunk instead of behind their last).
+    f32x4 bias4v[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        bias4v[g] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + ch0 + 16 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+        asm volatile("" : "+v"(bias4v[g]));
+    }
+
     f32x4 acc[16][2];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -427,7 +439,7 @@ __global__ __launch_bounds__(64 * TGN * NCG, TGN * NCG == 4 ? 2 : 1) void wino3x
                                                : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-        const f32x4 bias4 = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + ch0 + 16 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 bias4 = bias4v[g];
 #pragma unroll
         for (int oy = 0; oy < 2; ++oy)
 #pragma unroll
