@@ -264,6 +264,14 @@ def test_round5_host_planners_reject_bad_tables_and_stay_in_bounds(lib):
     assert lib.pa_wino_conv3x3(a4, a16, z, z, a16, 1, 8, 8, 8, 32, 32, 8, 32, 1, 0, 0, z) == _lib.PA_ERR_INVALID_ARG
     assert lib.pa_wino_conv3x3(a16, a16, z, z, a16, 1, 8, 8, 8, 32, 64, 8, 32, 1, 0, 0, z) == _lib.PA_ERR_INVALID_ARG
     assert lib.pa_wino_conv3x3(a16, a16, z, z, a16, 1, 6, 8, 8, 32, 32, 8, 32, 1, 0, 0, z) == _lib.PA_ERR_INVALID_ARG
+    # the split-K form (ABI 10) wants its scratch: a null or misaligned slab, null tickets or none of them is refused before any launch,
+    # and the shape checks of the plain form apply to it as well
+    sk = lambda slab, nf, tk, nt, ips=8: lib.pa_wino_conv3x3_splitk(a16, a16, z, z, a16, 1, 8, 8, 8, 32, 32, ips, 32, 1, 0, 0, slab, nf, tk, nt, z)
+    assert sk(z, 1 << 20, a16, 16) == _lib.PA_ERR_INVALID_ARG
+    assert sk(a4, 1 << 20, a16, 16) == _lib.PA_ERR_INVALID_ARG
+    assert sk(a16, 1 << 20, z, 16) == _lib.PA_ERR_INVALID_ARG
+    assert sk(a16, 1 << 20, a16, 0) == _lib.PA_ERR_INVALID_ARG
+    assert sk(a16, 1 << 20, a16, 16, ips=10) == _lib.PA_ERR_INVALID_ARG
     # this round's engine entries refuse a null engine / null tables before touching anything
     assert lib.pa_detector_plan(z, z, z, z, z, 4, z, z, z, z, z, z, z) == _lib.PA_ERR_INVALID_ARG
     assert lib.pa_detector_plan_desc(z, z, z, 4, 2, 100, z, 0, 0, z) == _lib.PA_ERR_INVALID_ARG
