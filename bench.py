@@ -289,8 +289,13 @@ def chain_inclusive(eng, sd, frames_dev, boxes_dev, steps=12, quality=95):
     front_eng = Engine(sd, device=str(dev), max_batch_frames=8, max_clip_frames=max(n, 64), max_frame_height=h, max_frame_width=w)
     pred_syn = synthetic_head_rows(boxes_dev, det.rows, 6, h, w)
     pred_net = torch.empty((n, det.rows, 11), dtype=torch.float32, device=dev)
-    s_dec = [torch.cuda.Stream(dev) for _ in range(ND)]
-    s_front, s_back = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    # the stages' streams are probed against each other like the lanes' (parallel._concurrent_streams): the HIP runtime multiplexes
+    # streams onto a few hardware queues, and when the detector's and the CNN's stream happened to share one the three-deep
+    # pipeline ran SLOWER than the stages one after the other (5.8 k against 7.0 k frames/s from one process to the next)
+    from playaid_core_amd.parallel import _concurrent_streams
+    picked = _concurrent_streams(eng, 2 + ND)
+    s_front, s_back = picked[0], picked[1]
+    s_dec = picked[2:2 + ND]
     ready = [torch.cuda.Event() for _ in range(ND)]
     free = [torch.cuda.Event() for _ in range(ND)]
     import ctypes as C
