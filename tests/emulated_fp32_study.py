@@ -3,8 +3,8 @@ every 3x3 / 1x1 / 7x7 convolution and linear layer of the oracle's ResNet-18 + h
 slices (x = x0 + x1 + x2, each slice the bf16 rounding of what is left) and the product taken as the sum of the leading
 cross terms, accumulated in fp32 -- what `v_mfma_f32_32x32x16_bf16` would compute (bf16 x bf16 products are exact in fp32).
 Reports max |dlogp| against a float64 run of the same operator for: plain fp32, 6 terms (i + j <= 2), 3 terms (i + j <= 1),
-1 term (plain bf16 operands, fp32 accumulate).  ORACLE-side study: imports oracle/, never shipped.
-  python scripts/emulated_fp32_study.py [windows]"""
+1 term (plain bf16 operands, fp32 accumulate).  Checker-side study (it lives under tests/ because it imports oracle/): never shipped, not collected by pytest.
+  python tests/emulated_fp32_study.py [windows]"""
 import os
 import sys
 
