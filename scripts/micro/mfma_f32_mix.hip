@@ -1,7 +1,8 @@
 // What an fp32 matrix instruction shares its SIMD with: 32 x v_mfma_f32_32x32x2_f32 per loop iteration (2048 issue cycles) with,
 // spread evenly between them, R LDS reads (ds_read_b128 or ds_read_b64, results feed the next iteration's operands), V full-rate
 // vector instructions (v_fma_f32) and T transcendental ones (v_exp_f32). Two waves per SIMD (workgroups of four waves, two per
-// CU), like the GEMM kernels. Prints SIMD cycles per iteration and wave -- 2048 when the extra work is free.
+// CU), like the GEMM kernels. Prints SIMD cycles per iteration and wave -- 2048 when the extra work is free. A second section does
+// the same around v_mfma_f32_32x32x16_bf16 (1024 cycles per iteration).
 //   hipcc --offload-arch=gfx950 -O3 scripts/micro/mfma_f32_mix.hip -o /tmp/mfma_mix && /tmp/mfma_mix
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -81,7 +82,70 @@ __global__ __launch_bounds__(256, 2) void mix(float* out, unsigned long long* cl
     if (lane == 0) clk[blockIdx.x * 4 + wave] = t1 - t0;
 }
 
+// The same loop around 32 x v_mfma_f32_32x32x16_bf16 (8 passes: 1024 issue cycles per iteration at full rate): does vector work run
+// BESIDE the bf16 matrix instruction, which has a pipe of its own?
+template <int R, int V, int T>
+__global__ __launch_bounds__(256, 2) void mixbf(float* out, unsigned long long* clk, int iters, float a0, float b0) {
+    __shared__ __attribute__((aligned(16))) float lds[4 * 64 * 32];
+    for (int i = threadIdx.x; i < 4 * 64 * 32; i += 256) lds[i] = a0 + i * 1e-6f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned row = (unsigned)(size_t)(__attribute__((address_space(3))) float*)(lds + (wave * 64 + lane) * 32);
+    const int swz = (lane >> 1) & 7;
+    unsigned addr[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) addr[r] = row + ((r ^ swz) * 16);
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    f32x4 opnd[2][8];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) opnd[s][i] = f32x4{a0, b0, a0, b0};
+    float va[4] = {a0, b0, a0 + 1.f, b0 + 1.f};
+    float ta[4] = {a0, b0, a0 * 0.5f, b0 * 0.5f};
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; it += 2) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int cur = half, nxt = half ^ 1;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+#pragma unroll
+                for (int r = (j * R) / 32; r < ((j + 1) * R) / 32; ++r)
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(opnd[nxt][r & 7]) : "v"(addr[r & 7]) : "memory");
+#pragma unroll
+                for (int q = (j * V) / 32; q < ((j + 1) * V) / 32; ++q) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(va[q & 3]) : "v"(a0), "v"(b0));
+#pragma unroll
+                for (int q = (j * T) / 32; q < ((j + 1) * T) / 32; ++q) asm volatile("v_exp_f32 %0, %0" : "+v"(ta[q & 3]));
+                // (eight bf16 values per operand = one 128-bit register quad; the bit patterns do not matter for the timing)
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[j & 3]) : "v"(opnd[cur][j & 7]), "v"(opnd[cur][(j + 1) & 7]));
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = va[0] + va[1] + va[2] + va[3] + ta[0] + ta[1] + ta[2] + ta[3];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += opnd[s2][i].x + opnd[s2][i].z;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s += acc[i][e];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (lane == 0) clk[blockIdx.x * 4 + wave] = t1 - t0;
+}
+
 static double ticks_per_cycle = 0.0;   // s_memtime ticks per SIMD cycle, from the bare loop (2048 cycles per iteration and wave, two waves)
+
+static double base_cycles = 2048.0;     // matrix issue cycles of one iteration and wave (bf16 section: 1024)
+static double flop_per_mfma = 4096.0;   // (bf16 32x32x16: 32768)
 
 template <typename K>
 void run(const char* name, K kern) {
@@ -102,8 +166,8 @@ void run(const char* name, K kern) {
     const double ticks_iter = (double)h[0] / iters;                 // of one wave; its SIMD ran two waves' iterations in that time
     if (ticks_per_cycle == 0.0) ticks_per_cycle = ticks_iter / 4096.0;
     const double cyc = ticks_iter / ticks_per_cycle / 2.0;
-    const double tflops = (double)grid * 4 * iters * 32 * 4096.0 / (ms * 1e-3) / 1e12;
-    printf("%-46s %7.0f SIMD cycles per iteration and wave (matrix: 2048), +%5.0f, %.3f ms, %.1f TFLOP/s\n", name, cyc, cyc - 2048.0, ms, tflops);
+    const double tflops = (double)grid * 4 * iters * 32 * flop_per_mfma / (ms * 1e-3) / 1e12;
+    printf("%-46s %7.0f SIMD cycles per iteration and wave (matrix: %.0f), +%5.0f, %.3f ms, %.1f TFLOP/s\n", name, cyc, base_cycles, cyc - base_cycles, ms, tflops);
     hipFree(out); hipFree(clk);
 }
 
@@ -127,5 +191,18 @@ int main() {
     run("64 v_exp_f32", mix<0, 4, 0, 64>);
     run("12 b128 + 32 fma", mix<12, 4, 32, 0>);
     run("12 b128 + 32 fma + 16 exp", mix<12, 4, 32, 16>);
+    printf("--- v_mfma_f32_32x32x16_bf16 (the cycle figure keeps the fp32 section's clock calibration)\n");
+    base_cycles = 1024.0;
+    flop_per_mfma = 32768.0;
+    run("bf16 bare", mixbf<0, 0, 0>);
+    run("bf16 + 16 ds_read_b128", mixbf<16, 0, 0>);
+    run("bf16 + 32 ds_read_b128", mixbf<32, 0, 0>);
+    run("bf16 + 32 v_fma_f32", mixbf<0, 32, 0>);
+    run("bf16 + 64 v_fma_f32", mixbf<0, 64, 0>);
+    run("bf16 + 128 v_fma_f32", mixbf<0, 128, 0>);
+    run("bf16 + 256 v_fma_f32", mixbf<0, 256, 0>);
+    run("bf16 + 32 v_exp_f32", mixbf<0, 0, 32>);
+    run("bf16 + 64 v_exp_f32", mixbf<0, 0, 64>);
+    run("bf16 + 32 b128 + 128 fma + 32 exp", mixbf<32, 128, 32>);
     return 0;
 }
