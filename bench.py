@@ -140,6 +140,73 @@ def pcie_inclusive(eng, frames_dev, boxes_dev, steps=8):
     }
 
 
+def compact_line(result):
+    """The ONE stdout line: what the round is judged on, under 1800 characters (the driver keeps the last 2000 of a run's
+    output). Everything else -- notes, per-kernel table, calibration, side measurements in full -- goes to bench_details.json
+    (and to stderr, before this line)."""
+    cfg = result.get("config", {})
+    out = {k: result.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                      "vs_baseline", "dtype", "data")}
+    out["metric"] = out["metric"].split(" (")[0] if out.get("metric") else None
+    out["config"] = {"workload": (cfg.get("workload") or "").split(", 2 fighters")[0], "parallelism": cfg.get("parallelism"),
+                     "lanes": cfg.get("lanes"), "ingest": "raw BGR frames resident in HBM"}
+    if cfg.get("exchange"):
+        out["config"]["exchange"] = cfg["exchange"]
+    r = result.get("roofline")
+    if r:
+        out["roofline"] = {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "algorithmic_tflops", "algorithmic_frac",
+                                                  "executed_frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms") if k in r}
+    c = result.get("cpu_baseline")
+    if c:
+        out["cpu_baseline"] = {"value": c["value"], "unit": c["unit"], "cores": c["cores"], "kind": c["kind"],
+                               "sample": c["sample"].split(" (")[0] + ", reference-literal", "batched_value": c.get("batched_value")}
+    def side(name, short):   # a side measurement's rate, or its error text
+        d = result.get(name)
+        if isinstance(d, dict):
+            out[short] = d.get("value", d.get("error"))
+    ch = result.get("chain_inclusive")
+    if isinstance(ch, dict) and "stage_ms_per_clip_alone" in ch:
+        st = ch["stage_ms_per_clip_alone"]
+        out["chain_frames_per_s"] = ch["value"]
+        out["chain_stage_ms"] = {"decode": st["mjpeg_decode"], "detector": st["detector_network"], "nms_repair": st["nms_and_label_repair"],
+                                 "crops_cnn_head": st["detector_crops_jpeg_runner_inputs_cnn_head"]}
+    else:
+        side("chain_inclusive", "chain_frames_per_s")
+    side("chain_inclusive_camera_like", "chain_camera_like_frames_per_s")
+    side("decode_inclusive", "decode_inclusive_frames_per_s")
+    side("decode_inclusive_camera_like", "decode_camera_like_frames_per_s")
+    side("pcie_inclusive_windows", "pcie_inclusive_frames_per_s")
+    e = result.get("emulated_fp32")
+    if isinstance(e, dict):
+        out["emulated_fp32"] = {k: e.get(k) for k in ("frames_per_s", "detector_ms", "chain_frames_per_s", "max_dlogp_vs_oracle", "error") if k in e}
+    out["details"] = "bench_details.json"
+    line = json.dumps(out, separators=(",", ":"))
+    if len(line) > 1800:   # never let a long note push the headline out of the driver's tail
+        for k in ("emulated_fp32", "chain_stage_ms", "cpu_baseline"):
+            if k == "cpu_baseline" and k in out:
+                out[k].pop("sample", None)
+            else:
+                out.pop(k, None)
+            line = json.dumps(out, separators=(",", ":"))
+            if len(line) <= 1800:
+                break
+    return line
+
+
+def emit(result):
+    """Full record -> bench_details.json (+ gpurun_out/ when present) and one stderr line; the compact record -> the LAST stdout line."""
+    full = json.dumps(result)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        try:
+            if os.path.isdir(d):
+                with open(os.path.join(d, "bench_details.json"), "w") as f:
+                    f.write(full + "\n")
+        except OSError:
+            pass
+    print(full, file=sys.stderr, flush=True)
+    print(compact_line(result), flush=True)
+
+
 _ENCODED = {}
 
 
@@ -721,6 +788,8 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse ranks > GPUs)")
     ap.add_argument("--no-pipeline", action="store_true", help="crop stage and backbone on one stream (no overlap across steps)")
+    ap.add_argument("--no-calibrate", action="store_true",
+                    help="two lanes on the first streams that pass the spin-kernel probe, without timing the stream pairs first (A/B of the queue lottery)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="f32 = the headline (reference arithmetic); bf16 = BASELINE.json configs[2]'s conv path, reported under its own dtype, never as the headline")
     args = ap.parse_args()
@@ -779,7 +848,8 @@ def main():
     lanes = None
     if world == 1 and not long_clip and args.lanes > 1 and not args.no_pipeline:
         lanes = ClipLanes(eng, S, DELTA, lanes=args.lanes)
-        lanes.calibrate(frames, boxes, n_total, batch_of=kb if kb > 1 else 0)   # untimed: which of the concurrent streams overlap best on this shape
+        if not args.no_calibrate:
+            lanes.calibrate(frames, boxes, n_total, batch_of=kb if kb > 1 else 0)   # untimed: which of the concurrent streams overlap best on this shape
     batch_of = kb if kb > 1 else 0
 
     def step(pipeline=None):
@@ -915,14 +985,16 @@ def main():
                 result["roofline"] = {
                     "kernel": dom["name"],
                     "bound": "mfma",
-                    "achieved": round(tf, 3),
+                    "achieved": round(tf_exec, 3),
                     "peak": PEAK_FP32_MATRIX_TFLOPS,
                     "unit": "TFLOP/s",
-                    "frac": round(tf / PEAK_FP32_MATRIX_TFLOPS, 4),
-                    "achieved_is": "ALGORITHMIC FLOP/s: the family's direct-form count (2 x outputs x 9 x cin per 3x3 convolution, SURVEY.md 8d) over its "
-                                   "HIP-event time -- what the contract asks for. Thirteen of its nineteen launches (sixteen convolutions + the three 1x1/2 branch GEMMs of layers 2-4) run as Winograd F(2x2, 3x3) "
-                                   "(csrc/wino.hip) and execute 4/9 of their direct-form multiply-adds, so this figure may pass the chip's peak; "
-                                   "`executed_*` is what the matrix cores ran",
+                    "frac": round(tf_exec / PEAK_FP32_MATRIX_TFLOPS, 4),
+                    "achieved_is": "EXECUTED FLOP/s of the family (pa_kernel_stat.flops_executed over its HIP-event time): what the matrix cores ran, a "
+                                   "fraction of the chip's peak by construction. Thirteen of its launches run as Winograd F(2x2, 3x3) (csrc/wino.hip) and "
+                                   "execute 4/9 of their direct-form multiply-adds; the direct-form count SURVEY.md 8d defines (2 x outputs x 9 x cin per 3x3 "
+                                   "convolution) over the same time is `algorithmic_tflops` / `algorithmic_frac`, an effective rate that may pass the peak",
+                    "algorithmic_tflops": round(tf, 3),
+                    "algorithmic_frac": round(tf / PEAK_FP32_MATRIX_TFLOPS, 4),
                     "executed_tflops": round(tf_exec, 3),
                     "executed_frac": round(tf_exec / PEAK_FP32_MATRIX_TFLOPS, 4),
                     "traffic": traffic,
@@ -993,9 +1065,16 @@ def main():
                         eng, quiet, boxes[:n_clip], quality=args.jpeg_quality, restart_blocks=args.jpeg_restart_blocks,
                         content="the headline's clip with three bits of noise per sample instead of five (0.3-0.6 MB per 1080p frame at "
                                 "quality 95, the range of camera / game footage)")
-                    del quiet
                 except Exception as exc:
+                    quiet = None
                     result["decode_inclusive_camera_like"] = {"error": f"{type(exc).__name__}: {exc}"}
+                try:  # the chain on the content it will meet (decode alone is ~2.3x faster there than on white noise)
+                    if quiet is not None:
+                        result["chain_inclusive_camera_like"] = chain_inclusive(eng, sd, quiet, boxes[:n_clip], quality=args.jpeg_quality)
+                        result["chain_inclusive_camera_like"]["content"] = result["decode_inclusive_camera_like"].get("content")
+                except Exception as exc:
+                    result["chain_inclusive_camera_like"] = {"error": f"{type(exc).__name__}: {exc}"}
+                quiet = None
         if world == 1 and not long_clip and kb == 1 and not args.no_pcie and not args.no_pipeline and args.clip_batch_side > 1:
             try:
                 result["clip_batches"] = clip_batch_side(eng, n_clip, args.clip_batch_side, args.height, args.width, S, DELTA, max(args.lanes, 1))
@@ -1003,7 +1082,7 @@ def main():
                 result["clip_batches"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(sd, args.height, args.width, args.cpu_sample_frames)
-        print(json.dumps(result), flush=True)
+        emit(result)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

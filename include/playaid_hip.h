@@ -518,9 +518,12 @@ const char* pa_lstm_last_error(const pa_lstm* h);
  * without batch_first fed [B, S, 300]) seq_len is the number of WINDOWS and batch (<= 16) the frames of a
  * window: the state runs from one window to the next. */
 int pa_lstm_forward(pa_lstm* h, const float* x, int32_t ld, int32_t seq_len, int32_t batch, float* logp, void* stream);
-/* A layer's time steps run in ONE cooperative launch (H / 4 workgroups) that hand h(t) to each other as tagged 8-byte
- * granules; a grid the device cannot hold co-resident is refused by the runtime and the handle launches one kernel per time
- * step instead. A granule that does not arrive within 20 ms ends the launch: that call's logp rows are then NaN (never garbage).
+/* A layer's time steps run in ONE launch (H / 4 workgroups, an ordinary launch since ABI 10) whose workgroups hand h(t) to each
+ * other as tagged 8-byte granules and therefore must all be resident at once. The library checks the grid against HALF of what
+ * the EMPTY device holds (occupancy query x CUs) and otherwise launches one kernel per time step; the query cannot see kernels of
+ * OTHER streams, so do not overlap pa_lstm_forward with launches that fill the chip for more than a few milliseconds (the
+ * engine's lanes, the chain's decode / detector stages). If part of the grid is nevertheless kept off the device, a granule that
+ * does not arrive within 20 ms ends the launch: that call's logp rows are then NaN (never garbage) and the status below says so.
  * Call this after synchronising the stream of a pa_lstm_forward: PA_ERR_HIP ONCE if that happened (the handle launches one
  * kernel per time step from then on and later calls are valid), PA_OK otherwise. */
 int pa_lstm_last_status(pa_lstm* h);

@@ -525,7 +525,7 @@ int pa_lstm_forward(pa_lstm* h, const float* x, int32_t ld, int32_t seq_len, int
                 if (h->sync_host[2 * q + 1]) h->persistent = false;
         }
         if (h->persistent) {
-            // all time steps of the layer in one cooperative launch
+            // all time steps of the layer in one launch whose workgroups must be co-resident
             static const int u_env = getenv("PA_LSTM_UNITS") ? atoi(getenv("PA_LSTM_UNITS")) : 0;   // tuning: hidden units per workgroup
             int U = u_env == 1 || u_env == 2 || u_env == 4 || u_env == 8 ? u_env : pa::LSTM_UNITS_DEFAULT;
             while (U > 1 && H % U) U >>= 1;
@@ -559,7 +559,13 @@ int pa_lstm_forward(pa_lstm* h, const float* x, int32_t ld, int32_t seq_len, int
                 (void)hipGetLastError();
                 h->occ_blocks = per_cu * cus;
             }
-            const hipError_t ce = H / U <= h->occ_blocks ? hipLaunchKernel(fn, dim3(H / U), dim3(256), args, lds, s) : hipErrorCooperativeLaunchTooLarge;
+            // HEADROOM: the occupancy query describes an EMPTY device; kernels of other streams (lanes, the chain's
+            // stages) hold slots of their own when this grid is dispatched. The grid may therefore use at most HALF of what the
+            // empty device holds (H = 512: 128 workgroups against 256 CUs x >= 2), so that it fits beside a neighbour that leaves
+            // every CU half free; a neighbour that fills the chip for longer than the kernel's 20 ms patience still ends in the
+            // timeout path below -- NaN rows and PA_ERR_HIP from pa_lstm_last_status, never silent garbage
+            // (tests/test_rnn_detector.py::test_lstm_forward_beside_a_busy_stream_is_correct_or_reported).
+            const hipError_t ce = 2 * (H / U) <= h->occ_blocks ? hipLaunchKernel(fn, dim3(H / U), dim3(256), args, lds, s) : hipErrorCooperativeLaunchTooLarge;
             if (ce == hipSuccess) {
                 (void)hipMemcpyAsync(h->sync_host + 2 * l, h->sync_words + 2 * l, 2 * sizeof(int), hipMemcpyDeviceToHost, s);
                 continue;

@@ -42,8 +42,12 @@
 // (profiles/r05_wino_pmc_coexec.txt) -- the fp32-input matrix instruction executes on the vector lanes, so every packed addition
 // of the transform and every LDS return takes its cycles from the matrix pipe.
 //
-// Summation order: chunks ascending, two channels per instruction pair, fixed by the launch geometry alone (no split, no
-// atomics): results are bitwise repeatable and do not depend on the batch size.
+// Summation order: chunks ascending, two channels per instruction pair, fixed by the launch geometry alone (no atomics; where
+// the launcher splits K the partial sums are added in split order by the last arriver): results are bitwise repeatable for a
+// given launch geometry. The geometry -- tile shape and ksplit -- is chosen from the number of tiles, i.e. from the BATCH: an
+// image's result is independent of the batch size only while no split engages (layers 1-2 of the ResNet); where it does
+// (layers 3-4 at 64-128 crops) the input channels are summed in a different grouping at different batch sizes and an image's
+// values move by fp32 rounding (bounded at 2e-5 by tests/test_wino.py::test_wino_split_k_results_move_by_rounding_only_across_batch_sizes).
 #include "pa_kernels.h"
 
 #include <cstdio>
@@ -78,6 +82,11 @@ __device__ __forceinline__ void wn_blds16(i32x4 rsrc, int voff_bytes, int soff_b
                  :
                  : "v"(voff_bytes), "s"(rsrc), "s"(soff_bytes), "s"(lds_addr)
                  : "memory");
+    // M0 is written here and cannot be declared: hipcc rejects "m0" on a clobber list ("reserved register ... undefined
+    // behaviour"). The invariant instead: NOTHING else in this translation unit's kernels may live in M0 across the statement --
+    // no s_movrel / v_movrel (indirect indexing of a register array: every acc / operand array here is fully unrolled), no
+    // LDS-direct, no s_sendmsg with a payload, no builtin LDS-DMA (which sets M0 itself). tests/test_abi.py::
+    // test_wino_object_uses_m0_only_for_its_lds_dma disassembles wino.o and fails the build check if any other use appears.
 }
 
 template <int TGN, int NCG> struct WinoGeo {
@@ -385,6 +394,25 @@ __global__ __launch_bounds__(64 * TGN * NCG, TGN * NCG == 4 ? 2 : 1) void wino3x
         // with agent-scope stores (write-through: the splits of a tile may sit on different XCDs, whose L2s do not see each
         // other), waits for them, and draws a ticket; the LAST to arrive sums the ksplit partials IN SPLIT ORDER -- its own from
         // the slab as well, so the result does not depend on who was last -- and runs the epilogue.
+        //
+        // Why this is a sufficient publish on gfx950 although the source holds no release / acquire edge (the C++ memory model
+        // alone would not promise it; this is the ISA-level hand-off MI355X_MICROARCH.md measures, "Valid forms" + the first row of
+        // its table of sc1 hand-offs, and prices as the "splitk-seam" / "publish-large" rows: write-through slab stores):
+        //   * EVERY store of the handed-off bytes is an agent-scope atomic store = global_store_dword ... sc1: written through the
+        //     storing XCD's L2 to memory, nothing left dirty in a cache another XCD cannot see (condition 2);
+        //   * every storing wave runs s_waitcnt vmcnt(0) after its stores (as inline assembly, which hipcc's wait pass cannot
+        //     drop), so its bytes have LEFT the CU's memory pipe before it reaches the workgroup barrier; the barrier therefore
+        //     orders the ticket add of lane 0 behind the completed stores of ALL waves of the workgroup (condition 3);
+        //   * the ticket is ONE unsharded counter of agent-scope atomic adds (performed at L2 / memory, never cached): the
+        //     workgroup whose add returns ksplit - 1 knows every other split's add -- and with it every other split's drained
+        //     stores -- came earlier; the second barrier hands that knowledge to the other waves;
+        //   * EVERY load of the slab by the last arriver is an agent-scope atomic load = global_load_dword ... sc1, which bypasses
+        //     the (never refreshed) vector L1 and is served by L2 / memory; the lines were written sc1, so no XCD's L2 holds a
+        //     stale copy of them (condition 1). A plain load here would be the "no acquire -> 24-50 % stale" row.
+        // The relaxed order of the atomics only means the COMPILER may not be relied on to keep them in place: the two
+        // __syncthreads and the asm volatile wait are its fences. tests/test_wino.py checks the split layers bitwise repeatable
+        // over repeated launches under load (two lanes); a release on the add + an acquire fence in the last arriver would add a
+        // buffer_wbl2 / buffer_inv pair (~3.5 us, the guide's fence rows) per workgroup for no further guarantee on this chip.
         constexpr int NT = 64 * TGN * NCG;
         float* const mine = p.slab + ((size_t)wgt_ * p.ksplit + ks) * (32 * NT) + tid;
 #pragma unroll

@@ -422,13 +422,18 @@ int pa_detector_create(int32_t device, const pa_net_layer* layers, int32_t n_lay
         // stride-1 3x3 convolutions on maps whose sides are multiples of four run as Winograd F(2x2, 3x3) (wino.hip: 4 / 9 of
         // the direct form's multiply-adds, the same fp32 matrix instructions); their filters are transformed here, once, in
         // fp64. PA_DET_WINO=0 keeps the direct patch-resident kernel (A/B)
-        static const int use_wino = getenv("PA_DET_WINO") ? atoi(getenv("PA_DET_WINO")) : 1;
+        // (read per create, not once per process: scripts/yolov5_parity.py makes detectors with one layer at a time in this form
+        // to see which of them moves the boxes; PA_DET_WINO_MASK = bit k set <=> the k-th eligible layer runs as Winograd)
+        const int use_wino = getenv("PA_DET_WINO") ? atoi(getenv("PA_DET_WINO")) : 1;
+        const unsigned long wino_mask = getenv("PA_DET_WINO_MASK") ? strtoul(getenv("PA_DET_WINO_MASK"), nullptr, 0) : ~0ul;
         h->wino_off.assign(n_layers, -1);
         h->wino_bn.assign(n_layers, 0);
         size_t total = 0;
+        int eligible = 0;
         for (int i = 0; i < n_layers; ++i) {
             const pa_net_layer& L = h->layers[i];
-            if (use_wino && L.kind == 0 && L.ksize == 3 && L.stride == 1 && L.in_pad == 1 && L.in_h % 4 == 0 && L.in_w % 4 == 0 && L.cin % 8 == 0) {
+            if (use_wino && L.kind == 0 && L.ksize == 3 && L.stride == 1 && L.in_pad == 1 && L.in_h % 4 == 0 && L.in_w % 4 == 0 && L.cin % 8 == 0 &&
+                ((wino_mask >> (eligible++ & 63)) & 1ul)) {
                 h->wino_off[i] = (long long)total;
                 h->wino_bn[i] = pa::wino_pick_bn(L.cout, (long long)max_images * (L.in_h / 4) * (L.in_w / 4));
                 total += pa::wino_weight_floats(L.cin, L.cout);

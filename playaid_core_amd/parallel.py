@@ -126,9 +126,12 @@ def broadcast_engine(make_engine, weights, device: torch.device, group=None):
 
 
 class FrameParallelClip:
-    def __init__(self, engine, sequence_length: int, frame_delta: int, group=None):
+    def __init__(self, engine, sequence_length: int, frame_delta: int, group=None, collectives_at_world_one: bool = False):
         self.engine = engine
         self.group = group
+        # a one-rank process group normally skips the record gather (nothing to collect); True runs it anyway, so that a
+        # one-GPU box can execute the collective code path of the backend (tests: RCCL at world size 1)
+        self.collectives_at_world_one = collectives_at_world_one
         self.distributed = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if self.distributed else 1
         self.rank = dist.get_rank(group) if self.distributed else 0
@@ -263,7 +266,7 @@ class FrameParallelClip:
             self.finish_halo(pending)
             head(f_lo, i_lo)             # the edge frames need the neighbours' rows
             head(i_hi, f_hi)
-        if not gather or self.world == 1:
+        if not gather or (self.world == 1 and not (self.collectives_at_world_one and self.distributed)):
             if reuse_buffers:
                 return records[:count], logp[:count]
             return records[:count].clone(), logp[:count].clone()

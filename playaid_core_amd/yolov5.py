@@ -230,8 +230,12 @@ class YoloV5Detector:
     """``pa_detector_*`` handle for a YOLOv5s state dict. ``net_hw``: the network input (what ``letterbox(auto=True)`` picks
     for the clip: 384 x 640 for 16:9 frames at ``--imgsz 640``)."""
 
-    def __init__(self, state_dict: Mapping, nc: int, net_hw: Tuple[int, int] = (384, 640), max_images: int = 64, device: str = "cuda:0"):
+    def __init__(self, state_dict: Mapping, nc: int, net_hw: Tuple[int, int] = (384, 640), max_images: int = 64, device: str = "cuda:0",
+                 compute_dtype: str = "f32"):
         self._lib = _lib.load()
+        if compute_dtype not in ("f32", "emulated_f32"):
+            raise ValueError("compute_dtype must be 'f32' or 'emulated_f32'")
+        self.compute_dtype = compute_dtype
         if not torch.cuda.is_available():
             raise _lib.HipLibraryError("no HIP device visible to PyTorch-ROCm; the detection network has no CPU fallback")
         self.device = torch.device(device)

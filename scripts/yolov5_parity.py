@@ -33,3 +33,35 @@ for h, w, n, seed in ((720, 1280, 3, 5), (1080, 1920, 2, 5), (270, 480, 5, 9)):
     worst = max(worst, e(got, w32, S))
 print(f"worst score error against the fp32 oracle: {worst:.3e} (test bar: see tests/test_yolov5.py)")
 det.close()
+
+# Which Winograd layers move the boxes: the 1080p case with NO layer in Winograd form, with each of the
+# eligible stride-1 3x3 convolutions alone in it (PA_DET_WINO_MASK, read at pa_detector_create), and with all of them.
+from playaid_core_amd.yolov5 import build_yolov5s_table  # noqa: E402
+
+layers = build_yolov5s_table(sd, NET, NC)[0]
+elig = [l for l in layers if l.kind == 0 and l.ksize == 3 and l.stride == 1 and l.in_h % 4 == 0 and l.in_w % 4 == 0]
+frames = synth.make_frames(2, 1080, 1920, seed=5)
+x = torch.from_numpy(np.stack([oy.letterbox(f, NET) for f in frames]))
+w64 = oy.forward(x.double(), sd64, NC).numpy()
+w32 = oy.forward(x, sd, NC).numpy().astype(np.float64)
+print(f"\n2 x 1080x1920 seed 5, box error (px) against the float64 run; the fp32 oracle itself: {np.abs(w32[..., :4] - w64[..., :4]).max():.2e}")
+
+
+def run(mask):
+    os.environ["PA_DET_WINO_MASK"] = hex(mask)
+    d = YoloV5Detector(sd, NC, NET, max_images=4)
+    g = d(frames)
+    torch.cuda.synchronize()
+    g = g.cpu().numpy().astype(np.float64)
+    d.close()
+    return float(np.abs(g[..., :4] - w64[..., :4]).max()), float(np.abs(g[..., 4:] - w64[..., 4:]).max())
+
+
+b, sc = run(0)
+print(f"  no layer as Winograd (direct patch kernel)        boxes {b:.2e}  scores {sc:.2e}")
+for k, l in enumerate(elig):
+    b, sc = run(1 << k)
+    print(f"  only #{k:2d} {l.in_h:3d}x{l.in_w:3d} cin {l.cin:3d} cout {l.cout:3d} as Winograd   boxes {b:.2e}  scores {sc:.2e}")
+b, sc = run((1 << len(elig)) - 1)
+print(f"  all {len(elig)} eligible layers as Winograd                boxes {b:.2e}  scores {sc:.2e}")
+os.environ.pop("PA_DET_WINO_MASK")

@@ -276,3 +276,34 @@ def test_round5_host_planners_reject_bad_tables_and_stay_in_bounds(lib):
     assert lib.pa_detector_plan(z, z, z, z, z, 4, z, z, z, z, z, z, z) == _lib.PA_ERR_INVALID_ARG
     assert lib.pa_detector_plan_desc(z, z, z, 4, 2, 100, z, 0, 0, z) == _lib.PA_ERR_INVALID_ARG
     assert lib.pa_square_crops_src(z, z, 1, 720, 1280, z, z, 1, 30, 0, z, z, z) == _lib.PA_ERR_INVALID_ARG
+
+
+def _device_disassembly(obj_name):
+    """gfx950 disassembly of one in-tree object (None when the LLVM tools of the ROCm image are not there)."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    obj = os.path.join(ROOT, "playaid_core_amd", "csrc", obj_name)
+    if not (os.path.exists(objdump) and os.path.exists(obj)):
+        return None
+    with tempfile.TemporaryDirectory() as td:
+        shutil.copy(obj, os.path.join(td, obj_name))
+        subprocess.run([objdump, "--offloading", obj_name], cwd=td, check=True, capture_output=True)
+        dev = glob.glob(os.path.join(td, obj_name + ".*gfx950"))
+        assert len(dev) == 1, dev
+        return subprocess.run([objdump, "-d", dev[0]], check=True, capture_output=True, text=True).stdout
+
+
+def test_wino_object_uses_m0_only_for_its_lds_dma(lib):
+    """csrc/wino.hip writes M0 inside an inline-assembly LDS-DMA and cannot declare it (hipcc rejects "m0" on a clobber list):
+    the static check ADVICE round 5 asked for instead -- in the built object every mention of M0 is that statement's own
+    `s_mov_b32 m0, ...`, and nothing indexes registers through it (no movrel: the accumulator arrays are fully unrolled)."""
+    asm = _device_disassembly("wino.o")
+    if asm is None:
+        pytest.skip("no llvm-objdump / object in this environment")
+    uses = [ln.split("//")[0].split() for ln in asm.splitlines() if re.search(r"\bm0\b", ln.split("//")[0])]
+    assert len(uses) > 100 and all(u[0] == "s_mov_b32" and u[1].rstrip(",") == "m0" for u in uses), [u for u in uses if u[0] != "s_mov_b32"][:5]
+    assert not re.search(r"movrel|s_sendmsg\b(?!.*MSG_DEALLOC)|lds_direct", asm)

@@ -56,6 +56,43 @@ def test_main_launches_children_before_any_gpu_call(monkeypatch):
 import pytest  # noqa: E402
 
 
+def test_compact_line_carries_the_judged_scalars_and_fits_the_drivers_tail():
+    """The driver keeps 2000 characters of a run's tail: the last stdout line must hold the headline, the roofline (frac = the
+    EXECUTED fraction), the CPU baseline and the chain's scalars in under 1800, however long the notes of the full record are."""
+    import json
+
+    bench = _bench()
+    note = "x" * 4000
+    full = {
+        "metric": "1080p frames/sec end-to-end (decode->labels; 'decode' here = ingest of raw BGR frames already resident in HBM)",
+        "value": 63445.1, "unit": "frames/s", "n_gpus": 1, "steps": 20, "warmup": 3, "ms_per_step": 1.0087, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: 64 x 1080x1920 BGR frames per GPU per clip, 2 fighters/frame, " + note, "parallelism": "single GPU",
+                   "lanes": 2, "lane_stream_calibration": {"rates": [1.0] * 6, "note": note}},
+        "roofline": {"kernel": "igemm_conv3x3", "bound": "mfma", "achieved": 85.8, "peak": 157.3, "unit": "TFLOP/s", "frac": 0.5455,
+                     "achieved_is": note, "algorithmic_tflops": 161.4, "algorithmic_frac": 1.0259, "executed_frac": 0.5455, "traffic": 71300000,
+                     "algorithmic_bytes_per_launch": 39300000, "avg_launch_ms": 0.04623, "traffic_source": note},
+        "cpu_baseline": {"value": 3.58, "unit": "frames/s", "cores": 128, "kind": "port", "sample": "40 synthetic 1080x1920 frames (78 windows, " + note,
+                         "batched_value": 17.0},
+        "chain_inclusive": {"value": 7181.0, "stage_ms_per_clip_alone": {"mjpeg_decode": 3.46, "detector_network": 5.58, "nms_and_label_repair": 0.2,
+                                                                           "detector_crops_jpeg_runner_inputs_cnn_head": 1.47}, "method": note},
+        "chain_inclusive_camera_like": {"value": 9000.0, "method": note},
+        "decode_inclusive": {"value": 18000.0, "method": note}, "decode_inclusive_camera_like": {"error": "RuntimeError: " + note[:50]},
+        "emulated_fp32": {"frames_per_s": 1.0, "detector_ms": 3.7, "chain_frames_per_s": 9600.0, "max_dlogp_vs_oracle": 2e-6, "note": note},
+        "kernels": {f"k{i}": {"share": 0.1, "note": note} for i in range(20)},
+    }
+    line = bench.compact_line(full)
+    assert len(line) < 1800 and "\n" not in line
+    d = json.loads(line)
+    assert d["value"] == 63445.1 and d["ms_per_step"] == 1.0087 and d["dtype"] == "f32" and d["metric"].startswith("1080p frames/sec")
+    assert d["config"]["workload"].startswith("configs[1]: 64 x 1080x1920")
+    assert d["roofline"]["frac"] == 0.5455 and d["roofline"]["algorithmic_frac"] == 1.0259 and d["roofline"]["traffic"] == 71300000
+    assert d["cpu_baseline"]["cores"] == 128 and d["cpu_baseline"]["kind"] == "port"
+    assert d["chain_frames_per_s"] == 7181.0 and d["chain_stage_ms"] == {"decode": 3.46, "detector": 5.58, "nms_repair": 0.2, "crops_cnn_head": 1.47}
+    assert d["chain_camera_like_frames_per_s"] == 9000.0 and d["decode_inclusive_frames_per_s"] == 18000.0
+    assert d["emulated_fp32"]["detector_ms"] == 3.7
+
+
 @pytest.mark.gpu
 def test_driver_scale_command_shape_on_two_ranks():
     """The command the driver's SCALE tier runs -- ``python3 bench.py --gpus N ...`` with no launcher around it -- as a FRESH child
@@ -74,6 +111,7 @@ def test_driver_scale_command_shape_on_two_ranks():
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
+    assert r.stdout.rstrip().splitlines()[-1] == lines[0] and len(lines[0]) < 1800, "the LAST stdout line is the compact record the driver's tail keeps"
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 1 and d["warmup"] == 0 and d["higher_is_better"] is True
     assert d["metric"].startswith("1080p frames/sec") and d["unit"] == "frames/s" and d["value"] > 0 and d["ms_per_step"] > 0

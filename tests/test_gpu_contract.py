@@ -428,6 +428,44 @@ def test_frame_parallel_hip_engine_two_ranks(engine, tmp_path, n_total):
     assert has_interior == (n_total == 90)
 
 
+def test_rccl_world_size_one_runs_the_device_collectives(tmp_path):
+    """RCCL itself, once: a FRESH child process (torch.distributed.run, one rank -- RCCL wants one GPU per rank and this box
+    has one) calls init_process_group("nccl", device_id=...), parallel.broadcast_engine (the uint8 weight arena broadcast as a
+    DEVICE tensor: the `_host_staged() == False` branch every gloo test skips) and FrameParallelClip.run (device
+    all_gather_into_tensor of records and log-probabilities, the device barrier), serial and pipelined. The clip goes through
+    the same 16-frame batches single-process infer_clip uses below, so the labels must be equal bit for bit. No scaling claim:
+    none can be measured on one GPU."""
+    import socket
+    import subprocess
+    import sys
+
+    n_total, h, w = 48, 720, 1280
+    out = str(tmp_path / "rccl_one_rank.npz")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "helpers", "two_rank_worker.py"), str(n_total), str(h), str(w), out, "nccl"]
+    env = dict(os.environ, OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    got = np.load(out)
+    assert str(got["backend"]) == "nccl" and bool(got["arena_on_device"])
+    from playaid_core_amd.engine import Engine
+
+    eng16 = Engine(synth.make_state_dict(seed=1234), max_batch_frames=16, max_clip_frames=64, max_frame_height=h, max_frame_width=w)
+    try:
+        single = eng16.infer_clip(synth.make_frames(n_total, h, w), synth.make_boxes(n_total, h, w))
+    finally:
+        eng16.close()
+    assert got["logp"].shape == (n_total - 1, 2, 63)
+    assert np.array_equal(got["logp"], single["logp"]), np.abs(got["logp"] - single["logp"]).max()
+    assert np.array_equal(got["rec"][..., 1], single["action_id"]) and np.array_equal(got["rec"][..., 0], single["char_id"])
+    assert np.array_equal(got["logp_p"], got["logp"]) and np.array_equal(got["rec_p"], got["rec"])  # pipelined == serial
+
+
 def test_indexed_backbone_rejects_frame_ids_outside_the_clip(engine):
     """a bad id must not become an out-of-bounds device write. The host path refuses it
     (pa_clip_mark_ready -> PA_ERR_CAPACITY); ids that only exist on the device are skipped by the

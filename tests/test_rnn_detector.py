@@ -143,3 +143,50 @@ print("RESULT" + json.dumps(out))
     steps = run({"PA_LSTM_STEPS": "1"})
     assert not steps["raised"] and not steps["first_nan"]
     assert np.array_equal(np.asarray(forced["second"]), np.asarray(steps["second"]))
+
+
+@pytest.mark.gpu
+def test_lstm_forward_beside_a_busy_stream_is_correct_or_reported():
+    """the per-layer LSTM kernel is an ordinary launch whose workgroups wait for each other; the check that they
+    fit looks at an empty device. Here a second stream keeps the chip busy with large fp32 matrix products while the forward runs.
+    The contract: either the result equals the quiet run's, or the rows are NaN AND ``check()`` reports the timeout (after which
+    the handle launches per time step and is valid again) -- never a silent wrong row."""
+    from playaid_core_amd.engine import EngineError
+    from playaid_core_amd.rnn_action_detector import RNNActionDetector
+
+    actions = [f"a{i}" for i in range(63)]
+    sd = synth.make_rnn_state_dict(seed=4321, num_actions=63)
+    model = RNNActionDetector("byleth", actions, state_dict=sd, max_rows=64).eval()
+    try:
+        x = _inputs(4, 7, seed=77).cuda()
+        quiet = model(x)
+        torch.cuda.synchronize()
+        model.check()
+        quiet = quiet.cpu().numpy()
+        assert np.isfinite(quiet).all()
+        side = torch.cuda.Stream()
+        a = torch.randn(8192, 8192, device="cuda")
+        busy_out = torch.empty_like(a)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            for _ in range(6):      # ~60 ms of chip-filling work on the other stream
+                torch.mm(a, a, out=busy_out)
+        got = model(x)              # enqueued beside it
+        torch.cuda.synchronize()
+        got = got.cpu().numpy()
+        try:
+            model.check()
+            reported = False
+        except EngineError:
+            reported = True
+        if reported:
+            assert np.isnan(got).all(), "a reported timeout must leave NaN rows, not partial results"
+            again = model(x)
+            torch.cuda.synchronize()
+            model.check()
+            assert np.abs(again.cpu().numpy() - quiet).max() <= 1e-5   # (per-step launches from here on: same sums)
+        else:
+            assert np.isfinite(got).all(), "NaN rows without a reported status"
+            assert np.array_equal(got, quiet)
+    finally:
+        model.close()

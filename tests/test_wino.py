@@ -188,3 +188,30 @@ def test_wino_conv_split_k():
     # a scratch too small for any split, or with too few tickets, runs the unsplit launch
     tiny = wino.SplitKScratch(dev, slab_floats=1024, n_tickets=4)
     assert torch.equal(wino.conv3x3(xd, ug, c, c, split_k=tiny).cpu(), plain)
+
+
+@pytest.mark.gpu
+def test_wino_split_k_results_move_by_rounding_only_across_batch_sizes():
+    """the launcher picks ksplit from the number of tiles, i.e. from the batch -- ResNet-18's layers 3 / 4 sum
+    their input channels in a different grouping at 128 crops (split) than at 6 (the tiles alone fill less of the chip: another
+    split, or none). An image's values are then NOT bitwise batch-independent; they move by fp32 rounding, bounded here at 2e-5 of
+    the layer's largest output. (Without split-K scratch the kernel never splits and batch independence is exact:
+    test_wino_conv_is_bitwise_repeatable_and_batch_independent.)"""
+    from playaid_core_amd import wino
+
+    dev = torch.device("cuda:0")
+    sk = wino.SplitKScratch(dev)
+    rng = np.random.default_rng(31)
+    for (h, w, c) in ((4, 4, 512), (8, 8, 256)):
+        n = 128
+        xp = torch.zeros((n, h + 2, w + 2, c))
+        xp[:, 1:-1, 1:-1] = torch.from_numpy(rng.standard_normal((n, h, w, c)).astype(np.float32))
+        wt = (rng.standard_normal((c, c, 3, 3)) / np.sqrt(9 * c)).astype(np.float32)
+        ug = torch.from_numpy(wino.transform_weights(wt)).to(dev)
+        xd = xp.to(dev)
+        full = wino.conv3x3(xd, ug, c, c, split_k=sk).cpu()
+        scale = float(full.abs().max())
+        for lo, cnt in ((0, 6), (40, 1), (64, 64)):
+            part = wino.conv3x3(xd[lo:lo + cnt].contiguous(), ug, c, c, split_k=sk).cpu()
+            assert float((part - full[lo:lo + cnt]).abs().max()) <= 2e-5 * scale, (h, w, c, lo, cnt)
+    assert int(sk.tickets.abs().sum()) == 0
