@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PA_ABI_VERSION 10
+#define PA_ABI_VERSION 11
 #define PA_WEIGHT_MAGIC 0x31574150 /* "PAW1" */
 #define PA_LSTM_MAGIC 0x314c4150   /* "PAL1" */
 #define PA_ENCODER_MAGIC 0x31454150 /* "PAE1" */
@@ -76,7 +76,7 @@ typedef struct pa_config {
     int32_t max_frame_height;  /* scratch sizing for the resampler */
     int32_t max_frame_width;
     int32_t fighter_class_ids[4]; /* CHAR_LIST index of each fighter slot (constants.py:51) */
-    int32_t compute_dtype;     /* PA_DTYPE_F32 (default, the reference's arithmetic) or PA_DTYPE_BF16 */
+    int32_t compute_dtype;     /* PA_DTYPE_F32 (default, the reference's arithmetic), PA_DTYPE_BF16 or PA_DTYPE_EMULATED_F32 */
 } pa_config;
 
 /* compute_dtype. PA_DTYPE_BF16 (BASELINE.json configs[2]) stores the activations and folded
@@ -85,6 +85,14 @@ typedef struct pa_config {
  * It is NOT within the 1e-4 parity bar of the fp32 path (tests state its own tolerance). */
 #define PA_DTYPE_F32 0
 #define PA_DTYPE_BF16 1
+/* PA_DTYPE_EMULATED_F32 (ABI 11; never the default): fp32 inputs, fp32 outputs and fp32-accurate sums, but the products of the
+ * convolutions run on the bf16 matrix cores -- every fp32 operand as three bf16 slices (an exact decomposition of its 24-bit
+ * significand), the six leading cross products per fp32 product on v_mfma_f32_32x32x16_bf16, fp32 accumulation
+ * (csrc/psgemm.hip). As close to a float64 run as the exact fp32 kernels are, and inside the same 1e-4 parity bars (the fp32
+ * parity tests run under both values); summation order and rounding differ from the fp32 instruction's, so results are NOT
+ * bit-identical to PA_DTYPE_F32. Layers without an emulated kernel run the exact fp32 one. bench.py's `value` / `dtype` stay
+ * on PA_DTYPE_F32; this value is reported as the side block `emulated_fp32`. */
+#define PA_DTYPE_EMULATED_F32 2
 
 /* Result record per (frame, fighter): the fields AIRunner.action_recognition
  * derives at ai_runner.py:474-479. confidence% = prob * 100 is left to the host
@@ -581,6 +589,23 @@ int pa_wino_conv3x3_splitk(const float* x, const float* ug, const float* bias, c
                            int32_t height, int32_t width, int32_t cin, int32_t cout, int32_t bn, int32_t in_px_stride, int32_t out_px_stride,
                            int32_t out_pad, int32_t act, int32_t res_after, float* slab, size_t slab_floats, int32_t* tickets,
                            int32_t n_tickets, void* stream);
+
+/* One convolution (1x1 or 3x3, stride 1 or 2, "same" padding) + bias + activation (+ residual) on the persistent implicit-GEMM
+ * kernels -- the operator the detection network's layers (ai_runner.py:191-224's YOLOv5s) and, under PA_DTYPE_EMULATED_F32, the
+ * ResNet-18's 3x3 convolutions (cnn_action_detector.py:16,32) run on -- exposed for parity tests and per-layer measurements.
+ * x: float32[n][height + 2 in_pad][width + 2 in_pad][in_px_stride] (device, zero border, the first cin channels of a pixel are
+ * read; in_pad >= (ksize - 1) / 2); out: float32[n][oh + 2 out_pad][ow + 2 out_pad][out_px_stride], oh = height / stride
+ * (interior written, first cout channels); residual: addressed like out (it may BE out), or NULL; act: 0 none, 1 ReLU, 2 SiLU;
+ * res_after: 1 = the residual is added after the activation. cin, cout multiples of 32. Weights: pa_conv_pack_weights turns
+ * BatchNorm-folded [cout][ky][kx][cin] fp32 (host) into what the kernel of `compute_dtype` reads (host, pa_conv_weight_bytes
+ * bytes; the caller uploads it): PA_DTYPE_F32 = the same fp32 values (csrc/pigemm.hip; no residual), PA_DTYPE_EMULATED_F32 = three
+ * bf16 slices per weight in the LDS stage-image order of csrc/psgemm.hip, whose tile width depends on has_residual. Enqueue only. */
+size_t pa_conv_weight_bytes(int32_t cin, int32_t cout, int32_t ksize, int32_t compute_dtype, int32_t has_residual);
+int pa_conv_pack_weights(const float* w_host, int32_t cin, int32_t cout, int32_t ksize, int32_t compute_dtype, int32_t has_residual,
+                         void* out_host);
+int pa_conv2d(const float* x, const void* w, const float* bias, const float* residual, float* out, int32_t n, int32_t height,
+              int32_t width, int32_t cin, int32_t cout, int32_t ksize, int32_t stride, int32_t in_pad, int32_t in_px_stride,
+              int32_t out_px_stride, int32_t out_pad, int32_t act, int32_t res_after, int32_t compute_dtype, void* stream);
 
 /* Head of ResnetTransformerDetector (resnet_transformer_detector.py:41-93,141): Linear(in_dim, hidden_dim), the
  * enc_dim-value time encoding of the frame slot appended (d_model = hidden_dim + enc_dim, 32 per head),

@@ -20,6 +20,7 @@ ARCH = "gfx950"
 SOURCES = [
     ("igemm.hip", []),
     ("pigemm.hip", []),
+    ("psgemm.hip", []),
     ("igemm_bf16.hip", []),
     ("patchconv.hip", []),
     ("patchconv_bf16.hip", []),

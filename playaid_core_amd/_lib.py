@@ -12,9 +12,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # PA_LIB_PATH: load a differently built library (e.g. the ablation build used by scripts/)
 LIB_PATH = os.environ.get("PA_LIB_PATH") or os.path.join(HERE, "libplayaid_hip.so")
 
-PA_ABI_VERSION = 10
+PA_ABI_VERSION = 11
 PA_DTYPE_F32 = 0
 PA_DTYPE_BF16 = 1
+PA_DTYPE_EMULATED_F32 = 2
+DTYPES = {"f32": PA_DTYPE_F32, "bf16": PA_DTYPE_BF16, "emulated_f32": PA_DTYPE_EMULATED_F32}
 PA_WEIGHT_MAGIC = 0x31574150
 PA_LSTM_MAGIC = 0x314C4150
 PA_ENCODER_MAGIC = 0x31454150
@@ -169,6 +171,9 @@ SYMBOLS = [
     ("pa_wino_channels_per_workgroup", C.c_int, [C.c_int32, C.c_int64]),
     ("pa_wino_transform_weights", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P]),
     ("pa_wino_conv3x3", C.c_int, [_P, _P, _P, _P, _P] + [C.c_int32] * 11 + [_P]),
+    ("pa_conv_weight_bytes", C.c_size_t, [C.c_int32] * 5),
+    ("pa_conv_pack_weights", C.c_int, [_P] + [C.c_int32] * 5 + [_P]),
+    ("pa_conv2d", C.c_int, [_P, _P, _P, _P, _P] + [C.c_int32] * 14 + [_P]),
     ("pa_wino_conv3x3_splitk", C.c_int, [_P, _P, _P, _P, _P] + [C.c_int32] * 11 + [_P, C.c_size_t, _P, C.c_int32, _P]),
     ("pa_crop_resize_width", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, _P, C.c_int32,
                                        C.POINTER(C.c_int32), _P]),

@@ -85,6 +85,13 @@ hipError_t launch_igemm(const GemmParams& p, GemmTile tile, hipStream_t s);
 // persistent form of the same engine for short tiles (pigemm.hip): conv mode, no residual / second source / split-K;
 // bm = 128 | 64, 64 output channels per tile; results equal to launch_igemm up to where the bias enters the sum
 hipError_t launch_pgemm(const GemmParams& p, int bm, hipStream_t s);
+// "emulated fp32" form of the persistent GEMM (psgemm.hip): fp32 activations, the weights as three bf16 slices in the kernel's
+// stage-image layout (psgemm_pack_weights, psgemm_weight_elems of them), six bf16 matrix instructions per fp32 product, fp32
+// accumulate. Conv mode; bias, ReLU / SiLU; out_floats = floats from p.out to the end of its buffer (the store descriptor's bounds).
+int psgemm_pick_bn(int N, int residual);          // channels per workgroup (128 | 64 | 32; with a residual 64 at most): part of the weight layout
+size_t psgemm_weight_elems(int N, int ktot, int residual);
+void psgemm_pack_weights(const float* w, int N, int ktot, int residual, unsigned short* out);
+hipError_t launch_psgemm(const GemmParams& p, const unsigned short* wsp, size_t out_floats, hipStream_t s);
 // bf16 activations / weights (uint16_t storage behind the float* fields, every count in elements),
 // f32 accumulate on v_mfma_f32_32x32x16_bf16; conv mode only (igemm_bf16.hip)
 hipError_t launch_igemm_bf16(const GemmParams& p, GemmTile tile, hipStream_t s);
