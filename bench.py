@@ -576,7 +576,8 @@ def bench_detect(args):
     frames = torch.from_numpy(synth.make_frames(n, args.height, args.width)).to(device)
     eng = Engine(synth.make_state_dict(seed=1234), device=str(device), max_batch_frames=8, max_clip_frames=64, max_frame_height=args.height,
                  max_frame_width=args.width)
-    det = YoloV5Detector(synth.make_yolov5s_state_dict(), 6, (384, 640), max_images=n, device=str(device))
+    det = YoloV5Detector(synth.make_yolov5s_state_dict(), 6, (384, 640), max_images=n, device=str(device),
+                         compute_dtype="emulated_f32" if args.dtype == "emulated_f32" else "f32")
     for _ in range(args.warmup):
         dets, counts = det.detections(eng, frames)
     torch.cuda.synchronize()
@@ -589,7 +590,7 @@ def bench_detect(args):
     print(json.dumps({
         "metric": f"{args.height}p frames/sec, detection stage (frames resident in HBM -> YOLOv5s -> NMS -> label rows)",
         "value": round(n / dt, 1), "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "ms_per_step": round(dt * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": det.compute_dtype,
         "data": "synthetic (seeded random-init weights, synthetic frames)",
         "config": {"workload": f"detect: {n} x {args.height}x{args.width} frames per step, YOLOv5s v7.0 at 384 x 640, 6 classes",
                    "layers": det.n_layers, "rows_per_image": det.rows},
@@ -790,7 +791,7 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="crop stage and backbone on one stream (no overlap across steps)")
     ap.add_argument("--no-calibrate", action="store_true",
                     help="two lanes on the first streams that pass the spin-kernel probe, without timing the stream pairs first (A/B of the queue lottery)")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "emulated_f32"],
                     help="f32 = the headline (reference arithmetic); bf16 = BASELINE.json configs[2]'s conv path, reported under its own dtype, never as the headline")
     args = ap.parse_args()
 

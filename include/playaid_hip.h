@@ -244,6 +244,12 @@ typedef struct pa_detector pa_detector;
 int pa_detector_create(int32_t device, const pa_net_layer* layers, int32_t n_layers, const int64_t* buf_floats_per_image, int32_t n_bufs,
                        const float* weights_host, size_t n_weights, int32_t max_images, int32_t net_h, int32_t net_w, int32_t num_classes,
                        pa_detector** out);
+/* The same with the convolutions' arithmetic chosen (ABI 11): PA_DTYPE_F32 (= pa_detector_create) or PA_DTYPE_EMULATED_F32 -- the
+ * 1x1 and stride-2 3x3 convolutions then run on the bf16 matrix cores with fp32-accurate sums (see PA_DTYPE_EMULATED_F32; the
+ * stride-1 3x3 layers keep their exact Winograd kernel, the stem its direct one). Never the default. */
+int pa_detector_create_dtype(int32_t device, const pa_net_layer* layers, int32_t n_layers, const int64_t* buf_floats_per_image, int32_t n_bufs,
+                             const float* weights_host, size_t n_weights, int32_t max_images, int32_t net_h, int32_t net_w, int32_t num_classes,
+                             int32_t compute_dtype, pa_detector** out);
 void pa_detector_destroy(pa_detector* h);
 const char* pa_detector_last_error(const pa_detector* h);
 int pa_detector_rows(const pa_detector* h); /* rows of pred per image: 3 x sum over the decode layers of in_h x in_w */

@@ -120,6 +120,8 @@ SYMBOLS = [
                                         C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     ("pa_detector_create", C.c_int, [C.c_int32, C.POINTER(pa_net_layer), C.c_int32, C.POINTER(C.c_int64), C.c_int32, _P, C.c_size_t,
                                      C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P)]),
+    ("pa_detector_create_dtype", C.c_int, [C.c_int32, C.POINTER(pa_net_layer), C.c_int32, C.POINTER(C.c_int64), C.c_int32, _P, C.c_size_t,
+                                           C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P)]),
     ("pa_detector_destroy", None, [_P]),
     ("pa_detector_last_error", C.c_char_p, [_P]),
     ("pa_detector_rows", C.c_int, [_P]),

@@ -38,7 +38,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
+
+// timing experiments only (results wrong when != 0; a diagnostic build: hipcc -DPA_PS_ABL=n): 1 = no copies after the prologue,
+// 2 = no matrix instructions
+#ifndef PA_PS_ABL
+#define PA_PS_ABL 0
+#endif
 
 namespace pa {
 
@@ -264,7 +271,7 @@ __global__ __launch_bounds__(512, 2) void psgemm_kernel(const GemmParams p, cons
             const int inflight = (g + NSTAGE < total ? g + NSTAGE : total) - (g + 2);
             wait_stage(inflight);
             __builtin_amdgcn_s_barrier();   // stage g + 1 landed; every consumer's reads of stage g have returned
-            if (g + NSTAGE < total) issue(slot);
+            if (g + NSTAGE < total && !(PA_PS_ABL & 1)) issue(slot);
             slot = slot + 1 == NSTAGE ? 0 : slot + 1;
         }
         __builtin_amdgcn_s_barrier();   // (the consumers' barrier of the last k-step)
@@ -319,46 +326,78 @@ __global__ __launch_bounds__(512, 2) void psgemm_kernel(const GemmParams p, cons
             for (int s = 0; s < 3; ++s) bb[cb][s] = *(lds_cu4*)(size_t)(b_rd[h] + sb + (s * BN + cb * 32) * 64);
     };
     // Half a k-step: NM matrix instructions (six cross products per 32-channel block, smallest terms first, the blocks taking
-    // turns) from the operand registers (a, bb), with the SPLIT of the next half's eight raw values (lo, hi -> an) dealt out
-    // among them in eight chunks of 5-6 vector instructions, starting `lead` matrix instructions in (their LDS reads are under
-    // way); `mid` runs once after the `pre`-th matrix instruction (the barrier block of the second half). Explicit placement:
-    // left to itself hipcc issues the twelve matrix instructions back to back and the 44 vector instructions after them.
-    auto half = [&](const u32x4 (&a)[3], const u32x4 (&bb)[CB][3], const f32x4& lo, const f32x4& hi, u32x4 (&an)[3], int pre, auto&& mid) {
+    // turns) from the operand registers (a, bb). Dealt out among them, ONE OR TWO PER GAP, go the next half's LDS reads (the raw
+    // pixels first, then the weight fragments -> bn) and the 44 vector instructions that split the raw values (-> an). A lone
+    // wave per SIMD hides nothing by itself: whatever stands between two matrix instructions and takes longer than the 32
+    // cycles one of them occupies the pipe idles it (measured on the first form of this loop, reads in bursts of 14 and the
+    // split in chunks of six: 2300 cycles per k-step for 1536 of matrix time; SQ_ACTIVE_INST / SQ_WAIT_INST in
+    // profiles/r06_pgemm_split_pmc.txt). Per gap the issue budget is 32 - 8 (the matrix instruction's own): one ds_read_b128
+    // (~13) and two or three vector instructions (4 each). The split's instruction order keeps every result two instructions away
+    // from its first reader (two value pairs in lock step), so no dependent-issue stall and no hazard nop.
+    // `pre`: matrix instructions issued before `open` runs (the barrier of the second half); reads start in gap `pre`.
+    constexpr unsigned HI16 = 0xffff0000u;
+    auto half = [&](const u32x4 (&a)[3], const u32x4 (&bb)[CB][3], u32x4 (&an)[3], u32x4 (&bn)[CB][3], unsigned sb, int h, auto pre_c, auto&& open) {
+        constexpr int PRE = decltype(pre_c)::value;
         constexpr int TA[6] = {0, 1, 2, 0, 1, 0}, TB[6] = {2, 1, 0, 1, 0, 0};
+        constexpr int NR = 2 + 3 * CB;                                     // LDS reads of the next half
+        constexpr int OS = PRE + (NM >= 24 ? 6 : (NM >= 12 ? 3 : 1));      // first gap that takes split instructions
+        f32x4 raw[2];
         float x[8], r[8];
-        unsigned q0[4], q1[4];
-        const int lead = pre + (NM >= 12 ? 3 : 1);
-        constexpr int STRIDE = NM >= 24 ? 2 : 1;
+        unsigned w[8], q0[4], q1[4];
+        auto sop = [&](int k) {   // one instruction of the split; k = 22 G + j, G = which raw quad (pairs 2 G, 2 G + 1)
+            const int G = k / 22, j = k % 22, pq = 2 * G + (j & 1), e = 2 * pq;
+            if (j < 2) {
+                if (j == 0) {
+                    x[4 * G] = raw[G].x; x[4 * G + 1] = raw[G].y; x[4 * G + 2] = raw[G].z; x[4 * G + 3] = raw[G].w;
+                }
+                q0[pq] = ps_cvt_pk_bf16(x[e], x[e + 1]);
+                an[0][pq] = q0[pq];
+            } else if (j < 4) {
+                asm("v_lshlrev_b32 %0, 16, %1" : "=v"(w[e]) : "v"(q0[pq]));
+            } else if (j < 6) {
+                asm("v_and_b32 %0, %1, %2" : "=v"(w[e + 1]) : "s"(HI16), "v"(q0[pq]));
+            } else if (j < 8) {
+                asm("v_sub_f32 %0, %1, %2" : "=v"(r[e]) : "v"(x[e]), "v"(w[e]));
+            } else if (j < 10) {
+                asm("v_sub_f32 %0, %1, %2" : "=v"(r[e + 1]) : "v"(x[e + 1]), "v"(w[e + 1]));
+            } else if (j < 12) {
+                q1[pq] = ps_cvt_pk_bf16(r[e], r[e + 1]);
+                an[1][pq] = q1[pq];
+            } else if (j < 14) {
+                asm("v_lshlrev_b32 %0, 16, %1" : "=v"(w[e]) : "v"(q1[pq]));
+            } else if (j < 16) {
+                asm("v_and_b32 %0, %1, %2" : "=v"(w[e + 1]) : "s"(HI16), "v"(q1[pq]));
+            } else if (j < 18) {
+                asm("v_sub_f32 %0, %1, %2" : "=v"(r[e]) : "v"(r[e]), "v"(w[e]));
+            } else if (j < 20) {
+                asm("v_sub_f32 %0, %1, %2" : "=v"(r[e + 1]) : "v"(r[e + 1]), "v"(w[e + 1]));
+            } else {
+                an[2][pq] = ps_cvt_pk_bf16(r[e], r[e + 1]);
+            }
+        };
+        auto rop = [&](int k) {   // one LDS read of the next half: the two raw pixel quads first (the split waits for them)
+            if (k == 0) raw[0] = *(lds_cf4*)(size_t)(a_rd[h] + sb);
+            else if (k == 1) raw[1] = *(lds_cf4*)(size_t)(a_rd2[h] + sb);
+            else bn[(k - 2) % CB][(k - 2) / CB] = *(lds_cu4*)(size_t)(b_rd[h] + sb + (((k - 2) / CB) * BN + ((k - 2) % CB) * 32) * 64);
+        };
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
-            if (i == pre) {
-                mid();
-                x[0] = lo.x; x[1] = lo.y; x[2] = lo.z; x[3] = lo.w; x[4] = hi.x; x[5] = hi.y; x[6] = hi.z; x[7] = hi.w;
-            }
+            if (i == PRE) open();
             const int term = i / CB, cb = i % CB;
-            acc[cb] = ps_mfma(bb[cb][TB[term]], a[TA[term]], acc[cb]);
+            if (!(PA_PS_ABL & 2)) acc[cb] = ps_mfma(bb[cb][TB[term]], a[TA[term]], acc[cb]);
             __builtin_amdgcn_sched_barrier(0);
-            {
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    int at = lead + c * STRIDE;
-                    at = at > NM - 1 ? NM - 1 : at;
-                    if (at != i) continue;
-                    const int q = c >> 1;
-                    if ((c & 1) == 0) {
-                        q0[q] = ps_cvt_pk_bf16(x[2 * q], x[2 * q + 1]);
-                        r[2 * q] = ps_sub_lo(x[2 * q], q0[q]);
-                        r[2 * q + 1] = ps_sub_hi(x[2 * q + 1], q0[q]);
-                        q1[q] = ps_cvt_pk_bf16(r[2 * q], r[2 * q + 1]);
-                        an[0][q] = q0[q];
-                        an[1][q] = q1[q];
-                    } else {
-                        const float t0 = ps_sub_lo(r[2 * q], q1[q]), t1 = ps_sub_hi(r[2 * q + 1], q1[q]);
-                        an[2][q] = ps_cvt_pk_bf16(t0, t1);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
+            for (int k = 0; k < NR; ++k) {
+                int at = PRE + k;
+                at = at > NM - 1 ? NM - 1 : at;
+                if (at == i) rop(k);
             }
+#pragma unroll
+            for (int k = 0; k < 44; ++k) {
+                int at = OS + (k * (NM - OS)) / 44;
+                if (at == i) sop(k);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     auto load_bias = [&]() {
@@ -386,40 +425,29 @@ __global__ __launch_bounds__(512, 2) void psgemm_kernel(const GemmParams p, cons
         const unsigned o_off = out_offset(tile_m * BM + wave_id * 32);
         for (int ks = 0; ks < nk; ++ks, ++g) {
             const unsigned sb = slot * STAGE;
-            // ---- first half: multiply k 0..15 from registers; read and split k 16..31. The reads go out BEHIND the first matrix
-            //      instruction: in front of it hipcc's wait for that instruction's operands (read in the previous iteration: it
-            //      loses the count over the loop's back edge) would wait for these brand-new reads as well ----
-            f32x4 lo1, hi1;
-            half(a_c, b_c, lo1, hi1, a_n, 1, [&] {
-                lo1 = *(lds_cf4*)(size_t)(a_rd[1] + sb);
-                hi1 = *(lds_cf4*)(size_t)(a_rd2[1] + sb);
-                read_b(b_n, sb, 1);
-                if (RES && ks == nk - 1) {   // the tile's residual values: requested a k-step ahead of their use
+            // ---- first half: multiply k 0..15 from registers; read and split k 16..31 of the same stage (the reads go out BEHIND the
+            //      first matrix instruction: in front of it hipcc's wait for that instruction's operands, read in the previous
+            //      iteration -- it loses the count over the loop's back edge -- would wait for brand-new reads as well) ----
+            if (RES && ks == nk - 1) {   // the tile's residual values: requested a k-step ahead of their use
 #pragma unroll
-                    for (int cb = 0; cb < CB; ++cb)
+                for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-                        for (int gq = 0; gq < 4; ++gq) {
-                            const unsigned off = o_off == 0x80000000u ? o_off : o_off + (unsigned)(cb * 32 + 8 * gq) * 4u;
-                            res4[cb][gq] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rs, off, 0, 0));
-                        }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            });
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const unsigned off = o_off == 0x80000000u ? o_off : o_off + (unsigned)(cb * 32 + 8 * gq) * 4u;
+                        res4[cb][gq] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rs, off, 0, 0));
+                    }
+            }
+            half(a_c, b_c, a_n, b_n, sb, 1, std::integral_constant<int, 0>{}, [] {});
             // every LDS read of stage g has returned: behind the barrier below its slot is overwritten
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            // ---- second half: multiply k 16..31 from registers; one matrix instruction in, open k-step g + 1 (barrier) and read
-            //      its first operands, split them under the rest (after the last k-step: a split of stale values, unused) ----
+            // ---- second half: multiply k 16..31 from registers; a few matrix instructions in, open k-step g + 1 (barrier) and read
+            //      and split its first operands under the rest. (No branch around this for the last k-step: it then reads a slot
+            //      nobody refills -- stale, unused -- and the loaders join one barrier more; straight-line code keeps hipcc's
+            //      operand waits out of the matrix instructions' way.) ----
             const int nslot = slot + 1 == NSTAGE ? 0 : slot + 1;
-            f32x4 lo0, hi0;
-            half(a_n, b_n, lo0, hi0, a_c, NM >= 24 ? 4 : 1, [&] {
-                // (no branch around this for the last k-step: it then reads a slot nobody refills -- stale, unused -- and the
-                // loaders join one barrier more; straight-line code keeps hipcc's operand waits out of the matrix instructions' way)
+            half(a_n, b_n, a_c, b_c, (unsigned)(nslot * STAGE), 0, std::integral_constant<int, (NM >= 24 ? 2 : 1)>{}, [] {
                 __builtin_amdgcn_s_barrier();   // stage g + 1 landed (the loaders waited for it); stage g's slot is free
-                const unsigned nsb = nslot * STAGE;
-                lo0 = *(lds_cf4*)(size_t)(a_rd[0] + nsb);
-                hi0 = *(lds_cf4*)(size_t)(a_rd2[0] + nsb);
-                read_b(b_c, nsb, 0);
                 __builtin_amdgcn_sched_barrier(0);
             });
             slot = nslot;
@@ -527,7 +555,7 @@ hipError_t launch_psgemm(const GemmParams& p_in, const unsigned short* wsp, size
         if (p.residual) PA_PS_LAUNCH1(BN_, NS_, true);                                                                               \
         else PA_PS_LAUNCH1(BN_, NS_, false);                                                                                         \
     } while (0)
-    if (bn == 128) PA_PS_LAUNCH(128, 3);
+    if (bn == 128) PA_PS_LAUNCH1(128, 3, false);   // (a residual caps the tile at 64 channels: psgemm_pick_bn)
     else if (bn == 64) PA_PS_LAUNCH(64, 4);
     else PA_PS_LAUNCH(32, 4);
 #undef PA_PS_LAUNCH1

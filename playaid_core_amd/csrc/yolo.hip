@@ -330,6 +330,9 @@ struct pa_detector {
     float* wino_weights = nullptr;      // the stride-1 3x3 layers' filters in the Winograd kernel's layout (wino.hip)
     std::vector<long long> wino_off;    // per layer: float offset into wino_weights, -1 = the layer runs in its direct form
     std::vector<int> wino_bn;           // per layer: output channels per workgroup its filters were laid out for
+    int compute_dtype = PA_DTYPE_F32;   // PA_DTYPE_EMULATED_F32: the layers listed in split_off run on psgemm.hip
+    unsigned short* split_weights = nullptr;   // those layers' weights as three bf16 slices in the kernel's stage-image order
+    std::vector<long long> split_off;   // per layer: element offset into split_weights, -1 = the layer keeps its exact fp32 kernel
     float* x0 = nullptr;       // letter-boxed input [max_images][net_h + 4][net_w + 4][4]
     float* anchors = nullptr;  // device copy of the decode layers' anchors [n_decode][8]
     std::string last_error;
@@ -343,6 +346,7 @@ void pa_detector_destroy(pa_detector* h) {
     if (!h) return;
     (void)hipFree(h->weights);
     (void)hipFree(h->wino_weights);
+    (void)hipFree(h->split_weights);
     (void)hipFree(h->x0);
     (void)hipFree(h->anchors);
     for (float* b : h->bufs) (void)hipFree(b);
@@ -354,14 +358,23 @@ int pa_detector_rows(const pa_detector* h) { return h ? h->rows : 0; }
 int pa_detector_create(int32_t device, const pa_net_layer* layers, int32_t n_layers, const int64_t* buf_floats_per_image, int32_t n_bufs,
                        const float* weights_host, size_t n_weights, int32_t max_images, int32_t net_h, int32_t net_w, int32_t num_classes,
                        pa_detector** out) {
+    return pa_detector_create_dtype(device, layers, n_layers, buf_floats_per_image, n_bufs, weights_host, n_weights, max_images, net_h, net_w, num_classes,
+                                    PA_DTYPE_F32, out);
+}
+
+int pa_detector_create_dtype(int32_t device, const pa_net_layer* layers, int32_t n_layers, const int64_t* buf_floats_per_image, int32_t n_bufs,
+                             const float* weights_host, size_t n_weights, int32_t max_images, int32_t net_h, int32_t net_w, int32_t num_classes,
+                             int32_t compute_dtype, pa_detector** out) {
     if (!out) return PA_ERR_INVALID_ARG;
     *out = nullptr;
     if (!layers || n_layers < 1 || !buf_floats_per_image || n_bufs < 1 || !weights_host || n_weights < 1 || max_images < 1 || net_h < 32 ||
-        net_w < 32 || net_h % 32 || net_w % 32 || num_classes < 1 || num_classes > 80)
+        net_w < 32 || net_h % 32 || net_w % 32 || num_classes < 1 || num_classes > 80 ||
+        (compute_dtype != PA_DTYPE_F32 && compute_dtype != PA_DTYPE_EMULATED_F32))
         return PA_ERR_INVALID_ARG;
     pa_detector* h = new pa_detector();
     *out = h;
     h->device = device; h->max_images = max_images; h->net_h = net_h; h->net_w = net_w; h->nc = num_classes;
+    h->compute_dtype = compute_dtype;
     h->layers.assign(layers, layers + n_layers);
     auto bad = [&](int i, const char* what) {
         h->last_error = "layer " + std::to_string(i) + ": " + what;
@@ -445,6 +458,32 @@ int pa_detector_create(int32_t device, const pa_net_layer* layers, int32_t n_lay
                 if (h->wino_off[i] >= 0) pa::wino_transform_weights(weights_host + h->layers[i].w_off, h->layers[i].cin, h->layers[i].cout, h->wino_bn[i], ug.data() + h->wino_off[i]);
             if (!chk(hipMalloc(&h->wino_weights, total * sizeof(float)), "hipMalloc Winograd filters")) return PA_ERR_HIP;
             if (!chk(hipMemcpy(h->wino_weights, ug.data(), total * sizeof(float), hipMemcpyHostToDevice), "upload Winograd filters")) return PA_ERR_HIP;
+        }
+    }
+    h->split_off.assign(n_layers, -1);
+    if (compute_dtype == PA_DTYPE_EMULATED_F32) {
+        // the 1x1 and the stride-2 3x3 convolutions (and, with PA_DET_EMU_S1=1, the stride-1 3x3 ones in place of their Winograd
+        // form) on the emulated-fp32 kernel (psgemm.hip): weights split into three bf16 slices here, once
+        const int emu_s1 = getenv("PA_DET_EMU_S1") ? atoi(getenv("PA_DET_EMU_S1")) : 0;
+        size_t total = 0;
+        for (int i = 0; i < n_layers; ++i) {
+            const pa_net_layer& L = h->layers[i];
+            if (L.kind != 0 || L.cin % 32 || L.cout % 32) continue;
+            if (L.ksize == 3 && L.stride == 1 && !emu_s1 && h->wino_off[i] >= 0) continue;
+            const size_t n_el = pa::psgemm_weight_elems(L.cout, L.ksize * L.ksize * L.cin, L.res_buf >= 0);
+            if (n_el == 0) continue;
+            h->split_off[i] = (long long)total;
+            total += n_el;
+        }
+        if (total) {
+            std::vector<unsigned short> sw(total);
+            for (int i = 0; i < n_layers; ++i)
+                if (h->split_off[i] >= 0) {
+                    const pa_net_layer& L = h->layers[i];
+                    pa::psgemm_pack_weights(weights_host + L.w_off, L.cout, L.ksize * L.ksize * L.cin, L.res_buf >= 0, sw.data() + h->split_off[i]);
+                }
+            if (!chk(hipMalloc(&h->split_weights, total * sizeof(unsigned short)), "hipMalloc split weights")) return PA_ERR_HIP;
+            if (!chk(hipMemcpy(h->split_weights, sw.data(), total * sizeof(unsigned short), hipMemcpyHostToDevice), "upload split weights")) return PA_ERR_HIP;
         }
     }
     h->bufs.assign(n_bufs, nullptr);
@@ -616,7 +655,11 @@ static int detector_run(pa_detector* h, const uint8_t* frames, int32_t n, int32_
         static const int use_pgemm = getenv("PA_DET_PGEMM") ? atoi(getenv("PA_DET_PGEMM")) : 1;  // 0: the one-tile-per-workgroup engine (A/B)
         static const int use_patch = getenv("PA_DET_PATCH") ? atoi(getenv("PA_DET_PATCH")) : 1;  // 0: im2col for the 3x3 convolutions (A/B)
         pe = hipErrorInvalidValue;
-        if (h->wino_off[li] >= 0) {
+        if (h->split_off[li] >= 0) {
+            // emulated fp32 (psgemm.hip); out_floats: from the layer's first output channel to the end of the images in flight
+            pe = pa::launch_psgemm(p, h->split_weights + h->split_off[li], (size_t)n * p.out_img_stride - (size_t)L.out_coff, s);
+        }
+        if (pe == hipErrorInvalidValue && h->wino_off[li] >= 0) {
             pa::WinoParams q;
             memset(&q, 0, sizeof(q));
             q.act = p.act; q.wgt = h->wino_weights + h->wino_off[li]; q.bias = p.bias; q.residual = p.residual; q.out = p.out;

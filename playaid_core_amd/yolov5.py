@@ -246,8 +246,8 @@ class YoloV5Detector:
         bf = (C.c_int64 * len(buf_floats))(*buf_floats)
         h = C.c_void_p()
         torch.cuda.set_device(self.device)
-        rc = self._lib.pa_detector_create(self.device.index or 0, arr, len(layers), bf, len(buf_floats), weights.ctypes.data_as(C.c_void_p),
-                                          weights.size, max_images, self.net_hw[0], self.net_hw[1], nc, C.byref(h))
+        rc = self._lib.pa_detector_create_dtype(self.device.index or 0, arr, len(layers), bf, len(buf_floats), weights.ctypes.data_as(C.c_void_p),
+                                                weights.size, max_images, self.net_hw[0], self.net_hw[1], nc, _lib.DTYPES[compute_dtype], C.byref(h))
         self._h = h
         if rc != 0:
             msg = self._lib.pa_detector_last_error(h).decode() if h else "bad argument"

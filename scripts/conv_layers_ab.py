@@ -115,7 +115,7 @@ for name, n, h, w, cin, cout, k, stride, act, res, count in LAYERS:
     es = float((out_s[:1, 1:-1, 1:-1].permute(0, 3, 1, 2).double().cpu() - ref).abs().max() / ref.abs().max())
     gf = 2.0 * n * oh * ow * cout * k * k * cin / 1e9
     floor = (n * oh * ow * (cin * (1 if k == 1 else (1.0 if stride == 2 else 1.0)) + cout * (2 if res else 1)) * 4 + wt.size * 4) / 5e12 * 1e6
-    print(f"{name:34s} {gf:7.2f} | {te:9.1f} {gf / te * 1e-3:6.1f} | {ts:8.1f} {gf / ts * 1e-3:6.1f} | {te / ts:7.2f}x | {ee:18.2e} {es:10.2e} | {floor:6.1f}   x{count}", flush=True)
+    print(f"{name:34s} {gf:7.2f} | {te:9.1f} {gf / te * 1e3:6.1f} | {ts:8.1f} {gf / ts * 1e3:6.1f} | {te / ts:7.2f}x | {ee:18.2e} {es:10.2e} | {floor:6.1f}   x{count}", flush=True)
     tot_e += te * count
     tot_s += ts * count
     del x, out_e, out_s, resid

@@ -14,7 +14,8 @@ from playaid_core_amd.yolov5 import YoloV5Detector, build_yolov5s_table  # noqa:
 n, H, W = int(os.environ.get("N", 64)), 1080, 1920
 dev = torch.device("cuda:0")
 sd = synth.make_yolov5s_state_dict()
-det = YoloV5Detector(sd, 6, (384, 640), max_images=n, device="cuda:0")
+DTYPE = os.environ.get("DTYPE", "f32")   # f32 | emulated_f32
+det = YoloV5Detector(sd, 6, (384, 640), max_images=n, device="cuda:0", compute_dtype=DTYPE)
 layers = build_yolov5s_table(sd, (384, 640), 6)[0]
 frames = torch.from_numpy(synth.make_frames(4, H, W)).to(dev).repeat((n + 3) // 4, 1, 1, 1)[:n].contiguous()
 pred = torch.empty((n, det.rows, 11), dtype=torch.float32, device=dev)
@@ -38,4 +39,5 @@ for i, L in enumerate(layers):
     tot_gf += gf
     print(f"{i:3d} {names[L.kind]:6s} k{L.ksize} s{L.stride} {L.in_h:3d}x{L.in_w:3d} cin {L.cin:4d} cout {L.cout:4d} M {n * oh * ow:8d} "
           f"{gf:7.2f} GF {med[i]:8.1f} us {gf / med[i] * 1e3 if med[i] > 0 else 0:6.1f} TF  res {int(L.res_buf >= 0)}")
+print(f"compute_dtype {DTYPE}")
 print(f"total {tot_gf:.1f} GFLOP executed in {tot_us:.0f} us (events between layers) = {tot_gf / tot_us * 1e3:.1f} TFLOP/s")

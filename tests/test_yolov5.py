@@ -11,6 +11,10 @@ NET = (384, 640)
 # 9e-3 px from a float64 run of the same graph, profiles/r05_yolov5_parity.txt. The label rows the path emits are normalised
 # by the frame size: 3.84e-2 px is 3e-5 there.) Scores: 1e-4 as before.
 BOX_TOL_PX = 1e-4 * min(NET)
+# Every GPU parity test of the network runs under both arithmetic choices of pa_detector_create_dtype: the exact fp32 kernels and
+# PA_DTYPE_EMULATED_F32 (csrc/psgemm.hip: the 1x1 and stride-2 3x3 convolutions on the bf16 matrix cores, three bf16 slices per
+# operand) -- same oracle, same tolerances.
+DTYPES = ["f32", "emulated_f32"]
 
 
 def test_table_covers_the_published_graph():
@@ -51,7 +55,8 @@ def test_oracle_front_end():
 
 
 @pytest.mark.gpu
-def test_detection_network_against_the_oracle(engine):
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_detection_network_against_the_oracle(engine, dtype):
     """frames -> letterbox -> YOLOv5s -> Detect decode on the device == the torch CPU oracle on the same state dict."""
     import torch
 
@@ -61,7 +66,7 @@ def test_detection_network_against_the_oracle(engine):
     from playaid_core_amd.yolov5 import YoloV5Detector
 
     sd = synth.make_yolov5s_state_dict()
-    det = YoloV5Detector(sd, NC, NET, max_images=4)
+    det = YoloV5Detector(sd, NC, NET, max_images=4, compute_dtype=dtype)
     try:
         for h, w, n in ((720, 1280, 3), (1080, 1920, 2)):
             frames = synth.make_frames(n, h, w, seed=5)
@@ -141,7 +146,8 @@ def test_detector_refuses_batches_its_32_bit_offsets_cannot_address():
 
 
 @pytest.mark.gpu
-def test_detection_network_batches_and_small_frames():
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_detection_network_batches_and_small_frames(dtype):
     """More frames than the handle's max_images are run in chunks; a frame smaller than the network input is enlarged
     (letterbox scales up as well) -- both equal the oracle."""
     import torch
@@ -150,7 +156,7 @@ def test_detection_network_batches_and_small_frames():
     from playaid_core_amd.yolov5 import YoloV5Detector
 
     sd = synth.make_yolov5s_state_dict()
-    det = YoloV5Detector(sd, NC, NET, max_images=2)
+    det = YoloV5Detector(sd, NC, NET, max_images=2, compute_dtype=dtype)
     try:
         frames = synth.make_frames(5, 270, 480, seed=9)  # 16:9, enlarged by 4 / 3 to 360 x 640
         got = det(frames)
@@ -164,8 +170,9 @@ def test_detection_network_batches_and_small_frames():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("net", [(320, 320), (352, 608), (64, 96)])
-def test_detection_network_other_network_inputs(net):
+def test_detection_network_other_network_inputs(net, dtype):
     """Network inputs other than 384 x 640: the map sizes decide which kernel form a layer takes (round 4) -- 8 x 16, 8 x 8 or
     4 x 4 blocks on the patch-resident kernel, the im2col engine where no block divides the map (10 x 10, 38-wide), partial
     row / column blocks in the direct stem, partial pixel tiles in the persistent GEMM -- and every form must equal the oracle.
@@ -176,7 +183,7 @@ def test_detection_network_other_network_inputs(net):
     from playaid_core_amd.yolov5 import YoloV5Detector
 
     sd = synth.make_yolov5s_state_dict()
-    det = YoloV5Detector(sd, NC, net, max_images=3)
+    det = YoloV5Detector(sd, NC, net, max_images=3, compute_dtype=dtype)
     try:
         frames = synth.make_frames(3, 360, 640, seed=11)
         got = det(frames)
@@ -186,14 +193,15 @@ def test_detection_network_other_network_inputs(net):
         want = oy.forward(x, sd, NC).numpy()
         assert got.shape == want.shape
         e_box, e_score = np.abs(got[..., :4] - want[..., :4]).max(), np.abs(got[..., 4:] - want[..., 4:]).max()
-        print(f"net {net}: boxes {e_box:.2e} px, scores {e_score:.2e}")
+        print(f"{dtype} net {net}: boxes {e_box:.2e} px, scores {e_score:.2e}")
         assert e_score <= 1e-4 and e_box <= BOX_TOL_PX
     finally:
         det.close()
 
 
 @pytest.mark.gpu
-def test_detection_network_full_batch_of_configs1():
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_detection_network_full_batch_of_configs1(dtype):
     """The batch BASELINE.json's configs[1] names -- 64 frames in one pa_detector_forward -- against the oracle, every row: the
     persistent GEMM then walks ~15 tiles per workgroup on the 96 x 160 maps (one-k-step tiles on the 32-channel layer, where a
     wave's counted wait spans the stores of two closed tiles), which the small batches above never reach."""
@@ -204,7 +212,7 @@ def test_detection_network_full_batch_of_configs1():
 
     n = 64
     sd = synth.make_yolov5s_state_dict()
-    det = YoloV5Detector(sd, NC, NET, max_images=n)
+    det = YoloV5Detector(sd, NC, NET, max_images=n, compute_dtype=dtype)
     try:
         # configs[1] itself: 64 x 1080p frames (the 3:1 letterbox), every row against the oracle (in chunks of 8)
         frames = synth.make_frames(n, 1080, 1920, seed=4)
@@ -214,7 +222,7 @@ def test_detection_network_full_batch_of_configs1():
         x = torch.from_numpy(np.stack([oy.letterbox(f, NET) for f in frames]))
         want = np.concatenate([oy.forward(x[i:i + 8], sd, NC).numpy() for i in range(0, n, 8)])
         e_box, e_score = np.abs(got[..., :4] - want[..., :4]).max(), np.abs(got[..., 4:] - want[..., 4:]).max()
-        print(f"64 x 1080p batch: boxes {e_box:.2e} px, scores {e_score:.2e}")
+        print(f"{dtype} 64 x 1080p batch: boxes {e_box:.2e} px, scores {e_score:.2e}")
         assert e_score <= 1e-4 and e_box <= BOX_TOL_PX
         del frames, x, want
         frames = synth.make_frames(n, 720, 1280, seed=3)
@@ -224,7 +232,7 @@ def test_detection_network_full_batch_of_configs1():
         x = torch.from_numpy(np.stack([oy.letterbox(f, NET) for f in frames]))
         want = np.concatenate([oy.forward(x[i:i + 8], sd, NC).numpy() for i in range(0, n, 8)])
         e_box, e_score = np.abs(got[..., :4] - want[..., :4]).max(), np.abs(got[..., 4:] - want[..., 4:]).max()
-        print(f"64-frame batch: boxes {e_box:.2e} px, scores {e_score:.2e}")
+        print(f"{dtype} 64-frame batch: boxes {e_box:.2e} px, scores {e_score:.2e}")
         assert e_score <= 1e-4 and e_box <= BOX_TOL_PX
         # and the same frames in another order give the same rows, bit for bit (no tile depends on its neighbours in the launch)
         perm = np.random.default_rng(0).permutation(n)
@@ -236,7 +244,8 @@ def test_detection_network_full_batch_of_configs1():
 
 
 @pytest.mark.gpu
-def test_detection_network_is_bitwise_repeatable():
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_detection_network_is_bitwise_repeatable(dtype):
     """The persistent GEMM orders LDS-DMA copies, operand reads and stores by COUNTED waits; a miscounted wait shows as rare wrong
     tiles that come and go with timing. Forty forwards of the same 16 frames (3-4 tiles per workgroup on the large maps), a
     second stream keeping the chip busy under half of them: every result must equal the first, bit for bit."""
@@ -244,7 +253,7 @@ def test_detection_network_is_bitwise_repeatable():
 
     from playaid_core_amd.yolov5 import YoloV5Detector
 
-    det = YoloV5Detector(synth.make_yolov5s_state_dict(), NC, NET, max_images=16)
+    det = YoloV5Detector(synth.make_yolov5s_state_dict(), NC, NET, max_images=16, compute_dtype=dtype)
     try:
         frames = torch.from_numpy(synth.make_frames(16, 720, 1280, seed=21)).cuda()
         first = det(frames).clone()
@@ -263,7 +272,8 @@ def test_detection_network_is_bitwise_repeatable():
 
 
 @pytest.mark.gpu
-def test_timed_forward_is_the_same_forward():
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_timed_forward_is_the_same_forward(dtype):
     """``pa_detector_forward_timed`` (the measurement aid behind scripts/detect_layer_times.py) runs the same table with an
     event between its layers: bit-identical predictions, one positive time per layer, and a refusal -- not a write past
     the caller's array -- when ``cap`` is smaller than the table."""
@@ -274,7 +284,7 @@ def test_timed_forward_is_the_same_forward():
     from playaid_core_amd.yolov5 import YoloV5Detector, build_yolov5s_table
 
     sd = synth.make_yolov5s_state_dict()
-    det = YoloV5Detector(sd, NC, NET, max_images=4)
+    det = YoloV5Detector(sd, NC, NET, max_images=4, compute_dtype=dtype)
     try:
         n_layers = len(build_yolov5s_table(sd, NET, NC)[0])
         frames = torch.from_numpy(synth.make_frames(4, 720, 1280, seed=5)).cuda()
