@@ -178,7 +178,8 @@ def compact_line(result):
     side("pcie_inclusive_windows", "pcie_inclusive_frames_per_s")
     e = result.get("emulated_fp32")
     if isinstance(e, dict):
-        out["emulated_fp32"] = {k: e.get(k) for k in ("frames_per_s", "detector_ms", "chain_frames_per_s", "max_dlogp_vs_oracle", "error") if k in e}
+        out["emulated_fp32"] = {k: e.get(k) for k in ("frames_per_s", "detector_ms", "detector_ms_exact_f32", "chain_frames_per_s", "max_dlogp_vs_oracle",
+                                                      "max_dlogp_vs_oracle_exact_f32", "error") if k in e}
     out["details"] = "bench_details.json"
     line = json.dumps(out, separators=(",", ":"))
     if len(line) > 1800:   # never let a long note push the headline out of the driver's tail
@@ -205,6 +206,70 @@ def emit(result):
             pass
     print(full, file=sys.stderr, flush=True)
     print(compact_line(result), flush=True)
+
+
+def emulated_fp32_side(sd, frames, boxes, n_clip, height, width, S, DELTA, device, quality):
+    """the fp32 path with its convolutions' products on the bf16 matrix cores (compute_dtype
+    "emulated_f32" = PA_DTYPE_EMULATED_F32: three bf16 slices per fp32 operand, six bf16 matrix instructions per fp32 product,
+    fp32 accumulation; csrc/psgemm.hip). Never `value`: the headline and `dtype` stay on the exact fp32 kernels. Reports the
+    headline shape's rate, the detector stage, the chain, and the error of BOTH paths against the CPU oracle on the same small
+    clip (the error against a float64 run of the detection network: profiles/r06_yolov5_parity.txt)."""
+    from oracle import pipeline  # checker only
+    from playaid_core_amd.yolov5 import YoloV5Detector
+
+    out = {"what": "compute_dtype emulated_f32: fp32 in / fp32 out, fp32-accurate sums; the detector's 1x1 and stride-2 3x3 convolutions and the "
+                   "ResNet-18's stride-2 openers + 1x1/2 branch GEMMs on v_mfma_f32_32x32x16_bf16 (csrc/psgemm.hip); the stride-1 3x3 layers "
+                   "keep their exact Winograd kernel (measured equal per layer, profiles/r06_pgemm_split_layers.txt), stems and heads exact"}
+    eng = Engine(sd, device=str(device), max_batch_frames=n_clip, max_clip_frames=max(n_clip, 64), max_frame_height=height, max_frame_width=width,
+                 compute_dtype="emulated_f32")
+    try:
+        lanes = ClipLanes(eng, S, DELTA, lanes=2)
+        try:
+            for _ in range(8):
+                lanes.submit(frames, boxes, n_clip)
+            torch.cuda.synchronize(device)
+            lanes.idle()
+            k = 100
+            t0 = time.perf_counter()
+            for _ in range(k):
+                lanes.submit(frames, boxes, n_clip)
+            torch.cuda.synchronize(device)
+            out["frames_per_s"] = round(n_clip * k / (time.perf_counter() - t0), 1)
+        finally:
+            lanes.close()
+        # both arithmetic choices against the CPU oracle on one small clip (8 x 720p frames, as __graft_entry__.smoke)
+        f8, b8 = synth.make_frames(8, 720, 1280), synth.make_boxes(8, 720, 1280)
+        ref = pipeline.run_action_recognition(f8, b8, sd, mode="cached")["logp"]
+        small = {}
+        for dt_ in ("f32", "emulated_f32"):
+            e8 = Engine(sd, device=str(device), max_batch_frames=8, max_clip_frames=64, max_frame_height=720, max_frame_width=1280, compute_dtype=dt_)
+            try:
+                small[dt_] = float(np.abs(e8.infer_clip(f8, b8)["logp"].astype(np.float64) - ref).max())
+            finally:
+                e8.close()
+        out["max_dlogp_vs_oracle"] = float(f"{small['emulated_f32']:.3e}")
+        out["max_dlogp_vs_oracle_exact_f32"] = float(f"{small['f32']:.3e}")
+        # detector stage alone (64 frames, events on one stream), both dtypes
+        for dt_, key in (("f32", "detector_ms_exact_f32"), ("emulated_f32", "detector_ms")):
+            det = YoloV5Detector(synth.make_yolov5s_state_dict(), 6, (384, 640), max_images=n_clip, device=str(device), compute_dtype=dt_)
+            try:
+                ts = []
+                for _ in range(6):
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    det(frames)
+                    b.record()
+                    torch.cuda.synchronize(device)
+                    ts.append(a.elapsed_time(b))
+                out[key] = round(float(np.median(ts[2:])), 3)
+            finally:
+                det.close()
+        ch = chain_inclusive(eng, sd, frames, boxes, quality=quality, compute_dtype="emulated_f32")
+        out["chain_frames_per_s"] = ch["value"]
+        out["chain_stage_ms"] = ch["stage_ms_per_clip_alone"]
+    finally:
+        eng.close()
+    return out
 
 
 _ENCODED = {}
@@ -334,7 +399,7 @@ def synthetic_head_rows(boxes_dev, rows, nc, height, width, net_hw=(384, 640)):
     return pred
 
 
-def chain_inclusive(eng, sd, frames_dev, boxes_dev, steps=12, quality=95):
+def chain_inclusive(eng, sd, frames_dev, boxes_dev, steps=12, quality=95, compute_dtype="f32"):
     """The path north_star names, chained (ai_runner.py:181-189 run_detection_setup -> :191-224 YOLO -> :226-424 repair -> :426-520
     windows -> CNN -> labels): the clip as Motion-JPEG bytes in pinned host memory -> pa_mjpeg_decode -> pa_detector_forward
     (YOLOv5s) -> pa_detect_postprocess (NMS, --max-det 2 --classes 2 3) -> pa_clean_detections -> pa_save_one_box_crops (+ the
@@ -352,7 +417,7 @@ def chain_inclusive(eng, sd, frames_dev, boxes_dev, steps=12, quality=95):
     decs = [video.MjpegDecoder(n, h, w, int(ends[-1]) + 4096, device=str(dev)) for _ in range(ND)]
     bufs = [torch.empty_like(frames_dev) for _ in range(ND)]
     st = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(ND)]
-    det = YoloV5Detector(synth.make_yolov5s_state_dict(), 6, (384, 640), max_images=n, device=str(dev))
+    det = YoloV5Detector(synth.make_yolov5s_state_dict(), 6, (384, 640), max_images=n, device=str(dev), compute_dtype=compute_dtype)
     front_eng = Engine(sd, device=str(dev), max_batch_frames=8, max_clip_frames=max(n, 64), max_frame_height=h, max_frame_width=w)
     pred_syn = synthetic_head_rows(boxes_dev, det.rows, 6, h, w)
     pred_net = torch.empty((n, det.rows, 11), dtype=torch.float32, device=dev)
@@ -458,6 +523,7 @@ def chain_inclusive(eng, sd, frames_dev, boxes_dev, steps=12, quality=95):
         "bound_by": max(stages, key=stages.get),
         "crops_plus_cnn_of_the_headline_formulation_ms": round(ms_cnn, 3),
         "compressed_MB_per_clip": round(float(ends[-1]) / 1e6, 2),
+        "compute_dtype": compute_dtype,
         "frames_with_decode_errors": bad,
         "labels_finite": finite,
         "actions_in_last_clip": int(len(np.unique(rec["action_id"]))),
@@ -789,8 +855,11 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse ranks > GPUs)")
     ap.add_argument("--no-pipeline", action="store_true", help="crop stage and backbone on one stream (no overlap across steps)")
-    ap.add_argument("--no-calibrate", action="store_true",
-                    help="two lanes on the first streams that pass the spin-kernel probe, without timing the stream pairs first (A/B of the queue lottery)")
+    ap.add_argument("--no-emulated", action="store_true", help="skip the emulated-fp32 side block (compute_dtype emulated_f32)")
+    ap.add_argument("--calibrate", action="store_true",
+                    help="time every pair of candidate streams before the timed region and keep the fastest (round 5's default; round 6 measured "
+                    "no difference between the pairs once warm: profiles/r06_hw_queues.txt)")
+    ap.add_argument("--no-calibrate", action="store_true", help="(default since round 6; kept so that scripts/hw_queues.sh's command lines still parse)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "emulated_f32"],
                     help="f32 = the headline (reference arithmetic); bf16 = BASELINE.json configs[2]'s conv path, reported under its own dtype, never as the headline")
     args = ap.parse_args()
@@ -849,7 +918,7 @@ def main():
     lanes = None
     if world == 1 and not long_clip and args.lanes > 1 and not args.no_pipeline:
         lanes = ClipLanes(eng, S, DELTA, lanes=args.lanes)
-        if not args.no_calibrate:
+        if args.calibrate and not args.no_calibrate:
             lanes.calibrate(frames, boxes, n_total, batch_of=kb if kb > 1 else 0)   # untimed: which of the concurrent streams overlap best on this shape
     batch_of = kb if kb > 1 else 0
 
@@ -1076,6 +1145,12 @@ def main():
                 except Exception as exc:
                     result["chain_inclusive_camera_like"] = {"error": f"{type(exc).__name__}: {exc}"}
                 quiet = None
+        if world == 1 and not long_clip and args.dtype == "f32" and not args.no_pcie and not args.no_decode and not args.no_emulated:
+            try:
+                result["emulated_fp32"] = emulated_fp32_side(sd, frames[:n_clip], boxes[:n_clip], n_clip, args.height, args.width, S, DELTA, device,
+                                                             args.jpeg_quality)
+            except Exception as exc:  # a side measurement must never cost the line its headline
+                result["emulated_fp32"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not long_clip and kb == 1 and not args.no_pcie and not args.no_pipeline and args.clip_batch_side > 1:
             try:
                 result["clip_batches"] = clip_batch_side(eng, n_clip, args.clip_batch_side, args.height, args.width, S, DELTA, max(args.lanes, 1))

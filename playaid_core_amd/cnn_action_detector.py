@@ -47,7 +47,9 @@ class CNNActionDetector:
         self.num_samples = num_samples
         self.dataset_kwargs = kwargs
         self.training = False
-        self._engine = Engine(state_dict, device=device, **{k: v for k, v in kwargs.items() if k.startswith("max_")})
+        # (beyond the reference's arguments: the engine's capacities and, never by default, the arithmetic of the fp32 path --
+        # compute_dtype="emulated_f32", PA_DTYPE_EMULATED_F32)
+        self._engine = Engine(state_dict, device=device, **{k: v for k, v in kwargs.items() if k.startswith("max_") or k == "compute_dtype"})
 
     @classmethod
     def load_from_checkpoint(cls, checkpoint_path: str, map_location=None, **kwargs):

@@ -52,6 +52,10 @@ struct ConvLayer {
     bool ds_fused = false;
     bool ds_probe = false;  // PA_BF16_DS_FUSE=2: the opener takes the fused launch's tile and K split, the branch stays separate
     double k_alg = 0;  // algorithmic K (unpadded) for FLOP accounting
+    // compute_dtype PA_DTYPE_EMULATED_F32: the layer's weights as three bf16 slices in psgemm.hip's stage-image order (the layer then
+    // runs on that kernel), and the same for the 1x1/2 branch GEMM of a Winograd-form block opener's conv2
+    unsigned short* split_wgt = nullptr;
+    unsigned short* ds_split_wgt = nullptr;
 };
 
 struct ProfEntry {
@@ -67,6 +71,7 @@ struct pa_engine {
     pa_config cfg;
     std::string last_error;
     int max_crops = 0;   // crops per backbone call
+    bool emu = false;    // cfg.compute_dtype == PA_DTYPE_EMULATED_F32: fp32 buffers and interfaces, the layers that have ConvLayer::split_wgt on psgemm.hip
     bool bf16 = false;   // cfg.compute_dtype == PA_DTYPE_BF16: the 3x3 conv stack stores bf16 (buffers keep their fp32 size)
     int cache_rows = 0;  // feature-cache rows
     // clip state
@@ -191,6 +196,14 @@ int upload_bf16(pa_engine* e, float** dst, const std::vector<float>& host) {
             h[i] = (uint16_t)(u >> 16);
         }
     return arena_put(e, reinterpret_cast<void**>(dst), h.data(), h.size() * sizeof(uint16_t));
+}
+
+// fp32 [cout][ktot] -> three bf16 slices per weight in psgemm.hip's stage-image order (PA_DTYPE_EMULATED_F32)
+int upload_split(pa_engine* e, unsigned short** dst, const std::vector<float>& host, int cout, int ktot, bool residual) {
+    std::vector<unsigned short> h(psgemm_weight_elems(cout, ktot, residual), 0);
+    if (h.empty()) return PA_ERR_INVALID_ARG;
+    if (!e->adopt) psgemm_pack_weights(host.data(), cout, ktot, residual, h.data());
+    return arena_put(e, reinterpret_cast<void**>(dst), h.data(), h.size() * sizeof(unsigned short));
 }
 
 // --- weight blob walking -----------------------------------------------------
@@ -420,10 +433,14 @@ int run_conv(pa_engine* e, const ConvLayer& L, int crop0, int ncrops, size_t sla
         d.relu = 0; d.splitk = 1;
         ProfScope ps(e, s, prof_name, 2.0 * d.M * d.N * L.in2_c,
                      4.0 * ((double)ncrops * L.in2_hw * L.in2_hw * L.in2_c / (L.in2_stride * L.in2_stride) + (double)d.M * d.N + (double)d.N * L.in2_c));
-        GemmTile dt;
-        int dsk;
-        choose_tile(d.M, d.N, L.in2_c / 32, &dt, &dsk);
-        HIPCHK(e, launch_igemm(d, dt, s));
+        if (e->emu && L.ds_split_wgt) {
+            HIPCHK(e, launch_psgemm(d, L.ds_split_wgt, (size_t)ncrops * out_crop, 0, s));
+        } else {
+            GemmTile dt;
+            int dsk;
+            choose_tile(d.M, d.N, L.in2_c / 32, &dt, &dsk);
+            HIPCHK(e, launch_igemm(d, dt, s));
+        }
         p.residual = d.out;
     } else if (L.in2) {
         const int w2 = L.in2_hw + 2;  // zero-bordered block input
@@ -462,7 +479,9 @@ int run_conv(pa_engine* e, const ConvLayer& L, int crop0, int ncrops, size_t sla
     // PA_PATCH=0 keeps the generic im2col engine for A/B runs
     static const int use_patch = getenv("PA_PATCH") ? atoi(getenv("PA_PATCH")) : 1;
     static const int use_bf16_patch = getenv("PA_BF16_PATCH") ? atoi(getenv("PA_BF16_PATCH")) : 1;
-    if (bf) {
+    if (e->emu && L.split_wgt && !p.act2 && !p.residual) {
+        HIPCHK(e, launch_psgemm(p, L.split_wgt, (size_t)ncrops * out_crop, 0, s));
+    } else if (bf) {
         hipError_t pe = hipErrorInvalidValue;
         if (use_bf16_patch && L.stride == 1 && !p.act2) pe = launch_conv3x3_bf16_patch(p, s);
         if (pe == hipErrorInvalidValue) {  // stride-2 convs, fused 1x1/2 second source
@@ -765,7 +784,7 @@ int create_impl(const pa_config* cfg, const void* blob, size_t src_bytes, const 
     const int S = cfg->sequence_length, A = cfg->num_actions, F = cfg->num_fighters;
     if (S < 1 || S % 2 == 0 || S > 15 || A < 1 || A > 64 || F < 1 || F > 4 || cfg->max_batch_frames < 1 ||
         cfg->max_clip_frames < 1 || cfg->max_frame_height < 1 || cfg->max_frame_width < 1 || cfg->crop_padding < 0 ||
-        (cfg->compute_dtype != PA_DTYPE_F32 && cfg->compute_dtype != PA_DTYPE_BF16))
+        (cfg->compute_dtype != PA_DTYPE_F32 && cfg->compute_dtype != PA_DTYPE_BF16 && cfg->compute_dtype != PA_DTYPE_EMULATED_F32))
         return PA_ERR_INVALID_ARG;
     const int32_t* hdr = reinterpret_cast<const int32_t*>(blob);
     if (blob && (src_bytes != pa_weight_blob_bytes(S, A) || hdr[0] != PA_WEIGHT_MAGIC || hdr[1] != 1 || hdr[2] != S || hdr[3] != A))
@@ -773,6 +792,7 @@ int create_impl(const pa_config* cfg, const void* blob, size_t src_bytes, const 
     pa_engine* e = new pa_engine();
     e->cfg = *cfg;
     e->bf16 = cfg->compute_dtype == PA_DTYPE_BF16;
+    e->emu = cfg->compute_dtype == PA_DTYPE_EMULATED_F32;
     e->adopt = blob == nullptr;
     {
         const char* pl = getenv("PA_PROFILE_LAYERS");
@@ -885,6 +905,9 @@ int create_impl(const pa_config* cfg, const void* blob, size_t src_bytes, const 
                 r2 = upload(e, &L.wino_wgt, ug);
                 if (r2) return r2;
             }
+            // PA_DTYPE_EMULATED_F32: the stride-2 3x3 openers of layers 2-4 on psgemm.hip (the stride-1 3x3 layers keep their exact
+            // Winograd kernel: per layer the two measure the same, profiles/r06_pgemm_split_layers.txt)
+            if (e->emu && k == 3 && stride == 2 && cin % 32 == 0 && (r2 = upload_split(e, &L.split_wgt, w, cout, 9 * cin, false))) return r2;
             if (e->bf16 && k == 7 && (r2 = upload_bf16(e, &e->stem_wgt_bf16, w))) return r2;
             r2 = upload(e, &L.bias, b);
             if (r2) return r2;
@@ -978,6 +1001,7 @@ int create_impl(const pa_config* cfg, const void* blob, size_t src_bytes, const 
                         if (rc) return rc;
                         rc = upload(e, &L.ds_wgt, wd);   // [co][cin] fp32
                         if (rc) return rc;
+                        if (e->emu && (rc = upload_split(e, &L.ds_split_wgt, wd, co, cin, false))) return rc;
                         ALLOC(L.ds_out, buf, true);
                     }
                 }

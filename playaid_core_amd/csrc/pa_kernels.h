@@ -91,7 +91,7 @@ hipError_t launch_pgemm(const GemmParams& p, int bm, hipStream_t s);
 int psgemm_pick_bn(int N, int residual);          // channels per workgroup (128 | 64 | 32; with a residual 64 at most): part of the weight layout
 size_t psgemm_weight_elems(int N, int ktot, int residual);
 void psgemm_pack_weights(const float* w, int N, int ktot, int residual, unsigned short* out);
-hipError_t launch_psgemm(const GemmParams& p, const unsigned short* wsp, size_t out_floats, hipStream_t s);
+hipError_t launch_psgemm(const GemmParams& p, const unsigned short* wsp, size_t out_floats, size_t up_floats, hipStream_t s);   // (up_floats: the same for p.up_out, 0 without one)
 // bf16 activations / weights (uint16_t storage behind the float* fields, every count in elements),
 // f32 accumulate on v_mfma_f32_32x32x16_bf16; conv mode only (igemm_bf16.hip)
 hipError_t launch_igemm_bf16(const GemmParams& p, GemmTile tile, hipStream_t s);

@@ -150,7 +150,7 @@ constexpr int ps_b_pieces(int bn) { return bn == 32 ? 8 : bn * 3 / 16; }   // 1 
 // want a slot every 32 cycles would idle the pipe a third of the time; in a partner wave they cost the consumer nothing but the
 // shared barrier. The consumers never wait on vmcnt (their only vector-memory instructions are the tile's stores and residual loads).
 template <int BN, int NSTAGE, int ACT, bool RES>
-__global__ __launch_bounds__(512, 2) void psgemm_kernel(const GemmParams p, const unsigned short* __restrict__ wsp, unsigned out_bytes) {
+__global__ __launch_bounds__(512, 2) void psgemm_kernel(const GemmParams p, const unsigned short* __restrict__ wsp, unsigned out_bytes, unsigned up_bytes) {
     constexpr int BM = 128, CB = BN / 32;
     constexpr int A_BYTES = BM * 128;
     constexpr int PB = ps_b_pieces(BN) / 4;       // weight pieces per loader wave and k-step
@@ -307,6 +307,33 @@ __global__ __launch_bounds__(512, 2) void psgemm_kernel(const GemmParams p, cons
         return m_base + lr < p.M ? (unsigned)off : 0x80000000u;   // past M: beyond num_records, dropped (the launcher keeps buffers under 2 GB)
     };
 
+    // the nearest-neighbour x2 up-sampled copy (p.up_out, YOLOv5's nn.Upsample behind model.10 / model.14 as four more stores of the
+    // producer): pixel (oy, ox) -> (2 oy, 2 ox) .. (2 oy + 1, 2 ox + 1): the same walk with doubled row and pixel strides
+    const __amdgpu_buffer_rsrc_t up_rs = __builtin_amdgcn_make_buffer_rsrc(p.up_out ? p.up_out : p.out, 0, (int)(p.up_out ? up_bytes : out_bytes), 0x00020000);
+    const int up_rs_b = 2 * p.up_row_stride * 4, up_ps_b = 2 * p.up_px_stride * 4;
+    const int up_wrap_x = up_rs_b - p.wo * up_ps_b, up_wrap_y = p.up_img_stride * 4 - p.pg_ho * up_rs_b;
+    int up_lane = lr * up_ps_b + (p.up_pad * (p.up_row_stride + p.up_px_stride) + ch0) * 4;
+    asm volatile("" : "+v"(up_lane));
+    auto up_offset = [&](int m_base) -> unsigned {
+        int rem, ox_b;
+        const int img_b = ps_sdiv(m_base, p.howo, p.pg_magic_howo, rem);
+        int oy = ps_sdiv(rem, p.wo, p.pg_magic_wo, ox_b);
+        int off = img_b * p.up_img_stride * 4 + oy * up_rs_b + ox_b * up_ps_b + up_lane;
+        int ox = ox_b + lr;
+        for (int w = 0; w < nwx; ++w) {
+            const bool c = ox >= p.wo;
+            ox -= c ? p.wo : 0;
+            off += c ? up_wrap_x : 0;
+            oy += c ? 1 : 0;
+        }
+        for (int w = 0; w < nwy; ++w) {
+            const bool c = oy >= p.pg_ho;
+            oy -= c ? p.pg_ho : 0;
+            off += c ? up_wrap_y : 0;
+        }
+        return m_base + lr < p.M ? (unsigned)off : 0x80000000u;
+    };
+
     // LDS read addresses (bytes) of the two k halves: this wave's pixel rows; the weight rows lr of each 32-channel block
     unsigned a_rd[2], a_rd2[2], b_rd[2];
 #pragma unroll
@@ -423,12 +450,13 @@ __global__ __launch_bounds__(512, 2) void psgemm_kernel(const GemmParams p, cons
         load_bias();
         f32x4 res4[CB][4];
         const unsigned o_off = out_offset(tile_m * BM + wave_id * 32);
+        const unsigned u_off = p.up_out ? up_offset(tile_m * BM + wave_id * 32) : 0u;
         for (int ks = 0; ks < nk; ++ks, ++g) {
             const unsigned sb = slot * STAGE;
             // ---- first half: multiply k 0..15 from registers; read and split k 16..31 of the same stage (the reads go out BEHIND the
             //      first matrix instruction: in front of it hipcc's wait for that instruction's operands, read in the previous
             //      iteration -- it loses the count over the loop's back edge -- would wait for brand-new reads as well) ----
-            if (RES && ks == nk - 1) {   // the tile's residual values: requested a k-step ahead of their use
+            if (RES && BN < 128 && ks == nk - 1) {   // the tile's residual values: requested a k-step ahead of their use
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
@@ -453,6 +481,15 @@ __global__ __launch_bounds__(512, 2) void psgemm_kernel(const GemmParams p, cons
             slot = nslot;
         }
         // ---- epilogue of the tile, straight from the accumulators: lane = pixel lr of the wave's 32, channels ch0 + 32 cb + 8 g + 0..3 ----
+        if (RES && BN >= 128) {   // 128-channel tiles: the residual's 64 registers are free only now (the operand sets of the last half are dead)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const unsigned off = o_off == 0x80000000u ? o_off : o_off + (unsigned)(cb * 32 + 8 * gq) * 4u;
+                    res4[cb][gq] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rs, off, 0, 0));
+                }
+        }
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
@@ -467,13 +504,24 @@ __global__ __launch_bounds__(512, 2) void psgemm_kernel(const GemmParams p, cons
                 if (RES && p.res_after) v += res4[cb][gq];
                 const unsigned off = o_off == 0x80000000u ? o_off : o_off + (unsigned)(cb * 32 + 8 * gq) * 4u;
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), out_rs, off, 0, 0);
+                if (p.up_out) {
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const unsigned uo = u_off == 0x80000000u ? u_off : u_off + (unsigned)((q4 >> 1) * p.up_row_stride + (q4 & 1) * p.up_px_stride + cb * 32 + 8 * gq) * 4u;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), up_rs, uo, 0, 0);
+                    }
+                }
             }
     }
 }
 
-// channels per workgroup = per stage image of the weight layout. With a residual 64 at most: its values wait in registers from a k-step
-// before the epilogue, and beside 128-channel accumulators and operand sets they would not fit the 256 registers of two waves per SIMD
-int psgemm_pick_bn(int N, int residual) { return N % 128 == 0 && !residual ? 128 : (N % 64 == 0 ? 64 : (N % 32 == 0 ? 32 : 0)); }
+// channels per workgroup = per stage image of the weight layout (`residual` is part of the choice only for the A/B switch PA_PS_RES128:
+// 64-channel tiles request the residual a k-step ahead of the epilogue, 128-channel tiles -- no registers to spare until the last
+// operand sets are dead -- at its start)
+int psgemm_pick_bn(int N, int residual) {
+    static const int res128 = getenv("PA_PS_RES128") ? atoi(getenv("PA_PS_RES128")) : 1;   // 0: residual layers on 64-channel tiles (A/B)
+    return N % 128 == 0 && (!residual || res128) ? 128 : (N % 64 == 0 ? 64 : (N % 32 == 0 ? 32 : 0));
+}
 
 size_t psgemm_weight_elems(int N, int ktot, int residual) {
     const int bn = psgemm_pick_bn(N, residual);
@@ -521,10 +569,10 @@ void psgemm_pack_weights(const float* w, int N, int ktot, int residual, unsigned
 
 // Conv mode of GemmParams (no gather, no second source, no split-K); p.wgt is ignored, wsp = psgemm_pack_weights' image of it.
 // out_floats: floats from p.out to the end of its buffer (bounds of the output descriptor, < 2^29).
-hipError_t launch_psgemm(const GemmParams& p_in, const unsigned short* wsp, size_t out_floats, hipStream_t s) {
+hipError_t launch_psgemm(const GemmParams& p_in, const unsigned short* wsp, size_t out_floats, size_t up_floats, hipStream_t s) {
     GemmParams p = p_in;
     const int bn = psgemm_pick_bn(p.N, p.residual != nullptr);
-    if (p.gather || p.k2_steps || p.up_out || bn == 0 || p.chunk % 32 != 0 || p.M <= 0 || p.M >= (1 << 24) || p.howo >= (1 << 16) ||
+    if (p.gather || p.k2_steps || bn == 0 || p.chunk % 32 != 0 || p.M <= 0 || p.M >= (1 << 24) || p.howo >= (1 << 16) ||
         p.ktot != p.taps * p.chunk || !wsp || out_floats == 0 || out_floats >= (1ull << 29))
         return hipErrorInvalidValue;
     p.tiles_n = p.N / bn;
@@ -544,18 +592,22 @@ hipError_t launch_psgemm(const GemmParams& p_in, const unsigned short* wsp, size
     p.pg_nwx = 1 + 30 / p.wo;
     p.pg_nwy = (p.pg_ho - 1 + p.pg_nwx) / p.pg_ho;
     const unsigned out_bytes = (unsigned)(out_floats * 4);
+    if (p.up_out && (up_floats == 0 || up_floats >= (1ull << 29) || p.up_px_stride % 4 || p.up_row_stride % 4 || p.up_img_stride % 4 ||
+                     (reinterpret_cast<unsigned long long>(p.up_out) & 15ull)))
+        return hipErrorInvalidValue;
+    const unsigned up_bytes = (unsigned)(up_floats * 4);
 #define PA_PS_LAUNCH1(BN_, NS_, RES_)                                                                                                \
     do {                                                                                                                             \
-        if (p.relu == 2) hipLaunchKernelGGL((psgemm_kernel<BN_, NS_, 2, RES_>), dim3(grid), dim3(512), 0, s, p, wsp, out_bytes);     \
-        else if (p.relu == 1) hipLaunchKernelGGL((psgemm_kernel<BN_, NS_, 1, RES_>), dim3(grid), dim3(512), 0, s, p, wsp, out_bytes); \
-        else hipLaunchKernelGGL((psgemm_kernel<BN_, NS_, 0, RES_>), dim3(grid), dim3(512), 0, s, p, wsp, out_bytes);                 \
+        if (p.relu == 2) hipLaunchKernelGGL((psgemm_kernel<BN_, NS_, 2, RES_>), dim3(grid), dim3(512), 0, s, p, wsp, out_bytes, up_bytes);     \
+        else if (p.relu == 1) hipLaunchKernelGGL((psgemm_kernel<BN_, NS_, 1, RES_>), dim3(grid), dim3(512), 0, s, p, wsp, out_bytes, up_bytes); \
+        else hipLaunchKernelGGL((psgemm_kernel<BN_, NS_, 0, RES_>), dim3(grid), dim3(512), 0, s, p, wsp, out_bytes, up_bytes);                 \
     } while (0)
 #define PA_PS_LAUNCH(BN_, NS_)                                                                                                       \
     do {                                                                                                                             \
         if (p.residual) PA_PS_LAUNCH1(BN_, NS_, true);                                                                               \
         else PA_PS_LAUNCH1(BN_, NS_, false);                                                                                         \
     } while (0)
-    if (bn == 128) PA_PS_LAUNCH1(128, 3, false);   // (a residual caps the tile at 64 channels: psgemm_pick_bn)
+    if (bn == 128) PA_PS_LAUNCH(128, 3);
     else if (bn == 64) PA_PS_LAUNCH(64, 4);
     else PA_PS_LAUNCH(32, 4);
 #undef PA_PS_LAUNCH1
@@ -622,7 +674,7 @@ int pa_conv2d(const float* x, const void* w, const float* bias, const float* res
     p.res_after = res_after;
     p.splitk = 1;
     hipError_t e;
-    if (compute_dtype == PA_DTYPE_EMULATED_F32) e = pa::launch_psgemm(p, static_cast<const unsigned short*>(w), (size_t)n * p.out_img_stride, static_cast<hipStream_t>(stream));
+    if (compute_dtype == PA_DTYPE_EMULATED_F32) e = pa::launch_psgemm(p, static_cast<const unsigned short*>(w), (size_t)n * p.out_img_stride, 0, static_cast<hipStream_t>(stream));
     else if (residual) return PA_ERR_INVALID_ARG;   // (the exact persistent kernel has no residual epilogue: Winograd / the patch kernel take those layers)
     else e = pa::launch_pgemm(p, 0, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? PA_OK : (e == hipErrorInvalidValue ? PA_ERR_INVALID_ARG : PA_ERR_HIP);

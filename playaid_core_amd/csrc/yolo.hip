@@ -655,9 +655,43 @@ static int detector_run(pa_detector* h, const uint8_t* frames, int32_t n, int32_
         static const int use_pgemm = getenv("PA_DET_PGEMM") ? atoi(getenv("PA_DET_PGEMM")) : 1;  // 0: the one-tile-per-workgroup engine (A/B)
         static const int use_patch = getenv("PA_DET_PATCH") ? atoi(getenv("PA_DET_PATCH")) : 1;  // 0: im2col for the 3x3 convolutions (A/B)
         pe = hipErrorInvalidValue;
+        // A convolution whose output slice the NEXT layer up-samples by two (model.10 -> model.11, model.14 -> model.15) writes the
+        // up-sampled copy itself -- four more stores per output instead of a pass over HBM -- and the up-sampling layer is skipped
+        // (PA_DET_UP_FUSE=0: A/B); the persistent GEMMs (exact and emulated) take it
+        static const int up_fuse = getenv("PA_DET_UP_FUSE") ? atoi(getenv("PA_DET_UP_FUSE")) : 1;
+        bool fused_up = false;
+        size_t up_floats = 0;
+        auto try_up = [&]() {
+            if (!(up_fuse && li + 1 < h->layers.size() && L.act == 2 && !p.residual)) return;
+            const pa_net_layer& U = h->layers[li + 1];
+            if (U.kind == 5 && U.in_buf == L.out_buf && U.in_coff == L.out_coff && U.in_cstride == L.out_cstride && U.in_pad == L.out_pad &&
+                U.cin == L.cout && U.in_h == oh && U.in_w == ow && U.out_buf != L.out_buf) {
+                const int up_wb = 2 * ow + 2 * U.out_pad, up_hb = 2 * oh + 2 * U.out_pad;
+                p.up_out = h->bufs[U.out_buf] + U.out_coff;
+                p.up_px_stride = U.out_cstride;
+                p.up_row_stride = up_wb * U.out_cstride;
+                p.up_img_stride = up_hb * up_wb * U.out_cstride;
+                p.up_pad = U.out_pad;
+                up_floats = (size_t)n * p.up_img_stride - (size_t)U.out_coff;
+                fused_up = true;
+            }
+        };
+        auto up_done = [&]() {
+            if (fused_up && pe == hipSuccess) {
+                ++li;   // the up-sampling layer is done
+                if (ev) (void)hipEventRecord((*ev)[li], s);   // (profiling call: the absorbed layer shows as empty)
+            }
+        };
         if (h->split_off[li] >= 0) {
             // emulated fp32 (psgemm.hip); out_floats: from the layer's first output channel to the end of the images in flight
-            pe = pa::launch_psgemm(p, h->split_weights + h->split_off[li], (size_t)n * p.out_img_stride - (size_t)L.out_coff, s);
+            try_up();
+            pe = pa::launch_psgemm(p, h->split_weights + h->split_off[li], (size_t)n * p.out_img_stride - (size_t)L.out_coff, up_floats, s);
+            if (fused_up && pe == hipErrorInvalidValue) {
+                p.up_out = nullptr;
+                fused_up = false;
+                pe = pa::launch_psgemm(p, h->split_weights + h->split_off[li], (size_t)n * p.out_img_stride - (size_t)L.out_coff, 0, s);
+            }
+            up_done();
         }
         if (pe == hipErrorInvalidValue && h->wino_off[li] >= 0) {
             pa::WinoParams q;
@@ -673,34 +707,15 @@ static int detector_run(pa_detector* h, const uint8_t* frames, int32_t n, int32_
             pe = pa::launch_conv3x3_patch_blocked(p, s);  // input patch resident in LDS across the nine taps (patchconv.hip)
         if (pe != hipErrorInvalidValue) {
         } else if ((use_pgemm || p.N % 64) && !p.residual) {
-            // 1x1 and stride-2 convolutions: persistent workgroups over runs of tiles (pigemm.hip). A convolution whose output slice
-            // the NEXT layer up-samples by two (model.10 -> model.11, model.14 -> model.15) writes the up-sampled copy itself -- four
-            // more stores per output instead of a pass over HBM -- and the up-sampling layer is skipped (PA_DET_UP_FUSE=0: A/B)
-            static const int up_fuse = getenv("PA_DET_UP_FUSE") ? atoi(getenv("PA_DET_UP_FUSE")) : 1;
-            bool fused_up = false;
-            if (up_fuse && li + 1 < h->layers.size() && L.act == 2) {
-                const pa_net_layer& U = h->layers[li + 1];
-                if (U.kind == 5 && U.in_buf == L.out_buf && U.in_coff == L.out_coff && U.in_cstride == L.out_cstride && U.in_pad == L.out_pad &&
-                    U.cin == L.cout && U.in_h == oh && U.in_w == ow && U.out_buf != L.out_buf) {
-                    const int up_wb = 2 * ow + 2 * U.out_pad, up_hb = 2 * oh + 2 * U.out_pad;
-                    p.up_out = h->bufs[U.out_buf] + U.out_coff;
-                    p.up_px_stride = U.out_cstride;
-                    p.up_row_stride = up_wb * U.out_cstride;
-                    p.up_img_stride = up_hb * up_wb * U.out_cstride;
-                    p.up_pad = U.out_pad;
-                    fused_up = true;
-                }
-            }
+            // 1x1 and stride-2 convolutions: persistent workgroups over runs of tiles (pigemm.hip)
+            try_up();
             pe = pa::launch_pgemm(p, 0, s);
             if (fused_up && pe == hipErrorInvalidValue) {   // (a shape the fused form does not take: the layer alone, then the up-sampling as a layer)
                 p.up_out = nullptr;
                 fused_up = false;
                 pe = pa::launch_pgemm(p, 0, s);
             }
-            if (fused_up && pe == hipSuccess) {
-                ++li;   // the up-sampling layer is done
-                if (ev) DT_HIP(hipEventRecord((*ev)[li], s));   // (profiling call: the absorbed layer shows as empty)
-            }
+            up_done();
         } else if (p.N % 64 == 0) {
             const pa::GemmTile tile = (p.N % 128 == 0 && t128 / 2 >= 512) ? pa::TILE_128x128 : (t128 >= 512 ? pa::TILE_128x64 : pa::TILE_64x64);
             pe = pa::launch_igemm(p, tile, s);

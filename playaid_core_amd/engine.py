@@ -56,8 +56,8 @@ class Engine:
         """``compute_dtype="bf16"`` selects the bf16 conv path (BASELINE.json configs[2]): 3x3
         convolutions on bf16 activations / weights with fp32 accumulation, everything else fp32.
         It is outside the 1e-4 parity bar of the default fp32 path."""
-        if compute_dtype not in ("f32", "bf16"):
-            raise ValueError("compute_dtype must be 'f32' or 'bf16'")
+        if compute_dtype not in _lib.DTYPES:
+            raise ValueError("compute_dtype must be 'f32', 'bf16' or 'emulated_f32'")
         self.compute_dtype = compute_dtype
         self._lib = _lib.load()  # raises HipLibraryError when the .so is missing
         self._weights = state_dict
@@ -98,7 +98,7 @@ class Engine:
         ids = list(fighter_class_ids) + [0] * (4 - len(fighter_class_ids))
         for i in range(4):
             cfg.fighter_class_ids[i] = ids[i]
-        cfg.compute_dtype = _lib.PA_DTYPE_BF16 if compute_dtype == "bf16" else _lib.PA_DTYPE_F32
+        cfg.compute_dtype = _lib.DTYPES[compute_dtype]
         self.cfg = cfg
         self._h = C.c_void_p(0)
         torch.cuda.set_device(self.device)

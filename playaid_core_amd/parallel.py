@@ -88,6 +88,9 @@ def halo_plan(n_total: int, world: int, rank: int, reach: int):
     return recvs, sends
 
 
+_DTYPE_CODES = {"f32": 0, "bf16": 1, "emulated_f32": 2}   # (== _lib.DTYPES; kept here so that the gloo tests' CPU stand-in needs no library)
+
+
 def _host_staged(group=None) -> bool:
     """True when the process group cannot move device tensors (gloo): collectives then go
     through host copies. Only used to rehearse the multi-rank path on boxes with fewer GPUs
@@ -111,17 +114,17 @@ def broadcast_engine(make_engine, weights, device: torch.device, group=None):
     if rank == 0:
         eng = make_engine(weights)
         arena = eng.weights_arena()
-        meta = torch.tensor([arena.data.numel(), arena.sequence_length, arena.num_actions, int(arena.compute_dtype == "bf16")],
+        meta = torch.tensor([arena.data.numel(), arena.sequence_length, arena.num_actions, _DTYPE_CODES[arena.compute_dtype]],
                             dtype=torch.int64, device=meta.device)
     dist.broadcast(meta, src=0, group=group)
-    nbytes, S, A, is_bf16 = (int(v) for v in meta.tolist())
+    nbytes, S, A, dtype_code = (int(v) for v in meta.tolist())
     if rank == 0:
         buf = arena.data.cpu() if staged else arena.data
     else:
         buf = torch.empty(nbytes, dtype=torch.uint8, device="cpu" if staged else device)
     dist.broadcast(buf, src=0, group=group)
     if rank != 0:
-        eng = make_engine(WeightsArena(buf, S, A, "bf16" if is_bf16 else "f32"))
+        eng = make_engine(WeightsArena(buf, S, A, {v: k for k, v in _DTYPE_CODES.items()}[dtype_code]))
     return eng
 
 
@@ -369,6 +372,14 @@ class ClipLanes:
         if n < 2 or len(self._candidates) <= n:
             return {}
         rates = {}
+        # warm-up: the first pair timed used to come out 6-8 % slow whichever pair it was (12 clips right after the engines were
+        # made: clocks, first-touch of the clones' buffers) -- the "queue lottery" of round 5's records was this, the same streams run
+        # the timed region at the calibrated rate (profiles/r06_hw_queues.txt)
+        self.streams = self._candidates[:n]
+        self._cold = True
+        for k in range(24):
+            self.submit(frames, boxes, n_total, batch_of)
+        torch.cuda.synchronize(self.engines[0].device)
         for combo in itertools.combinations(range(len(self._candidates)), n):
             self.streams = [self._candidates[i] for i in combo]
             self._cold = True

@@ -20,8 +20,8 @@ print(f"{label:44s} run {i}: value {d['value']:9.1f} frames/s  calibration rates
 PY
     done
 }
-run "default queues, calibrated" ""
+run "default queues, calibrated" "" --calibrate
 run "default queues, no calibration" "" --no-calibrate
-run "GPU_MAX_HW_QUEUES=8, calibrated" "GPU_MAX_HW_QUEUES=8"
+run "GPU_MAX_HW_QUEUES=8, calibrated" "GPU_MAX_HW_QUEUES=8" --calibrate
 run "GPU_MAX_HW_QUEUES=8, no calibration" "GPU_MAX_HW_QUEUES=8" --no-calibrate
 run "GPU_MAX_HW_QUEUES=16, no calibration" "GPU_MAX_HW_QUEUES=16" --no-calibrate

@@ -15,24 +15,26 @@ from playaid_core_amd.yolov5 import YoloV5Detector  # noqa: E402
 NC, NET = 6, (384, 640)
 sd = synth.make_yolov5s_state_dict()
 sd64 = {k: torch.from_numpy(np.asarray(v)).double() for k, v in sd.items()}
-det = YoloV5Detector(sd, NC, NET, max_images=4)
-print("case                     rows   | boxes (px): dev-o32   dev-o64   o32-o64 | scores: dev-o32    dev-o64    o32-o64  | max score")
-worst = 0.0
+dets = {dt: YoloV5Detector(sd, NC, NET, max_images=5, compute_dtype=dt) for dt in ("f32", "emulated_f32")}
+print("compute_dtype  case                     rows   | boxes (px): dev-o32   dev-o64   o32-o64 | scores: dev-o32    dev-o64    o32-o64  | max score")
+worst = {dt: 0.0 for dt in dets}
 for h, w, n, seed in ((720, 1280, 3, 5), (1080, 1920, 2, 5), (270, 480, 5, 9)):
     frames = synth.make_frames(n, h, w, seed=seed)
-    got = det(frames)
-    torch.cuda.synchronize()
-    got = got.cpu().numpy().astype(np.float64)
     x = torch.from_numpy(np.stack([oy.letterbox(f, NET) for f in frames]))
     w32 = oy.forward(x, sd, NC).numpy().astype(np.float64)
     w64 = oy.forward(x.double(), sd64, NC).numpy()
-    e = lambda a, b, sl: float(np.abs(a[..., sl] - b[..., sl]).max())
-    B, S = slice(0, 4), slice(4, None)
-    print(f"{n} x {h:4d}x{w:4d} seed {seed}  {got.shape[1]:6d} |          {e(got, w32, B):9.2e} {e(got, w64, B):9.2e} {e(w32, w64, B):9.2e} |"
-          f"       {e(got, w32, S):9.2e}  {e(got, w64, S):9.2e}  {e(w32, w64, S):9.2e} | {w64[..., 4].max():.3f}")
-    worst = max(worst, e(got, w32, S))
-print(f"worst score error against the fp32 oracle: {worst:.3e} (test bar: see tests/test_yolov5.py)")
-det.close()
+    for dt, det in dets.items():
+        got = det(frames)
+        torch.cuda.synchronize()
+        got = got.cpu().numpy().astype(np.float64)
+        e = lambda a, b, sl: float(np.abs(a[..., sl] - b[..., sl]).max())
+        B, S = slice(0, 4), slice(4, None)
+        print(f"{dt:13s}  {n} x {h:4d}x{w:4d} seed {seed}  {got.shape[1]:6d} |          {e(got, w32, B):9.2e} {e(got, w64, B):9.2e} {e(w32, w64, B):9.2e} |"
+              f"       {e(got, w32, S):9.2e}  {e(got, w64, S):9.2e}  {e(w32, w64, S):9.2e} | {w64[..., 4].max():.3f}")
+        worst[dt] = max(worst[dt], e(got, w32, S))
+for dt, det in dets.items():
+    print(f"{dt}: worst score error against the fp32 oracle {worst[dt]:.3e} (test bar: see tests/test_yolov5.py)")
+    det.close()
 
 # Which Winograd layers move the boxes: the 1080p case with NO layer in Winograd form, with each of the
 # eligible stride-1 3x3 convolutions alone in it (PA_DET_WINO_MASK, read at pa_detector_create), and with all of them.

@@ -186,7 +186,8 @@ def test_head_rows_to_labels_without_host_text_or_pixels(engine, state_dict):
         ckpt = tmp + "/seeded.ckpt"
         synth.save_checkpoint(ckpt, seed=1234)
         model = CNNActionDetector.load_from_checkpoint(ckpt, actions=list(MOVE_TO_CLASS_ID.keys()), max_batch_frames=64,
-                                                       max_clip_frames=512, max_frame_height=h, max_frame_width=w)
+                                                       max_clip_frames=512, max_frame_height=h, max_frame_width=w,
+                                                           compute_dtype=engine.compute_dtype)   # (the host route on the same arithmetic as the shared engine)
         runner = AIRunner(ClipSource(frames, labels, name="detected"), model=model, output_dir=tmp + "/out")
         runner.run_action_recognition()
         want = runner._results
@@ -292,7 +293,8 @@ def test_trailing_frames_without_detections_and_recycled_tables(engine, state_di
         ckpt = tmp + "/seeded.ckpt"
         synth.save_checkpoint(ckpt, seed=1234)
         model = CNNActionDetector.load_from_checkpoint(ckpt, actions=list(MOVE_TO_CLASS_ID.keys()), max_batch_frames=64,
-                                                       max_clip_frames=512, max_frame_height=h, max_frame_width=w)
+                                                       max_clip_frames=512, max_frame_height=h, max_frame_width=w,
+                                                           compute_dtype=engine.compute_dtype)   # (the host route on the same arithmetic as the shared engine)
         runner = AIRunner(ClipSource(frames, labels, name="trailing"), model=model, output_dir=tmp + "/out")
         runner.run_action_recognition()
         want = runner._results
