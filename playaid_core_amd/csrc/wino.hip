@@ -57,6 +57,9 @@
 namespace pa {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifndef WN_SCALAR_T
+#define WN_SCALAR_T 0   // 1: the input transform as scalar additions (A/B build; profiles/r06_wino_scalar_transform_ab.txt)
+#endif
 #ifndef WN_AHEAD
 #define WN_AHEAD 3   // positions the row-operand reads run ahead of their matrix instructions (2 and 5 measure the same: profiles/r05_wino_operand_read_variants.txt)
 #endif
@@ -148,21 +151,40 @@ __device__ __forceinline__ void wino_chunk(const lds_f* ul, const lds_f* pl, f32
     }
 #pragma unroll
     for (int p = 0; p < AHEAD; ++p) WN_LOAD_A(p);
+    // the input transform: 32 additions on channel PAIRS (hipcc: v_pk_add_f32). WN_SCALAR_T=1 (A/B build)
+    // issues them as 64 scalar v_add_f32 / v_sub_f32 instead -- as assembly, or hipcc pairs them up again.
+#if WN_SCALAR_T
+    auto add2 = [](f32x2 a_, f32x2 b_) {
+        f32x2 r_;
+        asm("v_add_f32 %0, %1, %2" : "=v"(r_.x) : "v"(a_.x), "v"(b_.x));
+        asm("v_add_f32 %0, %1, %2" : "=v"(r_.y) : "v"(a_.y), "v"(b_.y));
+        return r_;
+    };
+    auto sub2 = [](f32x2 a_, f32x2 b_) {
+        f32x2 r_;
+        asm("v_sub_f32 %0, %1, %2" : "=v"(r_.x) : "v"(a_.x), "v"(b_.x));
+        asm("v_sub_f32 %0, %1, %2" : "=v"(r_.y) : "v"(a_.y), "v"(b_.y));
+        return r_;
+    };
+#else
+    auto add2 = [](f32x2 a_, f32x2 b_) { return a_ + b_; };
+    auto sub2 = [](f32x2 a_, f32x2 b_) { return a_ - b_; };
+#endif
     f32x2 tt[4][4];
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
-        tt[0][x] = d[0][x] - d[2][x];
-        tt[1][x] = d[1][x] + d[2][x];
-        tt[2][x] = d[2][x] - d[1][x];
-        tt[3][x] = d[1][x] - d[3][x];
+        tt[0][x] = sub2(d[0][x], d[2][x]);
+        tt[1][x] = add2(d[1][x], d[2][x]);
+        tt[2][x] = sub2(d[2][x], d[1][x]);
+        tt[3][x] = sub2(d[1][x], d[3][x]);
     }
     f32x2 v[16];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        v[4 * i + 0] = tt[i][0] - tt[i][2];
-        v[4 * i + 1] = tt[i][1] + tt[i][2];
-        v[4 * i + 2] = tt[i][2] - tt[i][1];
-        v[4 * i + 3] = tt[i][1] - tt[i][3];
+        v[4 * i + 0] = sub2(tt[i][0], tt[i][2]);
+        v[4 * i + 1] = add2(tt[i][1], tt[i][2]);
+        v[4 * i + 2] = sub2(tt[i][2], tt[i][1]);
+        v[4 * i + 3] = sub2(tt[i][1], tt[i][3]);
     }
     if (ABL & 8) {  // (stamp build: when the transformed tile is complete)
         __builtin_amdgcn_sched_barrier(0);

@@ -142,6 +142,41 @@ __global__ __launch_bounds__(256, 2) void mixbf(float* out, unsigned long long* 
     if (lane == 0) clk[blockIdx.x * 4 + wave] = t1 - t0;
 }
 
+// Round 6: the Winograd kernel's own instruction, v_mfma_f32_16x16x4_f32 -- 64 per loop iteration (2048
+// issue cycles, as one chunk of wino.hip) -- with the chunk's input transform beside it either as PK packed additions
+// (v_pk_add_f32: two floats per instruction, what hipcc emits for the kernel's f32x2 arithmetic) or as V scalar ones (v_add_f32).
+// 32 packed = 64 scalar additions = one chunk's transform.
+template <int V, int PK>
+__global__ __launch_bounds__(256, 2) void mix16(float* out, unsigned long long* clk, int iters, float a0, float b0) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float va[8];
+    f32x2 pa[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { va[i] = a0 + i; pa[i] = f32x2{a0 + i, b0 - i}; }
+    f32x2 pb = f32x2{b0, a0};
+    asm volatile("" : "+v"(pb));
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+#pragma unroll
+            for (int q = (j * V) / 64; q < ((j + 1) * V) / 64; ++q) asm volatile("v_add_f32 %0, %0, %1" : "+v"(va[q & 7]) : "v"(b0));
+#pragma unroll
+            for (int q = (j * PK) / 64; q < ((j + 1) * PK) / 64; ++q) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(pa[q & 7]) : "v"(pb));
+            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[j & 7]) : "v"(a0), "v"(b0));
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += va[i] + pa[i].x + pa[i].y + acc[i].x + acc[i].y + acc[i].z + acc[i].w;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (lane == 0) clk[blockIdx.x * 4 + wave] = t1 - t0;
+}
+
 static double ticks_per_cycle = 0.0;   // s_memtime ticks per SIMD cycle, from the bare loop (2048 cycles per iteration and wave, two waves)
 
 static double base_cycles = 2048.0;     // matrix issue cycles of one iteration and wave (bf16 section: 1024)
@@ -204,5 +239,13 @@ int main() {
     run("bf16 + 32 v_exp_f32", mixbf<0, 0, 32>);
     run("bf16 + 64 v_exp_f32", mixbf<0, 0, 64>);
     run("bf16 + 32 b128 + 128 fma + 32 exp", mixbf<32, 128, 32>);
+    printf("--- v_mfma_f32_16x16x4_f32 x 64 per iteration (wino.hip's chunk): packed against scalar additions beside it\n");
+    base_cycles = 2048.0;
+    flop_per_mfma = 2048.0;
+    run("16x16x4 bare", mix16<0, 0>);
+    run("16x16x4 + 32 v_pk_add_f32 (a chunk's transform)", mix16<0, 32>);
+    run("16x16x4 + 64 v_add_f32 (the same, scalar)", mix16<64, 0>);
+    run("16x16x4 + 64 v_pk_add_f32", mix16<0, 64>);
+    run("16x16x4 + 128 v_add_f32", mix16<128, 0>);
     return 0;
 }
