@@ -465,9 +465,31 @@ int pa_detector_create_dtype(int32_t device, const pa_net_layer* layers, int32_t
         // the 1x1 and the stride-2 3x3 convolutions (and, with PA_DET_EMU_S1=1, the stride-1 3x3 ones in place of their Winograd
         // form) on the emulated-fp32 kernel (psgemm.hip): weights split into three bf16 slices here, once
         const int emu_s1 = getenv("PA_DET_EMU_S1") ? atoi(getenv("PA_DET_EMU_S1")) : 0;
+        // ... and the 6x6 / 2 stem as an implicit GEMM of its own shape: one "tap" per kernel ROW, whose 6 pixels x 3 channels are 24
+        // consecutive floats of the NHWC4 input -- read as a 32-float k-step (8 pixels x 4 channels, zero weights under the fourth
+        // channel and the two extra pixels): K = 6 x 32 = 192 for 108 real. Built, parity-green and SLOWER than the exact direct stem
+        // (486 against 342 us per 64 frames, profiles/r06_detect_stem_emulated_ab.txt: 32-channel tiles leave the split's 44 vector
+        // instructions per 8 values only six matrix instructions to hide under, and neighbouring pixels' k-steps overlap by three
+        // quarters, so the copies move the input four times): OFF by default, PA_DET_EMU_STEM=1 for the A/B
+        const int emu_stem = getenv("PA_DET_EMU_STEM") ? atoi(getenv("PA_DET_EMU_STEM")) : 0;
+        std::vector<std::vector<float>> stem_w(n_layers);
         size_t total = 0;
         for (int i = 0; i < n_layers; ++i) {
             const pa_net_layer& L = h->layers[i];
+            if (L.kind == 3 && emu_stem && L.cout % 32 == 0 && L.ksize == 6 && L.stride == 2) {
+                // lane layout of the direct kernel -> [cout][ky][kx * 4 + c]: W[ch][c][ky][3 half + j] sits at half * cout * 56 + ch * 56 + ky * 9 + j * 3 + c
+                std::vector<float>& w = stem_w[i];
+                w.assign((size_t)L.cout * 192, 0.f);
+                for (int ch = 0; ch < L.cout; ++ch)
+                    for (int ky = 0; ky < 6; ++ky)
+                        for (int kx = 0; kx < 6; ++kx)
+                            for (int c = 0; c < 3; ++c)
+                                w[(size_t)ch * 192 + ky * 32 + kx * 4 + c] =
+                                    weights_host[L.w_off + (size_t)(kx / 3) * L.cout * 56 + (size_t)ch * 56 + ky * 9 + (kx % 3) * 3 + c];
+                h->split_off[i] = (long long)total;
+                total += pa::psgemm_weight_elems(L.cout, 192, 0);
+                continue;
+            }
             if (L.kind != 0 || L.cin % 32 || L.cout % 32) continue;
             if (L.ksize == 3 && L.stride == 1 && !emu_s1 && h->wino_off[i] >= 0) continue;
             const size_t n_el = pa::psgemm_weight_elems(L.cout, L.ksize * L.ksize * L.cin, L.res_buf >= 0);
@@ -478,7 +500,9 @@ int pa_detector_create_dtype(int32_t device, const pa_net_layer* layers, int32_t
         if (total) {
             std::vector<unsigned short> sw(total);
             for (int i = 0; i < n_layers; ++i)
-                if (h->split_off[i] >= 0) {
+                if (h->split_off[i] >= 0 && !stem_w[i].empty()) {
+                    pa::psgemm_pack_weights(stem_w[i].data(), h->layers[i].cout, 192, 0, sw.data() + h->split_off[i]);
+                } else if (h->split_off[i] >= 0) {
                     const pa_net_layer& L = h->layers[i];
                     pa::psgemm_pack_weights(weights_host + L.w_off, L.cout, L.ksize * L.ksize * L.cin, L.res_buf >= 0, sw.data() + h->split_off[i]);
                 }
@@ -547,6 +571,32 @@ static int detector_run(pa_detector* h, const uint8_t* frames, int32_t n, int32_
     for (size_t li = 0; li < h->layers.size(); ++li) {
         const pa_net_layer& L = h->layers[li];
         if (ev) DT_HIP(hipEventRecord((*ev)[li], s));  // (profiling call only: layer li runs between events li and li + 1)
+        if (L.kind == 3 && h->split_off[li] >= 0) {   // PA_DTYPE_EMULATED_F32: the stem as a six-tap implicit GEMM on psgemm.hip
+            const int oh = h->net_h / 2, ow = h->net_w / 2;
+            pa::GemmParams p;
+            memset(&p, 0, sizeof(p));
+            p.act = h->x0;
+            p.bias = h->weights + L.b_off;
+            p.out = h->bufs[L.out_buf] + L.out_coff;
+            p.M = n * oh * ow;
+            p.N = L.cout;
+            p.taps = 6; p.kw_taps = 1; p.chunk = 32; p.ktot = 192;
+            p.howo = oh * ow; p.wo = ow;
+            p.in_px_stride = 4;
+            p.in_row_stride = (h->net_w + 4) * 4;
+            p.in_img_stride = (h->net_h + 4) * (h->net_w + 4) * 4;
+            p.stride = 2;
+            p.out_px_stride = L.out_cstride;
+            p.out_row_stride = (ow + 2 * L.out_pad) * L.out_cstride;
+            p.out_img_stride = (oh + 2 * L.out_pad) * (ow + 2 * L.out_pad) * L.out_cstride;
+            p.out_pad = L.out_pad;
+            p.relu = L.act;
+            p.splitk = 1;
+            const hipError_t pe = pa::launch_psgemm(p, h->split_weights + h->split_off[li], (size_t)n * p.out_img_stride - (size_t)L.out_coff, 0, s);
+            if (pe == hipSuccess) continue;
+            if (pe != hipErrorInvalidValue) return fail(PA_ERR_HIP, std::string("stem (emulated): ") + hipGetErrorString(pe));
+            // (a geometry the persistent GEMM does not take -- 65536 or more output pixels per image: the exact direct stem below)
+        }
         if (L.kind == 3) {
             const int oh = h->net_h / 2, ow = h->net_w / 2;
             pa::StemDirectParams q;
