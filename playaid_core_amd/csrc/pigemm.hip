@@ -360,7 +360,10 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const GemmParams p) {
                 // around them), so its vmcnt(NLD + k * NST) would under-wait if another k-step of this workgroup followed. None
                 // does: a workgroup walks its tiles in ASCENDING order (t_lo + lm, + LM, ...) and only the launch's last tile
                 // (tiles_m - 1) can be partial, so a partial tile is always the last thing its workgroup computes. Any other
-                // tile order must first make the store count independent of the predicate (launch_pgemm checks the premise).
+                // tile order must first make the store count independent of the predicate (launch_pgemm checks the premise). That the
+                // compiler emits exactly NST 16-byte stores per tile is checked on the built object
+                // (tests/test_abi.py::test_pgemm_store_count_matches_the_counted_waits); psgemm.hip, the emulated-fp32 form of this
+                // kernel, issues its stores unconditionally through a bounds-checked buffer descriptor instead.
                 if (live) *reinterpret_cast<f32x4*>(o_px + 8 * gq) = f32x4{lo.x, lo.y, hi.x, hi.y};
                 if (UP) { out4[gq] = f32x4{lo.x, lo.y, hi.x, hi.y}; }
             }

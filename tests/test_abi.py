@@ -307,3 +307,47 @@ def test_wino_object_uses_m0_only_for_its_lds_dma(lib):
     uses = [ln.split("//")[0].split() for ln in asm.splitlines() if re.search(r"\bm0\b", ln.split("//")[0])]
     assert len(uses) > 100 and all(u[0] == "s_mov_b32" and u[1].rstrip(",") == "m0" for u in uses), [u for u in uses if u[0] != "s_mov_b32"][:5]
     assert not re.search(r"movrel|s_sendmsg\b(?!.*MSG_DEALLOC)|lds_direct", asm)
+
+
+def test_pgemm_store_count_matches_the_counted_waits(lib):
+    """ADVICE round 5 (csrc/pigemm.hip): the persistent GEMM's waits are `s_waitcnt vmcnt(NLD + k * NST)` with NST = the 16-byte
+    stores a wave issues per tile -- MI * 4, five times that with the fused up-sampled copy -- a number the kernel states as a
+    constant while the stores themselves are ordinary C++. A compiler that split, merged or duplicated them would make the waits
+    under-wait silently. The build check: in the object every pgemm kernel holds exactly NST `global_store_dwordx4`."""
+    asm = _device_disassembly("pigemm.o")
+    if asm is None:
+        pytest.skip("no llvm-objdump / object in this environment")
+    kernels = re.split(r"\n[0-9a-f]+ <(_ZN2pa12pgemm_kernel[^>]*)>:\n", asm)
+    found = {}
+    for name, body in zip(kernels[1::2], kernels[2::2]):
+        m = re.match(r"_ZN2pa12pgemm_kernelILi(\d+)ELi(\d+)ELb([01])ELb([01])ELb([01])EEEvNS_10GemmParamsE", name)
+        assert m, name
+        bm, bn, _silu, _stamp, up = int(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(5))
+        wm = 2 if bn == 64 else 4
+        nst = (bm // wm // 32) * 4 * (5 if up else 1)
+        body = body.split("s_endpgm")[0]
+        found[name] = (len(re.findall(r"\bglobal_store_dwordx4\b", body)), nst)
+    assert len(found) >= 6, sorted(found)
+    for name, (count, nst) in found.items():
+        assert count == nst, f"{name}: {count} 16-byte stores in the object, the waits count {nst} per tile"
+
+
+def test_psgemm_copy_count_matches_the_loaders_waits(lib):
+    """csrc/psgemm.hip: the loader waves wait with `s_waitcnt vmcnt(k * NLD)`, NLD = 4 activation + BN * 3 / 64 weight LDS-DMA
+    instructions per k-step (BN = 32: 2 weight pieces, padding included). Every `issue()` must therefore be exactly NLD
+    `buffer_load_dwordx4 ... lds`: NSTAGE inlined copies of it in the prologue and one in the loop."""
+    asm = _device_disassembly("psgemm.o")
+    if asm is None:
+        pytest.skip("no llvm-objdump / object in this environment")
+    kernels = re.split(r"\n[0-9a-f]+ <(_ZN2pa13psgemm_kernel[^>]*)>:\n", asm)
+    seen = 0
+    for name, body in zip(kernels[1::2], kernels[2::2]):
+        m = re.match(r"_ZN2pa13psgemm_kernelILi(\d+)ELi(\d+)ELi(\d)ELb([01])EEE", name)
+        assert m, name
+        bn, nstage = int(m.group(1)), int(m.group(2))
+        nld = 4 + (8 if bn == 32 else bn * 3 // 16) // 4
+        body = "\n".join(body.split("s_endpgm")[:-1])   # (up to the kernel's last exit: the loader waves return early, the consumers at the end)
+        count = len(re.findall(r"\bbuffer_load_dwordx4\b[^\n]*\blds\b", body))
+        assert count == nld * (nstage + 1), f"{name}: {count} LDS-DMA instructions, expected {nld} x ({nstage} + 1)"
+        seen += 1
+    assert seen >= 12
