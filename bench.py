@@ -45,8 +45,8 @@ from playaid_core_amd.parallel import ClipLanes, FrameParallelClip, broadcast_en
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, = fp32 vector peak
 PEAK_HBM_GBS = 8000.0
-TRAFFIC_FILES = {"f32": "r05_traffic.json", "bf16": "r04_cfg2_bf16_traffic.json"}  # (the bf16 conv path is round 4's: its counter passes were not repeated)
-TRAFFIC_FALLBACK = {"f32": "r04_traffic.json", "bf16": "r01_cfg2_bf16_traffic.json"}
+TRAFFIC_FILES = {"f32": "r06_traffic.json", "bf16": "r04_cfg2_bf16_traffic.json"}  # (the bf16 conv path is round 4's: its counter passes were not repeated)
+TRAFFIC_FALLBACK = {"f32": "r05_traffic.json", "bf16": "r01_cfg2_bf16_traffic.json"}
 
 
 def _pmc_traffic(kernel_name, dtype, frames, height, width):
@@ -676,14 +676,16 @@ def bench_chain(args):
     torch.cuda.set_device(device)
     n = args.frames
     sd = synth.make_state_dict(seed=1234)
-    eng = Engine(sd, device=str(device), max_batch_frames=n, max_clip_frames=max(n, 64), max_frame_height=args.height, max_frame_width=args.width)
+    dt_ = "emulated_f32" if args.dtype == "emulated_f32" else "f32"
+    eng = Engine(sd, device=str(device), max_batch_frames=n, max_clip_frames=max(n, 64), max_frame_height=args.height, max_frame_width=args.width,
+                 compute_dtype=dt_)
     frames = torch.from_numpy(synth.make_frames(n, args.height, args.width)).to(device)
     boxes = torch.from_numpy(synth.make_boxes(n, args.height, args.width)).to(device)
-    r = chain_inclusive(eng, sd, frames, boxes, steps=max(args.steps, 3), quality=args.jpeg_quality)
+    r = chain_inclusive(eng, sd, frames, boxes, steps=max(args.steps, 3), quality=args.jpeg_quality, compute_dtype=dt_)
     print(json.dumps({
         "metric": f"{args.height}p frames/sec, Motion-JPEG bytes -> decode -> detector -> NMS -> repair -> crops -> CNN -> labels (all on the device)",
         "value": r["value"], "unit": "frames/s", "n_gpus": 1, "steps": max(args.steps, 3), "warmup": 3, "ms_per_step": r["ms_per_clip"],
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dt_, "data": "synthetic",
         "config": {"workload": f"chain: {n} x {args.height}x{args.width} frames per clip, quality-{args.jpeg_quality} 4:2:0 Motion-JPEG, YOLOv5s at 384 x 640, "
                                "ResNet-18 action CNN; three clips in flight"},
         "chain": r}), flush=True)

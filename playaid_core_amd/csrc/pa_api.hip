@@ -134,6 +134,7 @@ struct pa_engine {
     // two-way interleave of the backbone (two half batches on two streams)
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_ds_fork = nullptr, ev_ds_join = nullptr;   // PA_DS_SIDE: a block's 1x1/2 branch GEMM on the side stream, under its opener
     int interleave = 0;  // measured +0.5 % only (kernels of two streams do not overlap usefully); kept as a knob
     // profiling
     bool profiling = false;
@@ -354,7 +355,10 @@ struct ProfScope {
 
 // crop0: first crop of this launch inside the layer's buffers (the two interleaved half
 // batches address disjoint crop ranges of the same buffers); slab_off: its split-K slab region.
-int run_conv(pa_engine* e, const ConvLayer& L, int crop0, int ncrops, size_t slab_off, hipStream_t s, const char* prof_name) {
+// ds_stream: where the 1x1/2 branch GEMM of a Winograd-form block opener's conv2 goes (nullptr: `s`, right in front of the convolution);
+// ds_only: launch just that GEMM and return; ds_done: it has been launched already (by a ds_only call), only its result is added
+int run_conv(pa_engine* e, const ConvLayer& L, int crop0, int ncrops, size_t slab_off, hipStream_t s, const char* prof_name,
+             bool ds_only = false, bool ds_done = false) {
     GemmParams p;
     memset(&p, 0, sizeof(p));
     const int in_w = L.in_hw + 2 * L.in_pad;
@@ -431,9 +435,10 @@ int run_conv(pa_engine* e, const ConvLayer& L, int crop0, int ncrops, size_t sla
         d.out_px_stride = p.out_px_stride; d.out_row_stride = p.out_row_stride; d.out_img_stride = p.out_img_stride;
         d.out_pad = p.out_pad;
         d.relu = 0; d.splitk = 1;
-        ProfScope ps(e, s, prof_name, 2.0 * d.M * d.N * L.in2_c,
-                     4.0 * ((double)ncrops * L.in2_hw * L.in2_hw * L.in2_c / (L.in2_stride * L.in2_stride) + (double)d.M * d.N + (double)d.N * L.in2_c));
-        if (e->emu && L.ds_split_wgt) {
+        ProfScope ps(e, s, prof_name, ds_done ? 0.0 : 2.0 * d.M * d.N * L.in2_c,
+                     ds_done ? 0.0 : 4.0 * ((double)ncrops * L.in2_hw * L.in2_hw * L.in2_c / (L.in2_stride * L.in2_stride) + (double)d.M * d.N + (double)d.N * L.in2_c));
+        if (ds_done) {
+        } else if (e->emu && L.ds_split_wgt) {
             HIPCHK(e, launch_psgemm(d, L.ds_split_wgt, (size_t)ncrops * out_crop, 0, s));
         } else {
             GemmTile dt;
@@ -441,6 +446,7 @@ int run_conv(pa_engine* e, const ConvLayer& L, int crop0, int ncrops, size_t sla
             choose_tile(d.M, d.N, L.in2_c / 32, &dt, &dsk);
             HIPCHK(e, launch_igemm(d, dt, s));
         }
+        if (ds_only) return PA_OK;
         p.residual = d.out;
     } else if (L.in2) {
         const int w2 = L.in2_hw + 2;  // zero-bordered block input
@@ -594,10 +600,28 @@ int run_backbone_part(pa_engine* e, int crop0, int ncrops, const float* x_in, fl
         if ((rc = stem_part(crop0, ncrops, s))) return rc;
         if ((rc = pool_part(crop0, ncrops, s))) return rc;
     }
+    // PA_DS_SIDE=1 (A/B): the 1x1/2 branch GEMM of a block (layers 2-4: ~10 us each, a few dozen tiles) is
+    // launched on the side stream BEFORE the block's stride-2 opener instead of between the opener and conv2 -- both read the block
+    // input, so the small GEMM runs under the opener and conv2 only waits for an event
+    static const int ds_side = getenv("PA_DS_SIDE") ? atoi(getenv("PA_DS_SIDE")) : 0;
+    bool ds_pending = false;
     for (size_t i = 1; i < e->convs.size(); ++i) {
         const ConvLayer& L = e->convs[i];
-        rc = run_conv(e, L, crop0, ncrops, slab_off, s,
-                      e->profile_layers ? L.name.c_str() : (L.kh == 3 ? "igemm_conv3x3" : "igemm_conv1x1_ds"));
+        const char* pn = e->profile_layers ? L.name.c_str() : (L.kh == 3 ? "igemm_conv3x3" : "igemm_conv1x1_ds");
+        if (ds_side && !e->profiling && !e->bf16 && e->side && s != e->side && i + 1 < e->convs.size()) {
+            const ConvLayer& Nx = e->convs[i + 1];
+            if (Nx.in2 && Nx.ds_wgt && Nx.wino_wgt && Nx.in2 == L.in && L.stride == 2) {
+                HIPCHK(e, hipEventRecord(e->ev_ds_fork, s));
+                HIPCHK(e, hipStreamWaitEvent(e->side, e->ev_ds_fork, 0));
+                if ((rc = run_conv(e, Nx, crop0, ncrops, slab_off, e->side, "igemm_conv1x1_ds", /*ds_only=*/true))) return rc;
+                HIPCHK(e, hipEventRecord(e->ev_ds_join, e->side));
+                ds_pending = true;
+            }
+        }
+        const bool use_pending = ds_pending && L.in2 && L.ds_wgt && L.wino_wgt;
+        if (use_pending) HIPCHK(e, hipStreamWaitEvent(s, e->ev_ds_join, 0));
+        rc = run_conv(e, L, crop0, ncrops, slab_off, s, pn, false, use_pending);
+        if (use_pending) ds_pending = false;
         if (rc) return rc;
     }
     {
@@ -1132,6 +1156,8 @@ int create_impl(const pa_config* cfg, const void* blob, size_t src_bytes, const 
     HIPCHK(e, hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
     HIPCHK(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
     HIPCHK(e, hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+    HIPCHK(e, hipEventCreateWithFlags(&e->ev_ds_fork, hipEventDisableTiming));
+    HIPCHK(e, hipEventCreateWithFlags(&e->ev_ds_join, hipEventDisableTiming));
     HIPCHK(e, hipDeviceSynchronize());
     return PA_OK;
 }
@@ -1169,6 +1195,8 @@ void pa_destroy(pa_engine* e) {
     for (hipEvent_t ev : e->event_pool) (void)hipEventDestroy(ev);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+    if (e->ev_ds_fork) (void)hipEventDestroy(e->ev_ds_fork);
+    if (e->ev_ds_join) (void)hipEventDestroy(e->ev_ds_join);
     if (e->side) (void)hipStreamDestroy(e->side);
     if (e->gate_flag) (void)hipHostFree(e->gate_flag);
     for (void* p : e->allocs) (void)hipFree(p);

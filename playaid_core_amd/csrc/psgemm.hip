@@ -255,7 +255,7 @@ __global__ __launch_bounds__(512, 2) void psgemm_kernel(const GemmParams p, cons
             else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         };
-        static_assert(NSTAGE == 3 || NSTAGE == 4, "wait_stage covers rings of three and four stages");
+        static_assert(NSTAGE >= 2 && NSTAGE <= 4, "wait_stage covers rings of two to four stages");
         int slot = 0;
 #pragma unroll
         for (int s = 0; s < NSTAGE; ++s)
@@ -607,7 +607,14 @@ hipError_t launch_psgemm(const GemmParams& p_in, const unsigned short* wsp, size
         if (p.residual) PA_PS_LAUNCH1(BN_, NS_, true);                                                                               \
         else PA_PS_LAUNCH1(BN_, NS_, false);                                                                                         \
     } while (0)
-    if (bn == 128) PA_PS_LAUNCH(128, 3);
+    // ring depth: as deep as one workgroup per CU allows. PA_PS_STAGES=2 (A/B): a two-stage ring of 80 / 56 KB, which leaves a CU room for a
+    // workgroup of another stream's kernel (the Motion-JPEG passes' 52 KB) beside this one -- the chain runs three streams
+    static const int stages2 = getenv("PA_PS_STAGES") && atoi(getenv("PA_PS_STAGES")) == 2;
+    if (stages2) {
+        if (bn == 128) PA_PS_LAUNCH(128, 2);
+        else if (bn == 64) PA_PS_LAUNCH(64, 2);
+        else PA_PS_LAUNCH(32, 2);
+    } else if (bn == 128) PA_PS_LAUNCH(128, 3);
     else if (bn == 64) PA_PS_LAUNCH(64, 4);
     else PA_PS_LAUNCH(32, 4);
 #undef PA_PS_LAUNCH1

@@ -107,6 +107,10 @@ SHAPES = [
     (3, 16, 16, 128, 128, 3, 1),     # stride-1 3x3 as an implicit GEMM (ResNet-18 layer 2)
     (7, 4, 4, 512, 512, 3, 1),       # layer 4: 112 pixels, one partial tile
     (1, 8, 12, 96, 96, 1, 1),        # 96 channels: three 32-channel columns, 96 pixels: less than one tile
+    (1, 8, 8, 32, 64, 1, 1),         # ONE tile of ONE k-step: fewer stages than the ring holds (the prologue's counted waits)
+    (1, 8, 16, 64, 128, 1, 1),       # one tile, two k-steps
+    (1, 16, 24, 96, 128, 1, 1),      # three tiles of three k-steps on one workgroup column
+    (33, 12, 20, 128, 256, 1, 1),    # 7920 pixels = 61.9 tiles: every XCD's share is ragged
 ]
 
 
