@@ -562,6 +562,12 @@ typedef struct pa_conv_desc {
 typedef struct pa_convnet pa_convnet;
 int pa_convnet_create(int32_t device, const pa_conv_desc* descs, int32_t n_descs, const int64_t* buf_floats_per_crop,
                       int32_t n_bufs, const float* weights_host, size_t n_weights, int32_t max_crops, pa_convnet** out);
+/* The same with the convolutions' arithmetic chosen (ABI 11): PA_DTYPE_F32 (= pa_convnet_create) or PA_DTYPE_EMULATED_F32 -- every
+ * convolution that is not in Winograd form and has enough 128-pixel tiles at max_crops to fill half the chip runs on the emulated-fp32
+ * persistent GEMM (csrc/psgemm.hip), the rest on the exact kernels. Never the default. */
+int pa_convnet_create_dtype(int32_t device, const pa_conv_desc* descs, int32_t n_descs, const int64_t* buf_floats_per_crop,
+                            int32_t n_bufs, const float* weights_host, size_t n_weights, int32_t max_crops, int32_t compute_dtype,
+                            pa_convnet** out);
 void pa_convnet_destroy(pa_convnet* h);
 const char* pa_convnet_last_error(const pa_convnet* h);
 /* x float32[n,3,128,128] (NCHW, device) -> out: the last layer's output buffer, float32[n, out_floats_per_crop]. */

@@ -163,6 +163,8 @@ SYMBOLS = [
     ("pa_lstm_forward", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     ("pa_convnet_create", C.c_int, [C.c_int32, C.POINTER(pa_conv_desc), C.c_int32, C.POINTER(C.c_int64), C.c_int32, _P, C.c_size_t,
                                     C.c_int32, C.POINTER(_P)]),
+    ("pa_convnet_create_dtype", C.c_int, [C.c_int32, C.POINTER(pa_conv_desc), C.c_int32, C.POINTER(C.c_int64), C.c_int32, _P, C.c_size_t,
+                                          C.c_int32, C.c_int32, C.POINTER(_P)]),
     ("pa_convnet_destroy", None, [_P]),
     ("pa_convnet_last_error", C.c_char_p, [_P]),
     ("pa_convnet_forward", C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P]),

@@ -49,6 +49,9 @@ struct pa_convnet {
     float* wino_weights = nullptr;      // the stride-1 3x3 layers' filters in the Winograd kernel's layout (wino.hip)
     std::vector<long long> wino_off;    // per layer: float offset into wino_weights, -1 = direct form
     std::vector<int> wino_bn;           // per layer: output channels per workgroup its filters were laid out for
+    int compute_dtype = PA_DTYPE_F32;          // PA_DTYPE_EMULATED_F32: the layers listed in split_off run on psgemm.hip
+    unsigned short* split_weights = nullptr;   // those layers' weights as three bf16 slices (psgemm_pack_weights)
+    std::vector<long long> split_off;          // per layer: element offset into split_weights, -1 = the exact kernel
     float* x0 = nullptr;  // [max_crops][134][134][4] model input of the stem
     std::string last_error;
 };
@@ -75,13 +78,20 @@ const char* pa_convnet_last_error(const pa_convnet* h) { return h ? h->last_erro
 
 int pa_convnet_create(int32_t device, const pa_conv_desc* descs, int32_t n_descs, const int64_t* buf_floats_per_crop, int32_t n_bufs,
                       const float* weights_host, size_t n_weights, int32_t max_crops, pa_convnet** out) {
+    return pa_convnet_create_dtype(device, descs, n_descs, buf_floats_per_crop, n_bufs, weights_host, n_weights, max_crops, PA_DTYPE_F32, out);
+}
+
+int pa_convnet_create_dtype(int32_t device, const pa_conv_desc* descs, int32_t n_descs, const int64_t* buf_floats_per_crop, int32_t n_bufs,
+                            const float* weights_host, size_t n_weights, int32_t max_crops, int32_t compute_dtype, pa_convnet** out) {
     if (!out) return PA_ERR_INVALID_ARG;
     *out = nullptr;
-    if (!descs || n_descs < 1 || !buf_floats_per_crop || n_bufs < 1 || !weights_host || n_weights < 1 || max_crops < 1)
+    if (!descs || n_descs < 1 || !buf_floats_per_crop || n_bufs < 1 || !weights_host || n_weights < 1 || max_crops < 1 ||
+        (compute_dtype != PA_DTYPE_F32 && compute_dtype != PA_DTYPE_EMULATED_F32))
         return PA_ERR_INVALID_ARG;
     pa_convnet* h = new pa_convnet();
     *out = h;
     h->device = device;
+    h->compute_dtype = compute_dtype;
     h->max_crops = max_crops;
     h->descs.assign(descs, descs + n_descs);
     // validate the table: buffer indices, weight ranges, buffer sizes, one geometry per bordered buffer
@@ -157,6 +167,31 @@ int pa_convnet_create(int32_t device, const pa_conv_desc* descs, int32_t n_descs
             if (!chk(hipMemcpy(h->wino_weights, ug.data(), total * sizeof(float), hipMemcpyHostToDevice), "upload Winograd filters")) return PA_ERR_HIP;
         }
     }
+    h->split_off.assign(n_descs, -1);
+    if (compute_dtype == PA_DTYPE_EMULATED_F32) {
+        // every convolution that is not in Winograd form and whose 128-pixel tiles can fill at least half the chip at max_crops runs on
+        // the emulated-fp32 persistent GEMM (psgemm.hip; below that its one-workgroup-per-CU grid is mostly empty and the exact
+        // engine's 64 x 64 tiles are faster: profiles/r06_pgemm_split_layers.txt, ResNet-18's 8 x 8 and 4 x 4 maps)
+        size_t total = 0;
+        for (int i = 0; i < n_descs; ++i) {
+            const pa_conv_desc& d = h->descs[i];
+            if (d.kind != 0 || h->wino_off[i] >= 0 || d.cin % 32 || d.cout % 32) continue;
+            const int ohw = d.in_hw / d.stride, bn = pa::psgemm_pick_bn(d.cout, d.res_buf >= 0);
+            if (bn == 0 || (long long)(((long long)max_crops * ohw * ohw + 127) / 128) * (d.cout / bn) < 128) continue;
+            h->split_off[i] = (long long)total;
+            total += pa::psgemm_weight_elems(d.cout, d.ksize * d.ksize * d.cin, d.res_buf >= 0);
+        }
+        if (total) {
+            std::vector<unsigned short> sw(total);
+            for (int i = 0; i < n_descs; ++i)
+                if (h->split_off[i] >= 0) {
+                    const pa_conv_desc& d = h->descs[i];
+                    pa::psgemm_pack_weights(weights_host + d.w_off, d.cout, d.ksize * d.ksize * d.cin, d.res_buf >= 0, sw.data() + h->split_off[i]);
+                }
+            if (!chk(hipMalloc(&h->split_weights, total * sizeof(unsigned short)), "hipMalloc split weights")) return PA_ERR_HIP;
+            if (!chk(hipMemcpy(h->split_weights, sw.data(), total * sizeof(unsigned short), hipMemcpyHostToDevice), "upload split weights")) return PA_ERR_HIP;
+        }
+    }
     h->bufs.assign(n_bufs, nullptr);
     h->buf_floats.assign(buf_floats_per_crop, buf_floats_per_crop + n_bufs);
     for (int b = 0; b < n_bufs; ++b) {
@@ -175,6 +210,7 @@ void pa_convnet_destroy(pa_convnet* h) {
     if (!h) return;
     (void)hipFree(h->weights);
     (void)hipFree(h->wino_weights);
+    (void)hipFree(h->split_weights);
     (void)hipFree(h->x0);
     for (float* b : h->bufs) (void)hipFree(b);
     delete h;
@@ -244,7 +280,8 @@ int pa_convnet_forward(pa_convnet* h, const float* x, int32_t n, float* out, int
         const long long t128 = (long long)((p.M + 127) / 128) * (p.N / 64);
         const pa::GemmTile tile = (p.N % 128 == 0 && t128 / 2 >= 512) ? pa::TILE_128x128 : (t128 >= 512 ? pa::TILE_128x64 : pa::TILE_64x64);
         hipError_t pe = hipErrorInvalidValue;
-        if (h->wino_off[li] >= 0) {
+        if (h->split_off[li] >= 0) pe = pa::launch_psgemm(p, h->split_weights + h->split_off[li], (size_t)n * p.out_img_stride, 0, s);
+        if (pe == hipErrorInvalidValue && h->wino_off[li] >= 0) {
             pa::WinoParams q;
             memset(&q, 0, sizeof(q));
             q.act = p.act; q.wgt = h->wino_weights + h->wino_off[li]; q.bias = p.bias; q.residual = p.residual; q.out = p.out;

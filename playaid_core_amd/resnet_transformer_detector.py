@@ -159,8 +159,12 @@ def build_resnet50_table(state_dict: Mapping, prefix: str = "model.resnet."):
 class ConvNet:
     """A layer table on the device (``pa_convnet_create`` / ``pa_convnet_forward``)."""
 
-    def __init__(self, descs, buf_floats, weights: np.ndarray, out_floats: int, device: str = "cuda:0", max_crops: int = 64):
+    def __init__(self, descs, buf_floats, weights: np.ndarray, out_floats: int, device: str = "cuda:0", max_crops: int = 64,
+                 compute_dtype: str = "f32"):
         self._lib = _lib.load()
+        if compute_dtype not in ("f32", "emulated_f32"):
+            raise ValueError("compute_dtype must be 'f32' or 'emulated_f32'")
+        self.compute_dtype = compute_dtype
         if not torch.cuda.is_available():
             raise _lib.HipLibraryError("no HIP device visible to PyTorch-ROCm; this path has no CPU fallback")
         self.device = torch.device(device)
@@ -173,8 +177,8 @@ class ConvNet:
         bufs = (C.c_int64 * len(buf_floats))(*buf_floats)
         weights = np.ascontiguousarray(weights, dtype=np.float32)
         h = C.c_void_p()
-        rc = self._lib.pa_convnet_create(self.device.index or 0, arr, len(descs), bufs, len(buf_floats),
-                                         weights.ctypes.data_as(C.c_void_p), weights.size, max_crops, C.byref(h))
+        rc = self._lib.pa_convnet_create_dtype(self.device.index or 0, arr, len(descs), bufs, len(buf_floats),
+                                               weights.ctypes.data_as(C.c_void_p), weights.size, max_crops, _lib.DTYPES[compute_dtype], C.byref(h))
         self._h = h
         if rc != 0:
             msg = self._lib.pa_convnet_last_error(h).decode() if h else "bad argument"
@@ -270,7 +274,9 @@ class ResnetTransformerDetector:
         self.max_rows = max_rows
         self._lib = _lib.load()
         descs, bufs, weights, feat_dim = build_resnet50_table(state_dict)
-        self._net = ConvNet(descs, bufs, weights, feat_dim, device=device, max_crops=min(max_rows, 64))
+        # (compute_dtype: beyond the reference's arguments -- "emulated_f32" = pa_convnet_create_dtype(PA_DTYPE_EMULATED_F32); never the default)
+        self._net = ConvNet(descs, bufs, weights, feat_dim, device=device, max_crops=min(max_rows, 64),
+                            compute_dtype=kwargs.get("compute_dtype", "f32"))
         self.device = self._net.device
         blob = pack_encoder_blob(state_dict, a, s)
         enc_dim = 1 + 2 * NUM_FREQ

@@ -112,8 +112,10 @@ class RNNActionDetector:
         self.dataset_kwargs = kwargs
         self.training = False
         self.max_rows = max_rows
+        # (compute_dtype: beyond the reference's arguments -- "emulated_f32" puts the backbone's stride-2 openers and branch GEMMs on the
+        # emulated-fp32 kernels, PA_DTYPE_EMULATED_F32; never the default)
         self._engine = Engine(backbone_state_dict(state_dict), device=device, num_fighters=1, frame_delta=1,
-                              max_batch_frames=min(max_rows, 128), max_clip_frames=1)
+                              max_batch_frames=min(max_rows, 128), max_clip_frames=1, compute_dtype=kwargs.get("compute_dtype", "f32"))
         self._lib = self._engine._lib
         blob = pack_lstm_blob(state_dict, a)
         assert blob.nbytes == self._lib.pa_lstm_blob_bytes(INPUT_DIM, HIDDEN_DIM, NUM_LAYERS, a)

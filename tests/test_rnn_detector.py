@@ -63,12 +63,13 @@ def test_lstm_blob_layout():
 
 
 @pytest.mark.gpu
-def test_rnn_detector_matches_oracle():
+@pytest.mark.parametrize("dtype", ["f32", "emulated_f32"])
+def test_rnn_detector_matches_oracle(dtype):
     from playaid_core_amd.rnn_action_detector import RNNActionDetector
 
     actions = [f"a{i}" for i in range(63)]
     sd = synth.make_rnn_state_dict(seed=4321, num_actions=63)
-    model = RNNActionDetector("byleth", actions, state_dict=sd, max_rows=64).eval()
+    model = RNNActionDetector("byleth", actions, state_dict=sd, max_rows=64, compute_dtype=dtype).eval()
     try:
         for b, s in ((1, 7), (4, 7), (3, 4)):   # the vis script's shape (B = 1), several windows, another S
             x = _inputs(b, s, seed=b * 10 + s)
