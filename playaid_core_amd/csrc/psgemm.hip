@@ -444,9 +444,19 @@ __global__ __launch_bounds__(512, 2) void psgemm_kernel(const GemmParams p, cons
         ps_split8(lo, hi, a_c[0], a_c[1], a_c[2]);
     }
 
+    // diagnostic build only (-DPA_PS_STAMP, p.clk = 8 words per consumer wave): shader clock (s_memtime) and the constant 100 MHz clock
+    // (s_memrealtime) around the tile loop -> cycles per k-step and the clock the chip holds in this loop; and the same around the
+    // k-steps alone (epilogues excluded). Values go to a buffer nothing else reads; in the product kernel no stamp executes.
+#ifdef PA_PS_STAMP
+    unsigned long long st_t0 = 0, st_r0 = 0, st_k = 0;
+    if (p.clk) { st_t0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
     int slot = 0, g = 0;
     for (int t = 0; t < nt; ++t) {
         const int tile_m = t_lo + lm + t * LM;
+#ifdef PA_PS_STAMP
+        const unsigned long long st_ks = p.clk ? __builtin_amdgcn_s_memtime() : 0ull;
+#endif
         load_bias();
         f32x4 res4[CB][4];
         const unsigned o_off = out_offset(tile_m * BM + wave_id * 32);
@@ -480,6 +490,9 @@ __global__ __launch_bounds__(512, 2) void psgemm_kernel(const GemmParams p, cons
             });
             slot = nslot;
         }
+#ifdef PA_PS_STAMP
+        if (p.clk) st_k += __builtin_amdgcn_s_memtime() - st_ks;
+#endif
         // ---- epilogue of the tile, straight from the accumulators: lane = pixel lr of the wave's 32, channels ch0 + 32 cb + 8 g + 0..3 ----
         if (RES && BN >= 128) {   // 128-channel tiles: the residual's 64 registers are free only now (the operand sets of the last half are dead)
 #pragma unroll
@@ -513,6 +526,16 @@ __global__ __launch_bounds__(512, 2) void psgemm_kernel(const GemmParams p, cons
                 }
             }
     }
+#ifdef PA_PS_STAMP
+    if (p.clk && lane == 0) {
+        unsigned long long* c = p.clk + ((size_t)blockIdx.x * 4 + wave_id) * 8;
+        c[0] = __builtin_amdgcn_s_memtime() - st_t0;
+        c[1] = __builtin_amdgcn_s_memrealtime() - st_r0;
+        c[2] = st_k;
+        c[3] = (unsigned long long)total;
+        c[4] = (unsigned long long)nt;
+    }
+#endif
 }
 
 // channels per workgroup = per stage image of the weight layout (`residual` is part of the choice only for the A/B switch PA_PS_RES128:
@@ -592,6 +615,16 @@ hipError_t launch_psgemm(const GemmParams& p_in, const unsigned short* wsp, size
     p.pg_nwx = 1 + 30 / p.wo;
     p.pg_nwy = (p.pg_ho - 1 + p.pg_nwx) / p.pg_ho;
     const unsigned out_bytes = (unsigned)(out_floats * 4);
+#ifdef PA_PS_STAMP
+    // PA_PS_STAMP_FILE=<path>: every launch appends "M K N grid | median over consumer waves of: shader cycles, 100 MHz ticks, cycles in k-steps, k-steps, tiles" (synchronises)
+    static const char* stamp_file = getenv("PA_PS_STAMP_FILE");
+    unsigned long long* clk_dev = nullptr;
+    if (stamp_file) {
+        if (hipMalloc(&clk_dev, (size_t)grid * 4 * 8 * 8) != hipSuccess) return hipErrorOutOfMemory;
+        (void)hipMemsetAsync(clk_dev, 0, (size_t)grid * 4 * 8 * 8, s);
+        p.clk = clk_dev;
+    }
+#endif
     if (p.up_out && (up_floats == 0 || up_floats >= (1ull << 29) || p.up_px_stride % 4 || p.up_row_stride % 4 || p.up_img_stride % 4 ||
                      (reinterpret_cast<unsigned long long>(p.up_out) & 15ull)))
         return hipErrorInvalidValue;
@@ -618,6 +651,29 @@ hipError_t launch_psgemm(const GemmParams& p_in, const unsigned short* wsp, size
     else if (bn == 64) PA_PS_LAUNCH(64, 4);
     else PA_PS_LAUNCH(32, 4);
 #undef PA_PS_LAUNCH1
+#ifdef PA_PS_STAMP
+    if (clk_dev) {
+        std::vector<unsigned long long> hst((size_t)grid * 4 * 8);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(hst.data(), clk_dev, hst.size() * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(clk_dev);
+        std::vector<double> cyc, clkghz, perk, perk_in;
+        for (int w = 0; w < grid * 4; ++w) {
+            const unsigned long long* c = &hst[(size_t)w * 8];
+            if (c[3] == 0 || c[1] == 0) continue;
+            cyc.push_back((double)c[0]);
+            clkghz.push_back((double)c[0] / (double)c[1] * 0.1);
+            perk.push_back((double)c[0] / (double)c[3]);
+            perk_in.push_back((double)c[2] / (double)c[3]);
+        }
+        auto med = [](std::vector<double>& v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+        if (FILE* f = fopen(stamp_file, "a")) {
+            fprintf(f, "M %d K %d N %d bn %d grid %d | wave lifetime %.0f cycles, in-kernel clock %.3f GHz, %.0f cycles per k-step (whole loop), %.0f inside the k-steps\n",
+                    p.M, p.ktot, p.N, bn, grid, med(cyc), med(clkghz), med(perk), med(perk_in));
+            fclose(f);
+        }
+    }
+#endif
 #undef PA_PS_LAUNCH
     return hipGetLastError();
 }
