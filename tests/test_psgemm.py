@@ -26,7 +26,7 @@ def test_weight_slices_are_an_exact_decomposition_in_the_stage_image_order():
     for cin, cout, k, res in ((32, 32, 1, False), (64, 64, 1, False), (64, 128, 3, False), (128, 128, 3, True), (256, 96, 1, False)):
         w = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(k * k * cin)).astype(np.float32)
         img = conv.pack_weights(w, "emulated_f32", has_residual=res).view(np.uint16)
-        bn = 128 if (cout % 128 == 0 and not res) else (64 if cout % 64 == 0 else 32)
+        bn = 128 if cout % 128 == 0 else (64 if cout % 64 == 0 else 32)   # (with a residual too: PA_PS_RES128 defaults to 1)
         pieces = 8 if bn == 32 else bn * 3 // 16
         ktot, nk = k * k * cin, k * k * cin // 32
         assert img.size == (cout // bn) * nk * pieces * 512
