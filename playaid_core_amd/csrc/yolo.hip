@@ -333,6 +333,8 @@ struct pa_detector {
     int compute_dtype = PA_DTYPE_F32;   // PA_DTYPE_EMULATED_F32: the layers listed in split_off run on psgemm.hip
     unsigned short* split_weights = nullptr;   // those layers' weights as three bf16 slices in the kernel's stage-image order
     std::vector<long long> split_off;   // per layer: element offset into split_weights, -1 = the layer keeps its exact fp32 kernel
+    hipStream_t side = nullptr;         // PA_DET_LANES=2: the second half batch's stream
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     float* x0 = nullptr;       // letter-boxed input [max_images][net_h + 4][net_w + 4][4]
     float* anchors = nullptr;  // device copy of the decode layers' anchors [n_decode][8]
     std::string last_error;
@@ -349,6 +351,9 @@ void pa_detector_destroy(pa_detector* h) {
     (void)hipFree(h->split_weights);
     (void)hipFree(h->x0);
     (void)hipFree(h->anchors);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->side) (void)hipStreamDestroy(h->side);
     for (float* b : h->bufs) (void)hipFree(b);
     delete h;
 }
@@ -543,13 +548,17 @@ int pa_detector_create_dtype(int32_t device, const pa_net_layer* layers, int32_t
     return PA_OK;
 }
 
+// i0: the first image's slot in the handle's buffers (frames / pred point at that image's data): two half batches can run on two
+// streams side by side, each in its own image range of the same buffers (pa_detector_forward)
 static int detector_run(pa_detector* h, const uint8_t* frames, int32_t n, int32_t height, int32_t width, float* pred, void* stream,
-                        std::vector<hipEvent_t>* ev) {
+                        std::vector<hipEvent_t>* ev, int i0 = 0) {
     if (!h) return PA_ERR_INVALID_ARG;
     auto fail = [&](int code, const std::string& msg) { h->last_error = msg; return code; };
     if (!frames || !pred || n < 1 || height < 1 || width < 1) return fail(PA_ERR_INVALID_ARG, "pa_detector_forward: bad argument");
-    if (n > h->max_images) return fail(PA_ERR_CAPACITY, "pa_detector_forward: more images than max_images");
+    if (i0 < 0 || i0 + n > h->max_images) return fail(PA_ERR_CAPACITY, "pa_detector_forward: more images than max_images");
     hipStream_t s = (hipStream_t)stream;
+    float* const X0 = h->x0 + (size_t)i0 * (h->net_h + 4) * (h->net_w + 4) * 4;
+    auto BUF = [&](int b) -> float* { return h->bufs[b] + (size_t)i0 * h->buf_floats[b]; };
 #define DT_HIP(call)                                                                                         \
     do {                                                                                                     \
         hipError_t e__ = (call);                                                                             \
@@ -564,7 +573,7 @@ static int detector_run(pa_detector* h, const uint8_t* frames, int32_t n, int32_
     const int top = (int)lrint(dh - 0.1), left = (int)lrint(dw - 0.1);
     const double lb_scale_x = 1.0 / ((double)new_w / width), lb_scale_y = 1.0 / ((double)new_h / height);   // cv2.resize's inv_scale, inverted
     hipLaunchKernelGGL(pa::letterbox_kernel, dim3((h->net_w + 63) / 64, (h->net_h + 3) / 4, n), dim3(256), 0, s, frames, n, height, width, new_h,
-                       new_w, top, left, h->net_h, h->net_w, lb_scale_x, lb_scale_y, h->x0);
+                       new_w, top, left, h->net_h, h->net_w, lb_scale_x, lb_scale_y, X0);
     DT_HIP(hipGetLastError());
     const int no = 5 + h->nc;
     int row0 = 0, di = 0;
@@ -575,9 +584,9 @@ static int detector_run(pa_detector* h, const uint8_t* frames, int32_t n, int32_
             const int oh = h->net_h / 2, ow = h->net_w / 2;
             pa::GemmParams p;
             memset(&p, 0, sizeof(p));
-            p.act = h->x0;
+            p.act = X0;
             p.bias = h->weights + L.b_off;
-            p.out = h->bufs[L.out_buf] + L.out_coff;
+            p.out = BUF(L.out_buf) + L.out_coff;
             p.M = n * oh * ow;
             p.N = L.cout;
             p.taps = 6; p.kw_taps = 1; p.chunk = 32; p.ktot = 192;
@@ -600,10 +609,10 @@ static int detector_run(pa_detector* h, const uint8_t* frames, int32_t n, int32_
         if (L.kind == 3) {
             const int oh = h->net_h / 2, ow = h->net_w / 2;
             pa::StemDirectParams q;
-            q.x = h->x0;
+            q.x = X0;
             q.wlane = h->weights + L.w_off;
             q.bias = h->weights + L.b_off;
-            q.out = h->bufs[L.out_buf] + L.out_coff;
+            q.out = BUF(L.out_buf) + L.out_coff;
             q.n = n; q.net_h = h->net_h; q.net_w = h->net_w; q.oh = oh; q.ow = ow;
             q.out_px_stride = L.out_cstride;
             q.out_row_stride = (ow + 2 * L.out_pad) * L.out_cstride;
@@ -637,9 +646,9 @@ static int detector_run(pa_detector* h, const uint8_t* frames, int32_t n, int32_
                 pa::SliceGeom g3 = {L.in_h, L.in_w, L3.out_pad, L3.out_cstride, L3.out_coff};
                 const size_t lds = (size_t)4 * hw * cg * sizeof(float);
                 if (cg == 16)
-                    hipLaunchKernelGGL(pa::sppf_pools_kernel<16>, dim3(L.cin / 16, n), dim3(256), lds, s, h->bufs[L.in_buf], gi, h->bufs[L.out_buf], g1, g2, g3);
+                    hipLaunchKernelGGL(pa::sppf_pools_kernel<16>, dim3(L.cin / 16, n), dim3(256), lds, s, BUF(L.in_buf), gi, BUF(L.out_buf), g1, g2, g3);
                 else
-                    hipLaunchKernelGGL(pa::sppf_pools_kernel<8>, dim3(L.cin / 8, n), dim3(256), lds, s, h->bufs[L.in_buf], gi, h->bufs[L.out_buf], g1, g2, g3);
+                    hipLaunchKernelGGL(pa::sppf_pools_kernel<8>, dim3(L.cin / 8, n), dim3(256), lds, s, BUF(L.in_buf), gi, BUF(L.out_buf), g1, g2, g3);
                 DT_HIP(hipGetLastError());
                 if (ev) {  // (profiling call: the two absorbed layers show as empty)
                     DT_HIP(hipEventRecord((*ev)[li + 1], s));
@@ -655,15 +664,15 @@ static int detector_run(pa_detector* h, const uint8_t* frames, int32_t n, int32_
             pa::SliceGeom go = {oh, ow, L.out_pad, L.out_cstride, L.out_coff};
             const long long total = (long long)n * oh * ow * (L.cin / 4);
             if (L.kind == 4)
-                hipLaunchKernelGGL(pa::maxpool5_kernel, dim3(pa::grid_for(total)), dim3(256), 0, s, h->bufs[L.in_buf], gi, h->bufs[L.out_buf], go, n, L.cin);
+                hipLaunchKernelGGL(pa::maxpool5_kernel, dim3(pa::grid_for(total)), dim3(256), 0, s, BUF(L.in_buf), gi, BUF(L.out_buf), go, n, L.cin);
             else
-                hipLaunchKernelGGL(pa::upsample2_kernel, dim3(pa::grid_for(total)), dim3(256), 0, s, h->bufs[L.in_buf], gi, h->bufs[L.out_buf], go, n, L.cin);
+                hipLaunchKernelGGL(pa::upsample2_kernel, dim3(pa::grid_for(total)), dim3(256), 0, s, BUF(L.in_buf), gi, BUF(L.out_buf), go, n, L.cin);
             DT_HIP(hipGetLastError());
             continue;
         }
         if (L.kind == 6) {
             pa::SliceGeom gi = {L.in_h, L.in_w, L.in_pad, L.in_cstride, L.in_coff};
-            hipLaunchKernelGGL(pa::detect_decode_kernel, dim3((L.in_h * L.in_w * no + 255) / 256, n * 3), dim3(256), 0, s, h->bufs[L.in_buf], gi, 3, no,
+            hipLaunchKernelGGL(pa::detect_decode_kernel, dim3((L.in_h * L.in_w * no + 255) / 256, n * 3), dim3(256), 0, s, BUF(L.in_buf), gi, 3, no,
                                L.aux[0], h->anchors + (size_t)di * 8, pred, h->rows, row0);
             DT_HIP(hipGetLastError());
             row0 += 3 * L.in_h * L.in_w;
@@ -675,11 +684,11 @@ static int detector_run(pa_detector* h, const uint8_t* frames, int32_t n, int32_
         const int out_wb = ow + 2 * L.out_pad, out_hb = oh + 2 * L.out_pad;
         pa::GemmParams p;
         memset(&p, 0, sizeof(p));
-        p.act = h->bufs[L.in_buf] + L.in_coff;
+        p.act = BUF(L.in_buf) + L.in_coff;
         p.wgt = h->weights + L.w_off;
         p.bias = h->weights + L.b_off;
-        p.residual = L.res_buf >= 0 ? h->bufs[L.res_buf] + L.res_coff : nullptr;
-        p.out = h->bufs[L.out_buf] + L.out_coff;
+        p.residual = L.res_buf >= 0 ? BUF(L.res_buf) + L.res_coff : nullptr;
+        p.out = BUF(L.out_buf) + L.out_coff;
         p.M = n * oh * ow;
         p.N = L.cout;
         p.taps = L.ksize * L.ksize;
@@ -717,7 +726,7 @@ static int detector_run(pa_detector* h, const uint8_t* frames, int32_t n, int32_
             if (U.kind == 5 && U.in_buf == L.out_buf && U.in_coff == L.out_coff && U.in_cstride == L.out_cstride && U.in_pad == L.out_pad &&
                 U.cin == L.cout && U.in_h == oh && U.in_w == ow && U.out_buf != L.out_buf) {
                 const int up_wb = 2 * ow + 2 * U.out_pad, up_hb = 2 * oh + 2 * U.out_pad;
-                p.up_out = h->bufs[U.out_buf] + U.out_coff;
+                p.up_out = BUF(U.out_buf) + U.out_coff;
                 p.up_px_stride = U.out_cstride;
                 p.up_row_stride = up_wb * U.out_cstride;
                 p.up_img_stride = up_hb * up_wb * U.out_cstride;
@@ -778,7 +787,28 @@ static int detector_run(pa_detector* h, const uint8_t* frames, int32_t n, int32_
 }
 
 int pa_detector_forward(pa_detector* h, const uint8_t* frames, int32_t n, int32_t height, int32_t width, float* pred, void* stream) {
-    return detector_run(h, frames, n, height, width, pred, stream, nullptr);
+    // PA_DET_LANES=2 (A/B): the batch as two halves on two streams -- the caller's and one of the handle's own --, each in its own image
+    // range of the activation buffers: one half's launch ramps, kernel tails and short layers run under the other half's steady state
+    // (what parallel.ClipLanes does for the action CNN). Same kernels on the same images: results bit-identical to one batch
+    // wherever a layer's tile shape does not depend on the batch size.
+    static const int lanes = getenv("PA_DET_LANES") ? atoi(getenv("PA_DET_LANES")) : 1;
+    if (!h || lanes < 2 || n < 16 || !frames || !pred) return detector_run(h, frames, n, height, width, pred, stream, nullptr);
+    hipStream_t s = (hipStream_t)stream;
+    if (!h->side) {
+        if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+            h->last_error = "pa_detector_forward: cannot create the second lane's stream";
+            return PA_ERR_HIP;
+        }
+    }
+    const int half = n / 2;
+    if (hipEventRecord(h->ev_fork, s) != hipSuccess || hipStreamWaitEvent(h->side, h->ev_fork, 0) != hipSuccess) return PA_ERR_HIP;
+    int rc = detector_run(h, frames, half, height, width, pred, s, nullptr, 0);
+    if (rc) return rc;
+    rc = detector_run(h, frames + (size_t)half * height * width * 3, n - half, height, width, pred + (size_t)half * h->rows * (5 + h->nc), h->side, nullptr, half);
+    if (rc) return rc;
+    if (hipEventRecord(h->ev_join, h->side) != hipSuccess || hipStreamWaitEvent(s, h->ev_join, 0) != hipSuccess) return PA_ERR_HIP;
+    return PA_OK;
 }
 
 int pa_detector_forward_timed(pa_detector* h, const uint8_t* frames, int32_t n, int32_t height, int32_t width, float* pred, void* stream,
