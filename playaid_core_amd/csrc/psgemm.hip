@@ -13,9 +13,11 @@
 // never the default: compute_dtype PA_DTYPE_EMULATED_F32 selects it, `value` / `dtype` of bench.py stay on the exact path.
 //
 // Layout of the work (pigemm.hip's persistent scheme, re-cut for a matrix pipe that is 2.7x faster):
-//   * 256 threads = 4 waves, ONE workgroup per CU; a tile is 128 pixels x BN channels (BN = 128 | 64 | 32) and wave w owns
-//     pixels 32 w .. 32 w + 31 x ALL BN channels: every activation value is split exactly once per workgroup (a 2 x 2 wave
-//     grid would split it twice -- the split, 44 vector instructions per 8 values, is the loop's second cost).
+//   * 512 threads, ONE workgroup per CU: waves 0-3 CONSUME (LDS reads, split, matrix instructions, epilogue), waves 4-7 LOAD (every
+//     LDS-DMA copy, the pixel address arithmetic, the counted waits) -- one of each per SIMD. A tile is 128 pixels x BN channels
+//     (BN = 128 | 64 | 32) and consumer wave w owns pixels 32 w .. 32 w + 31 x ALL BN channels: every activation value is split
+//     exactly once per workgroup (a 2 x 2 wave grid would split it twice -- the split, 44 vector instructions per 8 values, is
+//     the loop's second cost; with 64-channel tiles it is the first).
 //   * activations stay fp32 in HBM and in LDS (LDS-DMA, pigemm's swizzled 128-byte rows) and are split in registers behind
 //     their ds_read_b128; the weights were split at fold time (psgemm_pack_weights) into the exact LDS stage image --
 //     [tile_n][k-step][3 planes][BN rows][32 k] bf16, 16-byte chunk c of row r at chunk c ^ ((r >> 2) & 3) -- so their DMA
@@ -23,13 +25,15 @@
 //   * the ring is NSTAGE k-steps (32 k each) deep and the pipeline is SKEWED by half a k-step: a k-step's second half
 //     (k 16..31) is multiplied AFTER the barrier that opens the next k-step, from operands already in registers, while the
 //     next k-step's first operands are read and split. A stage is therefore free as soon as its last operand read has
-//     returned, one barrier earlier than its last matrix instruction: NSTAGE stages are in flight, not NSTAGE - 1, and the
-//     wait + barrier + first LDS round trip of a k-step hide under twelve (BN = 64) matrix instructions.
-//   * waits are counted: every wave keeps the number of vector-memory instructions it has issued and, per ring slot, the
-//     count right after that stage's copies; the wait in front of a barrier is s_waitcnt vmcnt(issued - mark[slot]) --
-//     whatever was issued later (younger copies, the stores of closed tiles) may stay in flight. Stores are buffer stores
-//     whose descriptor drops the rows past M (offset beyond num_records), so a wave issues the SAME number of stores for
-//     every tile, live rows or not (ADVICE round 5 on pigemm.hip's predicate-dependent store count).
+//     returned, one barrier earlier than its last matrix instruction: NSTAGE stages are in flight, not NSTAGE - 1.
+//   * between two matrix instructions stand at most one LDS read and two or three instructions of the split, placed by hand
+//     (half()): a lone wave per SIMD hides nothing, whatever takes longer than the 32 cycles a matrix instruction occupies the
+//     pipe idles it. Measured (profiles/r06_pgemm_split_stamps.txt): 1592 cycles per k-step for 1536 of matrix time on the
+//     big-K layers, at the 1.53-1.57 GHz the chip holds in this loop.
+//   * the loaders' waits are counted: in front of barrier g + 1 exactly the copies of the (at most NSTAGE - 2) younger stages may
+//     be outstanding, s_waitcnt vmcnt(k * NLD) (NLD checked on the built object: tests/test_abi.py). The consumers never wait on
+//     vmcnt; their stores are buffer stores whose descriptor drops the rows past M (offset beyond num_records), so a wave issues
+//     the SAME stores for every tile, live rows or not (ADVICE round 5 on pigemm.hip's predicate-dependent store count).
 //   * the bias is the value the accumulators start from (read from LDS per tile); SiLU / ReLU and the 16-byte stores run
 //     from the accumulators: lane = pixel, runs of four consecutive channels.
 #include "pa_kernels.h"
@@ -84,19 +88,6 @@ __device__ __forceinline__ int ps_sdiv(int n, int d, unsigned magic, int& rem) {
     rem = r;
     return q;
 }
-
-// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the field is six bits: past 63 it waits at 63 -- for more than it must, never less)
-#define PS_W1(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-#define PS_W8(A, B, C, D, E, F, G, H) PS_W1(A) PS_W1(B) PS_W1(C) PS_W1(D) PS_W1(E) PS_W1(F) PS_W1(G) PS_W1(H)
-__device__ __forceinline__ void ps_wait_vm(int n) {
-    switch (n) {
-        PS_W8(0, 1, 2, 3, 4, 5, 6, 7) PS_W8(8, 9, 10, 11, 12, 13, 14, 15) PS_W8(16, 17, 18, 19, 20, 21, 22, 23) PS_W8(24, 25, 26, 27, 28, 29, 30, 31)
-        PS_W8(32, 33, 34, 35, 36, 37, 38, 39) PS_W8(40, 41, 42, 43, 44, 45, 46, 47) PS_W8(48, 49, 50, 51, 52, 53, 54, 55) PS_W8(56, 57, 58, 59, 60, 61, 62, 63)
-        default: asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
-    }
-}
-#undef PS_W8
-#undef PS_W1
 
 __device__ __forceinline__ unsigned ps_cvt_pk_bf16(float a, float b) {   // (lo = a, hi = b), round to nearest even
     unsigned r;
