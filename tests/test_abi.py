@@ -141,6 +141,18 @@ def test_product_path_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+    # bench.py: ONE import, inside cpu_baseline(); __graft_entry__.py: inside smoke(); scripts/ are measurement helpers run by hand
+    import ast
+
+    for name, func in (("bench.py", "cpu_baseline"), ("__graft_entry__.py", "smoke")):
+        tree = ast.parse(open(os.path.join(ROOT, name)).read())
+        inside = set()
+        for node in ast.walk(tree):
+            if isinstance(node, ast.FunctionDef) and node.name == func:
+                inside = {id(n) for n in ast.walk(node)}
+        hits = [n for n in ast.walk(tree) if (isinstance(n, ast.ImportFrom) and (n.module or "").split(".")[0] == "oracle") or
+                (isinstance(n, ast.Import) and any(a.name.split(".")[0] == "oracle" for a in n.names))]
+        assert hits and all(id(n) in inside for n in hits), f"{name}: the oracle may only be imported inside {func}()"
 
 
 def test_jpeg_header_probe_on_the_host(lib):
