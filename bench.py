@@ -186,6 +186,8 @@ def compact_line(result):
     if isinstance(e, dict):
         out["emulated_fp32"] = {k: e.get(k) for k in ("frames_per_s", "detector_ms", "detector_ms_exact_f32", "chain_frames_per_s", "max_dlogp_vs_oracle",
                                                       "max_dlogp_vs_oracle_exact_f32", "max_dlogp_emulated_vs_exact", "error") if k in e}
+        if isinstance(e.get("roofline"), dict):
+            out["emulated_fp32"]["roofline"] = {k: e["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "fp32_equivalent_tflops")}
     out["details"] = "bench_details.json"
     line = json.dumps(out, separators=(",", ":"))
     if len(line) > 1800:   # never let a long note push the headline out of the driver's tail
@@ -273,6 +275,32 @@ def emulated_fp32_side(sd, frames, boxes, n_clip, height, width, S, DELTA, devic
                     torch.cuda.synchronize(device)
                     ts.append(a.elapsed_time(b))
                 out[key] = round(float(np.median(ts[2:])), 3)
+                if dt_ == "emulated_f32":
+                    # roofline of the emulated kernel itself: the layers that run on psgemm.hip (every 1x1 / stride-2 3x3 convolution), timed
+                    # live with a HIP event between the table's layers (pa_detector_forward_timed), against the bf16 matrix peak: every fp32
+                    # multiply-add is six bf16 ones, so fp32-equivalent FLOP/s x 6 = the bf16 FLOP/s the matrix cores execute
+                    import ctypes as C
+                    from playaid_core_amd.yolov5 import build_yolov5s_table
+
+                    layers = build_yolov5s_table(synth.make_yolov5s_state_dict(), (384, 640), 6)[0]
+                    pred = torch.empty((n_clip, det.rows, 11), dtype=torch.float32, device=device)
+                    us = np.zeros((5, len(layers)), np.float32)
+                    for it in range(5):
+                        rc = det._lib.pa_detector_forward_timed(det._h, C.c_void_p(frames.data_ptr()), n_clip, height, width, C.c_void_p(pred.data_ptr()),
+                                                                C.c_void_p(torch.cuda.current_stream(device).cuda_stream), us[it].ctypes.data_as(C.c_void_p), len(layers))
+                        assert rc == 0
+                    med = np.median(us[1:], axis=0)
+                    gf = t_us = 0.0
+                    for i, L in enumerate(layers):
+                        if L.kind == 0 and not (L.ksize == 3 and L.stride == 1):
+                            gf += 2.0 * n_clip * (L.in_h // L.stride) * (L.in_w // L.stride) * L.cout * L.ksize * L.ksize * L.cin / 1e9
+                            t_us += float(med[i])
+                    tf_eq = gf / t_us * 1e3
+                    out["roofline"] = {"kernel": "psgemm_kernel (40 layers of the detector: 1x1 and stride-2 3x3)", "bound": "mfma",
+                                       "achieved": round(tf_eq * 6, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf_eq * 6 / 2500.0, 4),
+                                       "fp32_equivalent_tflops": round(tf_eq, 1), "gflop_fp32": round(gf, 1), "total_ms": round(t_us / 1e3, 3),
+                                       "note": "bf16 FLOP/s executed (six per fp32 multiply-add) against the 2.5 PFLOP/s dense bf16 peak at 2.4 GHz; in-kernel stamps "
+                                               "(profiles/r06_pgemm_split_stamps.txt): the loop runs at 0.96 of the matrix pipe's cycles, the chip holds 1.53-1.57 GHz in it"}
             finally:
                 det.close()
         ch = chain_inclusive(eng, sd, frames, boxes, quality=quality, compute_dtype="emulated_f32")
