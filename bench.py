@@ -725,7 +725,10 @@ def bench_chain(args):
     dt_ = "emulated_f32" if args.dtype == "emulated_f32" else "f32"
     eng = Engine(sd, device=str(device), max_batch_frames=n, max_clip_frames=max(n, 64), max_frame_height=args.height, max_frame_width=args.width,
                  compute_dtype=dt_)
-    frames = torch.from_numpy(synth.make_frames(n, args.height, args.width)).to(device)
+    if args.camera_like:   # three bits of noise per sample instead of five: the compressed size of camera / game footage
+        frames = synth.make_frames_torch(n, args.height, args.width, first_frame=0, device=device, noise_mask=7, fine_mask=7)
+    else:
+        frames = torch.from_numpy(synth.make_frames(n, args.height, args.width)).to(device)
     boxes = torch.from_numpy(synth.make_boxes(n, args.height, args.width)).to(device)
     r = chain_inclusive(eng, sd, frames, boxes, steps=max(args.steps, 3), quality=args.jpeg_quality, compute_dtype=dt_)
     print(json.dumps({
@@ -903,6 +906,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse ranks > GPUs)")
     ap.add_argument("--no-pipeline", action="store_true", help="crop stage and backbone on one stream (no overlap across steps)")
+    ap.add_argument("--camera-like", action="store_true", help="--workload chain: the clip with three bits of noise per sample (0.3-0.6 MB per 1080p frame at quality 95)")
     ap.add_argument("--no-emulated", action="store_true", help="skip the emulated-fp32 side block (compute_dtype emulated_f32)")
     ap.add_argument("--calibrate", action="store_true",
                     help="time every pair of candidate streams before the timed region and keep the fastest (round 5's default; round 6 measured "
