@@ -472,6 +472,10 @@ def chain_inclusive(eng, sd, frames_dev, boxes_dev, steps=12, quality=95, comput
     from playaid_core_amd.parallel import _concurrent_streams
     picked = _concurrent_streams(eng, 2 + ND)
     s_front, s_back = picked[0], picked[1]
+    if os.environ.get("PA_CHAIN_BACK_PRIO"):   # A/B: the oldest clip's stage (crops + CNN + head) on a stream of the greatest priority
+        s_back = torch.cuda.Stream(dev, priority=-1)
+    if os.environ.get("PA_CHAIN_FRONT_PRIO"):
+        s_front = torch.cuda.Stream(dev, priority=-1)
     s_dec = picked[2:2 + ND]
     ready = [torch.cuda.Event() for _ in range(ND)]
     free = [torch.cuda.Event() for _ in range(ND)]

@@ -1297,11 +1297,18 @@ int pa_mjpeg_create(int32_t device, int32_t max_frames, int32_t max_height, int3
         if (!chk(hipHostMalloc(&h->h_ts[i], n * sizeof(TableSet)), "hipHostMalloc")) return PA_ERR_HIP;
         if (!chk(hipEventCreateWithFlags(&h->staged[i], hipEventDisableTiming), "hipEventCreate")) return PA_ERR_HIP;
     }
+    // A/B knob PA_MJPEG_PRIO=1: the groups' streams at the device's greatest priority (the entropy passes are chains of
+    // short, thinly occupied kernels; beside a detector that fills every CU they wait for a slot at each link of the chain)
+    int prio = 0;
+    if (const char* e = std::getenv("PA_MJPEG_PRIO")) {
+        int least = 0, greatest = 0;
+        if (std::atoi(e) > 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess) prio = greatest;
+    }
     for (int g = 0; g < MAX_GROUPS; ++g) {
-        if (!chk(hipStreamCreateWithFlags(&h->gstream[g], hipStreamNonBlocking), "hipStreamCreate")) return PA_ERR_HIP;
+        if (!chk(hipStreamCreateWithPriority(&h->gstream[g], hipStreamNonBlocking, prio), "hipStreamCreate")) return PA_ERR_HIP;
         if (!chk(hipEventCreateWithFlags(&h->up[g], hipEventDisableTiming), "hipEventCreate")) return PA_ERR_HIP;
     }
-    if (!chk(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking), "hipStreamCreate")) return PA_ERR_HIP;
+    if (!chk(hipStreamCreateWithPriority(&h->copy_stream, hipStreamNonBlocking, prio), "hipStreamCreate")) return PA_ERR_HIP;
     if (!chk(hipEventCreateWithFlags(&h->fork, hipEventDisableTiming), "hipEventCreate")) return PA_ERR_HIP;
     if (!chk(hipEventCreateWithFlags(&h->prologue, hipEventDisableTiming), "hipEventCreate")) return PA_ERR_HIP;
     if (!chk(hipHostMalloc(&h->h_flag, n * sizeof(int32_t)), "hipHostMalloc")) return PA_ERR_HIP;
