@@ -608,7 +608,8 @@ int pa_wino_conv3x3_splitk(const float* x, const float* ug, const float* bias, c
  * x: float32[n][height + 2 in_pad][width + 2 in_pad][in_px_stride] (device, zero border, the first cin channels of a pixel are
  * read; in_pad >= (ksize - 1) / 2); out: float32[n][oh + 2 out_pad][ow + 2 out_pad][out_px_stride], oh = height / stride
  * (interior written, first cout channels); residual: addressed like out (it may BE out), or NULL; act: 0 none, 1 ReLU, 2 SiLU;
- * res_after: 1 = the residual is added after the activation. cin, cout multiples of 32. Weights: pa_conv_pack_weights turns
+ * res_after: 1 = the residual is added after the activation. cin, cout multiples of 32; pixel strides multiples of 4 floats and
+ * x, w, out, residual 16-byte aligned (PA_ERR_INVALID_ARG otherwise: the kernels move 16-byte units). Weights: pa_conv_pack_weights turns
  * BatchNorm-folded [cout][ky][kx][cin] fp32 (host) into what the kernel of `compute_dtype` reads (host, pa_conv_weight_bytes
  * bytes; the caller uploads it): PA_DTYPE_F32 = the same fp32 values (csrc/pigemm.hip; no residual), PA_DTYPE_EMULATED_F32 = three
  * bf16 slices per weight in the LDS stage-image order of csrc/psgemm.hip, whose tile width depends on has_residual. Enqueue only. */
