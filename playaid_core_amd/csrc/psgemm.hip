@@ -35,7 +35,10 @@
 //     vmcnt; their stores are buffer stores whose descriptor drops the rows past M (offset beyond num_records), so a wave issues
 //     the SAME stores for every tile, live rows or not (ADVICE round 5 on pigemm.hip's predicate-dependent store count).
 //   * the bias is the value the accumulators start from (read from LDS per tile); SiLU / ReLU and the 16-byte stores run
-//     from the accumulators: lane = pixel, runs of four consecutive channels.
+//     from the accumulators: lane = pixel, runs of four consecutive channels. (Measured and NOT kept, commit 32f1f5b: the epilogue
+//     handed to the loader waves through 64 KB of LDS staging, and stores transposed to whole cache lines -- same speed and 5-15 %
+//     slower: on the short-K layers the stores cost their bytes, 4.6 TB/s of mixed traffic, not issue slots.
+//     profiles/r06_pgemm_split_defer.txt)
 #include "pa_kernels.h"
 
 #include <algorithm>
@@ -46,7 +49,7 @@
 #include <vector>
 
 // timing experiments only (results wrong when != 0; a diagnostic build: hipcc -DPA_PS_ABL=n): 1 = no copies after the prologue,
-// 2 = no matrix instructions, 4 = no SiLU, 8 = the loaders skip the deferred epilogues
+// 2 = no matrix instructions
 #ifndef PA_PS_ABL
 #define PA_PS_ABL 0
 #endif
@@ -63,7 +66,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) const f32x4 lds_cf4;
 typedef __attribute__((address_space(3))) const u32x4 lds_cu4;
 typedef __attribute__((address_space(3))) float lds_f;
-typedef __attribute__((address_space(3))) f32x4 lds_f4;
 
 __device__ __forceinline__ i32x4 ps_rsrc(const void* base, unsigned num_bytes) {
     const unsigned long long a = (unsigned long long)base;
@@ -141,22 +143,8 @@ constexpr int ps_b_pieces(int bn) { return bn == 32 ? 8 : bn * 3 / 16; }   // 1 
 // cycles of issue (MI355X_MICROARCH.md, cycle constants) -- seven to ten of them per k-step in a wave whose matrix instructions
 // want a slot every 32 cycles would idle the pipe a third of the time; in a partner wave they cost the consumer nothing but the
 // shared barrier. The consumers never wait on vmcnt (their only vector-memory instructions are the tile's stores and residual loads).
-//
-// DEFER (the launcher: tiles of two or more k-steps, no residual, workgroups with more than one tile): a tile's epilogue is the
-// LOADER waves' work. A consumer writes its 16 x CB accumulator registers to a staging area in LDS (16 ds_write_b128) and goes
-// straight on to the next tile's k-steps; loader wave 4 + w takes consumer wave w's values back lane for lane and runs the
-// activation and the 16-byte stores in pieces, one piece per k-step of the NEXT tile, behind that k-step's copies. Its vector and
-// transcendental instructions issue beside the consumer's matrix instructions on the same SIMD (different waves, different
-// pipes) instead of in front of them: the epilogue was 5 200 of a 128-deep tile's 13 200 cycles (profiles/r06_pgemm_split_stamps.txt).
-// Synchronisation is the k-steps' own barriers: the values written behind the last k-step of tile t are visible from the barrier
-// inside the first k-step of tile t + 1, and are overwritten behind the LAST barrier of tile t + 1 -- so the pieces run in the
-// nk - 1 intervals between those barriers (hence nk >= 2). The last tile of a workgroup has no k-steps behind it: its consumers
-// run the epilogue themselves. Same instructions on the same values: the results are the bits of the undeferred kernel.
-// The loaders' counted waits stay valid with stores in the queue: loads return in order among themselves, a store still
-// outstanding only makes a wait longer, never shorter.
-template <int BN, int NSTAGE, int ACT, bool RES, int DEFER>
+template <int BN, int NSTAGE, int ACT, bool RES>
 __global__ __launch_bounds__(512, 2) void psgemm_kernel(const GemmParams p, const unsigned short* __restrict__ wsp, unsigned out_bytes, unsigned up_bytes) {
-    static_assert(!(DEFER && RES), "the deferred epilogue has no residual path (a loader's residual loads would wait for its copies)");
     constexpr int BM = 128, CB = BN / 32;
     constexpr int A_BYTES = BM * 128;
     constexpr int PB = ps_b_pieces(BN) / 4;       // weight pieces per loader wave and k-step
@@ -164,11 +152,7 @@ __global__ __launch_bounds__(512, 2) void psgemm_kernel(const GemmParams p, cons
     constexpr int STAGE = A_BYTES + B_BYTES;
     constexpr int NLD = 4 + PB;                   // LDS-DMA instructions per loader wave and k-step
     constexpr int NM = 6 * CB;                    // matrix instructions per half k-step
-    constexpr int NQ = 4 * CB;                    // accumulator quads (four consecutive channels of a pixel) per lane and tile
-    constexpr int STG_OFF = NSTAGE * STAGE;       // staging of the deferred epilogue: [consumer wave][quad][lane] 16 bytes
-    constexpr int STG_BYTES = DEFER ? 4 * NQ * 1024 : 0;
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[NSTAGE * STAGE + STG_BYTES + BN * 4];
-    static_assert(NSTAGE * STAGE + STG_BYTES + BN * 4 <= 160 * 1024, "LDS of one CU");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NSTAGE * STAGE + BN * 4];
 
     // --- this workgroup's tiles: one channel column, every lm-th pixel tile of its XCD's contiguous share (as pigemm.hip) ----
     const int b = blockIdx.x, xcd = b & 7, local = b >> 3, per = p.pg_per;
@@ -188,82 +172,8 @@ __global__ __launch_bounds__(512, 2) void psgemm_kernel(const GemmParams p, cons
     const int nwx = p.pg_nwx, nwy = p.pg_nwy;
 
     // bias of the column -> LDS (the accumulators of every tile start from it)
-    float* const bias_s = (float*)(lds + NSTAGE * STAGE + STG_BYTES);
+    float* const bias_s = (float*)(lds + NSTAGE * STAGE);
     if (tid < BN) bias_s[tid] = p.bias ? p.bias[tile_n * BN + tid] : 0.f;
-
-    // ---- output addressing (the consumers' epilogue and, deferred, the loaders'): lane = pixel lr of a wave's 32, channels ch0 + 8 q + 0..3 ----
-    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)out_bytes, 0x00020000);
-    const int ch0 = tile_n * BN + 4 * lh;
-    // output, in BYTES: O(m) = (img * OIS + (oy + pad) * ORS + (ox + pad) * OPS + ch0) * 4
-    const int out_wrap_x = (p.out_row_stride - p.wo * p.out_px_stride) * 4;
-    const int out_wrap_y = (p.out_img_stride - p.pg_ho * p.out_row_stride) * 4;
-    int out_lane = (lr * p.out_px_stride + p.out_pad * (p.out_row_stride + p.out_px_stride) + ch0) * 4;
-    asm volatile("" : "+v"(out_lane));
-    // (pl: the lane's pixel within the 32-pixel run at m_base; lane_c: the lane's constant part, bytes)
-    auto out_offset_at = [&](int m_base, int pl, int lane_c) -> unsigned {
-        int rem, ox_b;
-        const int img_b = ps_sdiv(m_base, p.howo, p.pg_magic_howo, rem);
-        int oy = ps_sdiv(rem, p.wo, p.pg_magic_wo, ox_b);
-        int off = (img_b * p.out_img_stride + oy * p.out_row_stride + ox_b * p.out_px_stride) * 4 + lane_c;
-        int ox = ox_b + pl;
-        for (int w = 0; w < nwx; ++w) {
-            const bool c = ox >= p.wo;
-            ox -= c ? p.wo : 0;
-            off += c ? out_wrap_x : 0;
-            oy += c ? 1 : 0;
-        }
-        for (int w = 0; w < nwy; ++w) {
-            const bool c = oy >= p.pg_ho;
-            oy -= c ? p.pg_ho : 0;
-            off += c ? out_wrap_y : 0;
-        }
-        return m_base + pl < p.M ? (unsigned)off : 0x80000000u;   // past M: beyond num_records, dropped (the launcher keeps buffers under 2 GB)
-    };
-    auto out_offset = [&](int m_base) -> unsigned { return out_offset_at(m_base, lr, out_lane); };
-    // the nearest-neighbour x2 up-sampled copy (p.up_out, YOLOv5's nn.Upsample behind model.10 / model.14 as four more stores of the
-    // producer): pixel (oy, ox) -> (2 oy, 2 ox) .. (2 oy + 1, 2 ox + 1): the same walk with doubled row and pixel strides
-    const __amdgpu_buffer_rsrc_t up_rs = __builtin_amdgcn_make_buffer_rsrc(p.up_out ? p.up_out : p.out, 0, (int)(p.up_out ? up_bytes : out_bytes), 0x00020000);
-    const int up_rs_b = 2 * p.up_row_stride * 4, up_ps_b = 2 * p.up_px_stride * 4;
-    const int up_wrap_x = up_rs_b - p.wo * up_ps_b, up_wrap_y = p.up_img_stride * 4 - p.pg_ho * up_rs_b;
-    int up_lane = lr * up_ps_b + (p.up_pad * (p.up_row_stride + p.up_px_stride) + ch0) * 4;
-    asm volatile("" : "+v"(up_lane));
-    auto up_offset_at = [&](int m_base, int pl, int lane_c) -> unsigned {
-        int rem, ox_b;
-        const int img_b = ps_sdiv(m_base, p.howo, p.pg_magic_howo, rem);
-        int oy = ps_sdiv(rem, p.wo, p.pg_magic_wo, ox_b);
-        int off = img_b * p.up_img_stride * 4 + oy * up_rs_b + ox_b * up_ps_b + lane_c;
-        int ox = ox_b + pl;
-        for (int w = 0; w < nwx; ++w) {
-            const bool c = ox >= p.wo;
-            ox -= c ? p.wo : 0;
-            off += c ? up_wrap_x : 0;
-            oy += c ? 1 : 0;
-        }
-        for (int w = 0; w < nwy; ++w) {
-            const bool c = oy >= p.pg_ho;
-            oy -= c ? p.pg_ho : 0;
-            off += c ? up_wrap_y : 0;
-        }
-        return m_base + pl < p.M ? (unsigned)off : 0x80000000u;
-    };
-    auto up_offset = [&](int m_base) -> unsigned { return up_offset_at(m_base, lr, up_lane); };
-    // one quad of a tile: activation, the 16-byte store, the four stores of the up-sampled copy
-    auto finish_quad = [&](f32x4 v, int q, unsigned o_off, unsigned u_off) {
-        if (ACT == 2 && !(PA_PS_ABL & 4)) {
-            v.x = silu_fast(v.x); v.y = silu_fast(v.y); v.z = silu_fast(v.z); v.w = silu_fast(v.w);
-        } else if (ACT == 1) {
-            v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
-        }
-        const unsigned off = o_off == 0x80000000u ? o_off : o_off + (unsigned)q * 32u;   // channels 32 cb + 8 gq, q = 4 cb + gq
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), out_rs, off, 0, 0);
-        if (p.up_out) {
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const unsigned uo = u_off == 0x80000000u ? u_off : u_off + (unsigned)((q4 >> 1) * p.up_row_stride + (q4 & 1) * p.up_px_stride) * 4u + (unsigned)q * 32u;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), up_rs, uo, 0, 0);
-            }
-        }
-    };
 
     if (wave_id >= 4) {
         // =============================== loader waves ===============================
@@ -350,25 +260,6 @@ __global__ __launch_bounds__(512, 2) void psgemm_kernel(const GemmParams p, cons
             else wait_stage(younger);
         }
         __builtin_amdgcn_s_barrier();   // stage 0 (and bias_s) in LDS
-        // deferred epilogue: e_t = the tile whose accumulators are staged (the one before the tile in progress), e_i = k-step in progress
-        // A loader lane does not take its consumer lane's quads back as they were: the matrix instruction's layout (lane = pixel,
-        // 16 bytes of it per store) makes every store instruction touch 32 cache lines, 32 bytes of each -- and the stores, not the
-        // activation, are what an epilogue costs (profiles/r06_pgemm_split_defer.txt: without SiLU the same time, without stores
-        // 20 % less). Here lane l reads chunk c = l & 7 (channels 4 c .. 4 c + 3 of a 32-channel block: quad c >> 1 of the consumer
-        // lanes with lh = c & 1) of pixel (l >> 3) + 8 j: eight lanes cover the 128 contiguous bytes a pixel has in one block, a
-        // store instruction writes eight whole lines. The consumers write quad gq of lane L at position L ^ (2 gq + 8 lh) of its
-        // 64 so that both sides' 16-lane groups hit 16 distinct 16-byte bank groups. Item e_q = 4 cb' + ... : j = e_q / CB, cb = e_q % CB.
-        int e_t = -1, e_i = 0, e_q = 0, e_num = 0;
-        unsigned e_o = 0, e_u = 0;
-        const int e_c = lane & 7, e_p0 = lane >> 3;
-        const unsigned stg_rd = lds_base + STG_OFF + ((lw * NQ + (e_c >> 1)) * 64) * 16;
-        const int e_x = 2 * (e_c >> 1) + 8 * (e_c & 1), e_h = (e_c & 1) * 32;
-        auto stg_addr = [&](int item) {   // item = j * CB + cb
-            const int j = item / CB, cb = item % CB;
-            return stg_rd + (unsigned)(cb * 4 * 1024) + (unsigned)(((e_h + e_p0 + 8 * j) ^ e_x) * 16);
-        };
-        const int e_lane_o = (p.out_pad * (p.out_row_stride + p.out_px_stride) + tile_n * BN + 4 * e_c) * 4;
-        const int e_lane_u = (p.up_pad * (p.up_row_stride + p.up_px_stride) + tile_n * BN + 4 * e_c) * 4;
         for (int g = 0; g + 1 < total; ++g) {
             // stages issued so far: min(g + NSTAGE, total); behind stage g + 1: min(g + NSTAGE, total) - (g + 2)
             const int inflight = (g + NSTAGE < total ? g + NSTAGE : total) - (g + 2);
@@ -376,41 +267,66 @@ __global__ __launch_bounds__(512, 2) void psgemm_kernel(const GemmParams p, cons
             __builtin_amdgcn_s_barrier();   // stage g + 1 landed; every consumer's reads of stage g have returned
             if (g + NSTAGE < total && !(PA_PS_ABL & 1)) issue(slot);
             slot = slot + 1 == NSTAGE ? 0 : slot + 1;
-            if (DEFER == 1) {
-                // between barrier g + 1 and barrier g + 2 (k-step e_i of its tile): piece e_i of the staged tile's nk - 1 pieces
-                if (e_t >= 0 && e_i + 1 < nk && !(PA_PS_ABL & 8)) {
-                    if (e_i == 0) {
-                        e_q = 0;
-                        e_num = 0;
-                    }
-                    int cnt = 0;
-                    for (e_num += NQ; e_num >= nk - 1; e_num -= nk - 1) ++cnt;   // NQ items over nk - 1 pieces, evenly
-                    if (cnt > 0) {
-                        const int m_base = (t_lo + lm + e_t * LM) * BM + lw * 32;
-                        f32x4 v = *(lds_cf4*)(size_t)stg_addr(e_q);
-                        for (int it = 0; it < cnt; ++it) {
-                            const f32x4 vn = *(lds_cf4*)(size_t)stg_addr(e_q + 1 < NQ ? e_q + 1 : NQ - 1);   // (the next item's read under this one's arithmetic)
-                            const int j = e_q / CB, cb = e_q % CB;
-                            if (cb == 0 || it == 0) {   // the lane's pixel of this group of CB items
-                                const int pl = e_p0 + 8 * j;
-                                e_o = out_offset_at(m_base, pl, e_lane_o + pl * p.out_px_stride * 4);
-                                e_u = p.up_out ? up_offset_at(m_base, pl, e_lane_u + pl * up_ps_b) : 0u;
-                            }
-                            finish_quad(v, 4 * cb, e_o, e_u);   // (channel offset 32 cb: finish_quad's q counts 8-channel steps)
-                            v = vn;
-                            ++e_q;
-                        }
-                    }
-                }
-                if (++e_i == nk) { e_i = 0; ++e_t; }
-            }
         }
         __builtin_amdgcn_s_barrier();   // (the consumers' barrier of the last k-step)
         return;
     }
 
     // =============================== consumer waves ===============================
+    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t res_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(RES ? p.residual : p.out), 0, (int)out_bytes, 0x00020000);
+    const int ch0 = tile_n * BN + 4 * lh;
+    // output, in BYTES: O(m) = (img * OIS + (oy + pad) * ORS + (ox + pad) * OPS + ch0) * 4
+    const int out_wrap_x = (p.out_row_stride - p.wo * p.out_px_stride) * 4;
+    const int out_wrap_y = (p.out_img_stride - p.pg_ho * p.out_row_stride) * 4;
+    int out_lane = (lr * p.out_px_stride + p.out_pad * (p.out_row_stride + p.out_px_stride) + ch0) * 4;
+    asm volatile("" : "+v"(out_lane));
+    auto out_offset = [&](int m_base) -> unsigned {
+        int rem, ox_b;
+        const int img_b = ps_sdiv(m_base, p.howo, p.pg_magic_howo, rem);
+        int oy = ps_sdiv(rem, p.wo, p.pg_magic_wo, ox_b);
+        int off = (img_b * p.out_img_stride + oy * p.out_row_stride + ox_b * p.out_px_stride) * 4 + out_lane;
+        int ox = ox_b + lr;
+        for (int w = 0; w < nwx; ++w) {
+            const bool c = ox >= p.wo;
+            ox -= c ? p.wo : 0;
+            off += c ? out_wrap_x : 0;
+            oy += c ? 1 : 0;
+        }
+        for (int w = 0; w < nwy; ++w) {
+            const bool c = oy >= p.pg_ho;
+            oy -= c ? p.pg_ho : 0;
+            off += c ? out_wrap_y : 0;
+        }
+        return m_base + lr < p.M ? (unsigned)off : 0x80000000u;   // past M: beyond num_records, dropped (the launcher keeps buffers under 2 GB)
+    };
+
+    // the nearest-neighbour x2 up-sampled copy (p.up_out, YOLOv5's nn.Upsample behind model.10 / model.14 as four more stores of the
+    // producer): pixel (oy, ox) -> (2 oy, 2 ox) .. (2 oy + 1, 2 ox + 1): the same walk with doubled row and pixel strides
+    const __amdgpu_buffer_rsrc_t up_rs = __builtin_amdgcn_make_buffer_rsrc(p.up_out ? p.up_out : p.out, 0, (int)(p.up_out ? up_bytes : out_bytes), 0x00020000);
+    const int up_rs_b = 2 * p.up_row_stride * 4, up_ps_b = 2 * p.up_px_stride * 4;
+    const int up_wrap_x = up_rs_b - p.wo * up_ps_b, up_wrap_y = p.up_img_stride * 4 - p.pg_ho * up_rs_b;
+    int up_lane = lr * up_ps_b + (p.up_pad * (p.up_row_stride + p.up_px_stride) + ch0) * 4;
+    asm volatile("" : "+v"(up_lane));
+    auto up_offset = [&](int m_base) -> unsigned {
+        int rem, ox_b;
+        const int img_b = ps_sdiv(m_base, p.howo, p.pg_magic_howo, rem);
+        int oy = ps_sdiv(rem, p.wo, p.pg_magic_wo, ox_b);
+        int off = img_b * p.up_img_stride * 4 + oy * up_rs_b + ox_b * up_ps_b + up_lane;
+        int ox = ox_b + lr;
+        for (int w = 0; w < nwx; ++w) {
+            const bool c = ox >= p.wo;
+            ox -= c ? p.wo : 0;
+            off += c ? up_wrap_x : 0;
+            oy += c ? 1 : 0;
+        }
+        for (int w = 0; w < nwy; ++w) {
+            const bool c = oy >= p.pg_ho;
+            oy -= c ? p.pg_ho : 0;
+            off += c ? up_wrap_y : 0;
+        }
+        return m_base + lr < p.M ? (unsigned)off : 0x80000000u;
+    };
 
     // LDS read addresses (bytes) of the two k halves: this wave's pixel rows; the weight rows lr of each 32-channel block
     unsigned a_rd[2], a_rd2[2], b_rd[2];
@@ -537,9 +453,8 @@ __global__ __launch_bounds__(512, 2) void psgemm_kernel(const GemmParams p, cons
 #endif
         load_bias();
         f32x4 res4[CB][4];
-        const bool staged = DEFER == 1 && t + 1 < nt;   // this tile's epilogue is the loaders' (see the kernel's head)
-        const unsigned o_off = staged ? 0u : out_offset(tile_m * BM + wave_id * 32);
-        const unsigned u_off = p.up_out && !staged ? up_offset(tile_m * BM + wave_id * 32) : 0u;
+        const unsigned o_off = out_offset(tile_m * BM + wave_id * 32);
+        const unsigned u_off = p.up_out ? up_offset(tile_m * BM + wave_id * 32) : 0u;
         for (int ks = 0; ks < nk; ++ks, ++g) {
             const unsigned sb = slot * STAGE;
             // ---- first half: multiply k 0..15 from registers; read and split k 16..31 of the same stage (the reads go out BEHIND the
@@ -572,46 +487,6 @@ __global__ __launch_bounds__(512, 2) void psgemm_kernel(const GemmParams p, cons
 #ifdef PA_PS_STAMP
         if (p.clk) st_k += __builtin_amdgcn_s_memtime() - st_ks;
 #endif
-        if (staged) {
-            // the accumulators -> staging (visible to the loaders from the barrier of the next k-step, behind this wave's lgkmcnt(0))
-            const unsigned stg_wr = lds_base + STG_OFF + wave_id * NQ * 1024;
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq)   // (position lane ^ (2 gq + 8 lh) of the quad's 64: the loaders' transposed reads, see there)
-                    *(lds_f4*)(size_t)(stg_wr + (4 * cb + gq) * 1024 + ((lane ^ (2 * gq + 8 * lh)) * 16)) =
-                        f32x4{acc[cb][4 * gq], acc[cb][4 * gq + 1], acc[cb][4 * gq + 2], acc[cb][4 * gq + 3]};
-            continue;
-        }
-        if (DEFER == 2) {
-            // A/B: the consumer's own epilogue through the staging area -- its quads out, transposed back (eight lanes = the 128
-            // contiguous bytes a pixel has in a 32-channel block), so that a store instruction writes eight whole cache lines
-            // instead of 32 bytes of 32 lines. Same wave writes and reads: LDS operations of a wave execute in order, no barrier.
-            const unsigned stg_wr = lds_base + STG_OFF + wave_id * NQ * 1024;
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq)
-                    *(lds_f4*)(size_t)(stg_wr + (4 * cb + gq) * 1024 + ((lane ^ (2 * gq + 8 * lh)) * 16)) =
-                        f32x4{acc[cb][4 * gq], acc[cb][4 * gq + 1], acc[cb][4 * gq + 2], acc[cb][4 * gq + 3]};
-            const int c8 = lane & 7, p0 = lane >> 3;
-            const int ex = 2 * (c8 >> 1) + 8 * (c8 & 1), eh = (c8 & 1) * 32;
-            const int lane_o = (p.out_pad * (p.out_row_stride + p.out_px_stride) + tile_n * BN + 4 * c8) * 4;
-            const int lane_u = (p.up_pad * (p.up_row_stride + p.up_px_stride) + tile_n * BN + 4 * c8) * 4;
-            const int m_base = tile_m * BM + wave_id * 32;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int pl = p0 + 8 * j;
-                const unsigned eo = out_offset_at(m_base, pl, lane_o + pl * p.out_px_stride * 4);
-                const unsigned eu = p.up_out ? up_offset_at(m_base, pl, lane_u + pl * up_ps_b) : 0u;
-#pragma unroll
-                for (int cb = 0; cb < CB; ++cb) {
-                    const f32x4 v = *(lds_cf4*)(size_t)(stg_wr + ((c8 >> 1) * 1024) + cb * 4096 + (((eh + pl) ^ ex) * 16));
-                    finish_quad(v, 4 * cb, eo, eu);
-                }
-            }
-            continue;
-        }
         // ---- epilogue of the tile, straight from the accumulators: lane = pixel lr of the wave's 32, channels ch0 + 32 cb + 8 g + 0..3 ----
         if (RES && BN >= 128) {   // 128-channel tiles: the residual's 64 registers are free only now (the operand sets of the last half are dead)
 #pragma unroll
@@ -748,33 +623,21 @@ hipError_t launch_psgemm(const GemmParams& p_in, const unsigned short* wsp, size
                      (reinterpret_cast<unsigned long long>(p.up_out) & 15ull)))
         return hipErrorInvalidValue;
     const unsigned up_bytes = (unsigned)(up_floats * 4);
-#define PA_PS_LAUNCH1(BN_, NS_, RES_, DEF_)                                                                                                \
-    do {                                                                                                                                   \
-        if (p.relu == 2) hipLaunchKernelGGL((psgemm_kernel<BN_, NS_, 2, RES_, DEF_>), dim3(grid), dim3(512), 0, s, p, wsp, out_bytes, up_bytes);     \
-        else if (p.relu == 1) hipLaunchKernelGGL((psgemm_kernel<BN_, NS_, 1, RES_, DEF_>), dim3(grid), dim3(512), 0, s, p, wsp, out_bytes, up_bytes); \
-        else hipLaunchKernelGGL((psgemm_kernel<BN_, NS_, 0, RES_, DEF_>), dim3(grid), dim3(512), 0, s, p, wsp, out_bytes, up_bytes);                 \
+#define PA_PS_LAUNCH1(BN_, NS_, RES_)                                                                                                \
+    do {                                                                                                                             \
+        if (p.relu == 2) hipLaunchKernelGGL((psgemm_kernel<BN_, NS_, 2, RES_>), dim3(grid), dim3(512), 0, s, p, wsp, out_bytes, up_bytes);     \
+        else if (p.relu == 1) hipLaunchKernelGGL((psgemm_kernel<BN_, NS_, 1, RES_>), dim3(grid), dim3(512), 0, s, p, wsp, out_bytes, up_bytes); \
+        else hipLaunchKernelGGL((psgemm_kernel<BN_, NS_, 0, RES_>), dim3(grid), dim3(512), 0, s, p, wsp, out_bytes, up_bytes);                 \
     } while (0)
 #define PA_PS_LAUNCH(BN_, NS_)                                                                                                       \
     do {                                                                                                                             \
-        if (p.residual) PA_PS_LAUNCH1(BN_, NS_, true, 0);                                                                        \
-        else PA_PS_LAUNCH1(BN_, NS_, false, 0);                                                                                  \
+        if (p.residual) PA_PS_LAUNCH1(BN_, NS_, true);                                                                               \
+        else PA_PS_LAUNCH1(BN_, NS_, false);                                                                                         \
     } while (0)
-    // The epilogue on the loader waves (the kernel's head): tiles of two or more k-steps, no residual, and a workgroup that has a
-    // tile behind its first (share > lm). 64 KB of staging beside a 128-channel ring leaves room for two stages, which measure
-    // like three (profiles/r06_pgemm_split_defer.txt). PA_PS_DEFER=0: off (A/B; the results are the same bits).
-    static const int defer_on = getenv("PA_PS_DEFER") ? atoi(getenv("PA_PS_DEFER")) : 0;
     // ring depth: as deep as one workgroup per CU allows. PA_PS_STAGES=2 (A/B): a two-stage ring of 80 / 56 KB, which leaves a CU room for a
     // workgroup of another stream's kernel (the Motion-JPEG passes' 52 KB) beside this one -- the chain runs three streams
     static const int stages2 = getenv("PA_PS_STAGES") && atoi(getenv("PA_PS_STAGES")) == 2;
-    if (defer_on == 1 && !p.residual && p.ktot >= 64 && share > lm) {
-        if (bn == 128) PA_PS_LAUNCH1(128, 2, false, 1);
-        else if (bn == 64) PA_PS_LAUNCH1(64, 4, false, 1);
-        else PA_PS_LAUNCH1(32, 4, false, 1);
-    } else if (defer_on == 2 && !p.residual) {
-        if (bn == 128) PA_PS_LAUNCH1(128, 2, false, 2);
-        else if (bn == 64) PA_PS_LAUNCH1(64, 4, false, 2);
-        else PA_PS_LAUNCH1(32, 4, false, 2);
-    } else if (stages2) {
+    if (stages2) {
         if (bn == 128) PA_PS_LAUNCH(128, 2);
         else if (bn == 64) PA_PS_LAUNCH(64, 2);
         else PA_PS_LAUNCH(32, 2);

@@ -18,7 +18,6 @@ KNOBS = [
     ({"PA_DET_EMU_STEM": "1"}, False),    # the detector's stem as an emulated six-tap GEMM
     ({"PA_PS_RES128": "0", "PA_DET_EMU_S1": "1"}, False),   # ... with 64-channel residual tiles
     ({"PA_DET_UP_FUSE": "0"}, True),      # up-sampling layers as passes of their own
-    ({"PA_PS_DEFER": "0"}, True),         # the emulated kernel's epilogues on the consumer waves (same instructions on the same values)
 ]
 
 

@@ -111,12 +111,12 @@ SHAPES = [
     (1, 8, 16, 64, 128, 1, 1),       # one tile, two k-steps
     (1, 16, 24, 96, 128, 1, 1),      # three tiles of three k-steps on one workgroup column
     (33, 12, 20, 128, 256, 1, 1),    # 7920 pixels = 61.9 tiles: every XCD's share is ragged
-    # workgroups with more than one tile: every tile but a workgroup's last has its epilogue on the LOADER waves (psgemm.hip, DEFER)
-    (26, 48, 80, 64, 64, 1, 1),      # 780 tiles of two k-steps, up to four per workgroup: the whole epilogue in ONE interval
-    (10, 48, 80, 128, 128, 1, 1),    # 300 tiles of four k-steps on 256 workgroups: one or two each (ragged), three pieces
-    (16, 48, 80, 96, 128, 1, 1),     # three k-steps: 16 quads over two pieces
+    # workgroups with MORE THAN ONE tile (the ring runs on across tile boundaries; the shapes above give every workgroup one)
+    (26, 48, 80, 64, 64, 1, 1),      # 780 tiles of two k-steps, up to four per workgroup
+    (10, 48, 80, 128, 128, 1, 1),    # 300 tiles of four k-steps on 256 workgroups: one or two each (ragged)
+    (16, 48, 80, 96, 128, 1, 1),     # three k-steps
     (20, 24, 40, 256, 256, 1, 1),    # two 128-channel columns, 150 pixel tiles
-    (12, 96, 160, 64, 128, 3, 2),    # stride-2 3x3, 18 k-steps: one quad per piece
+    (12, 96, 160, 64, 128, 3, 2),    # stride-2 3x3, 18 k-steps
     (9, 96, 160, 32, 32, 3, 1),      # 32-channel tiles, nine k-steps, 1080 tiles
 ]
 
@@ -155,7 +155,7 @@ def test_emulated_conv_epilogues_channel_slices_and_borders():
     assert _case(1, 96, 160, 32, 32, 3, 1, 5, act=2, residual=True, res_after=True, in_place=True, in_extra=32, out_extra=32, out_pad=1) <= 2e-5
     # no activation, stride 2 with a residual of the output's geometry
     assert _case(2, 16, 16, 64, 128, 3, 2, 6, act=0, residual=True, out_pad=1) <= 2e-5
-    # the same slices and borders where the loader waves run the epilogue (several tiles per workgroup): SiLU, ReLU, none
+    # the same slices and borders with several tiles per workgroup: SiLU, ReLU, none
     assert _case(12, 48, 80, 64, 64, 1, 1, 7, act=2, in_extra=64, out_extra=64, out_pad=1) <= 2e-5
     assert _case(10, 48, 80, 128, 128, 1, 1, 8, act=1, in_pad=1, out_pad=1, out_extra=32) <= 2e-5
     assert _case(12, 48, 80, 128, 64, 1, 1, 9, act=0, out_pad=2) <= 2e-5
