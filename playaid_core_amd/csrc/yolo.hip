@@ -550,8 +550,9 @@ int pa_detector_create_dtype(int32_t device, const pa_net_layer* layers, int32_t
 
 // i0: the first image's slot in the handle's buffers (frames / pred point at that image's data): two half batches can run on two
 // streams side by side, each in its own image range of the same buffers (pa_detector_forward)
+// [lbeg, lend): the layers to run (lend < 0: to the end; the letterbox belongs to layer 0) -- pa_detector_forward's blocked order.
 static int detector_run(pa_detector* h, const uint8_t* frames, int32_t n, int32_t height, int32_t width, float* pred, void* stream,
-                        std::vector<hipEvent_t>* ev, int i0 = 0) {
+                        std::vector<hipEvent_t>* ev, int i0 = 0, int lbeg = 0, int lend = -1) {
     if (!h) return PA_ERR_INVALID_ARG;
     auto fail = [&](int code, const std::string& msg) { h->last_error = msg; return code; };
     if (!frames || !pred || n < 1 || height < 1 || width < 1) return fail(PA_ERR_INVALID_ARG, "pa_detector_forward: bad argument");
@@ -572,12 +573,20 @@ static int detector_run(pa_detector* h, const uint8_t* frames, int32_t n, int32_
     const double dw = (h->net_w - new_w) / 2.0, dh = (h->net_h - new_h) / 2.0;
     const int top = (int)lrint(dh - 0.1), left = (int)lrint(dw - 0.1);
     const double lb_scale_x = 1.0 / ((double)new_w / width), lb_scale_y = 1.0 / ((double)new_h / height);   // cv2.resize's inv_scale, inverted
-    hipLaunchKernelGGL(pa::letterbox_kernel, dim3((h->net_w + 63) / 64, (h->net_h + 3) / 4, n), dim3(256), 0, s, frames, n, height, width, new_h,
-                       new_w, top, left, h->net_h, h->net_w, lb_scale_x, lb_scale_y, X0);
-    DT_HIP(hipGetLastError());
+    if (lbeg == 0) {
+        hipLaunchKernelGGL(pa::letterbox_kernel, dim3((h->net_w + 63) / 64, (h->net_h + 3) / 4, n), dim3(256), 0, s, frames, n, height, width, new_h,
+                           new_w, top, left, h->net_h, h->net_w, lb_scale_x, lb_scale_y, X0);
+        DT_HIP(hipGetLastError());
+    }
     const int no = 5 + h->nc;
     int row0 = 0, di = 0;
-    for (size_t li = 0; li < h->layers.size(); ++li) {
+    for (int li = 0; li < lbeg; ++li)
+        if (h->layers[li].kind == 6) {   // (the Detect rows in front of this range)
+            row0 += 3 * h->layers[li].in_h * h->layers[li].in_w;
+            ++di;
+        }
+    const size_t l_end = lend < 0 ? h->layers.size() : (size_t)lend;
+    for (size_t li = (size_t)lbeg; li < l_end; ++li) {
         const pa_net_layer& L = h->layers[li];
         if (ev) DT_HIP(hipEventRecord((*ev)[li], s));  // (profiling call only: layer li runs between events li and li + 1)
         if (L.kind == 3 && h->split_off[li] >= 0) {   // PA_DTYPE_EMULATED_F32: the stem as a six-tap implicit GEMM on psgemm.hip
@@ -792,6 +801,25 @@ int pa_detector_forward(pa_detector* h, const uint8_t* frames, int32_t n, int32_
     // (what parallel.ClipLanes does for the action CNN). Same kernels on the same images: results bit-identical to one batch
     // wherever a layer's tile shape does not depend on the batch size.
     static const int lanes = getenv("PA_DET_LANES") ? atoi(getenv("PA_DET_LANES")) : 1;
+    // PA_DET_BLOCK=b (A/B): the layers on the large maps (down to the stride-2 convolution that produces the 1/16 map) run over b
+    // images at a time, block after block on the caller's stream, then the rest of the network over the whole batch: a block's
+    // layer outputs (63 MB at b = 16 where the batch's are 252 MB) are still in the 256 MB memory-side cache when the next layer
+    // reads them. The short-K layers there run at the copy rate of their activations (profiles/r06_pgemm_split_defer.txt).
+    static const int block = getenv("PA_DET_BLOCK") ? atoi(getenv("PA_DET_BLOCK")) : 0;
+    if (h && block > 0 && n > block && frames && pred && lanes < 2) {
+        int lb = 0;
+        while (lb < (int)h->layers.size() && (h->layers[lb].kind == 3 || h->layers[lb].in_h > h->net_h / 16)) ++lb;
+        // (a range must not end inside a group one launch absorbs: SPPF pools, a fused up-sampling -- none on the large maps' prefix)
+        if (lb > 0 && lb < (int)h->layers.size() && h->layers[lb].kind == 0 && h->layers[lb - 1].kind == 0) {
+            for (int b0 = 0; b0 < n; b0 += block) {
+                const int nb = n - b0 < block ? n - b0 : block;
+                const int rc = detector_run(h, frames + (size_t)b0 * height * width * 3, nb, height, width, pred + (size_t)b0 * h->rows * (5 + h->nc), stream,
+                                            nullptr, b0, 0, lb);
+                if (rc) return rc;
+            }
+            return detector_run(h, frames, n, height, width, pred, stream, nullptr, 0, lb, -1);
+        }
+    }
     if (!h || lanes < 2 || n < 16 || !frames || !pred) return detector_run(h, frames, n, height, width, pred, stream, nullptr);
     hipStream_t s = (hipStream_t)stream;
     if (!h->side) {

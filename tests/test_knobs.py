@@ -18,6 +18,7 @@ KNOBS = [
     ({"PA_DET_EMU_STEM": "1"}, False),    # the detector's stem as an emulated six-tap GEMM
     ({"PA_PS_RES128": "0", "PA_DET_EMU_S1": "1"}, False),   # ... with 64-channel residual tiles
     ({"PA_DET_UP_FUSE": "0"}, True),      # up-sampling layers as passes of their own
+    ({"PA_DET_BLOCK": "8"}, False),       # the large-map layers over 8 images at a time (Winograd's split K follows the batch size)
 ]
 
 
