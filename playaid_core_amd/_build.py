@@ -63,7 +63,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
             rebuilt = True
-    if rebuilt or force or not os.path.exists(LIB):
+    # (an object compiled by hand is newer than the library without this call having rebuilt anything: link then too)
+    if rebuilt or force or not _newer(LIB, objs):
         cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd), flush=True)

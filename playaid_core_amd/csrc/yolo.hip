@@ -30,6 +30,9 @@ namespace {
 // coefficients, HResize into int, VResizeLinear: ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2 >> 2), then
 // copyMakeBorder(114), BGR -> RGB, / 255. out: [n][net_h + 4][net_w + 4][4] fp32 with a 2-pixel ZERO border (the stem's
 // padding) and channel 3 = 0.
+// AS_INT_BF16 (the emulated-fp32 stem, stem6x6_bf16_kernel): the same pixels as INTEGERS 0..255 in bf16 -- [..][4] bf16, exact --
+// the / 255 lives in that kernel's weights.
+template <bool AS_INT_BF16>
 __global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restrict__ frames, int n, int H, int W, int new_h, int new_w,
                                                         int top, int left, int net_h, int net_w, double scale_x, double scale_y,
                                                         float* __restrict__ out) {
@@ -79,8 +82,13 @@ __global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restric
             }
         }
     }
-    float4 o = make_float4((float)rgb[0] / 255.0f, (float)rgb[1] / 255.0f, (float)rgb[2] / 255.0f, 0.f);
-    reinterpret_cast<float4*>(out)[((size_t)img * (net_h + 4) + y + 2) * (net_w + 4) + x + 2] = o;
+    const size_t at = ((size_t)img * (net_h + 4) + y + 2) * (net_w + 4) + x + 2;
+    if (AS_INT_BF16) {
+        auto bf = [](int v) { return (unsigned)(__float_as_uint((float)v) >> 16); };   // (an integer below 256 has 8 significant bits: exact)
+        reinterpret_cast<uint2*>(out)[at] = make_uint2(bf(rgb[0]) | (bf(rgb[1]) << 16), bf(rgb[2]));
+    } else {
+        reinterpret_cast<float4*>(out)[at] = make_float4((float)rgb[0] / 255.0f, (float)rgb[1] / 255.0f, (float)rgb[2] / 255.0f, 0.f);
+    }
 }
 
 struct SliceGeom {
@@ -212,15 +220,17 @@ __global__ __launch_bounds__(256) void detect_decode_kernel(const float* __restr
 // The 6x6 / 2 stem (models/yolov5s.yaml layer 0: Conv(3, 32, 6, 2, 2) + BatchNorm + SiLU) as a direct convolution on the
 // matrix cores, operands straight from global memory -- no LDS, no barrier. One wave = a strip of 32 output columns x `rows`
 // output rows x all 32 output channels:
-//   * v_mfma_f32_32x32x2_f32 with the WEIGHTS as the row operand (lane = channel) and the pixels as the column operand
-//     (lane = output column); the k pair of a step is (kx = j, kx = 3 + j) of one (ky, channel): lanes 0-31 carry the first,
-//     lanes 32-63 the second. K = 6 ky x 3 j x 3 channels x 2 = 108 exactly -- the im2col form of this layer (igemm.hip, one
+//   * v_mfma_f32_32x32x2_f32 with the PIXELS as the row operand (a lane supplies output column lr) and the weights as the column
+//     operand (a lane supplies channel lr); the k pair of a step is (kx = j, kx = 3 + j) of one (ky, channel): lanes 0-31 carry
+//     the first, lanes 32-63 the second. K = 6 ky x 3 j x 3 channels x 2 = 108 exactly -- the im2col form of this layer (igemm.hip, one
 //     8-pixel x 4-channel chunk per kernel row = K 192, 64 output channels) executed 3.6x the multiply-adds for the same result;
 //   * a lane's 54 weights stay in registers for the whole kernel ([lane][ky][j][c], laid out by the host);
 //   * per (input row, j) a lane reads ONE NHWC4 pixel (16 bytes: column 2 ox + 3 (lane >> 5) + j) and feeds its three
 //     channels to three matrix instructions; the six input rows of an output row live in an eight-row register window that
 //     slides by two rows per output row (six new 16-byte loads per 54 matrix instructions, issued one output row ahead);
-//   * a lane ends up with ONE output pixel and runs of four consecutive channels: bias + SiLU + four 16-byte stores.
+//   * a lane ends up with ONE channel (lr) of 16 pixels (columns 8 g + 4 lh + e of the strip): bias + SiLU + 16 dword stores, each
+//     writing that channel for 2 pixels x 32 lanes = two whole 128-byte lines. (Rounds 4-5 had the operands the other way round:
+//     lane = pixel, four 16-byte stores each touching 32 lines -- 318 against 270 us per 64 frames, PA_STEM_LANE_IS_PIXEL below.)
 struct StemDirectParams {
     const float* x;      // [n][net_h + 4][net_w + 4][4], 2-pixel zero border, channel 3 = 0
     const float* wlane;  // [64 lanes][56]: W[lane & 31][c][ky][3 * (lane >> 5) + j] at ky * 9 + j * 3 + c
@@ -235,6 +245,14 @@ struct StemDirectParams {
 // only -- with a row loop and a branch around the stores it waited for the row's own prefetch (vmcnt(2) behind six loads
 // that nothing needed for another 54 matrix instructions), which cost the kernel half its matrix-pipe time. Rows and
 // columns past the image are loaded from clamped addresses and their stores are dropped by the buffer's bounds check.
+// A/B build -DPA_STEM_LANE_IS_PIXEL=1 (both stem kernels): the weights as the matrix instruction's ROW operand -- a lane ends up with
+// one pixel and 16 bytes of it per store, every store instruction touching 32 cache lines. The product has the PIXELS as the row
+// operand: a lane holds ONE channel of 16 pixels and a dword store writes that channel for 2 pixels x 32 lanes = two whole
+// 128-byte lines (same products, same order along k: the same bits). Measured on the bf16 form: 218 -> 123 us
+// (profiles/r06_detect_stem_bf16.txt).
+#ifndef PA_STEM_LANE_IS_PIXEL
+#define PA_STEM_LANE_IS_PIXEL 0
+#endif
 template <int ROWS>
 __global__ __launch_bounds__(256, 2) void stem6x6_direct_kernel(const StemDirectParams p) {
     typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -263,6 +281,7 @@ __global__ __launch_bounds__(256, 2) void stem6x6_direct_kernel(const StemDirect
     f32x4 bias4[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) bias4[g] = *reinterpret_cast<const f32x4*>(p.bias + 8 * g + 4 * lh);
+    const float bias1 = p.bias[lr];
     // this image's slice of the output as a buffer: a store at offset >= num_records (0xFFFFFFFF here) goes nowhere
     const __amdgpu_buffer_rsrc_t out_rs =
         __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)img * p.out_img_stride, 0, p.out_img_stride * 4, 0x00020000);
@@ -294,11 +313,31 @@ __global__ __launch_bounds__(256, 2) void stem6x6_direct_kernel(const StemDirect
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const f32x4 px = win[(2 * u + ky) & 7][j];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ky * 9 + j * 3 + 0], px.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ky * 9 + j * 3 + 1], px.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ky * 9 + j * 3 + 2], px.z, acc, 0, 0, 0);
+                if (PA_STEM_LANE_IS_PIXEL) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ky * 9 + j * 3 + 0], px.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ky * 9 + j * 3 + 1], px.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ky * 9 + j * 3 + 2], px.z, acc, 0, 0, 0);
+                } else {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(px.x, w[ky * 9 + j * 3 + 0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(px.y, w[ky * 9 + j * 3 + 1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(px.z, w[ky * 9 + j * 3 + 2], acc, 0, 0, 0);
+                }
             }
         __builtin_amdgcn_sched_barrier(0);
+        if (!PA_STEM_LANE_IS_PIXEL) {
+            // register 4 g + e: pixel column cb * 32 + 8 g + 4 lh + e, channel lr
+            const int px0 = cb * 32 + 4 * lh;
+            const unsigned o0 = (unsigned)(((px0 + p.out_pad) * p.out_px_stride + lr) * 4 + (oy + p.out_pad) * p.out_row_stride * 4);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = silu_fast(acc[4 * g + e] + bias1);
+                    const bool live = oy < p.oh && px0 + 8 * g + e < p.ow;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), out_rs, live ? o0 + (unsigned)((8 * g + e) * p.out_px_stride * 4) : 0xFFFFFFFFu, 0, 0);
+                }
+            continue;
+        }
         const unsigned row_off = oy < p.oh ? col_off + (unsigned)((oy + p.out_pad) * p.out_row_stride * 4) : 0xFFFFFFFFu;
         const unsigned off = col_off == 0xFFFFFFFFu ? 0xFFFFFFFFu : row_off;
 #pragma unroll
@@ -308,6 +347,142 @@ __global__ __launch_bounds__(256, 2) void stem6x6_direct_kernel(const StemDirect
             v.z = silu_fast(v.z); v.w = silu_fast(v.w);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), out_rs,
                                                    off == 0xFFFFFFFFu ? off : off + 32u * g, 0, 0);
+        }
+    }
+}
+
+// The same stem under PA_DTYPE_EMULATED_F32, on v_mfma_f32_32x32x16_bf16. The letter-boxed pixels are INTEGERS (cv2.resize's
+// 8-bit output, detect.py divides them by 255 afterwards): an integer below 256 is ONE exact bf16 value, so the pixel operand
+// needs no split at all and a product takes three matrix instructions -- the three bf16 slices of W / 255 -- instead of psgemm's
+// six. (The generic emulated form of this layer, a six-tap implicit GEMM with the pixels split in registers, was 1.42x SLOWER
+// than the exact kernel: 32 output channels give a split nothing to hide under. profiles/r06_detect_stem_emulated_ab.txt.)
+//   * K = 6 ky x 6 kx x 4 (channel 3: zero weights) = 144 = nine k-steps of 16; a lane's eight consecutive k are TWO input pixels
+//     = 16 bytes of the bf16 NHWC4 input, one load; lanes 0-31 take the even runs of eight, lanes 32-63 the odd ones;
+//   * the 27 weight fragments (9 steps x 3 slices) stay in registers for the whole kernel, laid out by pa_detector_create;
+//   * a lane's nine runs of an output row are a window that slides by three per output row (run r of row t + 1 = run r + 6 of
+//     row t): three new 16-byte loads per 27 matrix instructions, issued three output rows ahead (18 register slots);
+//   * accumulators start from the bias; SiLU and the four 16-byte stores as in the exact kernel.
+// Against the reference's fl(k / 255) * w this computes k * (w / 255 to 24 bits): both one rounding away from the real product.
+struct StemBf16Params {
+    const unsigned short* x;      // [n][net_h + 4][net_w + 4][4] bf16 integers, 2-pixel zero border, channel 3 = 0
+    const unsigned short* wfrag;  // [9 steps][3 slices][64 lanes][8]: slice of W[lane & 31][k] / 255, k = 16 s + 8 (lane >> 5) + i = 24 ky + 4 kx + c
+    const float* bias;            // [32]
+    float* out;
+    int32_t n, net_h, net_w, oh, ow;
+    int32_t out_px_stride, out_row_stride, out_img_stride, out_pad;
+    int32_t row_blocks, col_blocks;
+};
+
+// timing experiments only (diagnostic build -DPA_STEM_ABL=n, results wrong): 1 = no matrix instructions, 2 = no SiLU, 4 = no stores
+#ifndef PA_STEM_ABL
+#define PA_STEM_ABL 0
+#endif
+template <int ROWS>
+__global__ __launch_bounds__(256, 2) void stem6x6_bf16_kernel(const StemBf16Params p) {
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    // three new runs per output row, requested AHEAD output rows early (a row is only 27 matrix instructions, ~900 cycles, long)
+    constexpr int AHEAD = 3, NSLOT = 9 + 3 * AHEAD;
+    static_assert((3 * ROWS) % NSLOT == 0, "the run window rotates by three slots per output row");
+    const int lane = threadIdx.x & 63, lr = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int strips = p.n * p.row_blocks * p.col_blocks;
+    const int in_w = p.net_w + 4, in_h = p.net_h + 4;
+    // the 27 weight fragments: loaded ONCE per wave, the wave then walks strips (the grid is what fits the chip, not one
+    // workgroup per four strips: 10 240 strips would fetch the 27 KB 10 240 times and pay 10 240 window prologues cold)
+    u32x4 wf[9][3];
+#pragma unroll
+    for (int st = 0; st < 9; ++st)
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl) wf[st][sl] = *reinterpret_cast<const u32x4*>(p.wfrag + ((size_t)(st * 3 + sl) * 64 + lane) * 8);
+    // The PIXELS are the matrix instruction's row operand here and the weights its column operand (the exact kernel has it the other
+    // way round): a lane then ends up with ONE output channel (lr) of 16 pixels (8 g + 4 lh + e of the strip's 32 columns), and a
+    // store instruction writes that channel for 2 pixels x 32 lanes = two whole 128-byte lines. With the roles as in the exact kernel
+    // -- lane = pixel, 16 bytes of it per store -- every store touched 32 lines, 32 bytes of each, and the stores alone were 95 of
+    // the kernel's 215 us (ablation builds, profiles/r06_detect_stem_bf16.txt).
+    const float bias = p.bias[lr];
+    // step st of this lane: run r = 2 st + lh = 3 ky + m -> input row 2 oy + ky, pixels 2 ox + 2 m and 2 ox + 2 m + 1
+    int ky_of[9], m_of[9];
+#pragma unroll
+    for (int st = 0; st < 9; ++st) {
+        const int r = 2 * st + lh;
+        ky_of[st] = r / 3;
+        m_of[st] = r - 3 * ky_of[st];
+    }
+    for (int strip = blockIdx.x * 4 + wave; strip < strips; strip += gridDim.x * 4) {   // (whole waves; the kernel has no barrier)
+        const int cb = strip % p.col_blocks;
+        const int rb = (strip / p.col_blocks) % p.row_blocks;
+        const int img = strip / (p.col_blocks * p.row_blocks);
+        const int ox = cb * 32 + lr, oy0 = rb * ROWS;
+        const int oxc = ox < p.ow ? ox : p.ow - 1;
+        const unsigned short* xin = p.x + ((size_t)img * in_h * in_w + 2 * oxc) * 4;
+        // this image's slice of the output as a buffer: a store at offset >= num_records goes nowhere
+        const __amdgpu_buffer_rsrc_t out_rs =
+            __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)img * p.out_img_stride, 0, p.out_img_stride * 4, 0x00020000);
+        // accumulator register 4 g + e of this lane: pixel column cb * 32 + 8 g + 4 lh + e, channel lr
+        const int px0 = cb * 32 + 4 * lh;
+        const unsigned col0 = (unsigned)(((px0 + p.out_pad) * p.out_px_stride + lr) * 4);
+        u32x4 win[NSLOT];
+        auto load_run = [&](int slot, int st, int oy) {  // (rows past the image: clamped, they feed output rows nobody stores)
+            const int row = 2 * oy + ky_of[st];
+            const int rc = row < in_h ? row : in_h - 1;
+            win[slot] = *reinterpret_cast<const u32x4*>(xin + ((size_t)rc * in_w + 2 * m_of[st]) * 4);
+        };
+#pragma unroll
+        for (int st = 0; st < 9; ++st) load_run(st, st, oy0);
+#pragma unroll
+        for (int a = 1; a < AHEAD; ++a)
+#pragma unroll
+            for (int st = 6; st < 9; ++st) load_run((3 * a + st) % NSLOT, st, oy0 + a);
+#pragma unroll
+        for (int t = 0; t < ROWS; ++t) {
+            const int base = (3 * t) % NSLOT, oy = oy0 + t;
+            // the three new runs (steps 6, 7, 8) of the output row AHEAD rows on, into slots no row before it still reads
+            if (t + AHEAD < ROWS) {
+#pragma unroll
+                for (int st = 6; st < 9; ++st) load_run((base + 3 * AHEAD + st) % NSLOT, st, oy + AHEAD);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // (as in the exact kernel: keep the loads ahead of their use)
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = bias;
+#pragma unroll
+            for (int sl = 2; sl >= 0; --sl)   // smallest slice first
+#pragma unroll
+                for (int st = 0; st < 9; ++st) {
+                    if (PA_STEM_ABL & 1) { acc[0] += __builtin_bit_cast(f32x4, win[(base + st) % NSLOT]).x * __builtin_bit_cast(f32x4, wf[st][sl]).x; continue; }
+                    if (PA_STEM_LANE_IS_PIXEL)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[st][sl]), __builtin_bit_cast(bf16x8, win[(base + st) % NSLOT]), acc, 0, 0, 0);
+                    else
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, win[(base + st) % NSLOT]), __builtin_bit_cast(bf16x8, wf[st][sl]), acc, 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            if (PA_STEM_LANE_IS_PIXEL) {   // (bias added here: the accumulators started from one channel's value)
+                const unsigned coff = ox < p.ow && oy < p.oh ? (unsigned)(((ox + p.out_pad) * p.out_px_stride + 4 * lh) * 4 + (oy + p.out_pad) * p.out_row_stride * 4) : 0xFFFFFFFFu;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + 8 * g + 4 * lh);
+                    f32x4 v = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]} - f32x4{bias, bias, bias, bias} + b4;
+                    v.x = silu_fast(v.x); v.y = silu_fast(v.y); v.z = silu_fast(v.z); v.w = silu_fast(v.w);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), out_rs,
+                                                           coff == 0xFFFFFFFFu ? coff : coff + 32u * g, 0, 0);
+                }
+                continue;
+            }
+            const unsigned row_off = col0 + (unsigned)((oy + p.out_pad) * p.out_row_stride * 4);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[4 * g + e];
+                    if (!(PA_STEM_ABL & 2)) v = silu_fast(v);
+                    if ((PA_STEM_ABL & 4) && v != 12345.678f) continue;
+                    const bool live = oy < p.oh && px0 + 8 * g + e < p.ow;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), out_rs,
+                                                          live ? row_off + (unsigned)((8 * g + e) * p.out_px_stride * 4) : 0xFFFFFFFFu, 0, 0);
+                }
         }
     }
 }
@@ -331,6 +506,7 @@ struct pa_detector {
     std::vector<long long> wino_off;    // per layer: float offset into wino_weights, -1 = the layer runs in its direct form
     std::vector<int> wino_bn;           // per layer: output channels per workgroup its filters were laid out for
     int compute_dtype = PA_DTYPE_F32;   // PA_DTYPE_EMULATED_F32: the layers listed in split_off run on psgemm.hip
+    unsigned short* stem_frag = nullptr;       // PA_DTYPE_EMULATED_F32: the stem's W / 255 as stem6x6_bf16_kernel's 27 register fragments (x0 then holds bf16 integers)
     unsigned short* split_weights = nullptr;   // those layers' weights as three bf16 slices in the kernel's stage-image order
     std::vector<long long> split_off;   // per layer: element offset into split_weights, -1 = the layer keeps its exact fp32 kernel
     hipStream_t side = nullptr;         // PA_DET_LANES=2: the second half batch's stream
@@ -349,6 +525,7 @@ void pa_detector_destroy(pa_detector* h) {
     (void)hipFree(h->weights);
     (void)hipFree(h->wino_weights);
     (void)hipFree(h->split_weights);
+    (void)hipFree(h->stem_frag);
     (void)hipFree(h->x0);
     (void)hipFree(h->anchors);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -470,29 +647,40 @@ int pa_detector_create_dtype(int32_t device, const pa_net_layer* layers, int32_t
         // the 1x1 and the stride-2 3x3 convolutions (and, with PA_DET_EMU_S1=1, the stride-1 3x3 ones in place of their Winograd
         // form) on the emulated-fp32 kernel (psgemm.hip): weights split into three bf16 slices here, once
         const int emu_s1 = getenv("PA_DET_EMU_S1") ? atoi(getenv("PA_DET_EMU_S1")) : 0;
-        // ... and the 6x6 / 2 stem as an implicit GEMM of its own shape: one "tap" per kernel ROW, whose 6 pixels x 3 channels are 24
-        // consecutive floats of the NHWC4 input -- read as a 32-float k-step (8 pixels x 4 channels, zero weights under the fourth
-        // channel and the two extra pixels): K = 6 x 32 = 192 for 108 real. Built, parity-green and SLOWER than the exact direct stem
-        // (486 against 342 us per 64 frames, profiles/r06_detect_stem_emulated_ab.txt: 32-channel tiles leave the split's 44 vector
-        // instructions per 8 values only six matrix instructions to hide under, and neighbouring pixels' k-steps overlap by three
-        // quarters, so the copies move the input four times): OFF by default, PA_DET_EMU_STEM=1 for the A/B
-        const int emu_stem = getenv("PA_DET_EMU_STEM") ? atoi(getenv("PA_DET_EMU_STEM")) : 0;
-        std::vector<std::vector<float>> stem_w(n_layers);
+        // ... and the 6x6 / 2 stem on stem6x6_bf16_kernel: integer pixels as ONE exact bf16 value each, W / 255 as three bf16 slices
+        // (PA_DET_EMU_STEM=0: the exact direct stem, A/B). The generic emulated form -- a six-tap implicit GEMM on psgemm.hip with the
+        // pixels split in registers -- lived here until commit dd6847f and was 1.42x slower than the exact kernel
+        // (profiles/r06_detect_stem_emulated_ab.txt).
+        const int emu_stem = getenv("PA_DET_EMU_STEM") ? atoi(getenv("PA_DET_EMU_STEM")) : 1;
         size_t total = 0;
         for (int i = 0; i < n_layers; ++i) {
             const pa_net_layer& L = h->layers[i];
-            if (L.kind == 3 && emu_stem && L.cout % 32 == 0 && L.ksize == 6 && L.stride == 2) {
-                // lane layout of the direct kernel -> [cout][ky][kx * 4 + c]: W[ch][c][ky][3 half + j] sits at half * cout * 56 + ch * 56 + ky * 9 + j * 3 + c
-                std::vector<float>& w = stem_w[i];
-                w.assign((size_t)L.cout * 192, 0.f);
-                for (int ch = 0; ch < L.cout; ++ch)
-                    for (int ky = 0; ky < 6; ++ky)
-                        for (int kx = 0; kx < 6; ++kx)
-                            for (int c = 0; c < 3; ++c)
-                                w[(size_t)ch * 192 + ky * 32 + kx * 4 + c] =
-                                    weights_host[L.w_off + (size_t)(kx / 3) * L.cout * 56 + (size_t)ch * 56 + ky * 9 + (kx % 3) * 3 + c];
-                h->split_off[i] = (long long)total;
-                total += pa::psgemm_weight_elems(L.cout, 192, 0);
+            if (L.kind == 3 && emu_stem && L.cout == 32 && L.ksize == 6 && L.stride == 2 && !h->stem_frag) {
+                // lane layout of the direct kernel: W[ch][c][ky][3 half + j] sits at half * cout * 56 + ch * 56 + ky * 9 + j * 3 + c.
+                // -> [step][slice][lane][8]: lane = 32 khalf + ch supplies k = 16 step + 8 khalf + i, k = 24 ky + 4 kx + c
+                std::vector<unsigned short> frag((size_t)9 * 3 * 64 * 8, 0);
+                auto rne = [](double v) {   // bf16 nearest-even of a double, and its value
+                    float f = (float)v;
+                    uint32_t u;
+                    memcpy(&u, &f, 4);
+                    u += 0x7fffu + ((u >> 16) & 1u);
+                    return (unsigned short)(u >> 16);
+                };
+                auto val = [](unsigned short hq) { const uint32_t u = (uint32_t)hq << 16; float f; memcpy(&f, &u, 4); return (double)f; };
+                for (int st = 0; st < 9; ++st)
+                    for (int ln = 0; ln < 64; ++ln)
+                        for (int e = 0; e < 8; ++e) {
+                            const int ch = ln & 31, k = 16 * st + 8 * (ln >> 5) + e, ky = k / 24, kx = (k % 24) / 4, c = k % 4;
+                            if (c == 3) continue;
+                            double r = (double)weights_host[L.w_off + (size_t)(kx / 3) * L.cout * 56 + (size_t)ch * 56 + ky * 9 + (kx % 3) * 3 + c] / 255.0;
+                            for (int sl = 0; sl < 3; ++sl) {
+                                const unsigned short hq = rne(r);
+                                frag[((size_t)(st * 3 + sl) * 64 + ln) * 8 + e] = hq;
+                                r -= val(hq);
+                            }
+                        }
+                if (!chk(hipMalloc(&h->stem_frag, frag.size() * sizeof(unsigned short)), "hipMalloc stem fragments")) return PA_ERR_HIP;
+                if (!chk(hipMemcpy(h->stem_frag, frag.data(), frag.size() * sizeof(unsigned short), hipMemcpyHostToDevice), "upload stem fragments")) return PA_ERR_HIP;
                 continue;
             }
             if (L.kind != 0 || L.cin % 32 || L.cout % 32) continue;
@@ -505,9 +693,7 @@ int pa_detector_create_dtype(int32_t device, const pa_net_layer* layers, int32_t
         if (total) {
             std::vector<unsigned short> sw(total);
             for (int i = 0; i < n_layers; ++i)
-                if (h->split_off[i] >= 0 && !stem_w[i].empty()) {
-                    pa::psgemm_pack_weights(stem_w[i].data(), h->layers[i].cout, 192, 0, sw.data() + h->split_off[i]);
-                } else if (h->split_off[i] >= 0) {
+                if (h->split_off[i] >= 0) {
                     const pa_net_layer& L = h->layers[i];
                     pa::psgemm_pack_weights(weights_host + L.w_off, L.cout, L.ksize * L.ksize * L.cin, L.res_buf >= 0, sw.data() + h->split_off[i]);
                 }
@@ -559,6 +745,7 @@ static int detector_run(pa_detector* h, const uint8_t* frames, int32_t n, int32_
     if (i0 < 0 || i0 + n > h->max_images) return fail(PA_ERR_CAPACITY, "pa_detector_forward: more images than max_images");
     hipStream_t s = (hipStream_t)stream;
     float* const X0 = h->x0 + (size_t)i0 * (h->net_h + 4) * (h->net_w + 4) * 4;
+    unsigned short* const X0B = reinterpret_cast<unsigned short*>(h->x0) + (size_t)i0 * (h->net_h + 4) * (h->net_w + 4) * 4;   // the same buffer as bf16 (stem_frag)
     auto BUF = [&](int b) -> float* { return h->bufs[b] + (size_t)i0 * h->buf_floats[b]; };
 #define DT_HIP(call)                                                                                         \
     do {                                                                                                     \
@@ -574,8 +761,12 @@ static int detector_run(pa_detector* h, const uint8_t* frames, int32_t n, int32_
     const int top = (int)lrint(dh - 0.1), left = (int)lrint(dw - 0.1);
     const double lb_scale_x = 1.0 / ((double)new_w / width), lb_scale_y = 1.0 / ((double)new_h / height);   // cv2.resize's inv_scale, inverted
     if (lbeg == 0) {
-        hipLaunchKernelGGL(pa::letterbox_kernel, dim3((h->net_w + 63) / 64, (h->net_h + 3) / 4, n), dim3(256), 0, s, frames, n, height, width, new_h,
-                           new_w, top, left, h->net_h, h->net_w, lb_scale_x, lb_scale_y, X0);
+        if (h->stem_frag)   // (bf16 integers, four per pixel: image i0 starts half as many BYTES in)
+            hipLaunchKernelGGL(pa::letterbox_kernel<true>, dim3((h->net_w + 63) / 64, (h->net_h + 3) / 4, n), dim3(256), 0, s, frames, n, height, width, new_h,
+                               new_w, top, left, h->net_h, h->net_w, lb_scale_x, lb_scale_y, reinterpret_cast<float*>(X0B));
+        else
+            hipLaunchKernelGGL(pa::letterbox_kernel<false>, dim3((h->net_w + 63) / 64, (h->net_h + 3) / 4, n), dim3(256), 0, s, frames, n, height, width, new_h,
+                               new_w, top, left, h->net_h, h->net_w, lb_scale_x, lb_scale_y, X0);
         DT_HIP(hipGetLastError());
     }
     const int no = 5 + h->nc;
@@ -589,31 +780,28 @@ static int detector_run(pa_detector* h, const uint8_t* frames, int32_t n, int32_
     for (size_t li = (size_t)lbeg; li < l_end; ++li) {
         const pa_net_layer& L = h->layers[li];
         if (ev) DT_HIP(hipEventRecord((*ev)[li], s));  // (profiling call only: layer li runs between events li and li + 1)
-        if (L.kind == 3 && h->split_off[li] >= 0) {   // PA_DTYPE_EMULATED_F32: the stem as a six-tap implicit GEMM on psgemm.hip
+        if (L.kind == 3 && h->stem_frag) {   // PA_DTYPE_EMULATED_F32: integer pixels, three bf16 slices of W / 255
             const int oh = h->net_h / 2, ow = h->net_w / 2;
-            pa::GemmParams p;
-            memset(&p, 0, sizeof(p));
-            p.act = X0;
-            p.bias = h->weights + L.b_off;
-            p.out = BUF(L.out_buf) + L.out_coff;
-            p.M = n * oh * ow;
-            p.N = L.cout;
-            p.taps = 6; p.kw_taps = 1; p.chunk = 32; p.ktot = 192;
-            p.howo = oh * ow; p.wo = ow;
-            p.in_px_stride = 4;
-            p.in_row_stride = (h->net_w + 4) * 4;
-            p.in_img_stride = (h->net_h + 4) * (h->net_w + 4) * 4;
-            p.stride = 2;
-            p.out_px_stride = L.out_cstride;
-            p.out_row_stride = (ow + 2 * L.out_pad) * L.out_cstride;
-            p.out_img_stride = (oh + 2 * L.out_pad) * (ow + 2 * L.out_pad) * L.out_cstride;
-            p.out_pad = L.out_pad;
-            p.relu = L.act;
-            p.splitk = 1;
-            const hipError_t pe = pa::launch_psgemm(p, h->split_weights + h->split_off[li], (size_t)n * p.out_img_stride - (size_t)L.out_coff, 0, s);
-            if (pe == hipSuccess) continue;
-            if (pe != hipErrorInvalidValue) return fail(PA_ERR_HIP, std::string("stem (emulated): ") + hipGetErrorString(pe));
-            // (a geometry the persistent GEMM does not take -- 65536 or more output pixels per image: the exact direct stem below)
+            pa::StemBf16Params q;
+            q.x = X0B;
+            q.wfrag = h->stem_frag;
+            q.bias = h->weights + L.b_off;
+            q.out = BUF(L.out_buf) + L.out_coff;
+            q.n = n; q.net_h = h->net_h; q.net_w = h->net_w; q.oh = oh; q.ow = ow;
+            q.out_px_stride = L.out_cstride;
+            q.out_row_stride = (ow + 2 * L.out_pad) * L.out_cstride;
+            q.out_img_stride = (oh + 2 * L.out_pad) * (ow + 2 * L.out_pad) * L.out_cstride;
+            q.out_pad = L.out_pad;
+            q.row_blocks = (oh + 11) / 12;
+            q.col_blocks = (ow + 31) / 32;
+            if ((long long)q.out_img_stride * 4 >= (1ll << 32)) return fail(PA_ERR_INVALID_ARG, "stem: output image larger than a buffer descriptor spans");
+            const long long strips = (long long)n * q.row_blocks * q.col_blocks;
+            // two workgroups per CU (225 registers), each wave walking strips
+            static const int cus = [] { hipDeviceProp_t pr; int d = 0; return hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }();
+            const long long wgs = (strips + 3) / 4;
+            hipLaunchKernelGGL(pa::stem6x6_bf16_kernel<12>, dim3((unsigned)(wgs < 2ll * cus ? wgs : 2ll * cus)), dim3(256), 0, s, q);
+            DT_HIP(hipGetLastError());
+            continue;
         }
         if (L.kind == 3) {
             const int oh = h->net_h / 2, ow = h->net_w / 2;

@@ -15,7 +15,7 @@ KNOBS = [
     ({"PA_DS_SIDE": "1"}, True),          # ResNet's branch GEMMs on the side stream
     ({"PA_PS_STAGES": "2"}, True),        # a two-stage LDS ring in the emulated kernel: same k order
     ({"PA_DET_EMU_S1": "1"}, False),      # the detector's stride-1 3x3 layers as emulated implicit GEMMs instead of exact Winograd
-    ({"PA_DET_EMU_STEM": "1"}, False),    # the detector's stem as an emulated six-tap GEMM
+    ({"PA_DET_EMU_STEM": "0"}, False),    # the emulated detector's stem on the exact fp32 kernel instead of the integer-pixel bf16 one
     ({"PA_PS_RES128": "0", "PA_DET_EMU_S1": "1"}, False),   # ... with 64-channel residual tiles
     ({"PA_DET_UP_FUSE": "0"}, True),      # up-sampling layers as passes of their own
     ({"PA_DET_BLOCK": "8"}, False),       # the large-map layers over 8 images at a time (Winograd's split K follows the batch size)
