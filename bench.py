@@ -226,7 +226,8 @@ def emulated_fp32_side(sd, frames, boxes, n_clip, height, width, S, DELTA, devic
 
     out = {"what": "compute_dtype emulated_f32: fp32 in / fp32 out, fp32-accurate sums; the detector's 1x1 and stride-2 3x3 convolutions and the "
                    "ResNet-18's stride-2 openers + 1x1/2 branch GEMMs on v_mfma_f32_32x32x16_bf16 (csrc/psgemm.hip); the stride-1 3x3 layers "
-                   "keep their exact Winograd kernel (measured equal per layer, profiles/r06_pgemm_split_layers.txt), stems and heads exact"}
+                   "keep their exact Winograd kernel (measured equal per layer, profiles/r06_pgemm_split_layers.txt); the detector's 6x6 stem on integer "
+                   "pixels as one exact bf16 value each (stem6x6_bf16_kernel); the ResNet stem and the heads exact"}
     def two_lane_rate(e):   # the headline's shape, this block's own protocol (8 clips of warm-up, 100 timed) -- for BOTH dtypes, side by side
         lanes = ClipLanes(e, S, DELTA, lanes=2)
         try:

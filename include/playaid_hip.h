@@ -246,7 +246,8 @@ int pa_detector_create(int32_t device, const pa_net_layer* layers, int32_t n_lay
                        pa_detector** out);
 /* The same with the convolutions' arithmetic chosen (ABI 11): PA_DTYPE_F32 (= pa_detector_create) or PA_DTYPE_EMULATED_F32 -- the
  * 1x1 and stride-2 3x3 convolutions then run on the bf16 matrix cores with fp32-accurate sums (see PA_DTYPE_EMULATED_F32; the
- * stride-1 3x3 layers keep their exact Winograd kernel, the stem its direct one). Never the default. */
+ * stride-1 3x3 layers keep their exact Winograd kernel), and so does the 6x6 stem: the letter-boxed pixels are integers 0..255,
+ * one exact bf16 value each, multiplied with the three bf16 slices of W / 255 (csrc/yolo.hip, stem6x6_bf16_kernel). Never the default. */
 int pa_detector_create_dtype(int32_t device, const pa_net_layer* layers, int32_t n_layers, const int64_t* buf_floats_per_image, int32_t n_bufs,
                              const float* weights_host, size_t n_weights, int32_t max_images, int32_t net_h, int32_t net_w, int32_t num_classes,
                              int32_t compute_dtype, pa_detector** out);
