@@ -121,7 +121,8 @@ __device__ __forceinline__ int wn_div(int m, int d) {
 
 // one chunk: raw pixels -> V (registers), 16 positions x 2 channel quads-of-16 x 2 channels
 // ABL (timing experiments, PA_WINO_ABL; results wrong when != 0): 1 no DMA behind the prologue's, 2 no matrix instructions,
-// 4 no raw reads / input transform, 8 timeline stamps (results right), 16 no row-operand reads
+// 4 no raw reads / input transform, 8 timeline stamps (results right), 16 no row-operand reads; -DPA_WINO_DIAG builds: 32 no final
+// stores, 64 no residual loads
 //
 // One chunk: the lane's 16 raw pixels -> V (registers), then 16 positions x 2 channel groups x 2 channels of matrix
 // instructions, the row operands read three positions ahead. ISSUE: the DMA instructions of a later chunk are handed out
@@ -343,9 +344,9 @@ __global__ __launch_bounds__(64 * TGN * NCG, TGN * NCG == 4 ? 2 : 1) void wino3x
 
     // The epilogue's bias is fetched HERE, behind the first chunk's copies (its round trip runs under theirs; the wait for the first
     // chunk, which follows, covers it) and pinned in registers for the life of the kernel: in front of the output transform it was
-    // a round trip of its own per tile (every stride-1 3x3 of ResNet-18: -1.5 us). The residual stays in the epilogue: fetched here
-    // as well it made the detector's in-place Bottlenecks 3-5 us slower (all workgroups of a round asking for it at once, in
-    // front of their first chunk instead of behind their last).
+    // a round trip of its own per tile (every stride-1 3x3 of ResNet-18: -1.5 us). The residual is NOT fetched here: that made the
+    // detector's in-place Bottlenecks 3-5 us slower (all workgroups of a round asking for it at once, in front of their first chunk);
+    // it is requested in front of the LAST chunk's arithmetic (below).
     f32x4 bias4v[2];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
@@ -365,6 +366,12 @@ __global__ __launch_bounds__(64 * TGN * NCG, TGN * NCG == 4 ? 2 : 1) void wino3x
 
     float* const ust[3] = {u_lds0, u_lds1, u_lds2};
     float* const pst[3] = {p_lds0, p_lds1, p_lds2};
+    // The residual's eight 16-byte values per lane are requested in front of the LAST chunk's arithmetic (no copy is in flight any
+    // more then, so the counted waits above see nothing new) instead of behind it: a round trip less in front of the stores of a
+    // kernel that has one workgroup per CU and nothing to hide it under. (Requested at the tile's start -- round 5 -- every
+    // workgroup of a round asked at once, in front of its first chunk: slower.) A split tile's residual is the last arriver's alone.
+    f32x4 res4[2][2][2];
+    const bool res_early = p.residual && p.ksplit == 1 && !(ABL & 64);
     for (int c0 = 0; c0 < n_chunks; c0 += NST) {
 #pragma unroll
         for (int st = 0; st < NST; ++st) {
@@ -380,6 +387,13 @@ __global__ __launch_bounds__(64 * TGN * NCG, TGN * NCG == 4 ? 2 : 1) void wino3x
                 if (!more) return;
                 if (k < KU) { WN_ISSUE_U(ut, c + D, k); } else { WN_ISSUE_P(pt, c + D, k - KU); }
             };
+            if (res_early && c == n_chunks - 1) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        res4[g][i >> 1][i & 1] = *reinterpret_cast<const f32x4*>(p.residual + o00 + (long)(i >> 1) * p.out_row_stride + (i & 1) * p.out_px_stride + 16 * g);
+            }
             unsigned long long* const sp = (ABL & 8) && clk && 2 + 3 * c < 63 ? clk + 2 + 3 * c : nullptr;
             wino_chunk<G::BN / 16, ABL, KD, true>((const lds_f*)ust[st], (const lds_f*)pst[st], acc, a_off, r_off, issue, sp);
             WN_STAMP(3 + 3 * c);
@@ -480,13 +494,14 @@ __global__ __launch_bounds__(64 * TGN * NCG, TGN * NCG == 4 ? 2 : 1) void wino3x
     }
     // every residual value first, in one batch of loads: interleaved with the stores (which may alias them -- the detector's
     // Bottlenecks add in place) hipcc keeps load, wait, store, load, ... in program order, eight dependent round trips
-    f32x4 res4[2][2][2];
+    if (!res_early) {
 #pragma unroll
-    for (int g = 0; g < 2; ++g)
+        for (int g = 0; g < 2; ++g)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            res4[g][i >> 1][i & 1] = p.residual ? *reinterpret_cast<const f32x4*>(p.residual + o00 + (long)(i >> 1) * p.out_row_stride + (i & 1) * p.out_px_stride + 16 * g)
-                                               : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < 4; ++i)
+                res4[g][i >> 1][i & 1] = p.residual && !(ABL & 64) ? *reinterpret_cast<const f32x4*>(p.residual + o00 + (long)(i >> 1) * p.out_row_stride + (i & 1) * p.out_px_stride + 16 * g)
+                                                   : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const f32x4 bias4 = bias4v[g];
@@ -505,6 +520,7 @@ __global__ __launch_bounds__(64 * TGN * NCG, TGN * NCG == 4 ? 2 : 1) void wino3x
                     v.z = silu_fast(v.z); v.w = silu_fast(v.w);
                 }
                 if (p.res_after) v += r4;
+                if ((ABL & 32) && v.x != 12345.678f) continue;
                 *reinterpret_cast<f32x4*>(p.out + o) = v;
             }
     }
@@ -636,6 +652,11 @@ hipError_t launch_wino3x3(const WinoParams& p_in, hipStream_t s) {
         case 17: WN_LAUNCH(17); break;
         case 20: WN_LAUNCH(20); break;
         case 21: WN_LAUNCH(21); break;
+#ifdef PA_WINO_DIAG   // (diagnostic build only: 32 = no final stores, 64 = no residual loads)
+        case 32: WN_LAUNCH(32); break;
+        case 64: WN_LAUNCH(64); break;
+        case 96: WN_LAUNCH(96); break;
+#endif
         case 8: {
             // timeline stamps of one launch (the PA_WINO_STAMP_CALL-th) -> PA_WINO_STAMP_FILE: header {grid, waves, cin, n_sb}, then
             // [grid][waves][64] s_memtime values (scripts/wino_stamps.py)

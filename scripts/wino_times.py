@@ -20,8 +20,9 @@ for name, n, h, w, cin, cout in SHAPES:
     wt = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(9 * cin)).astype(np.float32)
     ug = torch.from_numpy(wino.transform_weights(wt)).to(dev)
     out = torch.zeros((n, h + 2, w + 2, cout), device=dev)
+    res = torch.randn((n, h + 2, w + 2, cout), device=dev) if os.environ.get("RES") else None   # RES=1: with a residual, as the networks' layers run
     for _ in range(5):
-        wino.conv3x3(xp, ug, cin, cout, out=out, act=1)
+        wino.conv3x3(xp, ug, cin, cout, out=out, act=1, residual=res)
     # 20 launches back to back between two events, five times: a launch's own time in a stream that is kept busy (a single
     # launch between two events with the host in between reads 5-10 us longer: the queue runs dry in front of it)
     ts = []
@@ -29,7 +30,7 @@ for name, n, h, w, cin, cout in SHAPES:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(20):
-            wino.conv3x3(xp, ug, cin, cout, out=out, act=1)
+            wino.conv3x3(xp, ug, cin, cout, out=out, act=1, residual=res)
         e1.record()
         e1.synchronize()
         ts.append(e0.elapsed_time(e1) * 1e3 / 20)
